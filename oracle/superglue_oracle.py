@@ -1,0 +1,239 @@
+"""CPU oracle for the OpenGlue SuperGlue hot path  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may import this
+module, and only as the checker / the reported CPU baseline.  Nothing under
+openglue_amd/ imports it; the product path fails loudly when the HIP library is missing.
+
+What it is: a functional, token-major ([B, n, C] rows = keypoints) restatement in plain
+torch CPU ops of the algorithm the reference implements with nn.Modules in channel-first
+layout.  Every function cites the reference lines it follows (paths relative to the
+reference repo root).  It takes the reference's own state-dict (SURVEY.md §3.6 names), so
+any checkpoint of the reference can be fed to it unchanged.
+
+Pinning status: the reference ships NO tests / golden vectors for this path,
+so the oracle is pinned against outputs of the reference itself, generated in the build
+container by importing /root/reference (tests/golden/make_golden.py, committed together with
+the fixtures it wrote).  tests/test_oracle_golden.py checks the oracle against those
+fixtures; tests/test_oracle_vs_reference.py re-checks against the live reference whenever
+/root/reference is present.
+
+`dtype=torch.float64` gives a higher-precision "truth" used to measure the fp32 noise floor.
+`attn_operand_dtype=torch.float16` rounds the QK^T / PV operands the way the HIP attention
+kernel does (MFMA f16 inputs, f32 accumulate) -- used only to budget the tolerance.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Mapping, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5  # nn.BatchNorm1d default, models/utils.py:55
+
+
+def _w(sd: Mapping[str, torch.Tensor], name: str, dtype) -> torch.Tensor:
+    t = sd[name].detach().to("cpu", dtype)
+    return t[:, :, 0] if t.dim() == 3 else t  # Conv1d k=1 weight [out, in, 1] -> [out, in]
+
+
+def conv1x1(x: torch.Tensor, sd, prefix: str) -> torch.Tensor:
+    """nn.Conv1d(kernel_size=1) on channel-first == a linear map on token rows."""
+    return F.linear(x, _w(sd, prefix + ".weight", x.dtype), _w(sd, prefix + ".bias", x.dtype))
+
+
+def batchnorm_eval(x: torch.Tensor, sd, prefix: str) -> torch.Tensor:
+    """nn.BatchNorm1d in eval mode (running statistics), per channel = last dim here."""
+    dt = x.dtype
+    mean, var = _w(sd, prefix + ".running_mean", dt), _w(sd, prefix + ".running_var", dt)
+    gamma, beta = _w(sd, prefix + ".weight", dt), _w(sd, prefix + ".bias", dt)
+    return (x - mean) / torch.sqrt(var + BN_EPS) * gamma + beta
+
+
+def feed_forward(x: torch.Tensor, sd, prefix: str, n_conv: int) -> torch.Tensor:
+    """FeedForwardNet: [Conv1d, ReLU, BatchNorm1d] * (n_conv-1) + Conv1d, in THAT order
+    (models/utils.py:48-58).  Sequential indices: conv 3i, relu 3i+1, bn 3i+2."""
+    for i in range(n_conv - 1):
+        x = conv1x1(x, sd, f"{prefix}.{3 * i}")
+        x = torch.relu(x)
+        x = batchnorm_eval(x, sd, f"{prefix}.{3 * i + 2}")
+    return conv1x1(x, sd, f"{prefix}.{3 * (n_conv - 1)}")
+
+
+def normalize_keypoints(kpts: torch.Tensor, width: float, height: float) -> torch.Tensor:
+    """superglue.py:74-78: 2*k / [W-1, H-1] - 1."""
+    return 2 * kpts / torch.tensor([width - 1, height - 1], dtype=kpts.dtype) - 1.0
+
+
+def keypoint_encoder(kpts_n: torch.Tensor, side: torch.Tensor, sd, config) -> torch.Tensor:
+    """MLPPositionalEncoding.forward, positional_encoding.py:16-19: cat([xy, side_info]) -> MLP."""
+    n_conv = len(config["positional_encoding"]["hidden_layers_sizes"]) + 1
+    return feed_forward(torch.cat([kpts_n, side], dim=-1), sd, "positional_encoding.encoder", n_conv)
+
+
+def softmax_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int,
+                      operand_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """attention.py:8-19 with the head split of attention_gnn.py:24-26: channel c belongs to head
+    c // d (contiguous blocks, `.view(B, H, d, N)`), A = softmax_keys(Q K^T / sqrt(d)), O = A V."""
+    B, nq, D = q.shape
+    d = D // num_heads
+    qh = q.view(B, nq, num_heads, d).transpose(1, 2)            # [B,H,nq,d]
+    kh = k.view(B, -1, num_heads, d).transpose(1, 2)
+    vh = v.view(B, -1, num_heads, d).transpose(1, 2)
+    if operand_dtype is not None:  # emulate MFMA f16 operands (scale folded into Q before rounding)
+        qh = (qh * d ** -0.5).to(operand_dtype).to(q.dtype)
+        kh = kh.to(operand_dtype).to(q.dtype)
+        vh = vh.to(operand_dtype).to(q.dtype)
+        logits = qh @ kh.transpose(-1, -2)
+        mx = logits.amax(-1, keepdim=True)
+        p = torch.exp(logits - mx)
+        l = p.sum(-1, keepdim=True)
+        o = (p.to(operand_dtype).to(q.dtype) @ vh) / l
+    else:
+        att = (qh @ kh.transpose(-1, -2)) * d ** -0.5
+        o = att.softmax(dim=-1) @ vh
+    return o.transpose(1, 2).reshape(B, nq, D)
+
+
+def message_passing(xq: torch.Tensor, xkv: torch.Tensor, sd, prefix: str, num_heads: int,
+                    use_offset: bool, attn_operand_dtype=None) -> torch.Tensor:
+    """ResidualAttentionMessagePropagation.forward, attention_gnn.py:43-55, with
+    MultiheadAttention.forward :22-32 inlined:  q + fc(cat[q, out_proj(MHA(q, kv, kv))])."""
+    q = conv1x1(xq, sd, prefix + ".mha.in_proj_q")
+    k = conv1x1(xkv, sd, prefix + ".mha.in_proj_k")
+    v = conv1x1(xkv, sd, prefix + ".mha.in_proj_v")
+    msg = conv1x1(softmax_attention(q, k, v, num_heads, attn_operand_dtype), sd, prefix + ".mha.out_proj")
+    y = torch.cat([xq - msg, msg], dim=-1) if use_offset else torch.cat([xq, msg], dim=-1)
+    return xq + feed_forward(y, sd, prefix + ".fc", 2)
+
+
+def attentional_gnn(x0: torch.Tensor, x1: torch.Tensor, sd, config, attn_operand_dtype=None):
+    """GraphAttentionNet.forward, attention_gnn.py:84-93.  Layer 2l = self (both images through the
+    SAME module, :63-66), layer 2l+1 = cross (:74-77): image 0 first, then image 1 attends to the
+    UPDATED image-0 descriptors."""
+    g = config["attention_gnn"]
+    H, off = g["num_heads"], g.get("use_offset", False)
+    for l in range(g["num_stages"]):
+        ps, pc = f"attention_gnn.layers.{2 * l}.module", f"attention_gnn.layers.{2 * l + 1}.module"
+        x0 = message_passing(x0, x0, sd, ps, H, off, attn_operand_dtype)
+        x1 = message_passing(x1, x1, sd, ps, H, off, attn_operand_dtype)
+        x0 = message_passing(x0, x1, sd, pc, H, off, attn_operand_dtype)
+        x1 = message_passing(x1, x0, sd, pc, H, off, attn_operand_dtype)
+    return x0, x1
+
+
+def log_sinkhorn(log_a: torch.Tensor, log_b: torch.Tensor, Mx: torch.Tensor, num_iters: int,
+                 reg: float) -> torch.Tensor:
+    """log_otp_solver, optimal_transport.py:20-28: u first (with v = 0), then v with the NEW u;
+    returns M/reg + u + v (not multiplied back by reg)."""
+    Mx = Mx / reg
+    u, v = torch.zeros_like(log_a), torch.zeros_like(log_b)
+    for _ in range(num_iters):
+        u = log_a - torch.logsumexp(Mx + v[:, None, :], dim=2)
+        v = log_b - torch.logsumexp(Mx + u[:, :, None], dim=1)
+    return Mx + u[:, :, None] + v[:, None, :]
+
+
+def matching_log_probs(S: torch.Tensor, dustbin: torch.Tensor, num_iters: int, reg: float) -> torch.Tensor:
+    """SuperGlue.get_matching_probs, superglue.py:88-111: dustbin row/column, log-marginals with
+    norm = -log(m+n), Sinkhorn, minus norm."""
+    B, m, n = S.shape
+    S_aug = torch.empty(B, m + 1, n + 1, dtype=S.dtype)
+    S_aug[:, :m, :n] = S
+    S_aug[:, m, :] = dustbin
+    S_aug[:, :, n] = dustbin
+    norm = -math.log(m + n)
+    log_a = torch.full((B, m + 1), norm, dtype=S.dtype)
+    log_b = torch.full((B, n + 1), norm, dtype=S.dtype)
+    log_a[:, -1] += math.log(n)
+    log_b[:, -1] += math.log(m)
+    return log_sinkhorn(log_a, log_b, S_aug, num_iters, reg) - norm
+
+
+def _image_wh(data: Mapping, idx: int) -> Tuple[float, float]:
+    """superglue.py:35-38: image tensor -> size()[-2:] = (H, W); else image{idx}_size = [W, H]."""
+    if "image0" in data and "image1" in data:
+        h, w = data[f"image{idx}"].shape[-2:]
+        return float(w), float(h)
+    w, h = data[f"image{idx}_size"][:2]
+    return float(w), float(h)
+
+
+def superglue_forward(sd: Mapping[str, torch.Tensor], config: Mapping, data: Mapping,
+                      dtype: torch.dtype = torch.float32, attn_operand_dtype=None,
+                      return_intermediates: bool = False) -> Dict[str, torch.Tensor]:
+    """SuperGlue.forward, superglue.py:29-72 (eval mode).  Returns the reference's dict:
+    'context_descriptors{0,1}' CHANNEL-FIRST [B, D, n] and 'scores' [B, m+1, n+1]."""
+    cvt = lambda t: t.detach().to("cpu", dtype)
+    k0, k1 = cvt(data["keypoints0"]), cvt(data["keypoints1"])
+    d0, d1 = cvt(data["local_descriptors0"]), cvt(data["local_descriptors1"])
+    s0, s1 = cvt(data["side_info0"]), cvt(data["side_info1"])
+    pe0 = keypoint_encoder(normalize_keypoints(k0, *_image_wh(data, 0)), s0, sd, config)
+    pe1 = keypoint_encoder(normalize_keypoints(k1, *_image_wh(data, 1)), s1, sd, config)
+    if config.get("no_descriptors", False):                      # superglue.py:45-49
+        x0, x1 = pe0, pe1
+    else:                                                        # :52-55
+        x0, x1 = d0 + pe0, d1 + pe1
+    inter = {"x0_in": x0, "x1_in": x1}
+    x0, x1 = attentional_gnn(x0, x1, sd, config, attn_operand_dtype)
+    inter.update(x0_gnn=x0, x1_gnn=x1)
+    g0, g1 = conv1x1(x0, sd, "linear_proj"), conv1x1(x1, sd, "linear_proj")   # :58
+    if config.get("residual", False):                            # :59-62, per-channel alpha
+        alpha = torch.sigmoid(_w(sd, "mix_coefs", dtype)[:, 0])
+        g0 = alpha * g0 + (1.0 - alpha) * d0
+        g1 = alpha * g1 + (1.0 - alpha) * d1
+    S = (g0 @ g1.transpose(1, 2)) * config["descriptor_dim"] ** -0.5           # :64, :81-86
+    scores = matching_log_probs(S, _w(sd, "dustbin_score", dtype),
+                                config["otp"]["num_iters"], config["otp"]["reg"])
+    out = {
+        "context_descriptors0": g0.transpose(1, 2).contiguous(),
+        "context_descriptors1": g1.transpose(1, 2).contiguous(),
+        "scores": scores,
+    }
+    if return_intermediates:
+        inter["S"] = S
+        out["_intermediates"] = inter
+    return out
+
+
+def extract_matches(scores: torch.Tensor, match_threshold: float) -> Dict[str, torch.Tensor]:
+    """models/matching_module.py:174-187 (matches0 / matching_scores0) and inference.py:176-190
+    (matches1 / matching_scores1): row/col max of scores[:, :-1, :-1], mutual check through
+    gather, exp of the max, threshold, -1 fill.  torch.max on CPU returns the FIRST maximal index."""
+    inner = scores[:, :-1, :-1]
+    max0, max1 = inner.max(2), inner.max(1)
+    idx0, idx1 = max0.indices, max1.indices
+    ar0 = torch.arange(idx0.shape[1], dtype=idx0.dtype)[None]          # utils/misc.py:116-117
+    ar1 = torch.arange(idx1.shape[1], dtype=idx1.dtype)[None]
+    mutual0 = ar0 == idx1.gather(1, idx0)
+    mutual1 = ar1 == idx0.gather(1, idx1)
+    zero = scores.new_tensor(0)
+    ms0 = torch.where(mutual0, max0.values.exp(), zero)
+    ms1 = torch.where(mutual1, ms0.gather(1, idx1), zero)
+    valid0 = mutual0 & (ms0 > match_threshold)
+    valid1 = mutual1 & valid0.gather(1, idx1)
+    return {
+        "matches0": torch.where(valid0, idx0, idx0.new_tensor(-1)),
+        "matching_scores0": ms0,
+        "matches1": torch.where(valid1, idx1, idx1.new_tensor(-1)),
+        "matching_scores1": ms1,
+        "_row_argmax": idx0, "_col_argmax": idx1,
+        "_row_max": max0.values, "_col_max": max1.values,
+    }
+
+
+def match_pairs(sd, config, data, match_threshold: float = 0.2, dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    """MatchingTrainingModule.forward from the `scores` onwards (matching_module.py:171-187)."""
+    out = superglue_forward(sd, config, data, dtype=dtype)
+    out.update(extract_matches(out["scores"], match_threshold))
+    return out
+
+
+def ambiguous_rows(scores64: torch.Tensor, gap: float = 1e-4) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Near-tie detector for the index-parity tests (SURVEY.md §7 'index parity is ill-posed on
+    near-ties'): rows / columns of the inner score block whose top-1 / top-2 gap (in the float64
+    oracle) is below `gap`.  Returns boolean masks [B, m], [B, n]."""
+    inner = scores64[:, :-1, :-1]
+    t0 = inner.topk(2, dim=2).values
+    t1 = inner.topk(2, dim=1).values
+    return (t0[..., 0] - t0[..., 1]) < gap, (t1[:, 0] - t1[:, 1]) < gap

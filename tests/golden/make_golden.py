@@ -1,0 +1,137 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory FROM THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference, which does not exist on the GPU
+box).  It imports the reference's own `models.superglue.superglue.SuperGlue` and sub-functions
+unchanged, feeds them the seeded synthetic inputs / weights of openglue_amd/synthetic.py and
+stores inputs + outputs as .npz.  The reference has no tests or known-answer vectors of its
+own, so these files are what pins both the CPU oracle (oracle/) and the HIP
+path.
+
+    python tests/golden/make_golden.py          # rewrites tests/golden/*.npz
+
+Match extraction (models/matching_module.py:174-187) lives in a module that cannot be imported
+here (pytorch_lightning etc. are absent), so the golden match indices are produced by a
+brute-force per-row Python loop below (independent of the oracle's vectorised restatement) from
+the REFERENCE's scores.
+"""
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, ROOT)
+
+from models.superglue.superglue import SuperGlue as RefSuperGlue           # noqa: E402
+from models.superglue.optimal_transport import log_otp_solver             # noqa: E402
+from models.superglue.attention import softmax_attention                  # noqa: E402
+from openglue_amd import synthetic as syn                                 # noqa: E402
+
+MATCH_THRESHOLD = 0.2  # config/config.yaml:40
+
+CASES = {
+    # name: (config kwargs, m, n, batch, data seed, how much of `scores` to store)
+    "c1": (dict(syn.CONFIGS["C1"]), 64, 64, 1, 1, "full"),
+    "mid": (dict(descriptor_dim=128, num_stages=3, num_heads=4, num_iters=20, side_info_size=6), 300, 257, 2, 2, "full"),
+    "flags": (dict(descriptor_dim=64, num_stages=2, num_heads=2, num_iters=10, side_info_size=3,
+                   residual=False, use_offset=True, reg=0.5, dustbin_score_init=0.3), 96, 130, 2, 3, "full"),
+    "nodesc": (dict(descriptor_dim=64, num_stages=1, num_heads=4, num_iters=5, side_info_size=1,
+                    no_descriptors=True), 70, 33, 1, 4, "full"),
+    "c2": (dict(syn.CONFIGS["C2"]), 1024, 1024, 2, 5, "sub8"),
+}
+
+
+def brute_force_matches(scores: torch.Tensor, thr: float):
+    """Per-row loops: first maximal index wins (torch.max CPU semantics), mutual check, exp, threshold."""
+    s = scores[:, :-1, :-1].numpy()
+    B, m, n = s.shape
+    matches0 = np.full((B, m), -1, np.int64)
+    ms0 = np.zeros((B, m), np.float32)
+    for b in range(B):
+        col_best = [int(np.argmax(s[b, :, j])) for j in range(n)]     # np.argmax: first max
+        for i in range(m):
+            j = int(np.argmax(s[b, i, :]))
+            if col_best[j] == i:
+                ms0[b, i] = np.exp(np.float32(s[b, i, j]))
+                if ms0[b, i] > thr:
+                    matches0[b, i] = j
+    return matches0, ms0
+
+
+def full_case(name, kw, m, n, batch, seed, store):
+    kw = {k: v for k, v in kw.items() if k not in ("kpts", "batch")}
+    cfg = syn.make_config(**kw)
+    sd = syn.make_state_dict(cfg, seed=0)
+    ref = RefSuperGlue(cfg)
+    ref.load_state_dict(sd, strict=True)      # also proves the state-dict names/shapes of synthetic.py
+    ref.eval()
+    data = syn.make_batch(batch, m, n, cfg["descriptor_dim"], cfg["positional_encoding"]["side_info_size"], seed=seed)
+    with torch.no_grad():
+        out = ref(data)
+        # encoder alone (positional_encoding.py:16-19) on image 0, channel-first [B, D, m]
+        k0n = RefSuperGlue.normalize_keypoints(data["keypoints0"], (syn.IMAGE_WH[1], syn.IMAGE_WH[0]))
+        enc0 = ref.positional_encoding(k0n, data["side_info0"])
+    scores = out["scores"]
+    matches0, ms0 = brute_force_matches(scores, MATCH_THRESHOLD)
+    arrays = {
+        "config_kwargs": np.array(repr(kw)),
+        "m": m, "n": n, "batch": batch, "seed": seed,
+        "matches0": matches0, "matching_scores0": ms0,
+        "row_sums64": scores.double().sum(2).numpy(), "col_sums64": scores.double().sum(1).numpy(),
+        "encoder0": enc0.numpy(),
+    }
+    if store == "full":
+        arrays["scores"] = scores.numpy()
+        arrays["context_descriptors0"] = out["context_descriptors0"].numpy()
+        arrays["context_descriptors1"] = out["context_descriptors1"].numpy()
+    else:  # strided subsample + the dustbin row/col in full
+        arrays["scores_sub8"] = scores[:, ::8, ::8].numpy()
+        arrays["scores_lastrow"] = scores[:, -1, :].numpy()
+        arrays["scores_lastcol"] = scores[:, :, -1].numpy()
+        arrays["context_descriptors0_sub"] = out["context_descriptors0"][:, ::4, ::16].numpy()
+        arrays["context_descriptors1_sub"] = out["context_descriptors1"][:, ::4, ::16].numpy()
+    if name == "c1":  # inputs and weights in full, so this case does not depend on torch's RNG stream
+        for k, v in data.items():
+            if torch.is_tensor(v):
+                arrays["in_" + k] = v.numpy()
+        for k, v in sd.items():
+            arrays["sd_" + k] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **arrays)
+    nvalid = int((matches0 >= 0).sum())
+    print(f"{name}: scores {tuple(scores.shape)} absmax {scores.abs().max():.3f} valid matches {nvalid}/{matches0.size}")
+
+
+def stage_cases():
+    g = torch.Generator().manual_seed(1234)
+    # log_otp_solver alone (optimal_transport.py:4-28), non-square, reg != 1
+    B, m, n = 3, 37, 53
+    Mx = 4.0 * torch.randn(B, m + 1, n + 1, generator=g)
+    norm = -math.log(m + n)
+    la = torch.full((B, m + 1), norm); la[:, -1] += math.log(n)
+    lb = torch.full((B, n + 1), norm); lb[:, -1] += math.log(m)
+    outs = {}
+    for iters, reg in ((1, 1.0), (7, 1.0), (25, 0.7)):
+        outs[f"sinkhorn_i{iters}_r{reg}"] = log_otp_solver(la, lb, Mx, num_iters=iters, reg=reg).numpy()
+    np.savez_compressed(os.path.join(HERE, "stage_sinkhorn.npz"), M=Mx.numpy(), log_a=la.numpy(), log_b=lb.numpy(), **outs)
+    # softmax_attention alone (attention.py:8-19), [B, H, d, N] layout, N_q != N_kv
+    q = 2.0 * torch.randn(2, 4, 16, 50, generator=g)
+    k = 2.0 * torch.randn(2, 4, 16, 70, generator=g)
+    v = torch.randn(2, 4, 16, 70, generator=g)
+    o, att = softmax_attention(q, k, v)
+    np.savez_compressed(os.path.join(HERE, "stage_attention.npz"), q=q.numpy(), k=k.numpy(), v=v.numpy(),
+                        out=o.numpy(), att_rowsum=att.sum(-1).numpy())
+    print("stage fixtures written")
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    for name, (kw, m, n, batch, seed, store) in CASES.items():
+        full_case(name, kw, m, n, batch, seed, store)
+    stage_cases()
+    print("torch", torch.__version__)

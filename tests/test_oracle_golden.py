@@ -1,0 +1,99 @@
+"""CPU: the oracle (oracle/superglue_oracle.py) against the fixtures generated from the reference
+itself (tests/golden/make_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import superglue_oracle as orc
+from tests.util import MATCH_THRESHOLD, load_case, GOLDEN
+import os
+
+# fp32 noise floor of the reference vs itself / vs float64 is 3e-6 .. 9e-5
+TOL_SCORES = 2e-4
+TOL_DESC = 2e-5
+
+
+@pytest.mark.parametrize("name", ["c1", "mid", "flags", "nodesc"])
+def test_forward_matches_reference_fixture(name):
+    z, cfg, sd, data = load_case(name)
+    with torch.no_grad():
+        out = orc.superglue_forward(sd, cfg, data)
+    assert np.abs(out["scores"].numpy() - z["scores"]).max() < TOL_SCORES
+    for k in ("context_descriptors0", "context_descriptors1"):
+        assert out[k].shape == z[k].shape            # channel-first [B, D, n]
+        assert np.abs(out[k].numpy() - z[k]).max() < TOL_DESC
+    m = orc.extract_matches(out["scores"], MATCH_THRESHOLD)
+    np.testing.assert_array_equal(m["matches0"].numpy(), z["matches0"])
+    np.testing.assert_allclose(m["matching_scores0"].numpy(), z["matching_scores0"], atol=1e-4)
+
+
+def test_c2_shape_matches_reference_fixture():
+    z, cfg, sd, data = load_case("c2")
+    with torch.no_grad():
+        out = orc.superglue_forward(sd, cfg, data)
+    s = out["scores"]
+    assert np.abs(s[:, ::8, ::8].numpy() - z["scores_sub8"]).max() < TOL_SCORES
+    assert np.abs(s[:, -1, :].numpy() - z["scores_lastrow"]).max() < TOL_SCORES
+    assert np.abs(s[:, :, -1].numpy() - z["scores_lastcol"]).max() < TOL_SCORES
+    assert np.abs(s.double().sum(2).numpy() - z["row_sums64"]).max() < 1025 * TOL_SCORES
+    m = orc.extract_matches(s, MATCH_THRESHOLD)
+    np.testing.assert_array_equal(m["matches0"].numpy(), z["matches0"])
+
+
+def test_extract_matches_on_reference_scores():
+    """The vectorised restatement of matching_module.py:174-187 against the brute-force loop result
+    stored in the fixture, on the REFERENCE's own scores (ties, dustbin-dominated rows included)."""
+    for name in ("c1", "mid", "flags", "nodesc"):
+        z, *_ = load_case(name)
+        m = orc.extract_matches(torch.from_numpy(z["scores"]), MATCH_THRESHOLD)
+        np.testing.assert_array_equal(m["matches0"].numpy(), z["matches0"])
+        np.testing.assert_allclose(m["matching_scores0"].numpy(), z["matching_scores0"], rtol=1e-6)  # np.exp vs torch.exp: 1 ulp
+        # inference.py:176-190 extras: matches1 is the inverse map of matches0 on valid entries
+        m0, m1 = m["matches0"], m["matches1"]
+        for b in range(m0.shape[0]):
+            for i in torch.nonzero(m0[b] >= 0).flatten().tolist():
+                assert m1[b, m0[b, i]] == i
+            assert int((m1[b] >= 0).sum()) == int((m0[b] >= 0).sum())
+
+
+def test_extract_matches_first_max_wins():
+    s = torch.full((1, 4, 5), -5.0)
+    s[0, 0, 1] = s[0, 0, 2] = 0.0           # tie in row 0 -> column 1
+    s[0, 1, 1] = s[0, 2, 1] = -1.0          # column 1: rows 1,2 tie below row 0
+    m = orc.extract_matches(s, 0.2)
+    assert m["_row_argmax"][0, 0] == 1 and m["matches0"][0, 0] == 1
+    assert m["matches0"][0, 1] == -1 and m["matching_scores0"][0, 1] == 0
+
+
+def test_sinkhorn_stage_fixture():
+    z = np.load(os.path.join(GOLDEN, "stage_sinkhorn.npz"))
+    Mx, la, lb = (torch.from_numpy(z[k]) for k in ("M", "log_a", "log_b"))
+    for key in z.files:
+        if not key.startswith("sinkhorn_"):
+            continue
+        iters, reg = key.split("_")[1:]
+        got = orc.log_sinkhorn(la, lb, Mx, int(iters[1:]), float(reg[1:]))
+        assert np.abs(got.numpy() - z[key]).max() < 1e-5
+    # after the last v update the column marginals are exact
+    P = orc.log_sinkhorn(la, lb, Mx, 7, 1.0)
+    np.testing.assert_allclose(torch.logsumexp(P, 1).numpy(), lb.numpy(), atol=1e-5)
+
+
+def test_attention_stage_fixture():
+    z = np.load(os.path.join(GOLDEN, "stage_attention.npz"))
+    q, k, v = (torch.from_numpy(z[n]) for n in "qkv")          # reference layout [B, H, d, N]
+    B, H, d, nq = q.shape
+    tok = lambda t: t.permute(0, 3, 1, 2).reshape(B, t.shape[3], H * d)   # -> token-major, head-contiguous channels
+    o = orc.softmax_attention(tok(q), tok(k), tok(v), H)
+    ref = torch.from_numpy(z["out"]).permute(0, 3, 1, 2).reshape(B, nq, H * d)
+    assert (o - ref).abs().max() < 1e-5
+
+
+def test_float64_truth_and_f16_attention_budget():
+    """Noise floor: fp32 oracle vs fp64 oracle; and the error budget of f16 attention operands
+    (hi/lo split Q,K,V as the HIP kernel does is ~fp32; P rounded to f16 only)."""
+    z, cfg, sd, data = load_case("c1")
+    with torch.no_grad():
+        s32 = orc.superglue_forward(sd, cfg, data)["scores"]
+        s64 = orc.superglue_forward(sd, cfg, data, dtype=torch.float64)["scores"]
+    assert (s32.double() - s64).abs().max() < 2e-4
