@@ -1,0 +1,191 @@
+/*
+ * openglue_amd.h -- C ABI of the MI355X (gfx950) SuperGlue hot path.
+ *
+ * Drop-in boundary for ucuapps/OpenGlue's keypoint-graph matcher.  The reference has no FFI or
+ * operator registry: its plugin point is the Python class
+ *     models/superglue/superglue.py:11   class SuperGlue(nn.Module)
+ *     models/superglue/superglue.py:29   def forward(self, data) -> dict
+ * constructed at models/matching_module.py:44 and inference.py:74, and the match extraction that
+ * consumes its `scores` at models/matching_module.py:174-187 / inference.py:176-190.
+ * openglue_amd/superglue.py keeps that Python signature and calls the functions below through
+ * ctypes; any other host (C, C++, a cgo/JNI stub) can bind the same symbols.
+ *
+ * Conventions
+ *   - plain C types only; no torch / HIP types in signatures (the stream is passed as void*,
+ *     i.e. a hipStream_t; NULL = the default stream).
+ *   - the library never allocates or frees device memory and keeps no global state: inputs,
+ *     packed weights, workspace and outputs are caller-owned device buffers (fp32 unless noted).
+ *   - every function only ENQUEUES work on `stream` (no internal synchronisation), so it composes
+ *     with the caller's stream/allocator semantics and can be captured into a hipGraph.
+ *   - return value: 0 = success; negative = OG_E_* invalid argument; positive = hipError_t of a
+ *     failed launch.  Nothing throws across the ABI.
+ *   - layouts are token-major: a set of n keypoints with C channels is an [n][C] row-major matrix.
+ */
+#ifndef OPENGLUE_AMD_H
+#define OPENGLUE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OG_ABI_VERSION 1
+
+#define OG_E_INVALID   (-1)  /* NULL pointer / non-positive size                         */
+#define OG_E_SHAPE     (-2)  /* unsupported shape (see og_check_shape)                   */
+#define OG_E_ALIGN     (-3)  /* a device pointer is not 16-byte aligned                  */
+#define OG_E_FLAG      (-4)  /* unknown flag bits                                        */
+
+/* config flags (reference keys: superglue.py:18-19 `residual`, `no_descriptors`;
+ * attention_gnn.py:51-52 `use_offset`) */
+#define OG_FLAG_RESIDUAL        1
+#define OG_FLAG_USE_OFFSET      2
+#define OG_FLAG_NO_DESCRIPTORS  4
+
+#define OG_MAX_HIDDEN 8
+
+/* Everything SuperGlue.__init__ reads from its config (superglue.py:16-27, 64, 108-109) plus the
+ * batch geometry of one call.  Within one call every pair has m keypoints in image 0 and n in
+ * image 1 (m != n allowed), as the reference requires. */
+typedef struct og_shape {
+    int32_t batch;                  /* B image pairs                                             */
+    int32_t m, n;                   /* keypoints per image 0 / image 1                           */
+    int32_t desc_dim;               /* D = descriptor_dim = attention_gnn.embed_dim (mult. of 64) */
+    int32_t num_heads;              /* H; head h owns channels h*D/H .. (h+1)*D/H-1 (attention_gnn.py:24-26); D/H in {16,32,64} */
+    int32_t num_stages;             /* L self+cross stages (attention_gnn.py:84-89)              */
+    int32_t side_info;              /* s = positional_encoding.side_info_size (2+s <= 32)        */
+    int32_t num_hidden;             /* len(positional_encoding.hidden_layers_sizes) <= OG_MAX_HIDDEN */
+    int32_t hidden[OG_MAX_HIDDEN];  /* e.g. 32, 64, 128 (config/config.yaml:45)                  */
+    int32_t sinkhorn_iters;         /* otp.num_iters                                             */
+    float   sinkhorn_reg;           /* otp.reg                                                   */
+    int32_t flags;                  /* OG_FLAG_*                                                 */
+    float   match_threshold;        /* inference.match_threshold (config/config.yaml:40)         */
+} og_shape;
+
+/* ---- host-side parameter views (fp32, HOST memory), names as in the reference state-dict ---- */
+typedef struct og_conv {            /* nn.Conv1d(kernel_size=1): weight [out][in] row-major, bias [out] */
+    const float* weight;
+    const float* bias;
+} og_conv;
+
+typedef struct og_bn {              /* nn.BatchNorm1d, eval mode (running statistics), eps = 1e-5 */
+    const float* weight;
+    const float* bias;
+    const float* running_mean;
+    const float* running_var;
+} og_bn;
+
+typedef struct og_layer_params {    /* attention_gnn.layers.{l}.module.*  (attention_gnn.py:35-41, 9-20) */
+    og_conv in_proj_q, in_proj_k, in_proj_v, out_proj;   /* mha.*  [D][D]          */
+    og_conv fc0;                                         /* fc.0   [2D][2D]        */
+    og_bn   fc_bn;                                       /* fc.2   BatchNorm1d(2D) */
+    og_conv fc3;                                         /* fc.3   [D][2D]         */
+} og_layer_params;
+
+typedef struct og_params {
+    og_conv enc_conv[OG_MAX_HIDDEN + 1];  /* positional_encoding.encoder.{0,3,6,..}            */
+    og_bn   enc_bn[OG_MAX_HIDDEN];        /* positional_encoding.encoder.{2,5,8,..}            */
+    const og_layer_params* layers;        /* 2*L entries: even = self, odd = cross             */
+    og_conv linear_proj;                  /* linear_proj [D][D]                  (superglue.py:22) */
+    const float* mix_coefs;               /* [D] (state-dict [D,1]); may be NULL without OG_FLAG_RESIDUAL (superglue.py:21) */
+    float dustbin_score;                  /* dustbin_score                       (superglue.py:23) */
+} og_params;
+
+/* ---- device-side call arguments ---- */
+typedef struct og_inputs {
+    const float* keypoints0;          /* [B][m][2] pixel xy                   data['keypoints0']         */
+    const float* keypoints1;          /* [B][n][2]                                                       */
+    const float* descriptors0;        /* [B][m][D]                            data['local_descriptors0'] */
+    const float* descriptors1;        /* [B][n][D]                                                       */
+    const float* side_info0;          /* [B][m][s]                            data['side_info0']         */
+    const float* side_info1;          /* [B][n][s]                                                       */
+    float image0_wh[2];               /* (W, H) of image 0   (superglue.py:35-38, 74-78)                 */
+    float image1_wh[2];
+} og_inputs;
+
+typedef struct og_outputs {
+    float*   scores;                  /* [B][m+1][n+1] log-assignment incl. dustbins   'scores'          */
+    float*   context_descriptors0;    /* [B][D][m] channel-first, as the reference returns them; may be NULL */
+    float*   context_descriptors1;    /* [B][D][n]; may be NULL                                          */
+    int64_t* matches0;                /* [B][m]  index into image 1 or -1 (matching_module.py:181); may be NULL */
+    float*   matching_scores0;        /* [B][m]  exp(max) if mutual else 0;  NULL iff matches0 is NULL   */
+    int64_t* matches1;                /* [B][n]  inference.py:188; may be NULL                           */
+    float*   matching_scores1;        /* [B][n]; NULL iff matches1 is NULL                               */
+} og_outputs;
+
+int og_abi_version(void);
+
+/* 0 if the shape is supported by this build, else OG_E_SHAPE / OG_E_FLAG. */
+int og_check_shape(const og_shape* shape);
+
+/* Size in bytes of the packed-weight blob / of the per-call workspace for `shape` (0 on error).
+ * The packed size does not depend on batch, m, n. */
+size_t og_packed_weights_bytes(const og_shape* shape);
+size_t og_workspace_bytes(const og_shape* shape);
+
+/* Host-side, one-off (re-run when parameters change): fold eval-mode BatchNorm into the following
+ * conv (the reference order is Conv -> ReLU -> BN, models/utils.py:52-56), fold out_proj into fc.0,
+ * concatenate and pre-scale the q/k/v projections, zero-pad the encoder MLP to MFMA tile sizes.
+ * `packed_host` (og_packed_weights_bytes bytes, host memory) is then copied to the device by the
+ * caller.  Arithmetic in double precision. */
+int og_pack_weights(const og_shape* shape, const og_params* params, void* packed_host);
+
+/* Introspection of the packed blob (offsets in floats).  All matrices are [out][in] row-major fp32.
+ *   enc_w[i] [enc_out[i]][enc_k[i]], enc_b[i] [enc_out[i]]   keypoint-encoder conv i, zero-padded (k: 32 | out: mult. of 64),
+ *                                                            BatchNorm i-1 folded in
+ *   layer l at layer0 + l*layer_stride:  wqkv [3D][D] (q rows pre-scaled by (D/H)^-1/2), bqkv [3D],
+ *                                        w0 [2D][2D] = [W0a | Wm*Wo], b0 [2D], w3 [D][2D] (BN folded), b3 [D]
+ *   wp [D][D], bp [D], alpha [D] = sigmoid(mix_coefs), dustbin [1] */
+typedef struct og_packed_layout_t {
+    int32_t n_enc;
+    int32_t enc_k[OG_MAX_HIDDEN + 1], enc_out[OG_MAX_HIDDEN + 1];
+    int64_t enc_w[OG_MAX_HIDDEN + 1], enc_b[OG_MAX_HIDDEN + 1];
+    int64_t layer0, layer_stride, o_wqkv, o_bqkv, o_w0, o_b0, o_w3, o_b3;
+    int64_t wp, bp, alpha, dustbin, total;
+} og_packed_layout_t;
+int og_packed_layout(const og_shape* shape, og_packed_layout_t* layout);
+
+/* The whole hot path: keypoint encoder -> L x (self, cross) attention -> final projection ->
+ * score matrix -> log-domain Sinkhorn with dustbins -> scores (+ optional mutual-NN matches).
+ * Replaces SuperGlue.forward (superglue.py:29-72) and, when outputs->matches0 != NULL, the match
+ * extraction of matching_module.py:174-187 / inference.py:176-190. */
+int og_forward(const og_shape* shape, const og_inputs* in, const void* packed_dev,
+               void* workspace_dev, const og_outputs* out, void* stream);
+
+/* ---- per-stage entry points (unit parity tests; also usable on their own) ---- */
+
+/* C[z] = epilogue(A[z] * B[z]^T): A [M][K] (lda), B [N][K] (ldb), exact fp32 MFMA.
+ * v = acc + bias[col]; relu; if res: alpha ? alpha[col]*v + (1-alpha[col])*res : v + res; v *= scale. */
+int og_gemm_nt(const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb, int64_t strideB,
+               float* C, int64_t ldc, int64_t strideC, int32_t M, int32_t N, int32_t K, int32_t batch,
+               const float* bias, int32_t relu, const float* res, int64_t ldr, const float* alpha,
+               float scale, void* stream);
+
+/* softmax attention (attention.py:8-19) for `batch` independent problems and H heads.
+ * q [batch][nq][ldq] (columns h*dh.. of row i = head h, PRE-SCALED by dh^-0.5), k, v [batch][nk][ld*],
+ * out [batch][nq][ldo].  dh in {16,32,64}. */
+int og_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                 float* out, int64_t ldo, int32_t batch, int32_t nq, int32_t nk, int32_t num_heads,
+                 int32_t dh, void* stream);
+
+/* log-domain Sinkhorn with implicit dustbins (superglue.py:88-111 + optimal_transport.py:20-28):
+ * S [B][m][lds] (lds % 4 == 0) is the raw score matrix, `dustbin` the learnt bin score; writes
+ * scores [B][m+1][n+1] = S_aug/reg + u + v - norm.  workspace: og_sinkhorn_workspace_bytes. */
+size_t og_sinkhorn_workspace_bytes(int32_t batch, int32_t m, int32_t n);
+int og_sinkhorn(const float* S, int64_t lds, float dustbin, int32_t batch, int32_t m, int32_t n,
+                int32_t iters, float reg, float* scores, void* workspace_dev, void* stream);
+
+/* mutual-NN match extraction from a scores tensor [B][m+1][n+1] (matching_module.py:174-187;
+ * matches1/matching_scores1 as inference.py:183-188, may be NULL).  First maximal index wins.
+ * workspace: og_matches_workspace_bytes. */
+size_t og_matches_workspace_bytes(int32_t batch, int32_t m, int32_t n);
+int og_extract_matches(const float* scores, int32_t batch, int32_t m, int32_t n, float match_threshold,
+                       int64_t* matches0, float* matching_scores0, int64_t* matches1,
+                       float* matching_scores1, void* workspace_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPENGLUE_AMD_H */

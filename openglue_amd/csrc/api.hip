@@ -1,0 +1,371 @@
+// C-ABI entry points: shape checks, host-side weight packing, workspace layout and the launch
+// sequence of the whole hot path (og_forward).  See include/openglue_amd.h for the contract.
+#include <math.h>
+#include <string.h>
+#include <vector>
+
+#include "og_common.h"
+
+namespace {
+
+constexpr double BN_EPS = 1e-5;   // nn.BatchNorm1d default (reference models/utils.py:55)
+
+struct PackedLayout {
+    int n_enc;                                  // conv layers of the keypoint encoder
+    int enc_k[OG_MAX_HIDDEN + 1];               // padded input width of layer i
+    int enc_out[OG_MAX_HIDDEN + 1];             // padded output width of layer i
+    int64_t enc_w[OG_MAX_HIDDEN + 1], enc_b[OG_MAX_HIDDEN + 1];
+    int64_t layer0, layer_stride;               // per GNN layer block
+    int64_t o_wqkv, o_bqkv, o_w0, o_b0, o_w3, o_b3;   // offsets inside a layer block
+    int64_t wp, bp, alpha, dustbin;
+    int64_t total;                              // floats
+    int enc_maxw;                               // widest padded hidden activation
+};
+
+inline int64_t al64(int64_t x) { return og_round_up(x, 64); }   // 256-byte aligned sections
+
+PackedLayout packed_layout(const og_shape& s) {
+    PackedLayout L{};
+    const int64_t D = s.desc_dim;
+    L.n_enc = s.num_hidden + 1;
+    int64_t off = 0;
+    int k = 32;
+    L.enc_maxw = 0;
+    for (int i = 0; i < L.n_enc; ++i) {
+        const int out = i < s.num_hidden ? (int)og_round_up(s.hidden[i], 64) : (int)D;
+        L.enc_k[i] = k; L.enc_out[i] = out;
+        L.enc_w[i] = off; off = al64(off + (int64_t)out * k);
+        L.enc_b[i] = off; off = al64(off + out);
+        if (i < s.num_hidden && out > L.enc_maxw) L.enc_maxw = out;
+        k = out;
+    }
+    int64_t lo = 0;
+    L.o_wqkv = lo; lo = al64(lo + 3 * D * D);
+    L.o_bqkv = lo; lo = al64(lo + 3 * D);
+    L.o_w0 = lo; lo = al64(lo + 4 * D * D);
+    L.o_b0 = lo; lo = al64(lo + 2 * D);
+    L.o_w3 = lo; lo = al64(lo + 2 * D * D);
+    L.o_b3 = lo; lo = al64(lo + D);
+    L.layer_stride = lo;
+    L.layer0 = off; off += lo * 2 * s.num_stages;
+    L.wp = off; off = al64(off + D * D);
+    L.bp = off; off = al64(off + D);
+    L.alpha = off; off = al64(off + D);
+    L.dustbin = off; off = al64(off + 1);
+    L.total = off;
+    return L;
+}
+
+struct WorkspaceLayout {
+    int64_t xo, qkv, hbuf, g, sbuf, sink, match, total;   // float offsets (match/sink: 16-byte aligned)
+    int64_t lds;
+};
+
+WorkspaceLayout workspace_layout(const og_shape& s) {
+    WorkspaceLayout W{};
+    const int64_t D = s.desc_dim, T = (int64_t)s.batch * ((int64_t)s.m + s.n);
+    W.lds = og_round_up(s.n, 4);
+    int64_t off = 0;
+    W.xo = off; off = al64(off + T * 2 * D);
+    W.qkv = off; off = al64(off + T * 3 * D);
+    W.hbuf = off; off = al64(off + T * 2 * D);
+    W.g = off; off = al64(off + T * D);
+    W.sbuf = off; off = al64(off + (int64_t)s.batch * s.m * W.lds);
+    W.sink = off; off = al64(off + (int64_t)(og_sinkhorn_workspace_bytes(s.batch, s.m, s.n) + 3) / 4);
+    W.match = off; off = al64(off + (int64_t)(og_matches_workspace_bytes(s.batch, s.m, s.n) + 3) / 4);
+    W.total = off;
+    return W;
+}
+
+int check_shape(const og_shape* s) {
+    if (!s) return OG_E_INVALID;
+    if (s->batch <= 0 || s->m <= 0 || s->n <= 0) return OG_E_SHAPE;
+    if (s->desc_dim <= 0 || s->desc_dim % 64) return OG_E_SHAPE;
+    if (s->num_heads <= 0 || s->desc_dim % s->num_heads) return OG_E_SHAPE;
+    const int dh = s->desc_dim / s->num_heads;
+    if (dh != 16 && dh != 32 && dh != 64) return OG_E_SHAPE;
+    if (s->num_stages < 0) return OG_E_SHAPE;
+    if (s->side_info < 0 || 2 + s->side_info > 32) return OG_E_SHAPE;
+    if (s->num_hidden < 0 || s->num_hidden > OG_MAX_HIDDEN) return OG_E_SHAPE;
+    for (int i = 0; i < s->num_hidden; ++i)
+        if (s->hidden[i] <= 0 || og_round_up(s->hidden[i], 64) > 2 * s->desc_dim) return OG_E_SHAPE;
+    if (s->n > 4096) return OG_E_SHAPE;                 // Sinkhorn register tile (sinkhorn.hip)
+    if (s->sinkhorn_iters < 0 || !(s->sinkhorn_reg > 0.f)) return OG_E_SHAPE;
+    if (s->flags & ~(OG_FLAG_RESIDUAL | OG_FLAG_USE_OFFSET | OG_FLAG_NO_DESCRIPTORS)) return OG_E_FLAG;
+    return 0;
+}
+
+// BatchNorm (eval) as y*g + c
+void bn_affine(const og_bn& bn, int C, std::vector<double>& g, std::vector<double>& c) {
+    g.resize(C); c.resize(C);
+    for (int i = 0; i < C; ++i) {
+        g[i] = (double)bn.weight[i] / sqrt((double)bn.running_var[i] + BN_EPS);
+        c[i] = (double)bn.bias[i] - (double)bn.running_mean[i] * g[i];
+    }
+}
+
+}  // namespace
+
+extern "C" int og_abi_version(void) { return OG_ABI_VERSION; }
+
+extern "C" int og_check_shape(const og_shape* shape) { return check_shape(shape); }
+
+extern "C" size_t og_packed_weights_bytes(const og_shape* shape) {
+    if (!shape) return 0;
+    og_shape s = *shape; s.batch = s.m = s.n = 1;
+    if (check_shape(&s)) return 0;
+    return (size_t)packed_layout(*shape).total * sizeof(float);
+}
+
+extern "C" int og_packed_layout(const og_shape* shape, og_packed_layout_t* o) {
+    if (!shape || !o) return OG_E_INVALID;
+    og_shape s = *shape; s.batch = s.m = s.n = 1;
+    if (int e = check_shape(&s)) return e;
+    const PackedLayout L = packed_layout(*shape);
+    memset(o, 0, sizeof(*o));
+    o->n_enc = L.n_enc;
+    for (int i = 0; i < L.n_enc; ++i) { o->enc_k[i] = L.enc_k[i]; o->enc_out[i] = L.enc_out[i]; o->enc_w[i] = L.enc_w[i]; o->enc_b[i] = L.enc_b[i]; }
+    o->layer0 = L.layer0; o->layer_stride = L.layer_stride;
+    o->o_wqkv = L.o_wqkv; o->o_bqkv = L.o_bqkv; o->o_w0 = L.o_w0; o->o_b0 = L.o_b0; o->o_w3 = L.o_w3; o->o_b3 = L.o_b3;
+    o->wp = L.wp; o->bp = L.bp; o->alpha = L.alpha; o->dustbin = L.dustbin; o->total = L.total;
+    return 0;
+}
+
+extern "C" size_t og_workspace_bytes(const og_shape* shape) {
+    if (check_shape(shape)) return 0;
+    return (size_t)workspace_layout(*shape).total * sizeof(float);
+}
+
+extern "C" int og_pack_weights(const og_shape* shape, const og_params* P, void* packed_host) {
+    if (!shape || !P || !packed_host) return OG_E_INVALID;
+    og_shape chk = *shape; chk.batch = chk.m = chk.n = 1;
+    if (int e = check_shape(&chk)) return e;
+    const og_shape& s = *shape;
+    const PackedLayout L = packed_layout(s);
+    const int D = s.desc_dim, D2 = 2 * D;
+    float* out = (float*)packed_host;
+    memset(out, 0, (size_t)L.total * sizeof(float));
+
+    // ---- keypoint encoder: [Conv, ReLU, BN]*h + Conv; BN_i folds into Conv_{i+1} ----
+    {
+        std::vector<double> g, c;
+        int in_real = 2 + s.side_info;
+        for (int i = 0; i < L.n_enc; ++i) {
+            const int out_real = i < s.num_hidden ? s.hidden[i] : D;
+            const og_conv& cv = P->enc_conv[i];
+            if (!cv.weight || !cv.bias) return OG_E_INVALID;
+            float* W = out + L.enc_w[i];
+            float* b = out + L.enc_b[i];
+            for (int o = 0; o < out_real; ++o) {
+                double bb = cv.bias[o];
+                for (int k = 0; k < in_real; ++k) {
+                    const double w = cv.weight[(int64_t)o * in_real + k];
+                    if (i == 0) W[(int64_t)o * L.enc_k[i] + k] = (float)w;
+                    else { W[(int64_t)o * L.enc_k[i] + k] = (float)(w * g[k]); bb += w * c[k]; }
+                }
+                b[o] = (float)bb;
+            }
+            if (i < s.num_hidden) {
+                const og_bn& bn = P->enc_bn[i];
+                if (!bn.weight || !bn.bias || !bn.running_mean || !bn.running_var) return OG_E_INVALID;
+                bn_affine(bn, out_real, g, c);
+            }
+            in_real = out_real;
+        }
+    }
+
+    // ---- GNN layers ----
+    const int dh = D / s.num_heads;
+    const double qscale = 1.0 / sqrt((double)dh);          // attention.py:12 `* embed_dim ** -0.5`
+    const bool offset = s.flags & OG_FLAG_USE_OFFSET;
+    std::vector<double> Wm((size_t)D2 * D), prod((size_t)D2 * D), g, c;
+    for (int l = 0; l < 2 * s.num_stages; ++l) {
+        if (!P->layers) return OG_E_INVALID;
+        const og_layer_params& lp = P->layers[l];
+        float* base = out + L.layer0 + (int64_t)l * L.layer_stride;
+        float* Wqkv = base + L.o_wqkv; float* bqkv = base + L.o_bqkv;
+        const og_conv* proj[3] = {&lp.in_proj_q, &lp.in_proj_k, &lp.in_proj_v};
+        for (int p = 0; p < 3; ++p) {
+            if (!proj[p]->weight || !proj[p]->bias) return OG_E_INVALID;
+            const double sc = p == 0 ? qscale : 1.0;
+            for (int64_t i = 0; i < (int64_t)D * D; ++i) Wqkv[(int64_t)p * D * D + i] = (float)(proj[p]->weight[i] * sc);
+            for (int i = 0; i < D; ++i) bqkv[p * D + i] = (float)(proj[p]->bias[i] * sc);
+        }
+        // fc.0 on y = [x ; msg] (or [x - msg ; msg] with use_offset, attention_gnn.py:51-54), msg = Wo O + bo:
+        //   W0 y = W0a x + Wm (Wo O + bo),  Wm = W0b (- W0a)   ->  [W0a | Wm Wo] [x ; O] + (b0 + Wm bo)
+        if (!lp.fc0.weight || !lp.fc0.bias || !lp.out_proj.weight || !lp.out_proj.bias || !lp.fc3.weight || !lp.fc3.bias)
+            return OG_E_INVALID;
+        float* W0 = base + L.o_w0; float* b0 = base + L.o_b0;
+        for (int o = 0; o < D2; ++o)
+            for (int k = 0; k < D; ++k) {
+                const double wa = lp.fc0.weight[(int64_t)o * D2 + k], wb = lp.fc0.weight[(int64_t)o * D2 + D + k];
+                W0[(int64_t)o * D2 + k] = (float)wa;
+                Wm[(size_t)o * D + k] = offset ? wb - wa : wb;
+            }
+        std::fill(prod.begin(), prod.end(), 0.0);
+        for (int o = 0; o < D2; ++o) {
+            double* pr = &prod[(size_t)o * D];
+            double bb = lp.fc0.bias[o];
+            for (int k = 0; k < D; ++k) {
+                const double w = Wm[(size_t)o * D + k];
+                const float* wo = lp.out_proj.weight + (int64_t)k * D;
+                for (int j = 0; j < D; ++j) pr[j] += w * (double)wo[j];
+                bb += w * (double)lp.out_proj.bias[k];
+            }
+            for (int j = 0; j < D; ++j) W0[(int64_t)o * D2 + D + j] = (float)pr[j];
+            b0[o] = (float)bb;
+        }
+        // fc.3 with BN(2D) folded in
+        if (!lp.fc_bn.weight || !lp.fc_bn.bias || !lp.fc_bn.running_mean || !lp.fc_bn.running_var) return OG_E_INVALID;
+        bn_affine(lp.fc_bn, D2, g, c);
+        float* W3 = base + L.o_w3; float* b3 = base + L.o_b3;
+        for (int o = 0; o < D; ++o) {
+            double bb = lp.fc3.bias[o];
+            for (int k = 0; k < D2; ++k) {
+                const double w = lp.fc3.weight[(int64_t)o * D2 + k];
+                W3[(int64_t)o * D2 + k] = (float)(w * g[k]);
+                bb += w * c[k];
+            }
+            b3[o] = (float)bb;
+        }
+    }
+
+    // ---- tail ----
+    if (!P->linear_proj.weight || !P->linear_proj.bias) return OG_E_INVALID;
+    memcpy(out + L.wp, P->linear_proj.weight, sizeof(float) * (size_t)D * D);
+    memcpy(out + L.bp, P->linear_proj.bias, sizeof(float) * (size_t)D);
+    if (s.flags & OG_FLAG_RESIDUAL) {
+        if (!P->mix_coefs) return OG_E_INVALID;
+        for (int i = 0; i < D; ++i) out[L.alpha + i] = (float)(1.0 / (1.0 + exp(-(double)P->mix_coefs[i])));   // superglue.py:60
+    }
+    out[L.dustbin] = P->dustbin_score;
+    return 0;
+}
+
+extern "C" int og_forward(const og_shape* shape, const og_inputs* in, const void* packed_dev, void* workspace_dev,
+                          const og_outputs* outp, void* stream) {
+    if (!shape || !in || !packed_dev || !workspace_dev || !outp) return OG_E_INVALID;
+    if (int e = check_shape(shape)) return e;
+    const og_shape& s = *shape;
+    if (!in->keypoints0 || !in->keypoints1 || !in->descriptors0 || !in->descriptors1 || !outp->scores) return OG_E_INVALID;
+    if (s.side_info > 0 && (!in->side_info0 || !in->side_info1)) return OG_E_INVALID;
+    if ((outp->matches0 == nullptr) != (outp->matching_scores0 == nullptr)) return OG_E_INVALID;
+    if ((outp->matches1 == nullptr) != (outp->matching_scores1 == nullptr)) return OG_E_INVALID;
+    if (outp->matches1 && !outp->matches0) return OG_E_INVALID;
+    if (((uintptr_t)packed_dev & 15) || ((uintptr_t)workspace_dev & 15) || ((uintptr_t)in->descriptors0 & 15) ||
+        ((uintptr_t)in->descriptors1 & 15))
+        return OG_E_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    const PackedLayout L = packed_layout(s);
+    const WorkspaceLayout W = workspace_layout(s);
+    const float* pk = (const float*)packed_dev;
+    float* ws = (float*)workspace_dev;
+    const int D = s.desc_dim, D2 = 2 * D, D3 = 3 * D, B = s.batch, m = s.m, n = s.n;
+    const int64_t T0 = (int64_t)B * m, T1 = (int64_t)B * n, T = T0 + T1;
+    float* XO = ws + W.xo; float* QKV = ws + W.qkv; float* Hb = ws + W.hbuf; float* G = ws + W.g; float* Sb = ws + W.sbuf;
+    int rc;
+
+    auto gemm = [&](const float* A, int64_t lda, const float* Bm, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
+                    const float* bias, int relu, const float* res, int64_t ldr, const float* alpha, float scale) -> int {
+        GemmArgs g{};
+        g.A = A; g.lda = lda; g.strideA = 0; g.B = Bm; g.ldb = ldb; g.strideB = 0; g.C = C; g.ldc = ldc; g.strideC = 0;
+        g.M = (int)M; g.N = N; g.K = K; g.batch = 1; g.bias = bias; g.relu = relu; g.res = res; g.ldr = ldr; g.strideR = 0;
+        g.alpha = alpha; g.scale = scale; g.Ct = nullptr; g.ldct = 0; g.strideCt = 0; g.ct_rows = 1;
+        return og_launch_gemm(g, st);
+    };
+
+    // ---- 1. keypoint encoder (superglue.py:41-55): x = desc + MLP([k^, side]) -> XO[:, 0:D] ----
+    {
+        float* EI = G;                 // [T][32]   (aliases: all three are free until the GNN starts)
+        float* Ea = QKV;               // [T][enc_maxw]
+        float* Eb = Hb;                // [T][enc_maxw]
+        if ((rc = og_launch_encoder_input(in->keypoints0, in->side_info0, T0, s.side_info, in->image0_wh[0], in->image0_wh[1], EI, st))) return rc;
+        if ((rc = og_launch_encoder_input(in->keypoints1, in->side_info1, T1, s.side_info, in->image1_wh[0], in->image1_wh[1], EI + T0 * 32, st))) return rc;
+        const float* cur = EI; int64_t ldcur = 32;
+        for (int i = 0; i < L.n_enc; ++i) {
+            const float* Wi = pk + L.enc_w[i]; const float* bi = pk + L.enc_b[i];
+            if (i + 1 < L.n_enc) {
+                float* dst = (i & 1) ? Eb : Ea;
+                if ((rc = gemm(cur, ldcur, Wi, L.enc_k[i], dst, L.enc_maxw, T, L.enc_out[i], L.enc_k[i], bi, 1, nullptr, 0, nullptr, 1.f))) return rc;
+                cur = dst; ldcur = L.enc_maxw;
+            } else {
+                const bool nd = s.flags & OG_FLAG_NO_DESCRIPTORS;
+                if ((rc = gemm(cur, ldcur, Wi, L.enc_k[i], XO, D2, T0, D, L.enc_k[i], bi, 0, nd ? nullptr : in->descriptors0, D, nullptr, 1.f))) return rc;
+                if ((rc = gemm(cur + T0 * ldcur, ldcur, Wi, L.enc_k[i], XO + T0 * D2, D2, T1, D, L.enc_k[i], bi, 0,
+                               nd ? nullptr : in->descriptors1, D, nullptr, 1.f))) return rc;
+            }
+        }
+    }
+
+    // ---- 2. attentional GNN (attention_gnn.py:84-93) ----
+    const int dh = D / s.num_heads;
+    auto attention = [&](int nz, int split, int64_t qb0, int64_t qs0, int nq0, int64_t kb0, int64_t ks0, int nk0,
+                         int64_t qb1, int64_t qs1, int nq1, int64_t kb1, int64_t ks1, int nk1) -> int {
+        AttnArgs a{};
+        a.q = QKV; a.ldq = D3; a.k = QKV + D; a.ldk = D3; a.v = QKV + D2; a.ldv = D3; a.out = XO + D; a.ldo = D2;
+        a.nz = nz; a.num_heads = s.num_heads; a.dh = dh; a.split = split;
+        a.q_base[0] = qb0; a.q_step[0] = qs0; a.nq[0] = nq0; a.kv_base[0] = kb0; a.kv_step[0] = ks0; a.nk[0] = nk0;
+        a.q_base[1] = qb1; a.q_step[1] = qs1; a.nq[1] = nq1; a.kv_base[1] = kb1; a.kv_step[1] = ks1; a.nk[1] = nk1;
+        return og_launch_attention(a, st);
+    };
+    // message MLP on token rows [r0, r0+R):  h = relu([x;O] W0'^T + b0') ; x += h W3'^T + b3'
+    auto mlp = [&](const float* lw, int64_t r0, int64_t R) -> int {
+        int e = gemm(XO + r0 * D2, D2, lw + L.o_w0, D2, Hb + r0 * D2, D2, R, D2, D2, lw + L.o_b0, 1, nullptr, 0, nullptr, 1.f);
+        if (e) return e;
+        return gemm(Hb + r0 * D2, D2, lw + L.o_w3, D2, XO + r0 * D2, D2, R, D, D2, lw + L.o_b3, 0, XO + r0 * D2, D2, nullptr, 1.f);
+    };
+    for (int l = 0; l < s.num_stages; ++l) {
+        // self layer 2l: both images through the same weights (attention_gnn.py:63-66)
+        const float* lw = pk + L.layer0 + (int64_t)(2 * l) * L.layer_stride;
+        if ((rc = gemm(XO, D2, lw + L.o_wqkv, D, QKV, D3, T, D3, D, lw + L.o_bqkv, 0, nullptr, 0, nullptr, 1.f))) return rc;
+        if ((rc = attention(2 * B, B, 0, m, m, 0, m, m, T0, n, n, T0, n, n))) return rc;
+        if ((rc = mlp(lw, 0, T))) return rc;
+        // cross layer 2l+1: image 0 first, then image 1 against the UPDATED image 0 (attention_gnn.py:74-77)
+        lw = pk + L.layer0 + (int64_t)(2 * l + 1) * L.layer_stride;
+        for (int side = 0; side < 2; ++side) {
+            const int64_t qr0 = side ? T0 : 0, qR = side ? T1 : T0;       // query rows
+            const int64_t kr0 = side ? 0 : T0, kR = side ? T0 : T1;       // key/value rows
+            if ((rc = gemm(XO + qr0 * D2, D2, lw + L.o_wqkv, D, QKV + qr0 * D3, D3, qR, D, D, lw + L.o_bqkv, 0, nullptr, 0, nullptr, 1.f))) return rc;
+            if ((rc = gemm(XO + kr0 * D2, D2, lw + L.o_wqkv + (int64_t)D * D, D, QKV + kr0 * D3 + D, D3, kR, D2, D,
+                           lw + L.o_bqkv + D, 0, nullptr, 0, nullptr, 1.f))) return rc;
+            if (side == 0) rc = attention(B, B, 0, m, m, T0, n, n, 0, 0, 0, 0, 0, 0);
+            else rc = attention(B, B, T0, n, n, 0, m, m, 0, 0, 0, 0, 0, 0);
+            if (rc) return rc;
+            if ((rc = mlp(lw, qr0, qR))) return rc;
+        }
+    }
+
+    // ---- 3. final projection + residual mix (superglue.py:58-62), token-major G and channel-first outputs ----
+    for (int side = 0; side < 2; ++side) {
+        const int64_t r0 = side ? T0 : 0, R = side ? T1 : T0;
+        const bool resid = s.flags & OG_FLAG_RESIDUAL;
+        GemmArgs g{};
+        g.A = XO + r0 * D2; g.lda = D2; g.B = pk + L.wp; g.ldb = D; g.C = G + r0 * D; g.ldc = D;
+        g.M = (int)R; g.N = D; g.K = D; g.batch = 1; g.bias = pk + L.bp; g.relu = 0;
+        g.res = resid ? (side ? in->descriptors1 : in->descriptors0) : nullptr; g.ldr = D;
+        g.alpha = resid ? pk + L.alpha : nullptr; g.scale = 1.f;
+        g.Ct = side ? outp->context_descriptors1 : outp->context_descriptors0;
+        g.ct_rows = side ? n : m; g.ldct = g.ct_rows;
+        if ((rc = og_launch_gemm(g, st))) return rc;
+    }
+
+    // ---- 4. score matrix S = g0 g1^T * D^-1/2 (superglue.py:64, 81-86) ----
+    {
+        GemmArgs g{};
+        g.A = G; g.lda = D; g.strideA = (int64_t)m * D; g.B = G + T0 * D; g.ldb = D; g.strideB = (int64_t)n * D;
+        g.C = Sb; g.ldc = W.lds; g.strideC = (int64_t)m * W.lds; g.M = m; g.N = n; g.K = D; g.batch = B;
+        g.scale = (float)pow((double)D, -0.5); g.ct_rows = 1;
+        if ((rc = og_launch_gemm(g, st))) return rc;
+    }
+
+    // ---- 5. Sinkhorn with dustbins -> scores (superglue.py:88-111) ----
+    if ((rc = og_launch_sinkhorn(Sb, W.lds, pk + L.dustbin, 0.f, B, m, n, s.sinkhorn_iters, s.sinkhorn_reg, outp->scores,
+                                 ws + W.sink, st))) return rc;
+
+    // ---- 6. mutual-NN matches (matching_module.py:174-187) ----
+    if (outp->matches0) {
+        if ((rc = og_launch_matches(outp->scores, B, m, n, s.match_threshold, outp->matches0, outp->matching_scores0,
+                                    outp->matches1, outp->matching_scores1, ws + W.match, st))) return rc;
+    }
+    return 0;
+}

@@ -1,0 +1,260 @@
+// Flash-style multi-head softmax attention for keypoint sets on gfx950 matrix cores.
+//
+// Replaces MultiheadAttention's head split + softmax_attention (reference attention_gnn.py:24-29,
+// attention.py:8-19): per head, O = softmax_keys(Q Kᵀ / sqrt(d)) V.  The reference materialises the
+// [B,H,N,N] attention matrix; here a workgroup owns 128 queries of one (problem, head), streams
+// 64-key tiles of K and V through LDS and keeps the running max / sum / output in registers.
+//
+// Precision (DESIGN.md "attention numerics"): the parity bar is 1e-3 on the final log-scores and
+// plain f16 operands miss it on small problems (logit error dominates).  Q, K and V are therefore
+// split x = hi + lo * 2^-11 with hi, lo both f16 (lo is pre-scaled by 2^11 so it never lands in the
+// f16 subnormal range); QKᵀ = Qh·Kh + 2^-11 (Qh·Kl + Ql·Kh) (3 MFMAs) and PV = P·Vh + 2^-11 P·Vl
+// (2 MFMAs), all with f32 accumulation.  Only P (in [0,1]) is rounded to f16 once.
+//
+// MFMA bookkeeping (v_mfma_f32_32x32x16_f16, lane l holds 8 k-values of row/col l&31, k-group l>>5):
+//   Sᵀ[key][query] = K · Qᵀ   (A = K tile, B = Qᵀ)  -> lane owns ONE query column (l&31) and 16 keys
+//                               per 32-key block: softmax statistics are lane-local + one xor-32 exchange.
+//   Oᵀ[dv][query]  = Vᵀ · Pᵀ   (A = Vᵀ, B = Pᵀ)    -> same query column per lane, so the exp'd Sᵀ
+//                               registers ARE the B operand: register 8t+e of key block kb is key
+//                               kb*32 + 16t + 8(e>>2) + 4(l>>5) + (e&3); Vᵀ is staged in LDS as [dv][key]
+//                               so those keys are two 8-byte reads.  (The k order inside an MFMA is free
+//                               as long as A and B agree.)
+// Q is expected PRE-SCALED by d^-1/2 (folded into the packed q-projection weights).
+#include "og_common.h"
+
+namespace {
+
+constexpr int KV_TILE = 64;
+constexpr int Q_TILE = 128;
+constexpr float LO_SCALE = 2048.f;           // 2^11
+constexpr float LO_INV = 1.f / 2048.f;
+
+__device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)x;
+    lo = (_Float16)((x - (float)hi) * LO_SCALE);
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
+    constexpr int DHP = DH < 32 ? 32 : DH;        // Vᵀ rows padded to a full 32-row MFMA tile
+    constexpr int NDV = DHP / 32;                 // output row blocks
+    constexpr int NCH = DH / 16;                  // 16-wide k chunks of the QKᵀ contraction
+    constexpr int KW = DH + 8;                    // K LDS row (halves): 16 B pad -> conflict-free b128
+    constexpr int VW = KV_TILE + 4;               // Vᵀ LDS row (halves): 8 B pad -> conflict-free b64
+    constexpr int D4 = DH / 4;                    // float4 per row
+
+    __shared__ __attribute__((aligned(16))) _Float16 Kh[KV_TILE * KW];
+    __shared__ __attribute__((aligned(16))) _Float16 Kl[KV_TILE * KW];
+    __shared__ __attribute__((aligned(16))) _Float16 Vh[DHP * VW];
+    __shared__ __attribute__((aligned(16))) _Float16 Vl[DHP * VW];
+
+    const int z = blockIdx.z, h = blockIdx.y;
+    const int gsel = z < a.split ? 0 : 1;
+    const int zz = gsel ? z - a.split : z;
+    const int nq = a.nq[gsel], nk = a.nk[gsel];
+    const int q0 = blockIdx.x * Q_TILE;
+    if (q0 >= nq) return;
+    const int64_t q_row0 = a.q_base[gsel] + (int64_t)zz * a.q_step[gsel];
+    const int64_t kv_row0 = a.kv_base[gsel] + (int64_t)zz * a.kv_step[gsel];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    if (DH < 32) {   // zero the padding rows of Vᵀ once; staging never touches them
+        for (int i = tid; i < (DHP - DH) * VW; i += 256) {
+            Vh[DH * VW + i] = (_Float16)0.f;
+            Vl[DH * VW + i] = (_Float16)0.f;
+        }
+    }
+
+    // ---- Q fragments (B operand): lane (query l31, k-group hi) holds Q[q][16c + 8hi + e] ----
+    f16x8 qh[NCH], ql[NCH];
+    {
+        int qi = q0 + wave * 32 + l31;
+        if (qi >= nq) qi = nq - 1;     // clamp: computed but never stored
+        const float* qp = a.q + (q_row0 + qi) * a.ldq + h * DH + 8 * hi;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(qp + 16 * c);
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(qp + 16 * c + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                _Float16 th, tl;
+                split_f16(x0[e], th, tl); qh[c][e] = th; ql[c][e] = tl;
+                split_f16(x1[e], th, tl); qh[c][4 + e] = th; ql[c][4 + e] = tl;
+            }
+        }
+    }
+
+    f32x16 oh[NDV], ol[NDV];
+#pragma unroll
+    for (int d = 0; d < NDV; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { oh[d][r] = 0.f; ol[d][r] = 0.f; }
+    float m_run = OG_NEG_INF, l_run = 0.f;
+
+    // staging maps
+    constexpr int K_KEYS_PER_PASS = 256 / D4;
+    constexpr int K_PASSES = KV_TILE / K_KEYS_PER_PASS;
+    const int k_d4 = tid % D4, k_key = tid / D4;
+    const int v_dg = tid % D4, v_kg = tid / D4;       // V: 4 keys x 4 dv per active thread
+    const bool v_active = v_kg < KV_TILE / 4;
+
+    const int ntiles = (nk + KV_TILE - 1) / KV_TILE;
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int key0 = kt * KV_TILE;
+        // ---- stage K (row-major [key][d]) and Vᵀ ([dv][key]) as f16 hi/lo ----
+#pragma unroll
+        for (int p = 0; p < K_PASSES; ++p) {
+            const int key = k_key + p * K_KEYS_PER_PASS;
+            int gk = key0 + key; if (gk >= nk) gk = nk - 1;      // clamp (masked below)
+            const f32x4 x = *reinterpret_cast<const f32x4*>(a.k + (kv_row0 + gk) * a.ldk + h * DH + 4 * k_d4);
+            f16x4 xh, xl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { _Float16 th, tl; split_f16(x[e], th, tl); xh[e] = th; xl[e] = tl; }
+            *reinterpret_cast<f16x4*>(&Kh[key * KW + 4 * k_d4]) = xh;
+            *reinterpret_cast<f16x4*>(&Kl[key * KW + 4 * k_d4]) = xl;
+        }
+        if (v_active) {
+            f32x4 x[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                int gk = key0 + 4 * v_kg + kk; if (gk >= nk) gk = nk - 1;
+                x[kk] = *reinterpret_cast<const f32x4*>(a.v + (kv_row0 + gk) * a.ldv + h * DH + 4 * v_dg);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {       // dv = 4*v_dg + e : 4 consecutive keys
+                f16x4 xh, xl;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) { _Float16 th, tl; split_f16(x[kk][e], th, tl); xh[kk] = th; xl[kk] = tl; }
+                *reinterpret_cast<f16x4*>(&Vh[(4 * v_dg + e) * VW + 4 * v_kg]) = xh;
+                *reinterpret_cast<f16x4*>(&Vl[(4 * v_dg + e) * VW + 4 * v_kg]) = xl;
+            }
+        }
+        __syncthreads();
+
+        // ---- Sᵀ = K Qᵀ for the two 32-key blocks ----
+        float s[2][16];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16 shh, sx;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { shh[r] = 0.f; sx[r] = 0.f; }
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const f16x8 kh = *reinterpret_cast<const f16x8*>(&Kh[(kb * 32 + l31) * KW + 16 * c + 8 * hi]);
+                const f16x8 kl = *reinterpret_cast<const f16x8*>(&Kl[(kb * 32 + l31) * KW + 16 * c + 8 * hi]);
+                shh = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[c], shh, 0, 0, 0);
+                sx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[c], sx, 0, 0, 0);
+                sx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[c], sx, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = key0 + kb * 32 + mfma32_row(r, lane);
+                const float v = shh[r] + sx[r] * LO_INV;
+                s[kb][r] = key < nk ? v : OG_NEG_INF;
+            }
+        }
+
+        // ---- online softmax over keys (this lane: 32 of the tile's 64 keys of ONE query) ----
+        float mt = s[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[kb][r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, mt);            // finite: every tile holds >= 1 valid key
+        const float alpha = __expf(m_run - m_new);       // first tile: exp(-inf) = 0
+        float psum = 0.f;
+        f16x8 pf[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __expf(s[kb][r] - m_new);
+                psum += p;
+                pf[kb][r >> 3][r & 7] = (_Float16)p;
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < NDV; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { oh[d][r] *= alpha; ol[d][r] *= alpha; }
+
+        // ---- Oᵀ += Vᵀ Pᵀ ----
+#pragma unroll
+        for (int d = 0; d < NDV; ++d)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int off = (d * 32 + l31) * VW + kb * 32 + 16 * t + 4 * hi;
+                    const f16x4 h0 = *reinterpret_cast<const f16x4*>(&Vh[off]);
+                    const f16x4 h1 = *reinterpret_cast<const f16x4*>(&Vh[off + 8]);
+                    const f16x4 l0 = *reinterpret_cast<const f16x4*>(&Vl[off]);
+                    const f16x4 l1 = *reinterpret_cast<const f16x4*>(&Vl[off + 8]);
+                    f16x8 vh, vl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { vh[e] = h0[e]; vh[4 + e] = h1[e]; vl[e] = l0[e]; vl[4 + e] = l1[e]; }
+                    oh[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pf[kb][t], oh[d], 0, 0, 0);
+                    ol[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, pf[kb][t], ol[d], 0, 0, 0);
+                }
+        __syncthreads();
+    }
+
+    // ---- normalise and store O[q][h*DH + dv] ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.f / l_tot;
+    const int qi = q0 + wave * 32 + l31;
+    if (qi < nq) {
+        float* op = a.out + (q_row0 + qi) * a.ldo + h * DH;
+#pragma unroll
+        for (int d = 0; d < NDV; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int dv = d * 32 + 8 * g4 + 4 * hi;
+                if (dv < DH) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (oh[d][4 * g4 + e] + ol[d][4 * g4 + e] * LO_INV) * inv;
+                    *reinterpret_cast<f32x4*>(op + dv) = o;
+                }
+            }
+    }
+}
+
+}  // namespace
+
+int og_launch_attention(const AttnArgs& a, hipStream_t stream) {
+    if (!a.q || !a.k || !a.v || !a.out || a.nz <= 0 || a.num_heads <= 0) return OG_E_INVALID;
+    if ((a.ldq & 3) || (a.ldk & 3) || (a.ldv & 3) || (a.ldo & 3)) return OG_E_ALIGN;
+    if (((uintptr_t)a.q & 15) || ((uintptr_t)a.k & 15) || ((uintptr_t)a.v & 15) || ((uintptr_t)a.out & 15)) return OG_E_ALIGN;
+    int nqmax = 0;
+    for (int g = 0; g < 2; ++g) {
+        const bool used = g == 0 ? a.split > 0 : a.split < a.nz;
+        if (!used) continue;
+        if (a.nq[g] <= 0 || a.nk[g] <= 0) return OG_E_INVALID;
+        if (a.nq[g] > nqmax) nqmax = a.nq[g];
+    }
+    dim3 grid((nqmax + Q_TILE - 1) / Q_TILE, a.num_heads, a.nz), block(256);
+    switch (a.dh) {
+        case 16: hipLaunchKernelGGL(attention_kernel<16>, grid, block, 0, stream, a); break;
+        case 32: hipLaunchKernelGGL(attention_kernel<32>, grid, block, 0, stream, a); break;
+        case 64: hipLaunchKernelGGL(attention_kernel<64>, grid, block, 0, stream, a); break;
+        default: return OG_E_SHAPE;
+    }
+    return og_launch_status();
+}
+
+extern "C" int og_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
+                            int64_t ldv, float* out, int64_t ldo, int32_t batch, int32_t nq, int32_t nk,
+                            int32_t num_heads, int32_t dh, void* stream) {
+    AttnArgs a{};
+    a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.out = out; a.ldo = ldo;
+    a.nz = batch; a.num_heads = num_heads; a.dh = dh; a.split = batch;
+    a.q_base[0] = 0; a.q_step[0] = nq; a.kv_base[0] = 0; a.kv_step[0] = nk;
+    a.nq[0] = nq; a.nk[0] = nk;
+    a.q_base[1] = a.q_step[1] = a.kv_base[1] = a.kv_step[1] = 0; a.nq[1] = a.nk[1] = 0;
+    return og_launch_attention(a, (hipStream_t)stream);
+}

@@ -1,0 +1,71 @@
+// Shared device/host helpers for the gfx950 SuperGlue kernels.  Internal (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/openglue_amd.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+#define OG_WAVE 64
+#define OG_NEG_INF (-__builtin_huge_valf())
+
+// Row of a 32x32 MFMA accumulator element: lane holds column (lane & 31); register r of the 16
+// holds row (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)   (cdna_hip_programming.md §3, C/D layout,
+// dtype-independent on gfx950).
+__device__ __forceinline__ int mfma32_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+static inline int og_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+static inline int64_t og_round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+// ---- internal launchers shared between api.hip and the per-stage entry points ----
+struct GemmArgs {
+    const float* A; int64_t lda, strideA;
+    const float* B; int64_t ldb, strideB;
+    float* C; int64_t ldc, strideC;
+    int M, N, K, batch;
+    const float* bias;        // [N] or null
+    int relu;
+    const float* res; int64_t ldr, strideR;   // residual / mix source, rows like C
+    const float* alpha;       // [N] or null: v = alpha*v + (1-alpha)*res
+    float scale;
+    float* Ct; int64_t ldct, strideCt; int ct_rows;   // optional transposed copy: Ct[row / ct_rows][col][row % ct_rows]
+};
+int og_launch_gemm(const GemmArgs& a, hipStream_t stream);
+
+struct AttnArgs {
+    const float* q; int64_t ldq;
+    const float* k; int64_t ldk;
+    const float* v; int64_t ldv;
+    float* out; int64_t ldo;
+    // problem z in [0, nz): rows of q/out start at q_row0(z), rows of k/v at kv_row0(z)
+    int nz, num_heads, dh;
+    int split;                // problems z < split use geometry A, the others geometry B
+    int64_t q_base[2], q_step[2], kv_base[2], kv_step[2];
+    int nq[2], nk[2];
+};
+int og_launch_attention(const AttnArgs& a, hipStream_t stream);
+
+int og_launch_sinkhorn(const float* S, int64_t lds, const float* dustbin_dev /*or null*/, float dustbin_host, int batch, int m, int n, int iters,
+                       float reg, float* scores, void* workspace, hipStream_t stream);
+int og_launch_matches(const float* scores, int batch, int m, int n, float thr, int64_t* matches0,
+                      float* ms0, int64_t* matches1, float* ms1, void* workspace, hipStream_t stream);
+int og_launch_encoder_input(const float* kpts, const float* side, int64_t tokens, int s, float wx, float wy,
+                            float* out /*[tokens][32]*/, hipStream_t stream);

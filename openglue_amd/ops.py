@@ -1,0 +1,101 @@
+"""Thin torch-tensor wrappers over the per-stage C-ABI entry points (include/openglue_amd.h).
+
+PyTorch is plumbing here: it owns the device buffers and the current HIP stream; all arithmetic
+happens in libopenglue_amd.so.  Every function requires CUDA(HIP) fp32 tensors and raises otherwise.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a tensor on the GPU; openglue_amd has no CPU path")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False,
+            res: Optional[torch.Tensor] = None, alpha: Optional[torch.Tensor] = None, scale: float = 1.0) -> torch.Tensor:
+    """epilogue(a @ b^T): a [M,K] or [Z,M,K], b [N,K] or [Z,N,K] (exact fp32 MFMA)."""
+    lib = _lib.load()
+    a, b = _req(a, "a"), _req(b, "b")
+    batched = a.dim() == 3
+    Z = a.shape[0] if batched else 1
+    M, K = a.shape[-2:]
+    N = b.shape[-2]
+    out = torch.empty((Z, M, N) if batched else (M, N), device=a.device, dtype=torch.float32)
+    if bias is not None: bias = _req(bias, "bias")
+    if res is not None: res = _req(res, "res")
+    if alpha is not None: alpha = _req(alpha, "alpha")
+    rc = lib.og_gemm_nt(a.data_ptr(), K, M * K if batched else 0, b.data_ptr(), K, N * K if b.dim() == 3 else 0,
+                        out.data_ptr(), N, M * N, M, N, K, Z, _ptr(bias), int(relu), _ptr(res), N, _ptr(alpha),
+                        float(scale), _stream())
+    _lib.check(rc, "og_gemm_nt")
+    return out
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int) -> torch.Tensor:
+    """Multi-head softmax attention on token-major tensors q [Z,nq,D], k,v [Z,nk,D]; head h owns
+    channels h*d..(h+1)*d-1.  q must already carry the d^-1/2 scale."""
+    lib = _lib.load()
+    q, k, v = _req(q, "q"), _req(k, "k"), _req(v, "v")
+    Z, nq, D = q.shape
+    nk = k.shape[1]
+    out = torch.empty_like(q)
+    rc = lib.og_attention(q.data_ptr(), D, k.data_ptr(), D, v.data_ptr(), D, out.data_ptr(), D, Z, nq, nk,
+                          num_heads, D // num_heads, _stream())
+    _lib.check(rc, "og_attention")
+    return out
+
+
+def sinkhorn(S: torch.Tensor, dustbin: float, iters: int, reg: float = 1.0) -> torch.Tensor:
+    """S [B,m,n] raw scores -> log-assignment [B,m+1,n+1] (superglue.py:88-111)."""
+    lib = _lib.load()
+    S = _req(S, "S")
+    B, m, n = S.shape
+    lds = (n + 3) // 4 * 4
+    if lds != n:
+        Sp = torch.zeros(B, m, lds, device=S.device, dtype=torch.float32)
+        Sp[:, :, :n] = S
+        S = Sp
+    ws = torch.empty(lib.og_sinkhorn_workspace_bytes(B, m, n), device=S.device, dtype=torch.uint8)
+    out = torch.empty(B, m + 1, n + 1, device=S.device, dtype=torch.float32)
+    rc = lib.og_sinkhorn(S.data_ptr(), lds, float(dustbin), B, m, n, int(iters), float(reg), out.data_ptr(),
+                         ws.data_ptr(), _stream())
+    _lib.check(rc, "og_sinkhorn")
+    return out
+
+
+def extract_matches(scores: torch.Tensor, match_threshold: float, both_sides: bool = True) -> Dict[str, torch.Tensor]:
+    """scores [B,m+1,n+1] -> matches0/matching_scores0 (matching_module.py:174-187) and, if
+    both_sides, matches1/matching_scores1 (inference.py:183-188)."""
+    lib = _lib.load()
+    scores = _req(scores, "scores")
+    B, m1, n1 = scores.shape
+    m, n = m1 - 1, n1 - 1
+    dev = scores.device
+    ws = torch.empty(lib.og_matches_workspace_bytes(B, m, n), device=dev, dtype=torch.uint8)
+    out = {"matches0": torch.empty(B, m, device=dev, dtype=torch.int64),
+           "matching_scores0": torch.empty(B, m, device=dev, dtype=torch.float32)}
+    if both_sides:
+        out["matches1"] = torch.empty(B, n, device=dev, dtype=torch.int64)
+        out["matching_scores1"] = torch.empty(B, n, device=dev, dtype=torch.float32)
+    rc = lib.og_extract_matches(scores.data_ptr(), B, m, n, float(match_threshold), out["matches0"].data_ptr(),
+                                out["matching_scores0"].data_ptr(), _ptr(out.get("matches1")),
+                                _ptr(out.get("matching_scores1")), ws.data_ptr(), _stream())
+    _lib.check(rc, "og_extract_matches")
+    return out

@@ -1,0 +1,238 @@
+"""Drop-in `SuperGlue` module for OpenGlue's scaffolding, backed by the gfx950 HIP library.
+
+Mirrors the reference plugin point (models/superglue/superglue.py:11-72):
+    SuperGlue(config)            same config keys (SURVEY.md §5 "Config")
+    .forward(data) -> {'context_descriptors0', 'context_descriptors1', 'scores'}
+    .state_dict() / .load_state_dict()   same names and shapes, so Lightning
+                                         checkpoints of the reference load unchanged
+and adds `.match(data, match_threshold)` = forward + the mutual-NN extraction that
+MatchingTrainingModule.forward / OpenGlueMatcher.forward run on `scores`
+(models/matching_module.py:174-187, inference.py:176-190).
+
+The torch.nn modules below are PARAMETER CONTAINERS only (they give identical names, shapes and
+default initialisation); none of their forward() methods is ever called.  All arithmetic is in
+libopenglue_amd.so, reached through the C ABI of include/openglue_amd.h.  There is no CPU or
+eager-PyTorch fallback: off-GPU inputs or a missing library raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Mapping, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+_ENCODERS = ("FeedForwardNet",)          # FeedForwardNetSiren: SURVEY.md §8 f4 ("next")
+_ATTENTIONS = ("softmax",)               # linear / FAVOR: SURVEY.md §8 f4 ("next")
+
+
+def _mlp_container(*sizes: int) -> nn.Sequential:
+    """Same child indices as the reference FeedForwardNet (models/utils.py:48-58):
+    conv 3i, relu 3i+1, bn 3i+2, ..., last conv."""
+    layers: List[nn.Module] = []
+    for i in range(1, len(sizes) - 1):
+        layers += [nn.Conv1d(sizes[i - 1], sizes[i], kernel_size=1), nn.ReLU(inplace=True), nn.BatchNorm1d(sizes[i])]
+    layers.append(nn.Conv1d(sizes[-2], sizes[-1], kernel_size=1))
+    return nn.Sequential(*layers)
+
+
+class _Holder(nn.Module):
+    """A named bag of sub-modules (keeps the reference's attribute paths)."""
+
+    def __init__(self, **children: nn.Module):
+        super().__init__()
+        for k, v in children.items():
+            self.add_module(k, v)
+
+
+def _get_wh(data: Mapping, idx: int):
+    """superglue.py:35-38."""
+    if "image0" in data and "image1" in data:
+        h, w = data[f"image{idx}"].shape[-2:]
+        return float(w), float(h)
+    w, h = data[f"image{idx}_size"][:2]
+    return float(w), float(h)
+
+
+class SuperGlue(nn.Module):
+    def __init__(self, config: Mapping):
+        super().__init__()
+        self.config = config
+        pe = dict(config["positional_encoding"])
+        gnn = dict(config["attention_gnn"])
+        enc_name = pe.get("encoder_name", "FeedForwardNet")
+        if enc_name not in _ENCODERS:      # reference: NameError from get_positional_encoder (__init__.py:39-42)
+            raise NameError(f"{enc_name} module was not found among positional encoders supported on MI355X: {_ENCODERS}")
+        attn = gnn.get("attention", "softmax")
+        if attn not in _ATTENTIONS:
+            raise ValueError(f"Attention type {attn} is not supported by the MI355X path (supported: {_ATTENTIONS}).")
+        D = int(config["descriptor_dim"])
+        if int(gnn["embed_dim"]) != D or int(pe["output_size"]) != D:
+            raise ValueError("descriptor_dim, attention_gnn.embed_dim and positional_encoding.output_size must agree")
+        self.descriptor_dim = D
+        self.hidden = [int(h) for h in (pe.get("hidden_layers_sizes") or [])]
+        self.side_info_size = int(pe.get("side_info_size", 1))
+        self.num_stages, self.num_heads = int(gnn["num_stages"]), int(gnn["num_heads"])
+        self.use_offset = bool(gnn.get("use_offset", False))
+        self.residual = bool(config.get("residual", False))
+        self.no_descriptors = bool(config.get("no_descriptors", False))
+
+        # ---- parameter tree with the reference's names ----
+        self.positional_encoding = _Holder(encoder=_mlp_container(2 + self.side_info_size, *self.hidden, D))
+        layers = nn.ModuleList()
+        for _ in range(2 * self.num_stages):       # even = self, odd = cross (attention_gnn.py:84-89)
+            mha = _Holder(in_proj_q=nn.Conv1d(D, D, 1), in_proj_k=nn.Conv1d(D, D, 1),
+                          in_proj_v=nn.Conv1d(D, D, 1), out_proj=nn.Conv1d(D, D, 1))
+            layers.append(_Holder(module=_Holder(mha=mha, fc=_mlp_container(2 * D, 2 * D, D))))
+        self.attention_gnn = _Holder(layers=layers)
+        if self.residual:
+            self.mix_coefs = nn.Parameter(torch.zeros(D, 1))
+        self.linear_proj = nn.Conv1d(D, D, kernel_size=1)
+        self.dustbin_score = nn.Parameter(torch.tensor(float(config["dustbin_score_init"])))
+
+        weights_path = config.get("weights", None)
+        if weights_path is not None:                 # superglue.py:25-27
+            print("SuperGlue loading... ", self.load_state_dict(torch.load(str(weights_path), map_location="cpu")))
+
+        self._packed: Optional[torch.Tensor] = None
+        self._packed_key = None
+        self._workspace: Dict[tuple, torch.Tensor] = {}
+
+    # ------------------------------------------------------------------ shape / packing
+    def _shape(self, B: int, m: int, n: int, match_threshold: float = 0.0) -> _lib.og_shape:
+        s = _lib.og_shape()
+        s.batch, s.m, s.n = B, m, n
+        s.desc_dim, s.num_heads, s.num_stages = self.descriptor_dim, self.num_heads, self.num_stages
+        s.side_info, s.num_hidden = self.side_info_size, len(self.hidden)
+        for i, h in enumerate(self.hidden):
+            s.hidden[i] = h
+        s.sinkhorn_iters = int(self.config["otp"]["num_iters"])
+        s.sinkhorn_reg = float(self.config["otp"]["reg"])
+        s.flags = ((_lib.OG_FLAG_RESIDUAL if self.residual else 0) | (_lib.OG_FLAG_USE_OFFSET if self.use_offset else 0)
+                   | (_lib.OG_FLAG_NO_DESCRIPTORS if self.no_descriptors else 0))
+        s.match_threshold = float(match_threshold)
+        return s
+
+    def _param_key(self, device):
+        return (str(device),) + tuple((id(t), t._version, t.data_ptr())
+                                      for t in list(self.parameters()) + list(self.buffers()))
+
+    def _pack(self, device: torch.device) -> torch.Tensor:
+        """Packed weights on `device`, cached until a parameter changes."""
+        key = self._param_key(device)
+        if self._packed is not None and self._packed_key == key:
+            return self._packed
+        self._packed = torch.from_numpy(self.pack_host()).to(device)
+        self._packed_key = key
+        return self._packed
+
+    def pack_host(self) -> np.ndarray:
+        """og_pack_weights on host copies of the parameters -> float32 blob (layout: og_packed_layout)."""
+        lib = _lib.load()
+        shape = self._shape(1, 1, 1)
+        keep: List[np.ndarray] = []
+
+        def host(t: torch.Tensor) -> int:
+            a = np.ascontiguousarray(t.detach().to("cpu", torch.float32).numpy())
+            keep.append(a)
+            return a.ctypes.data
+
+        def conv(mod: nn.Conv1d) -> _lib.og_conv:
+            return _lib.og_conv(host(mod.weight), host(mod.bias))
+
+        def bn(mod: nn.BatchNorm1d) -> _lib.og_bn:
+            return _lib.og_bn(host(mod.weight), host(mod.bias), host(mod.running_mean), host(mod.running_var))
+
+        P = _lib.og_params()
+        enc = self.positional_encoding.encoder
+        for i in range(len(self.hidden) + 1):
+            P.enc_conv[i] = conv(enc[3 * i])
+            if i < len(self.hidden):
+                P.enc_bn[i] = bn(enc[3 * i + 2])
+        LayerArr = _lib.og_layer_params * max(1, 2 * self.num_stages)
+        layer_arr = LayerArr()
+        for l, holder in enumerate(self.attention_gnn.layers):
+            mod = holder.module
+            lp = layer_arr[l]
+            lp.in_proj_q, lp.in_proj_k = conv(mod.mha.in_proj_q), conv(mod.mha.in_proj_k)
+            lp.in_proj_v, lp.out_proj = conv(mod.mha.in_proj_v), conv(mod.mha.out_proj)
+            lp.fc0, lp.fc_bn, lp.fc3 = conv(mod.fc[0]), bn(mod.fc[2]), conv(mod.fc[3])
+        P.layers = C.cast(layer_arr, C.POINTER(_lib.og_layer_params))
+        P.linear_proj = conv(self.linear_proj)
+        P.mix_coefs = host(self.mix_coefs) if self.residual else None
+        P.dustbin_score = float(self.dustbin_score.detach())
+        nbytes = lib.og_packed_weights_bytes(C.byref(shape))
+        if nbytes == 0:
+            _lib.check(lib.og_check_shape(C.byref(shape)), "og_check_shape")
+        blob = np.empty(nbytes // 4, dtype=np.float32)
+        _lib.check(lib.og_pack_weights(C.byref(shape), C.byref(P), blob.ctypes.data), "og_pack_weights")
+        return blob
+
+    # ------------------------------------------------------------------ the hot path
+    def _run(self, data: Mapping, want_matches: bool, match_threshold: float, both_sides: bool) -> Dict[str, torch.Tensor]:
+        if self.training:
+            raise RuntimeError("openglue_amd.SuperGlue implements the eval()/inference path only "
+                               "(train-mode BatchNorm + backward is the next scope row, SURVEY.md §8 f2); call .eval()")
+        lib = _lib.load()
+        names = ("keypoints0", "keypoints1", "local_descriptors0", "local_descriptors1", "side_info0", "side_info1")
+        t = {}
+        for k in names:
+            v = data[k]
+            if not isinstance(v, torch.Tensor) or not v.is_cuda:
+                raise RuntimeError(f"data['{k}'] must be a tensor on the MI355X; openglue_amd has no CPU fallback")
+            t[k] = v.detach().to(torch.float32).contiguous()
+        dev = t["keypoints0"].device
+        B, m, _ = t["keypoints0"].shape
+        n = t["keypoints1"].shape[1]
+        D, s = self.descriptor_dim, self.side_info_size
+        if t["local_descriptors0"].shape != (B, m, D) or t["local_descriptors1"].shape != (B, n, D):
+            raise ValueError("local_descriptors must be [B, n, descriptor_dim]")
+        if t["side_info0"].shape != (B, m, s) or t["side_info1"].shape != (B, n, s):
+            raise ValueError("side_info must be [B, n, side_info_size]")
+        shape = self._shape(B, m, n, match_threshold)
+        _lib.check(lib.og_check_shape(C.byref(shape)), "og_check_shape")
+        with torch.cuda.device(dev):
+            packed = self._pack(dev)
+            wkey = (str(dev), B, m, n)
+            ws = self._workspace.get(wkey)
+            if ws is None:
+                self._workspace.clear()          # one live workspace; shapes rarely change between calls
+                ws = torch.empty(lib.og_workspace_bytes(C.byref(shape)), device=dev, dtype=torch.uint8)
+                self._workspace[wkey] = ws
+            out = {
+                "context_descriptors0": torch.empty(B, D, m, device=dev, dtype=torch.float32),
+                "context_descriptors1": torch.empty(B, D, n, device=dev, dtype=torch.float32),
+                "scores": torch.empty(B, m + 1, n + 1, device=dev, dtype=torch.float32),
+            }
+            if want_matches:
+                out["matches0"] = torch.empty(B, m, device=dev, dtype=torch.int64)
+                out["matching_scores0"] = torch.empty(B, m, device=dev, dtype=torch.float32)
+                if both_sides:
+                    out["matches1"] = torch.empty(B, n, device=dev, dtype=torch.int64)
+                    out["matching_scores1"] = torch.empty(B, n, device=dev, dtype=torch.float32)
+            inp = _lib.og_inputs(t["keypoints0"].data_ptr(), t["keypoints1"].data_ptr(),
+                                 t["local_descriptors0"].data_ptr(), t["local_descriptors1"].data_ptr(),
+                                 t["side_info0"].data_ptr() if s else None, t["side_info1"].data_ptr() if s else None)
+            inp.image0_wh[0], inp.image0_wh[1] = _get_wh(data, 0)
+            inp.image1_wh[0], inp.image1_wh[1] = _get_wh(data, 1)
+            ptr = lambda k: out[k].data_ptr() if k in out else None
+            o = _lib.og_outputs(ptr("scores"), ptr("context_descriptors0"), ptr("context_descriptors1"),
+                                ptr("matches0"), ptr("matching_scores0"), ptr("matches1"), ptr("matching_scores1"))
+            rc = lib.og_forward(C.byref(shape), C.byref(inp), packed.data_ptr(), ws.data_ptr(), C.byref(o),
+                                torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(rc, "og_forward")
+        return out
+
+    @torch.no_grad()
+    def forward(self, data: Mapping) -> Dict[str, torch.Tensor]:
+        """Same contract as the reference SuperGlue.forward (superglue.py:29-72)."""
+        return self._run(data, want_matches=False, match_threshold=0.0, both_sides=False)
+
+    @torch.no_grad()
+    def match(self, data: Mapping, match_threshold: float = 0.2, both_sides: bool = True) -> Dict[str, torch.Tensor]:
+        """forward + mutual-NN extraction in one enqueue: adds 'matches0', 'matching_scores0'
+        (matching_module.py:183-187) and, with both_sides, 'matches1', 'matching_scores1' (inference.py:183-188)."""
+        return self._run(data, want_matches=True, match_threshold=match_threshold, both_sides=both_sides)

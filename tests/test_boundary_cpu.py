@@ -1,0 +1,122 @@
+"""CPU: the drop-in boundary -- library exports, state-dict layout, weight packing, error behaviour.
+No kernel is launched here (no GPU in the build container)."""
+import ctypes as C
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from openglue_amd import _lib, synthetic as syn
+from openglue_amd.superglue import SuperGlue
+from oracle import superglue_oracle as orc
+from tests.packed_model import forward_from_packed
+from tests.util import load_case
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "openglue_amd.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|size_t)\s+(og_\w+)\s*\(", header, flags=re.M))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.og_abi_version() == _lib.OG_ABI_VERSION
+
+
+def test_struct_sizes_match_header():
+    # og_shape: 8 ints + 8 hidden + int + float + int + float = 20 * 4 bytes
+    assert C.sizeof(_lib.og_shape) == 80
+    assert C.sizeof(_lib.og_conv) == 16 and C.sizeof(_lib.og_bn) == 32
+    assert C.sizeof(_lib.og_layer_params) == 5 * 16 + 32 + 16
+    assert C.sizeof(_lib.og_inputs) == 6 * 8 + 16 and C.sizeof(_lib.og_outputs) == 7 * 8
+
+
+def test_state_dict_layout_matches_reference_names():
+    cfg = syn.make_config(**{k: v for k, v in syn.CONFIGS["C1"].items() if k not in ("kpts", "batch")})
+    model = SuperGlue(cfg)
+    spec = syn.state_dict_spec(cfg)             # proven against the reference by make_golden.py (strict load)
+    sd = model.state_dict()
+    assert set(sd) == set(spec)
+    for k, (shape, *_rest) in spec.items():
+        assert tuple(sd[k].shape) == tuple(shape), k
+    # Lightning checkpoints prefix keys with 'superglue.' (inference.py:71-73): strip + strict load
+    ck = {"superglue." + k: v for k, v in syn.make_state_dict(cfg, 0).items()}
+    stripped = {k[len("superglue."):]: v for k, v in ck.items()}
+    assert not any(model.load_state_dict(stripped, strict=True))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/models"), reason="reference not mounted")
+def test_state_dict_equals_live_reference():
+    sys.path.insert(0, "/root/reference")
+    from models.superglue.superglue import SuperGlue as Ref
+    cfg = syn.make_config(descriptor_dim=64, num_stages=2, num_heads=4, num_iters=3, side_info_size=6)
+    a, b = Ref(cfg).state_dict(), SuperGlue(cfg).state_dict()
+    assert list(a.keys()).sort() == list(b.keys()).sort()
+    assert {k: tuple(v.shape) for k, v in a.items()} == {k: tuple(v.shape) for k, v in b.items()}
+
+
+@pytest.mark.parametrize("name", ["c1", "flags", "nodesc", "mid"])
+def test_pack_weights_algebra_against_oracle(name):
+    """og_pack_weights (BN folds, out_proj -> fc.0 fold, q pre-scale, padding) evaluated on the CPU in
+    float64 must reproduce the oracle: proves the packed blob og_forward consumes is right."""
+    z, cfg, sd, data = load_case(name)
+    model = SuperGlue(cfg).eval()
+    model.load_state_dict(sd, strict=True)
+    with torch.no_grad():
+        got = forward_from_packed(model, data)
+        ref = orc.superglue_forward(sd, cfg, data, dtype=torch.float64)
+    assert (got["scores"] - ref["scores"]).abs().max() < 2e-4      # packed weights are fp32-rounded
+    assert (got["context_descriptors0"] - ref["context_descriptors0"]).abs().max() < 2e-5
+    assert np.abs(got["scores"].float().numpy() - z["scores"]).max() < 3e-4
+
+
+def test_repack_when_parameters_change():
+    cfg = syn.make_config(descriptor_dim=64, num_stages=1, num_heads=4, num_iters=3)
+    model = SuperGlue(cfg).eval()
+    a = model.pack_host().copy()
+    k0 = model._param_key("cpu")
+    with torch.no_grad():
+        model.linear_proj.bias.add_(1.0)
+    assert model._param_key("cpu") != k0
+    assert np.abs(model.pack_host() - a).max() > 0.5
+
+
+def test_error_behaviour():
+    cfg = syn.make_config(descriptor_dim=64, num_stages=1, num_heads=4, num_iters=3)
+    bad = dict(cfg); bad["positional_encoding"] = dict(cfg["positional_encoding"], encoder_name="Nope")
+    with pytest.raises(NameError):           # reference: get_positional_encoder raises NameError (__init__.py:39-42)
+        SuperGlue(bad)
+    bad = dict(cfg); bad["attention_gnn"] = dict(cfg["attention_gnn"], attention="favor_relu")
+    with pytest.raises(ValueError):
+        SuperGlue(bad)
+    model = SuperGlue(cfg).eval()
+    data = syn.make_batch(1, 16, 16, 64, 1, seed=0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):      # product path never computes on the CPU
+        model(data)
+    with pytest.raises(RuntimeError, match="eval"):
+        model.train()(data)
+    lib = _lib.load()
+    s = model._shape(1, 16, 16)
+    assert lib.og_check_shape(C.byref(s)) == 0
+    s.desc_dim = 100
+    assert lib.og_check_shape(C.byref(s)) == -2 and lib.og_workspace_bytes(C.byref(s)) == 0
+    s = model._shape(1, 16, 5000)
+    assert lib.og_check_shape(C.byref(s)) == -2
+    s = model._shape(1, 16, 16); s.flags = 64
+    assert lib.og_check_shape(C.byref(s)) == -4
+    # NULL arguments are rejected before any launch (no GPU needed)
+    assert lib.og_forward(None, None, None, None, None, None) == -1
+    assert lib.og_gemm_nt(None, 4, 0, None, 4, 0, None, 4, 0, 1, 1, 4, 1, None, 0, None, 0, None, 1.0, None) == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU / eager fallback"):
+        _lib.load()
