@@ -154,6 +154,20 @@ int og_packed_layout(const og_shape* shape, og_packed_layout_t* layout);
 int og_forward(const og_shape* shape, const og_inputs* in, const void* packed_dev,
                void* workspace_dev, const og_outputs* out, void* stream);
 
+/* Profiling variant of og_forward (bench.py): same work, but every launch group is bracketed by HIP
+ * events recorded on `stream`; the call SYNCHRONISES the stream and returns the summed elapsed
+ * milliseconds and the number of bracketed launch groups per kernel class.  GEMM and attention are
+ * bracketed per kernel launch, Sinkhorn / matches per stage (many small launches). */
+#define OG_STAGE_ENCODER_INPUT 0
+#define OG_STAGE_GEMM          1
+#define OG_STAGE_ATTENTION     2
+#define OG_STAGE_SINKHORN      3
+#define OG_STAGE_MATCHES       4
+#define OG_NUM_STAGES          5
+int og_forward_profiled(const og_shape* shape, const og_inputs* in, const void* packed_dev,
+                        void* workspace_dev, const og_outputs* out, void* stream,
+                        float* stage_ms /*[OG_NUM_STAGES]*/, int32_t* stage_launches /*[OG_NUM_STAGES]*/);
+
 /* ---- per-stage entry points (unit parity tests; also usable on their own) ---- */
 
 /* C[z] = epilogue(A[z] * B[z]^T): A [M][K] (lda), B [N][K] (ldb), exact fp32 MFMA.

@@ -242,8 +242,30 @@ extern "C" int og_pack_weights(const og_shape* shape, const og_params* P, void* 
     return 0;
 }
 
-extern "C" int og_forward(const og_shape* shape, const og_inputs* in, const void* packed_dev, void* workspace_dev,
-                          const og_outputs* outp, void* stream) {
+namespace {
+
+// Optional per-kernel-class timing with HIP events recorded on the launch stream (og_forward_profiled).
+struct Profiler {
+    hipStream_t st;
+    std::vector<hipEvent_t> ev;     // start/stop pairs
+    std::vector<int> cls;
+    int begin(int c) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1;
+        ev.push_back(a); ev.push_back(b); cls.push_back(c);
+        (void)hipEventRecord(a, st);
+        return (int)cls.size() - 1;
+    }
+    void end(int i) { if (i >= 0) (void)hipEventRecord(ev[2 * i + 1], st); }
+};
+struct Scope {
+    Profiler* p; int i;
+    Scope(Profiler* pp, int c) : p(pp), i(pp ? pp->begin(c) : -1) {}
+    ~Scope() { if (p) p->end(i); }
+};
+
+int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_dev, void* workspace_dev,
+                 const og_outputs* outp, void* stream, Profiler* prof) {
     if (!shape || !in || !packed_dev || !workspace_dev || !outp) return OG_E_INVALID;
     if (int e = check_shape(shape)) return e;
     const og_shape& s = *shape;
@@ -271,6 +293,7 @@ extern "C" int og_forward(const og_shape* shape, const og_inputs* in, const void
         g.A = A; g.lda = lda; g.strideA = 0; g.B = Bm; g.ldb = ldb; g.strideB = 0; g.C = C; g.ldc = ldc; g.strideC = 0;
         g.M = (int)M; g.N = N; g.K = K; g.batch = 1; g.bias = bias; g.relu = relu; g.res = res; g.ldr = ldr; g.strideR = 0;
         g.alpha = alpha; g.scale = scale; g.Ct = nullptr; g.ldct = 0; g.strideCt = 0; g.ct_rows = 1;
+        Scope sc(prof, OG_STAGE_GEMM);
         return og_launch_gemm(g, st);
     };
 
@@ -279,8 +302,11 @@ extern "C" int og_forward(const og_shape* shape, const og_inputs* in, const void
         float* EI = G;                 // [T][32]   (aliases: all three are free until the GNN starts)
         float* Ea = QKV;               // [T][enc_maxw]
         float* Eb = Hb;                // [T][enc_maxw]
-        if ((rc = og_launch_encoder_input(in->keypoints0, in->side_info0, T0, s.side_info, in->image0_wh[0], in->image0_wh[1], EI, st))) return rc;
-        if ((rc = og_launch_encoder_input(in->keypoints1, in->side_info1, T1, s.side_info, in->image1_wh[0], in->image1_wh[1], EI + T0 * 32, st))) return rc;
+        {
+            Scope sc(prof, OG_STAGE_ENCODER_INPUT);
+            if ((rc = og_launch_encoder_input(in->keypoints0, in->side_info0, T0, s.side_info, in->image0_wh[0], in->image0_wh[1], EI, st))) return rc;
+            if ((rc = og_launch_encoder_input(in->keypoints1, in->side_info1, T1, s.side_info, in->image1_wh[0], in->image1_wh[1], EI + T0 * 32, st))) return rc;
+        }
         const float* cur = EI; int64_t ldcur = 32;
         for (int i = 0; i < L.n_enc; ++i) {
             const float* Wi = pk + L.enc_w[i]; const float* bi = pk + L.enc_b[i];
@@ -306,6 +332,7 @@ extern "C" int og_forward(const og_shape* shape, const og_inputs* in, const void
         a.nz = nz; a.num_heads = s.num_heads; a.dh = dh; a.split = split;
         a.q_base[0] = qb0; a.q_step[0] = qs0; a.nq[0] = nq0; a.kv_base[0] = kb0; a.kv_step[0] = ks0; a.nk[0] = nk0;
         a.q_base[1] = qb1; a.q_step[1] = qs1; a.nq[1] = nq1; a.kv_base[1] = kb1; a.kv_step[1] = ks1; a.nk[1] = nk1;
+        Scope sc(prof, OG_STAGE_ATTENTION);
         return og_launch_attention(a, st);
     };
     // message MLP on token rows [r0, r0+R):  h = relu([x;O] W0'^T + b0') ; x += h W3'^T + b3'
@@ -346,6 +373,7 @@ extern "C" int og_forward(const og_shape* shape, const og_inputs* in, const void
         g.alpha = resid ? pk + L.alpha : nullptr; g.scale = 1.f;
         g.Ct = side ? outp->context_descriptors1 : outp->context_descriptors0;
         g.ct_rows = side ? n : m; g.ldct = g.ct_rows;
+        Scope sc(prof, OG_STAGE_GEMM);
         if ((rc = og_launch_gemm(g, st))) return rc;
     }
 
@@ -355,17 +383,49 @@ extern "C" int og_forward(const og_shape* shape, const og_inputs* in, const void
         g.A = G; g.lda = D; g.strideA = (int64_t)m * D; g.B = G + T0 * D; g.ldb = D; g.strideB = (int64_t)n * D;
         g.C = Sb; g.ldc = W.lds; g.strideC = (int64_t)m * W.lds; g.M = m; g.N = n; g.K = D; g.batch = B;
         g.scale = (float)pow((double)D, -0.5); g.ct_rows = 1;
+        Scope sc(prof, OG_STAGE_GEMM);
         if ((rc = og_launch_gemm(g, st))) return rc;
     }
 
     // ---- 5. Sinkhorn with dustbins -> scores (superglue.py:88-111) ----
-    if ((rc = og_launch_sinkhorn(Sb, W.lds, pk + L.dustbin, 0.f, B, m, n, s.sinkhorn_iters, s.sinkhorn_reg, outp->scores,
-                                 ws + W.sink, st))) return rc;
+    {
+        Scope sc(prof, OG_STAGE_SINKHORN);
+        if ((rc = og_launch_sinkhorn(Sb, W.lds, pk + L.dustbin, 0.f, B, m, n, s.sinkhorn_iters, s.sinkhorn_reg, outp->scores,
+                                     ws + W.sink, st))) return rc;
+    }
 
     // ---- 6. mutual-NN matches (matching_module.py:174-187) ----
     if (outp->matches0) {
+        Scope sc(prof, OG_STAGE_MATCHES);
         if ((rc = og_launch_matches(outp->scores, B, m, n, s.match_threshold, outp->matches0, outp->matching_scores0,
                                     outp->matches1, outp->matching_scores1, ws + W.match, st))) return rc;
     }
     return 0;
+}
+
+}  // namespace
+
+extern "C" int og_forward(const og_shape* shape, const og_inputs* in, const void* packed_dev, void* workspace_dev,
+                          const og_outputs* outp, void* stream) {
+    return forward_impl(shape, in, packed_dev, workspace_dev, outp, stream, nullptr);
+}
+
+extern "C" int og_forward_profiled(const og_shape* shape, const og_inputs* in, const void* packed_dev, void* workspace_dev,
+                                   const og_outputs* outp, void* stream, float* stage_ms, int32_t* stage_launches) {
+    if (!stage_ms || !stage_launches) return OG_E_INVALID;
+    Profiler prof{(hipStream_t)stream, {}, {}};
+    int rc = forward_impl(shape, in, packed_dev, workspace_dev, outp, stream, &prof);
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    for (int c = 0; c < OG_NUM_STAGES; ++c) { stage_ms[c] = 0.f; stage_launches[c] = 0; }
+    for (size_t i = 0; i < prof.cls.size(); ++i) {
+        float ms = 0.f;
+        if (e == hipSuccess && rc == 0 && hipEventElapsedTime(&ms, prof.ev[2 * i], prof.ev[2 * i + 1]) == hipSuccess) {
+            stage_ms[prof.cls[i]] += ms;
+            stage_launches[prof.cls[i]] += 1;
+        }
+        (void)hipEventDestroy(prof.ev[2 * i]);
+        (void)hipEventDestroy(prof.ev[2 * i + 1]);
+    }
+    if (rc) return rc;
+    return e == hipSuccess ? 0 : (int)e;
 }

@@ -108,8 +108,8 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g, int tiles_
     }
 
     // ---- epilogue ----
-    float* __restrict__ C = g.C + (int64_t)z * g.strideC;
-    const float* __restrict__ R = g.res ? g.res + (int64_t)z * g.strideR : nullptr;
+    float* C = g.C + (int64_t)z * g.strideC;      // may alias R (in-place residual): no __restrict__
+    const float* R = g.res ? g.res + (int64_t)z * g.strideR : nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);

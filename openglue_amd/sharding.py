@@ -1,0 +1,109 @@
+"""Multi-GPU driver for the matcher: image pairs are independent (eval-mode BatchNorm, no cross-pair
+op anywhere on the path -- SURVEY.md §8e), so a job of P pairs is split into `world_size` shards, one
+process per GPU, with NO collective on the data path and ONE gather of the match lists at the end
+(RCCL over xGMI with backend "nccl"; each rank's message is KBs, i.e. latency-bound on its direct
+link to the root).  The same code runs under gloo on CPU tensors, which is how it is tested here.
+
+The reference's only parallelism is Lightning DDP for training (train.py:69-81); inference sharding is
+new and deliberately minimal.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Mapping, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def pair_cost(m: int, n: int, desc_dim: int = 256, num_stages: int = 9, iters: int = 100) -> float:
+    """Relative cost of one pair: algorithmic FLOPs + Sinkhorn bytes weighted by the
+    MI355X flop:byte ratio of the kernels that execute them (fp32 MFMA 157 TF vs ~5 TB/s)."""
+    D, L = desc_dim, num_stages
+    flops = L * (40.0 * D * D * (m + n) + 4.0 * D * (m * m + n * n) + 8.0 * D * m * n) + 2.0 * D * D * (m + n) + 2.0 * m * n * D
+    bytes_ = 4.0 * ((m + 1) * (n + 1) * (2 * iters + 1) + 2 * m * n)
+    return flops / 157e12 + bytes_ / 5e12
+
+
+def shard_pairs(num_pairs: int, world_size: int, costs: Optional[Sequence[float]] = None) -> List[List[int]]:
+    """Pair indices per rank.  Uniform pairs: contiguous equal split (remainder to the low ranks).
+    Ragged pairs (`costs` given): longest-processing-time greedy, then indices sorted per rank."""
+    if world_size <= 0 or num_pairs < 0:
+        raise ValueError("bad world_size / num_pairs")
+    if costs is None:
+        base, rem = divmod(num_pairs, world_size)
+        out, start = [], 0
+        for r in range(world_size):
+            cnt = base + (1 if r < rem else 0)
+            out.append(list(range(start, start + cnt)))
+            start += cnt
+        return out
+    if len(costs) != num_pairs:
+        raise ValueError("len(costs) != num_pairs")
+    load = [0.0] * world_size
+    out = [[] for _ in range(world_size)]
+    for i in sorted(range(num_pairs), key=lambda i: (-costs[i], i)):
+        r = min(range(world_size), key=lambda r: (load[r], r))
+        out[r].append(i)
+        load[r] += costs[i]
+    return [sorted(x) for x in out]
+
+
+def take_pairs(data: Mapping, idx: Sequence[int]) -> Dict:
+    """Sub-batch of a data dict (tensors indexed on dim 0; image sizes passed through)."""
+    sel = torch.as_tensor(list(idx), dtype=torch.long)
+    return {k: (v.index_select(0, sel.to(v.device)) if torch.is_tensor(v) and v.dim() > 0 and not k.startswith("image") else v)
+            for k, v in data.items()}
+
+
+def gather_matches(local: Mapping[str, torch.Tensor], pair_ids: Sequence[int], num_pairs: int, dst: int = 0,
+                   group=None) -> Optional[Dict[str, torch.Tensor]]:
+    """The one collective: every rank contributes matches0 [b, m] (int64) and matching_scores0 [b, m]
+    (fp32) of its shard; rank `dst` returns them re-assembled in job order [num_pairs, m]; others None.
+    Shards are padded to the largest shard so a single fixed-size gather suffices."""
+    m0, s0 = local["matches0"], local["matching_scores0"]
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        order = torch.as_tensor(list(pair_ids), dtype=torch.long, device=m0.device)
+        out_m = torch.full((num_pairs, m0.shape[1]), -1, dtype=torch.int64, device=m0.device)
+        out_s = torch.zeros((num_pairs, m0.shape[1]), dtype=torch.float32, device=m0.device)
+        out_m[order], out_s[order] = m0, s0
+        return {"matches0": out_m, "matching_scores0": out_s}
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    cap = (num_pairs + world - 1) // world
+    width = m0.shape[1]
+    # one packed fp32 payload per rank: [cap, 1 + 2*width] = pair id | matches (exact in fp32 below 2^24) | scores
+    if width >= (1 << 24) or num_pairs >= (1 << 24):
+        raise ValueError("index does not fit the packed fp32 payload")
+    payload = torch.full((cap, 1 + 2 * width), -1.0, dtype=torch.float32, device=m0.device)
+    b = m0.shape[0]
+    if b:
+        payload[:b, 0] = torch.as_tensor(list(pair_ids), dtype=torch.float32, device=m0.device)
+        payload[:b, 1:1 + width] = m0.to(torch.float32)
+        payload[:b, 1 + width:] = s0
+    bufs = [torch.empty_like(payload) for _ in range(world)] if rank == dst else None
+    dist.gather(payload, bufs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    allp = torch.cat(bufs, 0)
+    ids = allp[:, 0].to(torch.long)
+    keep = ids >= 0
+    out_m = torch.full((num_pairs, width), -1, dtype=torch.int64, device=m0.device)
+    out_s = torch.zeros((num_pairs, width), dtype=torch.float32, device=m0.device)
+    out_m[ids[keep]] = allp[keep, 1:1 + width].to(torch.int64)
+    out_s[ids[keep]] = allp[keep, 1 + width:]
+    return {"matches0": out_m, "matching_scores0": out_s}
+
+
+def match_sharded(match_fn: Callable[[Mapping], Mapping[str, torch.Tensor]], data: Mapping, num_pairs: int,
+                  costs: Optional[Sequence[float]] = None, dst: int = 0, group=None) -> Optional[Dict[str, torch.Tensor]]:
+    """Run `match_fn` (e.g. SuperGlue.match bound to this rank's GPU) on this rank's shard of a job whose
+    full input `data` every rank can index, then gather the match lists on `dst`."""
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    mine = shard_pairs(num_pairs, world, costs)[rank]
+    local = match_fn(take_pairs(data, mine)) if mine else None
+    if local is None:
+        width = data["keypoints0"].shape[1]
+        dev = data["keypoints0"].device
+        local = {"matches0": torch.empty(0, width, dtype=torch.int64, device=dev),
+                 "matching_scores0": torch.empty(0, width, dtype=torch.float32, device=dev)}
+    return gather_matches(local, mine, num_pairs, dst, group)
