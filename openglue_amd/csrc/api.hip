@@ -268,6 +268,7 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
                  const og_outputs* outp, void* stream, Profiler* prof) {
     if (!shape || !in || !packed_dev || !workspace_dev || !outp) return OG_E_INVALID;
     if (int e = check_shape(shape)) return e;
+    og_clear_status();
     const og_shape& s = *shape;
     if (!in->keypoints0 || !in->keypoints1 || !in->descriptors0 || !in->descriptors1 || !outp->scores) return OG_E_INVALID;
     if (s.side_info > 0 && (!in->side_info0 || !in->side_info1)) return OG_E_INVALID;

@@ -8,8 +8,9 @@
 // Precision (DESIGN.md "attention numerics"): the parity bar is 1e-3 on the final log-scores and
 // plain f16 operands miss it on small problems (logit error dominates).  Q, K and V are therefore
 // split x = hi + lo * 2^-11 with hi, lo both f16 (lo is pre-scaled by 2^11 so it never lands in the
-// f16 subnormal range); QKᵀ = Qh·Kh + 2^-11 (Qh·Kl + Ql·Kh) (3 MFMAs) and PV = P·Vh + 2^-11 P·Vl
-// (2 MFMAs), all with f32 accumulation.  Only P (in [0,1]) is rounded to f16 once.
+// f16 subnormal range); QKᵀ = Qh·Kh + 2^-11 (Qh·Kl + Ql·Kh) and PV = Ph·Vh + 2^-11 (Ph·Vl + Pl·Vh)
+// (3 MFMAs each), all with f32 accumulation: every product carries ~22 mantissa bits.  (Rounding P
+// alone to f16 already costs 1.2e-3 on the `flags` golden case.)
 //
 // MFMA bookkeeping (v_mfma_f32_32x32x16_f16, lane l holds 8 k-values of row/col l&31, k-group l>>5):
 //   Sᵀ[key][query] = K · Qᵀ   (A = K tile, B = Qᵀ)  -> lane owns ONE query column (l&31) and 16 keys
@@ -166,14 +167,17 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
         const float m_new = fmaxf(m_run, mt);            // finite: every tile holds >= 1 valid key
         const float alpha = __expf(m_run - m_new);       // first tile: exp(-inf) = 0
         float psum = 0.f;
-        f16x8 pf[2][2];
+        f16x8 pf[2][2], pl[2][2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float p = __expf(s[kb][r] - m_new);
                 psum += p;
-                pf[kb][r >> 3][r & 7] = (_Float16)p;
+                _Float16 th, tl;
+                split_f16(p, th, tl);
+                pf[kb][r >> 3][r & 7] = th;
+                pl[kb][r >> 3][r & 7] = tl;
             }
         l_run = l_run * alpha + psum;
         m_run = m_new;
@@ -199,6 +203,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
                     for (int e = 0; e < 4; ++e) { vh[e] = h0[e]; vh[4 + e] = h1[e]; vl[e] = l0[e]; vl[4 + e] = l1[e]; }
                     oh[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pf[kb][t], oh[d], 0, 0, 0);
                     ol[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, pf[kb][t], ol[d], 0, 0, 0);
+                    ol[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[kb][t], ol[d], 0, 0, 0);
                 }
         __syncthreads();
     }
@@ -250,6 +255,7 @@ int og_launch_attention(const AttnArgs& a, hipStream_t stream) {
 extern "C" int og_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
                             int64_t ldv, float* out, int64_t ldo, int32_t batch, int32_t nq, int32_t nk,
                             int32_t num_heads, int32_t dh, void* stream) {
+    og_clear_status();
     AttnArgs a{};
     a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.out = out; a.ldo = ldo;
     a.nz = batch; a.num_heads = num_heads; a.dh = dh; a.split = batch;

@@ -162,6 +162,7 @@ extern "C" int og_gemm_nt(const float* A, int64_t lda, int64_t strideA, const fl
                           int64_t strideB, float* C, int64_t ldc, int64_t strideC, int32_t M, int32_t N,
                           int32_t K, int32_t batch, const float* bias, int32_t relu, const float* res,
                           int64_t ldr, const float* alpha, float scale, void* stream) {
+    og_clear_status();
     GemmArgs g{};
     g.A = A; g.lda = lda; g.strideA = strideA;
     g.B = B; g.ldb = ldb; g.strideB = strideB;

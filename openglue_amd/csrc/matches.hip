@@ -151,6 +151,7 @@ int og_launch_matches(const float* scores, int B, int m, int n, float thr, int64
 extern "C" int og_extract_matches(const float* scores, int32_t batch, int32_t m, int32_t n, float match_threshold,
                                   int64_t* matches0, float* matching_scores0, int64_t* matches1,
                                   float* matching_scores1, void* workspace_dev, void* stream) {
+    og_clear_status();
     return og_launch_matches(scores, batch, m, n, match_threshold, matches0, matching_scores0, matches1,
                              matching_scores1, workspace_dev, (hipStream_t)stream);
 }

@@ -28,6 +28,11 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// hipGetLastError() is sticky per thread and also reports errors left behind by OTHER users of the
+// runtime in this process (e.g. a benign probe inside torch).  Every ABI entry clears it first, so a
+// non-zero status after our launches is ours.
+static inline void og_clear_status() { (void)hipGetLastError(); }
+
 static inline int og_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

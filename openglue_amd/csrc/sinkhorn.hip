@@ -202,9 +202,25 @@ __global__ __launch_bounds__(256) void sinkhorn_combine_kernel(int M, int N, con
         const float* pmb = pm + (int64_t)b * RB * ldp + j;
         const float* psb = ps + (int64_t)b * RB * ldp + j;
         float cm = zr + uM;                      // dustbin row entry of column j
-        for (int rb = 0; rb < RB; ++rb) cm = fmaxf(cm, pmb[(int64_t)rb * ldp]);
-        float cs = __expf(zr + uM - cm);
-        for (int rb = 0; rb < RB; ++rb) cs += psb[(int64_t)rb * ldp] * __expf(pmb[(int64_t)rb * ldp] - cm);
+        // chunks of 8 row blocks: 16 independent loads in flight per thread (the naive dependent
+        // loop is latency-bound), online (max, sum) merge per chunk
+        float cs = 1.f;                          // exp(zr + uM - cm)
+        for (int rb0 = 0; rb0 < RB; rb0 += 8) {
+            float pmv[8], psv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const bool ok = rb0 + q < RB;
+                pmv[q] = ok ? pmb[(int64_t)(rb0 + q) * ldp] : OG_NEG_INF;
+                psv[q] = ok ? psb[(int64_t)(rb0 + q) * ldp] : 0.f;
+            }
+            float mx = cm;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) mx = fmaxf(mx, pmv[q]);
+            cs *= __expf(cm - mx);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) cs += psv[q] * __expf(pmv[q] - mx);
+            cm = mx;
+        }
         v_out[(int64_t)b * ldv + j] = lb - (cm + __logf(cs));
     }
     if (blockIdx.x == gridDim.x - 1) {
@@ -294,5 +310,6 @@ int og_launch_sinkhorn(const float* S, int64_t lds, const float* zdev, float dus
 
 extern "C" int og_sinkhorn(const float* S, int64_t lds, float dustbin, int32_t batch, int32_t m, int32_t n,
                            int32_t iters, float reg, float* scores, void* workspace_dev, void* stream) {
+    og_clear_status();
     return og_launch_sinkhorn(S, lds, nullptr, dustbin, batch, m, n, iters, reg, scores, workspace_dev, (hipStream_t)stream);
 }

@@ -68,7 +68,8 @@ def test_attention_vs_oracle(gpu_device, H, dh, nq, nk):
     ref = _attn_ref(q, k, v, H)
     out = ops.attention((q * dh ** -0.5).to(gpu_device), k.to(gpu_device), v.to(gpu_device), H).cpu()
     err = (out.double() - ref).abs().max().item()
-    assert err < 3e-3 * 2.0, err          # P is rounded to f16 (2^-11 relative) -> ~|v| * 5e-4 worst case
+    print(f"[attention H={H} dh={dh} nq={nq} nk={nk}] max abs err {err:.2e}")
+    assert err < 5e-5, err                # split-f16 operands: ~22 mantissa bits per product
 
 
 def test_attention_reference_fixture(gpu_device):
@@ -78,7 +79,7 @@ def test_attention_reference_fixture(gpu_device):
     tok = lambda t: t.permute(0, 3, 1, 2).reshape(B, t.shape[3], H * d).contiguous()
     out = ops.attention((tok(q) * d ** -0.5).to(gpu_device), tok(k).to(gpu_device), tok(v).to(gpu_device), H).cpu()
     ref = torch.from_numpy(z["out"]).permute(0, 3, 1, 2).reshape(B, nq, H * d)
-    assert (out - ref).abs().max() < 3e-3
+    assert (out - ref).abs().max() < 5e-5
 
 
 def test_attention_online_softmax_rescale_branch(gpu_device):
@@ -92,7 +93,7 @@ def test_attention_online_softmax_rescale_branch(gpu_device):
     k[0, 3, dh:] = q[0, 40, dh:] * 6.0           # and an early spike for (query 40, head 1): later tiles must not disturb it
     ref = _attn_ref(q, k, v, H)
     out = ops.attention((q * dh ** -0.5).to(gpu_device), k.to(gpu_device), v.to(gpu_device), H).cpu()
-    assert (out.double() - ref).abs().max() < 5e-3
+    assert (out.double() - ref).abs().max() < 5e-5
     assert torch.isfinite(out).all()
 
 
