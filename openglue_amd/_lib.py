@@ -97,6 +97,11 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7).  If OUR library were
+    # dlopen'ed first it would pull /opt/rocm's copy and the process would end up with TWO HIP runtimes
+    # (ours then sees no device: hipErrorNoDevice at the first launch).  Importing torch first makes the
+    # loader resolve our DT_NEEDED libamdhip64.so.7 to the copy torch already loaded.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} not found: build it with `python -m openglue_amd.build` "

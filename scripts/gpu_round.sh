@@ -19,7 +19,7 @@ tail -2 $OUT/bench.log
 if [ "${1:-}" != "noprof" ]; then
   echo "== rocprof"
   rm -rf $OUT/prof; mkdir -p $OUT/prof
-  timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o trace -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/rocprof.log 2>&1; echo "rocprof rc=$?" >> $OUT/rocprof.log
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/rocprof.log 2>&1; echo "rocprof rc=$?" >> $OUT/rocprof.log
   tail -2 $OUT/rocprof.log
   find $OUT/prof -name "*kernel_stats*" | head; 
   for f in $(find $OUT/prof -name "*kernel_stats.csv"); do cp $f $OUT/kernel_stats.csv; done
