@@ -132,17 +132,19 @@ size_t og_workspace_bytes(const og_shape* shape);
  * caller.  Arithmetic in double precision. */
 int og_pack_weights(const og_shape* shape, const og_params* params, void* packed_host);
 
-/* Introspection of the packed blob (offsets in floats).  All matrices are [out][in] row-major fp32.
+/* Introspection of the packed blob (offsets in floats).  All matrices are [out][in] row-major; the
+ * GNN matrices are stored as two f16 planes (suffix _h, _l; w = h + l * 2^-11; an f16 plane of n
+ * elements occupies n/2 floats), everything else as fp32.
  *   enc_w[i] [enc_out[i]][enc_k[i]], enc_b[i] [enc_out[i]]   keypoint-encoder conv i, zero-padded (k: 32 | out: mult. of 64),
  *                                                            BatchNorm i-1 folded in
- *   layer l at layer0 + l*layer_stride:  wqkv [3D][D] (q rows pre-scaled by (D/H)^-1/2), bqkv [3D],
- *                                        w0 [2D][2D] = [W0a | Wm*Wo], b0 [2D], w3 [D][2D] (BN folded), b3 [D]
+ *   layer l at layer0 + l*layer_stride:  wqkv_{h,l} [3D][D] (q rows pre-scaled by (D/H)^-1/2), bqkv [3D],
+ *                                        w0_{h,l} [2D][2D] = [W0a | Wm*Wo], b0 [2D], w3_{h,l} [D][2D] (BN folded), b3 [D]
  *   wp [D][D], bp [D], alpha [D] = sigmoid(mix_coefs), dustbin [1] */
 typedef struct og_packed_layout_t {
     int32_t n_enc;
     int32_t enc_k[OG_MAX_HIDDEN + 1], enc_out[OG_MAX_HIDDEN + 1];
     int64_t enc_w[OG_MAX_HIDDEN + 1], enc_b[OG_MAX_HIDDEN + 1];
-    int64_t layer0, layer_stride, o_wqkv, o_bqkv, o_w0, o_b0, o_w3, o_b3;
+    int64_t layer0, layer_stride, o_wqkv_h, o_wqkv_l, o_bqkv, o_w0_h, o_w0_l, o_b0, o_w3_h, o_w3_l, o_b3;
     int64_t wp, bp, alpha, dustbin, total;
 } og_packed_layout_t;
 int og_packed_layout(const og_shape* shape, og_packed_layout_t* layout);
@@ -163,7 +165,8 @@ int og_forward(const og_shape* shape, const og_inputs* in, const void* packed_de
 #define OG_STAGE_ATTENTION     2
 #define OG_STAGE_SINKHORN      3
 #define OG_STAGE_MATCHES       4
-#define OG_NUM_STAGES          5
+#define OG_STAGE_GEMM_F16X3    5   /* split-f16 GEMMs of the GNN; OG_STAGE_GEMM = the exact-fp32 ones */
+#define OG_NUM_STAGES          6
 int og_forward_profiled(const og_shape* shape, const og_inputs* in, const void* packed_dev,
                         void* workspace_dev, const og_outputs* out, void* stream,
                         float* stage_ms /*[OG_NUM_STAGES]*/, int32_t* stage_launches /*[OG_NUM_STAGES]*/);
@@ -177,12 +180,24 @@ int og_gemm_nt(const float* A, int64_t lda, int64_t strideA, const float* B, int
                const float* bias, int32_t relu, const float* res, int64_t ldr, const float* alpha,
                float scale, void* stream);
 
-/* softmax attention (attention.py:8-19) for `batch` independent problems and H heads.
- * q [batch][nq][ldq] (columns h*dh.. of row i = head h, PRE-SCALED by dh^-0.5), k, v [batch][nk][ld*],
- * out [batch][nq][ldo].  dh in {16,32,64}. */
-int og_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
-                 float* out, int64_t ldo, int32_t batch, int32_t nq, int32_t nk, int32_t num_heads,
-                 int32_t dh, void* stream);
+/* Split-f16 representation used inside the GNN: x = hi + lo * 2^-11 with hi, lo IEEE binary16
+ * (|x| < 65504).  og_split_f16 converts n (multiple of 4) fp32 values into the two planes. */
+int og_split_f16(const float* x, int64_t n, void* hi, void* lo, void* stream);
+
+/* C = epilogue(A * B^T) with A [M][K], B [N][K] given as split-f16 planes (leading dimensions in
+ * elements, multiples of 8): 3 f16 MFMAs per product, fp32 accumulate, fp32-class accuracy.
+ * v = acc + bias[col]; relu; + res[row][col] (fp32, ldr); written as fp32 (C32, may be NULL) and/or as
+ * split planes (Ch/Cl, may be NULL).  N % 4 == 0. */
+int og_gemm_nt_f16x3(const void* Ah, const void* Al, int64_t lda, const void* Bh, const void* Bl, int64_t ldb,
+                     int32_t M, int32_t N, int32_t K, const float* bias, int32_t relu, const float* res,
+                     int64_t ldr, float* C32, int64_t ldc, void* Ch, void* Cl, int64_t ldch, void* stream);
+
+/* softmax attention (attention.py:8-19) for `batch` independent problems and H heads, operands and
+ * result as split-f16 planes: q [batch][nq][ldq] (columns h*dh.. of row i = head h, PRE-SCALED by
+ * dh^-0.5), k, v [batch][nk][ld*], out [batch][nq][ldo]; leading dimensions in elements.  dh in {16,32,64}. */
+int og_attention(const void* qh, const void* ql, int64_t ldq, const void* kh, const void* kl, int64_t ldk,
+                 const void* vh, const void* vl, int64_t ldv, void* oh, void* ol, int64_t ldo, int32_t batch,
+                 int32_t nq, int32_t nk, int32_t num_heads, int32_t dh, void* stream);
 
 /* log-domain Sinkhorn with implicit dustbins (superglue.py:88-111 + optimal_transport.py:20-28):
  * S [B][m][lds] (lds % 4 == 0) is the raw score matrix, `dustbin` the learnt bin score; writes

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libopenglue_amd.so")
 OG_ABI_VERSION = 1
 OG_FLAG_RESIDUAL, OG_FLAG_USE_OFFSET, OG_FLAG_NO_DESCRIPTORS = 1, 2, 4
 OG_MAX_HIDDEN = 8
-OG_STAGES = ("encoder_input", "gemm", "attention", "sinkhorn", "matches")
+OG_STAGES = ("encoder_input", "gemm_f32", "attention", "sinkhorn", "matches", "gemm_f16x3")
 
 _ERRORS = {-1: "OG_E_INVALID (null pointer / bad size)", -2: "OG_E_SHAPE (unsupported shape)",
            -3: "OG_E_ALIGN (pointer or leading dimension not 16-byte aligned)", -4: "OG_E_FLAG (unknown flag)"}
@@ -64,7 +64,8 @@ class og_outputs(C.Structure):
 class og_packed_layout_t(C.Structure):
     _fields_ = [("n_enc", C.c_int32), ("enc_k", C.c_int32 * (OG_MAX_HIDDEN + 1)), ("enc_out", C.c_int32 * (OG_MAX_HIDDEN + 1)),
                 ("enc_w", C.c_int64 * (OG_MAX_HIDDEN + 1)), ("enc_b", C.c_int64 * (OG_MAX_HIDDEN + 1))] + \
-               [(k, C.c_int64) for k in ("layer0", "layer_stride", "o_wqkv", "o_bqkv", "o_w0", "o_b0", "o_w3", "o_b3",
+               [(k, C.c_int64) for k in ("layer0", "layer_stride", "o_wqkv_h", "o_wqkv_l", "o_bqkv", "o_w0_h", "o_w0_l", "o_b0",
+                                         "o_w3_h", "o_w3_l", "o_b3",
                                          "wp", "bp", "alpha", "dustbin", "total")]
 
 
@@ -82,7 +83,11 @@ SYMBOLS = {
                                       C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "og_gemm_nt": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _i32,
                              _vp, _i64, _vp, _f, _vp]),
-    "og_attention": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "og_split_f16": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
+    "og_gemm_nt_f16x3": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _i64, _vp, _i64,
+                                   _vp, _vp, _i64, _vp]),
+    "og_attention": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32,
+                               _i32, _vp]),
     "og_sinkhorn_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "og_sinkhorn": (C.c_int, [_vp, _i64, _f, _i32, _i32, _i32, _i32, _f, _vp, _vp, _vp]),
     "og_matches_workspace_bytes": (_sz, [_i32, _i32, _i32]),

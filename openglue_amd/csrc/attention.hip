@@ -21,6 +21,8 @@
 //                               so those keys are two 8-byte reads.  (The k order inside an MFMA is free
 //                               as long as A and B agree.)
 // Q is expected PRE-SCALED by d^-1/2 (folded into the packed q-projection weights).
+// I/O: q, k, v arrive as f16 (hi, lo) PLANES written by the producing GEMM's epilogue and O leaves as planes
+// (it is the A operand of the fc.0 GEMM), so no conversion sits on the load path of either kernel.
 #include "og_common.h"
 
 namespace {
@@ -36,7 +38,7 @@ __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
 }
 
 template <int DH>
-__global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a) {
     constexpr int DHP = DH < 32 ? 32 : DH;        // Vᵀ rows padded to a full 32-row MFMA tile
     constexpr int NDV = DHP / 32;                 // output row blocks
     constexpr int NCH = DH / 16;                  // 16-wide k chunks of the QKᵀ contraction
@@ -73,17 +75,11 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     {
         int qi = q0 + wave * 32 + l31;
         if (qi >= nq) qi = nq - 1;     // clamp: computed but never stored
-        const float* qp = a.q + (q_row0 + qi) * a.ldq + h * DH + 8 * hi;
+        const int64_t qo = (q_row0 + qi) * a.ldq + h * DH + 8 * hi;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            const f32x4 x0 = *reinterpret_cast<const f32x4*>(qp + 16 * c);
-            const f32x4 x1 = *reinterpret_cast<const f32x4*>(qp + 16 * c + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                _Float16 th, tl;
-                split_f16(x0[e], th, tl); qh[c][e] = th; ql[c][e] = tl;
-                split_f16(x1[e], th, tl); qh[c][4 + e] = th; ql[c][4 + e] = tl;
-            }
+            qh[c] = *reinterpret_cast<const f16x8*>(a.qh + qo + 16 * c);
+            ql[c] = *reinterpret_cast<const f16x8*>(a.ql + qo + 16 * c);
         }
     }
 
@@ -94,42 +90,44 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) { oh[d][r] = 0.f; ol[d][r] = 0.f; }
     float m_run = OG_NEG_INF, l_run = 0.f;
 
-    // staging maps
-    constexpr int K_KEYS_PER_PASS = 256 / D4;
-    constexpr int K_PASSES = KV_TILE / K_KEYS_PER_PASS;
-    const int k_d4 = tid % D4, k_key = tid / D4;
-    const int v_dg = tid % D4, v_kg = tid / D4;       // V: 4 keys x 4 dv per active thread
+    // staging maps: K as 16-byte chunks (8 halves), V as 4 keys x 4 dv register transposes
+    constexpr int C8 = DH / 8;                       // chunks per K row
+    constexpr int K_KEYS_PER_PASS = 256 / C8;
+    constexpr int K_PASSES = (KV_TILE + K_KEYS_PER_PASS - 1) / K_KEYS_PER_PASS;
+    const int k_c8 = tid % C8, k_key = tid / C8;
+    const int v_dg = tid % D4, v_kg = tid / D4;
     const bool v_active = v_kg < KV_TILE / 4;
 
     const int ntiles = (nk + KV_TILE - 1) / KV_TILE;
     for (int kt = 0; kt < ntiles; ++kt) {
         const int key0 = kt * KV_TILE;
-        // ---- stage K (row-major [key][d]) and Vᵀ ([dv][key]) as f16 hi/lo ----
+        // ---- stage K (row-major [key][d]) and Vᵀ ([dv][key]), hi and lo planes ----
 #pragma unroll
         for (int p = 0; p < K_PASSES; ++p) {
             const int key = k_key + p * K_KEYS_PER_PASS;
-            int gk = key0 + key; if (gk >= nk) gk = nk - 1;      // clamp (masked below)
-            const f32x4 x = *reinterpret_cast<const f32x4*>(a.k + (kv_row0 + gk) * a.ldk + h * DH + 4 * k_d4);
-            f16x4 xh, xl;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { _Float16 th, tl; split_f16(x[e], th, tl); xh[e] = th; xl[e] = tl; }
-            *reinterpret_cast<f16x4*>(&Kh[key * KW + 4 * k_d4]) = xh;
-            *reinterpret_cast<f16x4*>(&Kl[key * KW + 4 * k_d4]) = xl;
+            if (key < KV_TILE) {
+                int gk = key0 + key; if (gk >= nk) gk = nk - 1;      // clamp (masked below)
+                const int64_t go = (kv_row0 + gk) * a.ldk + h * DH + 8 * k_c8;
+                *reinterpret_cast<f16x8*>(&Kh[key * KW + 8 * k_c8]) = *reinterpret_cast<const f16x8*>(a.kh + go);
+                *reinterpret_cast<f16x8*>(&Kl[key * KW + 8 * k_c8]) = *reinterpret_cast<const f16x8*>(a.kl + go);
+            }
         }
         if (v_active) {
-            f32x4 x[4];
+            f16x4 xh[4], xl[4];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 int gk = key0 + 4 * v_kg + kk; if (gk >= nk) gk = nk - 1;
-                x[kk] = *reinterpret_cast<const f32x4*>(a.v + (kv_row0 + gk) * a.ldv + h * DH + 4 * v_dg);
+                const int64_t go = (kv_row0 + gk) * a.ldv + h * DH + 4 * v_dg;
+                xh[kk] = *reinterpret_cast<const f16x4*>(a.vh + go);
+                xl[kk] = *reinterpret_cast<const f16x4*>(a.vl + go);
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {       // dv = 4*v_dg + e : 4 consecutive keys
-                f16x4 xh, xl;
+                f16x4 th, tl;
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) { _Float16 th, tl; split_f16(x[kk][e], th, tl); xh[kk] = th; xl[kk] = tl; }
-                *reinterpret_cast<f16x4*>(&Vh[(4 * v_dg + e) * VW + 4 * v_kg]) = xh;
-                *reinterpret_cast<f16x4*>(&Vl[(4 * v_dg + e) * VW + 4 * v_kg]) = xl;
+                for (int kk = 0; kk < 4; ++kk) { th[kk] = xh[kk][e]; tl[kk] = xl[kk][e]; }
+                *reinterpret_cast<f16x4*>(&Vh[(4 * v_dg + e) * VW + 4 * v_kg]) = th;
+                *reinterpret_cast<f16x4*>(&Vl[(4 * v_dg + e) * VW + 4 * v_kg]) = tl;
             }
         }
         __syncthreads();
@@ -213,17 +211,23 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     const float inv = 1.f / l_tot;
     const int qi = q0 + wave * 32 + l31;
     if (qi < nq) {
-        float* op = a.out + (q_row0 + qi) * a.ldo + h * DH;
+        const int64_t oo = (q_row0 + qi) * a.ldo + h * DH;
 #pragma unroll
         for (int d = 0; d < NDV; ++d)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int dv = d * 32 + 8 * g4 + 4 * hi;
                 if (dv < DH) {
-                    f32x4 o;
+                    f16x4 vh, vl;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (oh[d][4 * g4 + e] + ol[d][4 * g4 + e] * LO_INV) * inv;
-                    *reinterpret_cast<f32x4*>(op + dv) = o;
+                    for (int e = 0; e < 4; ++e) {
+                        const float o = (oh[d][4 * g4 + e] + ol[d][4 * g4 + e] * LO_INV) * inv;
+                        _Float16 th, tl;
+                        split_f16(o, th, tl);
+                        vh[e] = th; vl[e] = tl;
+                    }
+                    *reinterpret_cast<f16x4*>(a.oh + oo + dv) = vh;
+                    *reinterpret_cast<f16x4*>(a.ol + oo + dv) = vl;
                 }
             }
     }
@@ -232,9 +236,11 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
 }  // namespace
 
 int og_launch_attention(const AttnArgs& a, hipStream_t stream) {
-    if (!a.q || !a.k || !a.v || !a.out || a.nz <= 0 || a.num_heads <= 0) return OG_E_INVALID;
-    if ((a.ldq & 3) || (a.ldk & 3) || (a.ldv & 3) || (a.ldo & 3)) return OG_E_ALIGN;
-    if (((uintptr_t)a.q & 15) || ((uintptr_t)a.k & 15) || ((uintptr_t)a.v & 15) || ((uintptr_t)a.out & 15)) return OG_E_ALIGN;
+    if (!a.qh || !a.ql || !a.kh || !a.kl || !a.vh || !a.vl || !a.oh || !a.ol || a.nz <= 0 || a.num_heads <= 0) return OG_E_INVALID;
+    if ((a.ldq & 7) || (a.ldk & 7) || (a.ldv & 7) || (a.ldo & 3)) return OG_E_ALIGN;
+    const void* ps[8] = {a.qh, a.ql, a.kh, a.kl, a.vh, a.vl, a.oh, a.ol};
+    for (int i = 0; i < 8; ++i)
+        if ((uintptr_t)ps[i] & 15) return OG_E_ALIGN;
     int nqmax = 0;
     for (int g = 0; g < 2; ++g) {
         const bool used = g == 0 ? a.split > 0 : a.split < a.nz;
@@ -252,12 +258,15 @@ int og_launch_attention(const AttnArgs& a, hipStream_t stream) {
     return og_launch_status();
 }
 
-extern "C" int og_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
-                            int64_t ldv, float* out, int64_t ldo, int32_t batch, int32_t nq, int32_t nk,
-                            int32_t num_heads, int32_t dh, void* stream) {
+extern "C" int og_attention(const void* qh, const void* ql, int64_t ldq, const void* kh, const void* kl, int64_t ldk,
+                            const void* vh, const void* vl, int64_t ldv, void* oh, void* ol, int64_t ldo, int32_t batch,
+                            int32_t nq, int32_t nk, int32_t num_heads, int32_t dh, void* stream) {
     og_clear_status();
     AttnArgs a{};
-    a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.out = out; a.ldo = ldo;
+    a.qh = (const _Float16*)qh; a.ql = (const _Float16*)ql; a.ldq = ldq;
+    a.kh = (const _Float16*)kh; a.kl = (const _Float16*)kl; a.ldk = ldk;
+    a.vh = (const _Float16*)vh; a.vl = (const _Float16*)vl; a.ldv = ldv;
+    a.oh = (_Float16*)oh; a.ol = (_Float16*)ol; a.ldo = ldo;
     a.nz = batch; a.num_heads = num_heads; a.dh = dh; a.split = batch;
     a.q_base[0] = 0; a.q_step[0] = nq; a.kv_base[0] = 0; a.kv_step[0] = nk;
     a.nq[0] = nq; a.nk[0] = nk;

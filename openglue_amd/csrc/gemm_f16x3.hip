@@ -30,7 +30,7 @@ constexpr float LO_INV = 1.f / 2048.f;
 constexpr float LO_SCALE = 2048.f;
 
 template <int OC>
-__global__ __launch_bounds__(256) void gemm_nt_f16x3_kernel(GemmHArgs g, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmHArgs g, int tiles_m, int tiles_n) {
     constexpr int TI = OC / 64;            // MFMA tiles per wave along channels
     constexpr int WP = OC / 64;            // staging passes for W (64 rows per pass)
     __shared__ __attribute__((aligned(16))) _Float16 Xh[TOK * LW];

@@ -52,14 +52,28 @@ struct GemmArgs {
     const float* alpha;       // [N] or null: v = alpha*v + (1-alpha)*res
     float scale;
     float* Ct; int64_t ldct, strideCt; int ct_rows;   // optional transposed copy: Ct[row / ct_rows][col][row % ct_rows]
+    _Float16* Ch; _Float16* Cl; int64_t ldch;         // optional split-f16 copy (hi, lo*2^11 planes), batch == 1 only
 };
 int og_launch_gemm(const GemmArgs& a, hipStream_t stream);
 
+// split-f16 GEMM (gemm_f16x3.hip): tokens A [M][K] and weights B [N][K] as (hi, lo) f16 planes
+struct GemmHArgs {
+    const _Float16* Ah; const _Float16* Al; int64_t lda;
+    const _Float16* Bh; const _Float16* Bl; int64_t ldb;
+    int M, N, K;
+    const float* bias; int relu;
+    const float* res; int64_t ldr;            // fp32 residual [M][N] (may alias C32)
+    float* C32; int64_t ldc;                  // optional fp32 output
+    _Float16* Ch; _Float16* Cl; int64_t ldch; // optional split-f16 output planes
+};
+int og_launch_gemm_f16x3(const GemmHArgs& a, hipStream_t stream);
+int og_launch_split_f16(const float* x, int64_t n, void* hi, void* lo, hipStream_t stream);
+
 struct AttnArgs {
-    const float* q; int64_t ldq;
-    const float* k; int64_t ldk;
-    const float* v; int64_t ldv;
-    float* out; int64_t ldo;
+    const _Float16* qh; const _Float16* ql; int64_t ldq;     // leading dimensions in halves
+    const _Float16* kh; const _Float16* kl; int64_t ldk;
+    const _Float16* vh; const _Float16* vl; int64_t ldv;
+    _Float16* oh; _Float16* ol; int64_t ldo;
     // problem z in [0, nz): rows of q/out start at q_row0(z), rows of k/v at kv_row0(z)
     int nz, num_heads, dh;
     int split;                // problems z < split use geometry A, the others geometry B

@@ -28,11 +28,15 @@ struct SinkhornWs {
 };
 
 __host__ __device__ inline int sk_cpt(int n) { return n <= 1024 ? 1 : (n <= 2048 ? 2 : 4); }
+// rows-per-wave sweep (n <= 2048): float4 chunks per lane and rows per block
+constexpr int SK_RW = 8;                                            // rows per wave -> 32 rows per block
+inline int sk_cpl(int n) { return n <= 256 ? 1 : (n <= 512 ? 2 : (n <= 1024 ? 4 : 8)); }
+inline bool sk_rows_variant(int n) { return n <= 2048; }
 
 static SinkhornWs sk_layout(void* ws, int B, int m, int n) {
     SinkhornWs w{};
     w.CPT = sk_cpt(n);
-    w.R = 16 / w.CPT;
+    w.R = sk_rows_variant(n) ? 4 * SK_RW : 16 / w.CPT;
     w.RB = (m + w.R - 1) / w.R;
     w.ldu = (int)og_round_up(m + 1, 4);
     w.ldv = (int)og_round_up(n + 1, 4);
@@ -175,6 +179,127 @@ __global__ __launch_bounds__(256) void sinkhorn_sweep_kernel(const float* __rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Sweep, n <= 2048: "a wave owns rows".  Block = 4 waves x RW rows; a wave streams its rows in groups of
+// RG, lane l holds columns 4l + 256k + e (k < CPL).  Row log-sum-exps are wave-local (no LDS, no barrier);
+// the column (max, sum-exp) partials are carried ONLINE in registers across the wave's row groups and the
+// four waves are merged once per block through LDS.  Row blocks of 4*RW rows -> RB partials per column.
+template <int CPL, int RG, int RW>
+__global__ __launch_bounds__(256) void sinkhorn_sweep_rows_kernel(const float* __restrict__ S, int64_t lds, int M, int N,
+                                                                  const float* __restrict__ zdev, float zhost,
+                                                                  float inv_reg, float la,
+                                                                  const float* __restrict__ v_in, int ldv,
+                                                                  float* __restrict__ u, int ldu,
+                                                                  float* __restrict__ pm, float* __restrict__ ps,
+                                                                  int ldp, int RB) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // [4 waves][2][256*CPL*4] (max | sum)
+    constexpr int NC = 256 * CPL;                                   // columns covered by a wave
+    const int b = blockIdx.y, rb = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float zr = (zdev ? zdev[0] : zhost) * inv_reg;
+    const float* vb = v_in + (int64_t)b * ldv;
+    const float dcol = zr + vb[N];
+
+    float vv[CPL][4], cm[CPL][4], cs[CPL][4];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        const int c0 = 4 * lane + 256 * k;
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if (c0 < N) t = *reinterpret_cast<const f32x4*>(vb + c0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { vv[k][e] = t[e]; cm[k][e] = OG_NEG_INF; cs[k][e] = 0.f; }
+    }
+
+    const int wrow0 = rb * (4 * RW) + wave * RW;
+#pragma unroll 1
+    for (int g0 = 0; g0 < RW; g0 += RG) {
+        const int row0 = wrow0 + g0;
+        if (row0 >= M) break;                                       // wave-uniform
+        float x[RG][CPL][4];
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+            const int row = row0 + r;
+            const float* sp = S + ((int64_t)b * M + row) * lds;
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                const int c0 = 4 * lane + 256 * k;
+                if (row < M && c0 < N) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(sp + c0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[r][k][e] = (c0 + e < N) ? t[e] * inv_reg : OG_NEG_INF;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[r][k][e] = OG_NEG_INF;
+                }
+            }
+        }
+        // row log-sum-exp (wave-local) -> u for the RG rows
+        float ur[RG];
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+            float mx = OG_NEG_INF;
+#pragma unroll
+            for (int k = 0; k < CPL; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) mx = fmaxf(mx, x[r][k][e] + vv[k][e]);
+            mx = fmaxf(wave_max(mx), dcol);
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < CPL; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sum += __expf(x[r][k][e] + vv[k][e] - mx);
+            sum = wave_sum(sum) + __expf(dcol - mx);
+            ur[r] = la - (mx + __logf(sum));
+            if (lane == 0 && row0 + r < M) u[(int64_t)b * ldu + row0 + r] = ur[r];
+        }
+        // online column partials with the new u
+#pragma unroll
+        for (int k = 0; k < CPL; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float gm = cm[k][e];
+#pragma unroll
+                for (int r = 0; r < RG; ++r) gm = fmaxf(gm, x[r][k][e] + ur[r]);
+                float acc = cs[k][e] * __expf(cm[k][e] - gm);        // first group: 0 * exp(-inf - gm) = 0
+#pragma unroll
+                for (int r = 0; r < RG; ++r) acc += __expf(x[r][k][e] + ur[r] - gm);
+                // columns >= N: gm = -inf -> NaN, never stored (guarded below)
+                cm[k][e] = gm; cs[k][e] = acc;
+            }
+    }
+
+    // merge the four waves (a wave with no valid row contributes (-inf, 0))
+    float* smm = sm + (size_t)wave * 2 * NC;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        const int c0 = 4 * lane + 256 * k;
+        *reinterpret_cast<f32x4*>(smm + c0) = f32x4{cm[k][0], cm[k][1], cm[k][2], cm[k][3]};
+        *reinterpret_cast<f32x4*>(smm + NC + c0) = f32x4{cs[k][0], cs[k][1], cs[k][2], cs[k][3]};
+    }
+    __syncthreads();
+    float* pmb = pm + ((int64_t)b * RB + rb) * ldp;
+    float* psb = ps + ((int64_t)b * RB + rb) * ldp;
+    for (int c0 = 4 * tid; c0 < N; c0 += 1024) {
+        f32x4 wm[4], wsum[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            wm[w] = *reinterpret_cast<const f32x4*>(sm + (size_t)w * 2 * NC + c0);
+            wsum[w] = *reinterpret_cast<const f32x4*>(sm + (size_t)w * 2 * NC + NC + c0);
+        }
+        f32x4 om, os;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float mx = fmaxf(fmaxf(wm[0][e], wm[1][e]), fmaxf(wm[2][e], wm[3][e]));
+            float acc = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) acc += (wm[w][e] == OG_NEG_INF) ? 0.f : wsum[w][e] * __expf(wm[w][e] - mx);
+            om[e] = mx; os[e] = acc;
+        }
+        *reinterpret_cast<f32x4*>(pmb + c0) = om;
+        *reinterpret_cast<f32x4*>(psb + c0) = os;
+    }
+}
+
 // Combine: grid (ceil((N+1)/256), B).  Finishes iteration t: dustbin-row u, all v.
 __global__ __launch_bounds__(256) void sinkhorn_combine_kernel(int M, int N, const float* __restrict__ zdev,
                                                                float zhost, float inv_reg, float la_bin, float lb,
@@ -272,7 +397,7 @@ void launch_sweep(const float* S, int64_t lds, int B, int m, int n, const float*
 
 extern "C" size_t og_sinkhorn_workspace_bytes(int32_t batch, int32_t m, int32_t n) {
     if (batch <= 0 || m <= 0 || n <= 0 || n > 4096) return 0;
-    const int cpt = sk_cpt(n), R = 16 / cpt, RB = (m + R - 1) / R;
+    const int cpt = sk_cpt(n), R = sk_rows_variant(n) ? 4 * SK_RW : 16 / cpt, RB = (m + R - 1) / R;
     const int64_t ldu = og_round_up(m + 1, 4), ldv = og_round_up(n + 1, 4), ldp = og_round_up(n, 4);
     const int64_t floats = (int64_t)batch * (ldu + 2 * ldv) + 4 + 2 * (int64_t)batch * RB * ldp;
     return (size_t)floats * sizeof(float);
@@ -294,6 +419,19 @@ int og_launch_sinkhorn(const float* S, int64_t lds, const float* zdev, float dus
     if (e != hipSuccess) return (int)e;
     int cur = 0;
     for (int it = 0; it < iters; ++it) {
+        if (sk_rows_variant(n)) {
+            const dim3 grid(w.RB, B), block(256);
+#define OG_SWEEP_ROWS(CPL, RG)                                                                                          \
+    hipLaunchKernelGGL((sinkhorn_sweep_rows_kernel<CPL, RG, SK_RW>), grid, block, sizeof(float) * 4 * 2 * 256 * CPL, st, S,     \
+                       lds, m, n, zdev, dustbin, inv_reg, la, w.v[cur], w.ldv, w.u, w.ldu, w.pm, w.ps, w.ldp, w.RB)
+            switch (sk_cpl(n)) {
+                case 1: OG_SWEEP_ROWS(1, 4); break;
+                case 2: OG_SWEEP_ROWS(2, 4); break;
+                case 4: OG_SWEEP_ROWS(4, 4); break;
+                default: OG_SWEEP_ROWS(8, 2); break;
+            }
+#undef OG_SWEEP_ROWS
+        } else
         switch (w.CPT) {
             case 1: launch_sweep<1>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, w.v[cur], w, st); break;
             case 2: launch_sweep<2>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, w.v[cur], w, st); break;

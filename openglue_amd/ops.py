@@ -48,18 +48,61 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
     return out
 
 
+def split_f16(x: torch.Tensor):
+    """fp32 tensor -> (hi, lo) float16 planes with x = hi + lo * 2^-11 (the GNN's operand format)."""
+    lib = _lib.load()
+    x = _req(x, "x")
+    if x.numel() % 4:
+        raise ValueError("split_f16: numel must be a multiple of 4")
+    hi = torch.empty(x.shape, device=x.device, dtype=torch.float16)
+    lo = torch.empty(x.shape, device=x.device, dtype=torch.float16)
+    _lib.check(lib.og_split_f16(x.data_ptr(), x.numel(), hi.data_ptr(), lo.data_ptr(), _stream()), "og_split_f16")
+    return hi, lo
+
+
+def merge_f16(hi: torch.Tensor, lo: torch.Tensor) -> torch.Tensor:
+    """Inverse of split_f16 (plain torch; for tests and debugging only)."""
+    return hi.float() + lo.float() * (1.0 / 2048.0)
+
+
+def gemm_nt_f16x3(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False,
+                  res: Optional[torch.Tensor] = None, want_planes: bool = False):
+    """epilogue(a @ b^T) through the split-f16 3-pass MFMA kernel: a [M,K], b [N,K] fp32 are split on the
+    device first.  Returns the fp32 result, plus the (hi, lo) output planes if want_planes."""
+    lib = _lib.load()
+    a, b = _req(a, "a"), _req(b, "b")
+    M, K = a.shape
+    N = b.shape[0]
+    ah, al = split_f16(a)
+    bh, bl = split_f16(b)
+    out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    ch = cl = None
+    if want_planes:
+        ch = torch.empty(M, N, device=a.device, dtype=torch.float16)
+        cl = torch.empty(M, N, device=a.device, dtype=torch.float16)
+    if bias is not None: bias = _req(bias, "bias")
+    if res is not None: res = _req(res, "res")
+    rc = lib.og_gemm_nt_f16x3(ah.data_ptr(), al.data_ptr(), K, bh.data_ptr(), bl.data_ptr(), K, M, N, K, _ptr(bias),
+                              int(relu), _ptr(res), N, out.data_ptr(), N, _ptr(ch), _ptr(cl), N, _stream())
+    _lib.check(rc, "og_gemm_nt_f16x3")
+    return (out, ch, cl) if want_planes else out
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int) -> torch.Tensor:
-    """Multi-head softmax attention on token-major tensors q [Z,nq,D], k,v [Z,nk,D]; head h owns
-    channels h*d..(h+1)*d-1.  q must already carry the d^-1/2 scale."""
+    """Multi-head softmax attention on token-major fp32 tensors q [Z,nq,D], k,v [Z,nk,D]; head h owns
+    channels h*d..(h+1)*d-1.  q must already carry the d^-1/2 scale.  Operands are converted to the
+    kernel's split-f16 planes on the device; the result planes are merged back to fp32."""
     lib = _lib.load()
     q, k, v = _req(q, "q"), _req(k, "k"), _req(v, "v")
     Z, nq, D = q.shape
     nk = k.shape[1]
-    out = torch.empty_like(q)
-    rc = lib.og_attention(q.data_ptr(), D, k.data_ptr(), D, v.data_ptr(), D, out.data_ptr(), D, Z, nq, nk,
-                          num_heads, D // num_heads, _stream())
+    (qh, ql), (kh, kl), (vh, vl) = split_f16(q), split_f16(k), split_f16(v)
+    oh = torch.empty(Z, nq, D, device=q.device, dtype=torch.float16)
+    ol = torch.empty_like(oh)
+    rc = lib.og_attention(qh.data_ptr(), ql.data_ptr(), D, kh.data_ptr(), kl.data_ptr(), D, vh.data_ptr(), vl.data_ptr(), D,
+                          oh.data_ptr(), ol.data_ptr(), D, Z, nq, nk, num_heads, D // num_heads, _stream())
     _lib.check(rc, "og_attention")
-    return out
+    return merge_f16(oh, ol)
 
 
 def sinkhorn(S: torch.Tensor, dustbin: float, iters: int, reg: float = 1.0) -> torch.Tensor:

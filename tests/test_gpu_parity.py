@@ -55,6 +55,34 @@ def test_gemm_nt_batched_scores_shape(gpu_device):
     assert (out.double() - ref).abs().max() < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 192, 96), (77, 64, 64), (1000, 768, 256), (4099, 512, 512)])
+def test_gemm_nt_f16x3_fp32_class_accuracy(gpu_device, M, N, K):
+    """The split-f16 3-pass GEMM must be as accurate as an fp32 GEMM (both measured against float64)."""
+    g = torch.Generator().manual_seed(M * 3 + K)
+    a, b = _rand(g, M, K, scale=3.0), _rand(g, N, K, scale=0.05)
+    bias, res = _rand(g, N), _rand(g, M, N)
+    ref = a.double() @ b.double().T
+    dev = lambda t: t.to(gpu_device)
+    fp32_err = ((a @ b.T).double() - ref).abs().max().item()
+    out = ops.gemm_nt_f16x3(dev(a), dev(b)).cpu()
+    err = (out.double() - ref).abs().max().item()
+    print(f"[f16x3 {M}x{N}x{K}] err {err:.2e} (fp32 CPU GEMM err {fp32_err:.2e})")
+    assert err < max(2.0 * fp32_err, 1e-6)
+    out, ch, cl = ops.gemm_nt_f16x3(dev(a), dev(b), bias=dev(bias), relu=True, res=dev(res), want_planes=True)
+    want = torch.relu(ref + bias.double()) + res.double()
+    assert (out.cpu().double() - want).abs().max() < max(2.0 * fp32_err, 1e-6)
+    merged = ops.merge_f16(ch, cl).cpu()
+    assert (merged.double() - want).abs().max() < max(2.0 * fp32_err, 1e-6) + 1e-6 * want.abs().max()
+
+
+def test_split_f16_roundtrip(gpu_device):
+    g = torch.Generator().manual_seed(1)
+    x = torch.cat([_rand(g, 1000, scale=s) for s in (1e-3, 1.0, 50.0, 3000.0)])
+    hi, lo = ops.split_f16(x.to(gpu_device))
+    back = ops.merge_f16(hi, lo).cpu()
+    assert ((back - x).abs() <= 2.0 ** -21 * x.abs() + 1e-9).all()
+
+
 # ----------------------------------------------------------------------------- attention
 def _attn_ref(q, k, v, H):
     return orc.softmax_attention(q.double(), k.double(), v.double(), H)     # applies d^-1/2 itself
