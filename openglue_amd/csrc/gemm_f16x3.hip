@@ -19,6 +19,8 @@
 // and all stores (fp32 float4 / f16x4 planes) are vectorised along the channel axis.
 // v_mfma_f32_32x32x16_f16; block tile 128 tokens x OC channels x 32 k, 4 waves as 2x2; LDS rows of 40
 // halves (80 B) keep every 16-lane ds_read_b128 group on 16 distinct 4-bank slots.
+#include <stdlib.h>
+
 #include "og_common.h"
 
 namespace {
@@ -28,15 +30,113 @@ constexpr int BKH = 32;          // k per tile (halves)
 constexpr int LW = BKH + 8;      // padded LDS row (halves)
 constexpr float LO_INV = 1.f / 2048.f;
 constexpr float LO_SCALE = 2048.f;
+constexpr int EPI_SLAB = 64 * 144;   // per-wave epilogue scratch: 64 rows x (128 B + 16 B pad)
+
+// Epilogue.  After the MFMAs a lane owns ONE token and 4 consecutive channels per register group; storing
+// that directly means 8-byte pieces scattered over 32 rows per instruction (measured: 113 of 210 us of the
+// qkv GEMM).  Instead every wave transposes its 64 token x OC/2 channel tile through its own LDS slab and
+// writes whole rows: 16 B per lane, 128-byte (or 64-byte) contiguous row segments.
+// `slab` = this wave's private LDS scratch (EPI_SLAB bytes), free once all waves passed the last
+// k-tile barrier.  No block barrier is needed: a wave only re-reads what it wrote itself.
+template <int OC, int TI>
+__device__ __forceinline__ void gemm_f16x3_epilogue(const GemmHArgs& g, f32x16 (&acc0)[TI][2], f32x16 (&acc1)[TI][2], int t0,
+                                                    int n0, int wt, int wo, int lane, char* slab) {
+    constexpr int OCW = OC / 2;                 // channels of a wave tile
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int tok0 = t0 + wt * 64;              // first token of the wave tile
+    const int oc0 = n0 + wo * OCW;              // first channel of the wave tile
+
+    // finish the arithmetic in registers: v = acc0 + acc1 * 2^-11 + bias (+relu) (+res)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int tok = tok0 + j * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int oc = oc0 + i * 32 + 8 * q + 4 * hi;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc0[i][j][4 * q + e] + acc1[i][j][4 * q + e] * LO_INV;
+                if (g.bias && oc < g.N) v += *reinterpret_cast<const f32x4*>(g.bias + oc);
+                if (g.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (g.res && tok < g.M && oc < g.N) v += *reinterpret_cast<const f32x4*>(g.res + (int64_t)tok * g.ldr + oc);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc0[i][j][4 * q + e] = v[e];
+            }
+    }
+
+    // ---- split-f16 planes: two passes (hi, lo) through a [64 tok][OCW halves] slab ----
+    if (g.Ch) {
+        constexpr int ROWB = OCW * 2 + 16;              // padded LDS row (bytes), 16-byte aligned
+        constexpr int CPR = OCW * 2 / 16;               // 16-byte chunks per row
+        constexpr int RPI = 64 / CPR;                   // rows per store instruction
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f16x4 t;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float v = acc0[i][j][4 * q + e];
+                            const _Float16 h = (_Float16)v;
+                            t[e] = pass == 0 ? h : (_Float16)((v - (float)h) * LO_SCALE);
+                        }
+                        *reinterpret_cast<f16x4*>(slab + (j * 32 + l31) * ROWB + (i * 32 + 8 * q + 4 * hi) * 2) = t;
+                    }
+            _Float16* dst = pass == 0 ? g.Ch : g.Cl;
+#pragma unroll
+            for (int it = 0; it < 64 / RPI; ++it) {
+                const int r = it * RPI + lane / CPR, c = lane % CPR;
+                const f16x8 t = *reinterpret_cast<const f16x8*>(slab + r * ROWB + c * 16);
+                const int tok = tok0 + r, oc = oc0 + c * 8;
+                if (tok < g.M && oc < g.N) *reinterpret_cast<f16x8*>(dst + (int64_t)tok * g.ldch + oc) = t;
+            }
+        }
+    }
+    // ---- fp32 output: one pass per 32-channel half through a [64 tok][32 floats] slab ----
+    if (g.C32) {
+        constexpr int ROWB = 32 * 4 + 16;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 t;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = acc0[i][j][4 * q + e];
+                    *reinterpret_cast<f32x4*>(slab + (j * 32 + l31) * ROWB + (8 * q + 4 * hi) * 4) = t;
+                }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int r = it * 8 + (lane >> 3), c = lane & 7;
+                const f32x4 t = *reinterpret_cast<const f32x4*>(slab + r * ROWB + c * 16);
+                const int tok = tok0 + r, oc = oc0 + i * 32 + c * 4;
+                if (tok < g.M && oc < g.N) *reinterpret_cast<f32x4*>(g.C32 + (int64_t)tok * g.ldc + oc) = t;
+            }
+        }
+    }
+}
 
 template <int OC>
 __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmHArgs g, int tiles_m, int tiles_n) {
     constexpr int TI = OC / 64;            // MFMA tiles per wave along channels
     constexpr int WP = OC / 64;            // staging passes for W (64 rows per pass)
-    __shared__ __attribute__((aligned(16))) _Float16 Xh[TOK * LW];
-    __shared__ __attribute__((aligned(16))) _Float16 Xl[TOK * LW];
-    __shared__ __attribute__((aligned(16))) _Float16 Wh[OC * LW];
-    __shared__ __attribute__((aligned(16))) _Float16 Wl[OC * LW];
+    constexpr int STG = (2 * TOK + 2 * OC) * LW * 2;                      // staging bytes
+    constexpr int EPI = 4 * EPI_SLAB;                                     // epilogue slabs (4 waves)
+    __shared__ __attribute__((aligned(16))) char smem[STG > EPI ? STG : EPI];
+    _Float16* Xh = reinterpret_cast<_Float16*>(smem);
+    _Float16* Xl = Xh + TOK * LW;
+    _Float16* Wh = Xl + TOK * LW;
+    _Float16* Wl = Wh + OC * LW;
 
     const int id = blockIdx.x;
     const int xcd = id & 7, local = id >> 3;
@@ -100,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmHArgs g, int 
     for (int kt = 0; kt < nk; ++kt) {
         store_tiles();
         __syncthreads();
-        if (kt + 1 < nk) load_tiles((kt + 1) * BKH);
+        if (kt + 1 < nk && !(g.ablate & 4)) load_tiles((kt + 1) * BKH);
 #pragma unroll
         for (int ks = 0; ks < BKH / 16; ++ks) {
             f16x8 wh[TI], wl[TI], xh[2], xl[2];
@@ -114,6 +214,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmHArgs g, int 
                 xh[j] = *reinterpret_cast<const f16x8*>(&Xh[x_off + j * 32 * LW + 16 * ks]);
                 xl[j] = *reinterpret_cast<const f16x8*>(&Xl[x_off + j * 32 * LW + 16 * ks]);
             }
+            if (g.ablate & 2) {          // keep the fragment reads alive, skip the matrix pipe
+#pragma unroll
+                for (int i = 0; i < TI; ++i) asm volatile("" ::"v"(wh[i]), "v"(wl[i]));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(xh[j]), "v"(xl[j]));
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -125,44 +232,146 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmHArgs g, int 
         }
         __syncthreads();
     }
-
-    // ---- epilogue: lane = one token, 4 consecutive channels per register group ----
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int tok = t0 + wt * 64 + j * 32 + l31;
-        if (tok >= g.M) continue;
+    if (g.ablate & 1) {                  // no epilogue: keep the accumulators alive with a never-taken store
+        float t = 0.f;
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int oc = n0 + wo * (OC / 2) + i * 32 + 8 * q + 4 * hi;
-                if (oc >= g.N) continue;
-                f32x4 v;
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc0[i][j][4 * q + e] + acc1[i][j][4 * q + e] * LO_INV;
-                if (g.bias) {
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(g.bias + oc);
-                    v += b;
-                }
-                if (g.relu) {
+                for (int r = 0; r < 16; ++r) t += acc0[i][j][r] + acc1[i][j][r];
+        if (t == 1.2345e30f && g.C32) g.C32[0] = t;
+        return;
+    }
+
+    gemm_f16x3_epilogue<OC, TI>(g, acc0, acc1, t0, n0, wt, wo, lane, smem + wave * EPI_SLAB);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Variant 2: the same tile and MFMA schedule, but operands reach LDS by LDS-DMA (global_load_lds, 16 B per
+// lane, no staging registers) into an NS-deep ring, so NS-1 k-tiles of loads are in flight: the activation
+// panel is streamed from HBM / Infinity Cache (1-2 us latency) while one k-tile of MFMAs lasts ~0.35 us, so
+// the one-tile-deep register prefetch of variant 1 leaves the matrix pipe idle ~80 % of the time.
+// LDS rows are unpadded (64 B = 4 chunks of 16 B; an LDS-DMA writes wave-uniform base + lane*16), bank
+// conflicts are avoided by an XOR swizzle applied on the SOURCE address and again on the fragment read:
+// chunk c of tile row r lives at chunk position c ^ ((r >> 2) & 3).
+// Waits are counted by hand: s_waitcnt vmcnt(N) + raw s_barrier (a __syncthreads() would drain the ring).
+typedef __attribute__((address_space(3))) void og_lds_void;
+typedef __attribute__((address_space(1))) const void og_glb_void;
+
+template <int OC, int NS>
+__global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void gemm_nt_f16x3_glds_kernel(GemmHArgs g, int tiles_m, int tiles_n) {
+    constexpr int TI = OC / 64;
+    constexpr int XB = TOK * 64;               // bytes of one X plane per stage
+    constexpr int WB = OC * 64;
+    constexpr int STAGE = 2 * XB + 2 * WB;
+    constexpr int PIECES = STAGE / 1024;       // 1 KiB = 16 rows x 64 B per wave-instruction
+    constexpr int PPW = PIECES / 4;            // pieces per wave per stage
+    __shared__ __attribute__((aligned(16))) char smem[NS * STAGE > 4 * EPI_SLAB ? NS * STAGE : 4 * EPI_SLAB];
+
+    const int id = blockIdx.x;
+    const int xcd = id & 7, local = id >> 3;
+    const int tm = (local / tiles_n) * 8 + xcd;
+    const int tn = local % tiles_n;
+    if (tm >= tiles_m) return;
+    const int t0 = tm * TOK, n0 = tn * OC;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wt = wave >> 1, wo = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    // ---- this wave's DMA pieces (1 KiB = 16 rows x 64 B each): rows [32w, 32w+32) of both X planes and rows
+    //      [w*OC/4, (w+1)*OC/4) of both W planes -> 4 + OC/32 pieces per wave per stage ----
+    constexpr int WPC = OC / 64;                           // W pieces per plane per wave
+    static_assert(PPW == 4 + 2 * WPC, "piece accounting");
+    const char* src[PPW];
+    {
+        const int rl = lane >> 2;                          // row inside the 16-row piece
+        const int cl = (lane & 3) ^ ((lane >> 4) & 3);     // logical chunk fetched into physical chunk lane&3
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                }
-                if (g.res) v += *reinterpret_cast<const f32x4*>(g.res + (int64_t)tok * g.ldr + oc);
-                if (g.C32) *reinterpret_cast<f32x4*>(g.C32 + (int64_t)tok * g.ldc + oc) = v;
-                if (g.Ch) {
-                    f16x4 vh, vl;
+        for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const _Float16 h = (_Float16)v[e];
-                        vh[e] = h;
-                        vl[e] = (_Float16)((v[e] - (float)h) * LO_SCALE);
-                    }
-                    *reinterpret_cast<f16x4*>(g.Ch + (int64_t)tok * g.ldch + oc) = vh;
-                    *reinterpret_cast<f16x4*>(g.Cl + (int64_t)tok * g.ldch + oc) = vl;
-                }
+            for (int h = 0; h < 2; ++h) {
+                int row = t0 + wave * 32 + h * 16 + rl; if (row >= g.M) row = g.M - 1;
+                src[pl * 2 + h] = reinterpret_cast<const char*>((pl ? g.Al : g.Ah) + (int64_t)row * g.lda) + cl * 16;
+            }
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int h = 0; h < WPC; ++h) {
+                int row = n0 + wave * (OC / 4) + h * 16 + rl; if (row >= g.N) row = g.N - 1;
+                src[4 + pl * WPC + h] = reinterpret_cast<const char*>((pl ? g.Bl : g.Bh) + (int64_t)row * g.ldb) + cl * 16;
             }
     }
+    auto issue_stage = [&](int kt) {
+        char* sbase = smem + (kt % NS) * STAGE;
+        const int64_t koff = (int64_t)kt * 64;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                __builtin_amdgcn_global_load_lds((og_glb_void*)(src[pl * 2 + h] + koff),
+                                                 (og_lds_void*)(sbase + pl * XB + (wave * 32 + h * 16) * 64), 16, 0, 0);
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int h = 0; h < WPC; ++h)
+                __builtin_amdgcn_global_load_lds((og_glb_void*)(src[4 + pl * WPC + h] + koff),
+                                                 (og_lds_void*)(sbase + 2 * XB + pl * WB + (wave * (OC / 4) + h * 16) * 64), 16, 0, 0);
+    };
+
+    f32x16 acc0[TI][2], acc1[TI][2];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[i][j][r] = 0.f; acc1[i][j][r] = 0.f; }
+
+    const int swz = (l31 >> 2) & 3;
+    const int x_row = (wt * 64 + l31) * 64;            // byte offset of this lane's X row (j = 0)
+    const int w_row = (wo * (OC / 2) + l31) * 64;
+
+    const int nk = g.K / BKH;
+    const int pre = nk < NS - 1 ? nk : NS - 1;
+    for (int kt = 0; kt < pre; ++kt) issue_stage(kt);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int issued = (kt + NS - 1 < nk) ? kt + NS - 1 : nk;
+        const int ahead = issued - kt - 1;              // later stages that may stay in flight
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + NS - 1 < nk) issue_stage(kt + NS - 1);   // slot (kt-1)%NS: every wave is past its reads of k-tile kt-1
+        const char* sb = smem + (kt % NS) * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < BKH / 16; ++ks) {
+            const int coff = ((2 * ks + hi) ^ swz) * 16;
+            f16x8 wh[TI], wl[TI], xh[2], xl[2];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                wh[i] = *reinterpret_cast<const f16x8*>(sb + 2 * XB + w_row + i * 32 * 64 + coff);
+                wl[i] = *reinterpret_cast<const f16x8*>(sb + 2 * XB + WB + w_row + i * 32 * 64 + coff);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                xh[j] = *reinterpret_cast<const f16x8*>(sb + x_row + j * 32 * 64 + coff);
+                xl[j] = *reinterpret_cast<const f16x8*>(sb + XB + x_row + j * 32 * 64 + coff);
+            }
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i], xh[j], acc0[i][j], 0, 0, 0);
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i], xl[j], acc1[i][j], 0, 0, 0);
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[i], xh[j], acc1[i][j], 0, 0, 0);
+                }
+        }
+    }
+
+    __builtin_amdgcn_s_barrier();      // every wave is past its last fragment reads: the ring is free
+    gemm_f16x3_epilogue<OC, TI>(g, acc0, acc1, t0, n0, wt, wo, lane, smem + wave * EPI_SLAB);
 }
 
 // x -> (hi, lo) planes, elementwise (test helper and weight/activation conversion outside the GEMMs)
@@ -184,19 +393,32 @@ __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict_
 
 }  // namespace
 
-int og_launch_gemm_f16x3(const GemmHArgs& a, hipStream_t stream) {
-    if (!a.Ah || !a.Al || !a.Bh || !a.Bl || a.M <= 0 || a.N <= 0 || a.K <= 0) return OG_E_INVALID;
-    if (!a.C32 && !a.Ch) return OG_E_INVALID;
-    if ((a.Ch == nullptr) != (a.Cl == nullptr)) return OG_E_INVALID;
-    if ((a.lda & 7) || (a.ldb & 7) || (a.K & 7) || (a.N & 3)) return OG_E_ALIGN;
-    if (((uintptr_t)a.Ah & 15) || ((uintptr_t)a.Al & 15) || ((uintptr_t)a.Bh & 15) || ((uintptr_t)a.Bl & 15)) return OG_E_ALIGN;
-    if (a.C32 && (((uintptr_t)a.C32 & 15) || (a.ldc & 3))) return OG_E_ALIGN;
-    if (a.Ch && (((uintptr_t)a.Ch & 7) || ((uintptr_t)a.Cl & 7) || (a.ldch & 3))) return OG_E_ALIGN;
-    if (a.res && (((uintptr_t)a.res & 15) || (a.ldr & 3))) return OG_E_ALIGN;
-    if (a.bias && ((uintptr_t)a.bias & 15)) return OG_E_ALIGN;
+int og_launch_gemm_f16x3(const GemmHArgs& a_in, hipStream_t stream) {
+    const GemmHArgs& a0 = a_in;
+    if (!a0.Ah || !a0.Al || !a0.Bh || !a0.Bl || a0.M <= 0 || a0.N <= 0 || a0.K <= 0) return OG_E_INVALID;
+    if (!a0.C32 && !a0.Ch) return OG_E_INVALID;
+    if ((a0.Ch == nullptr) != (a0.Cl == nullptr)) return OG_E_INVALID;
+    if ((a0.lda & 7) || (a0.ldb & 7) || (a0.K & 7) || (a0.N & 3)) return OG_E_ALIGN;
+    if (((uintptr_t)a0.Ah & 15) || ((uintptr_t)a0.Al & 15) || ((uintptr_t)a0.Bh & 15) || ((uintptr_t)a0.Bl & 15)) return OG_E_ALIGN;
+    if (a0.C32 && (((uintptr_t)a0.C32 & 15) || (a0.ldc & 3))) return OG_E_ALIGN;
+    if (a0.Ch && (((uintptr_t)a0.Ch & 7) || ((uintptr_t)a0.Cl & 7) || (a0.ldch & 3))) return OG_E_ALIGN;
+    if (a0.res && (((uintptr_t)a0.res & 15) || (a0.ldr & 3))) return OG_E_ALIGN;
+    if (a0.bias && ((uintptr_t)a0.bias & 15)) return OG_E_ALIGN;
+    static const int variant = [] { const char* e = getenv("OG_GEMM_VARIANT"); return e ? atoi(e) : 4; }();
+    static const int ablate = [] { const char* e = getenv("OG_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
+    GemmHArgs a = a_in;
+    a.ablate = ablate;
     const int tiles_m = (a.M + TOK - 1) / TOK;
     const int tiles_m8 = (tiles_m + 7) / 8 * 8;
-    if (a.N > 64) {
+    if (variant >= 2 && a.N > 64 && a.K % BKH == 0) {
+        const int tiles_n = (a.N + 127) / 128;
+        if (variant == 4)
+            hipLaunchKernelGGL((gemm_nt_f16x3_glds_kernel<128, 2>), dim3(tiles_m8 * tiles_n), dim3(256), 0, stream, a, tiles_m, tiles_n);
+        else if (variant == 3)
+            hipLaunchKernelGGL((gemm_nt_f16x3_glds_kernel<128, 3>), dim3(tiles_m8 * tiles_n), dim3(256), 0, stream, a, tiles_m, tiles_n);
+        else
+            hipLaunchKernelGGL((gemm_nt_f16x3_glds_kernel<128, 4>), dim3(tiles_m8 * tiles_n), dim3(256), 0, stream, a, tiles_m, tiles_n);
+    } else if (a.N > 64) {
         const int tiles_n = (a.N + 127) / 128;
         hipLaunchKernelGGL(gemm_nt_f16x3_kernel<128>, dim3(tiles_m8 * tiles_n), dim3(256), 0, stream, a, tiles_m, tiles_n);
     } else {

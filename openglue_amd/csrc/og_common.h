@@ -65,6 +65,7 @@ struct GemmHArgs {
     const float* res; int64_t ldr;            // fp32 residual [M][N] (may alias C32)
     float* C32; int64_t ldc;                  // optional fp32 output
     _Float16* Ch; _Float16* Cl; int64_t ldch; // optional split-f16 output planes
+    int ablate;                               // profiling only (OG_GEMM_ABLATE): 1 = no epilogue, 2 = no MFMA, 4 = no global loads in the k loop
 };
 int og_launch_gemm_f16x3(const GemmHArgs& a, hipStream_t stream);
 int og_launch_split_f16(const float* x, int64_t n, void* hi, void* lo, hipStream_t stream);
