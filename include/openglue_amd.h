@@ -137,7 +137,7 @@ int og_pack_weights(const og_shape* shape, const og_params* params, void* packed
  * elements occupies n/2 floats), everything else as fp32.
  *   enc_w[i] [enc_out[i]][enc_k[i]], enc_b[i] [enc_out[i]]   keypoint-encoder conv i, zero-padded (k: 32 | out: mult. of 64),
  *                                                            BatchNorm i-1 folded in
- *   layer l at layer0 + l*layer_stride:  wqkv_{h,l} [3D][D] (q rows pre-scaled by (D/H)^-1/2), bqkv [3D],
+ *   layer l at layer0 + l*layer_stride:  wqkv_{h,l} [3D][D] (q rows pre-scaled by (D/H)^-1/2 * log2 e), bqkv [3D],
  *                                        w0_{h,l} [2D][2D] = [W0a | Wm*Wo], b0 [2D], w3_{h,l} [D][2D] (BN folded), b3 [D]
  *   wp [D][D], bp [D], alpha [D] = sigmoid(mix_coefs), dustbin [1] */
 typedef struct og_packed_layout_t {
@@ -194,7 +194,8 @@ int og_gemm_nt_f16x3(const void* Ah, const void* Al, int64_t lda, const void* Bh
 
 /* softmax attention (attention.py:8-19) for `batch` independent problems and H heads, operands and
  * result as split-f16 planes: q [batch][nq][ldq] (columns h*dh.. of row i = head h, PRE-SCALED by
- * dh^-0.5), k, v [batch][nk][ld*], out [batch][nq][ldo]; leading dimensions in elements.  dh in {16,32,64}. */
+ * dh^-0.5 * log2(e): the kernel evaluates softmax as 2^(q.k - max)), k, v [batch][nk][ld*],
+ * out [batch][nq][ldo]; leading dimensions in elements.  dh in {16,32,64}. */
 int og_attention(const void* qh, const void* ql, int64_t ldq, const void* kh, const void* kl, int64_t ldk,
                  const void* vh, const void* vl, int64_t ldv, void* oh, void* ol, int64_t ldo, int32_t batch,
                  int32_t nq, int32_t nk, int32_t num_heads, int32_t dh, void* stream);

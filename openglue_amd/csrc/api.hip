@@ -199,7 +199,8 @@ extern "C" int og_pack_weights(const og_shape* shape, const og_params* P, void* 
 
     // ---- GNN layers ----
     const int dh = D / s.num_heads;
-    const double qscale = 1.0 / sqrt((double)dh);          // attention.py:12 `* embed_dim ** -0.5`
+    // attention.py:12 `* embed_dim ** -0.5`, times log2(e): the attention kernel's softmax is base 2
+    const double qscale = 1.4426950408889634 / sqrt((double)dh);
     const bool offset = s.flags & OG_FLAG_USE_OFFSET;
     std::vector<double> Wm((size_t)D2 * D), prod((size_t)D2 * D), g, c;
     for (int l = 0; l < 2 * s.num_stages; ++l) {

@@ -20,7 +20,11 @@
 //                               kb*32 + 16t + 8(e>>2) + 4(l>>5) + (e&3); Vᵀ is staged in LDS as [dv][key]
 //                               so those keys are two 8-byte reads.  (The k order inside an MFMA is free
 //                               as long as A and B agree.)
-// Q is expected PRE-SCALED by d^-1/2 (folded into the packed q-projection weights).
+// Q is expected PRE-SCALED by d^-1/2 * log2(e) (folded into the packed q-projection weights): the
+// softmax then runs in the base-2 domain, p = 2^(s - m) is one v_exp_f32 with no extra multiply.
+// The running max is only advanced (and O, l rescaled) when some row's max grew by more than 2^11
+// in the current tile ("deferred rescale"): p stays <= 2^11, exactly representable in the f16 hi plane,
+// and the 64-register rescale of O leaves the common path.
 // I/O: q, k, v arrive as f16 (hi, lo) PLANES written by the producing GEMM's epilogue and O leaves as planes
 // (it is the A operand of the fc.0 GEMM), so no conversion sits on the load path of either kernel.
 #include "og_common.h"
@@ -31,6 +35,7 @@ constexpr int KV_TILE = 64;
 constexpr int Q_TILE = 128;
 constexpr float LO_SCALE = 2048.f;           // 2^11
 constexpr float LO_INV = 1.f / 2048.f;
+constexpr float RESCALE_THR = 11.f;          // base-2 exponent headroom before the running max is advanced
 
 __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
     hi = (_Float16)x;
@@ -147,15 +152,19 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a) {
                 sx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[c], sx, 0, 0, 0);
                 sx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[c], sx, 0, 0, 0);
             }
+            if (key0 + KV_TILE > nk) {                  // only the last tile can hold padded keys (block-uniform)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = key0 + kb * 32 + mfma32_row(r, lane);
-                const float v = shh[r] + sx[r] * LO_INV;
-                s[kb][r] = key < nk ? v : OG_NEG_INF;
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key0 + kb * 32 + mfma32_row(r, lane);
+                    s[kb][r] = key < nk ? shh[r] + sx[r] * LO_INV : OG_NEG_INF;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kb][r] = shh[r] + sx[r] * LO_INV;
             }
         }
 
-        // ---- online softmax over keys (this lane: 32 of the tile's 64 keys of ONE query) ----
+        // ---- online softmax over keys, base 2 (this lane: 32 of the tile's 64 keys of ONE query) ----
         float mt = s[0][0];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -163,26 +172,29 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a) {
             for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[kb][r]);
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
         const float m_new = fmaxf(m_run, mt);            // finite: every tile holds >= 1 valid key
-        const float alpha = __expf(m_run - m_new);       // first tile: exp(-inf) = 0
+        if (__any(m_new - m_run > RESCALE_THR)) {        // wave-uniform; first tile: inf > THR
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // rows that did not grow: 2^0 = 1
+            l_run *= alpha;
+            m_run = m_new;
+#pragma unroll
+            for (int d = 0; d < NDV; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { oh[d][r] *= alpha; ol[d][r] *= alpha; }
+        }
         float psum = 0.f;
         f16x8 pf[2][2], pl[2][2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = __expf(s[kb][r] - m_new);
+                const float p = __builtin_amdgcn_exp2f(s[kb][r] - m_run);    // <= 2^RESCALE_THR
                 psum += p;
                 _Float16 th, tl;
                 split_f16(p, th, tl);
                 pf[kb][r >> 3][r & 7] = th;
                 pl[kb][r >> 3][r & 7] = tl;
             }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int d = 0; d < NDV; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { oh[d][r] *= alpha; ol[d][r] *= alpha; }
+        l_run += psum;
 
         // ---- Oᵀ += Vᵀ Pᵀ ----
 #pragma unroll

@@ -15,6 +15,8 @@
 //     partials into v (and handles the dustbin row / column, which only need u and v).
 // HBM/L2 traffic per iteration: 4mn bytes read + 8n(m/R) bytes of partials, instead of >= 8mn.
 // Numerics: exact max-subtracted two-pass LSE like torch.logsumexp, in fp32.
+#include <stdlib.h>
+
 #include "og_common.h"
 
 namespace {
@@ -29,14 +31,17 @@ struct SinkhornWs {
 
 __host__ __device__ inline int sk_cpt(int n) { return n <= 1024 ? 1 : (n <= 2048 ? 2 : 4); }
 // rows-per-wave sweep (n <= 2048): float4 chunks per lane and rows per block
-constexpr int SK_RW = 8;                                            // rows per wave -> 32 rows per block
+inline int sk_rw() {                                                // rows per wave (block = 4 waves)
+    static const int rw = [] { const char* e = getenv("OG_SINKHORN_RW"); const int v = e ? atoi(e) : 8; return (v == 4 || v == 16) ? v : 8; }();
+    return rw;
+}
 inline int sk_cpl(int n) { return n <= 256 ? 1 : (n <= 512 ? 2 : (n <= 1024 ? 4 : 8)); }
 inline bool sk_rows_variant(int n) { return n <= 2048; }
 
 static SinkhornWs sk_layout(void* ws, int B, int m, int n) {
     SinkhornWs w{};
     w.CPT = sk_cpt(n);
-    w.R = sk_rows_variant(n) ? 4 * SK_RW : 16 / w.CPT;
+    w.R = sk_rows_variant(n) ? 4 * sk_rw() : 16 / w.CPT;
     w.RB = (m + w.R - 1) / w.R;
     w.ldu = (int)og_round_up(m + 1, 4);
     w.ldv = (int)og_round_up(n + 1, 4);
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(256) void sinkhorn_sweep_rows_kernel(const float* _
                                                                   const float* __restrict__ v_in, int ldv,
                                                                   float* __restrict__ u, int ldu,
                                                                   float* __restrict__ pm, float* __restrict__ ps,
-                                                                  int ldp, int RB) {
+                                                                  int ldp, int RB, int abl) {
     extern __shared__ __attribute__((aligned(16))) float sm[];      // [4 waves][2][256*CPL*4] (max | sum)
     constexpr int NC = 256 * CPL;                                   // columns covered by a wave
     const int b = blockIdx.y, rb = blockIdx.x;
@@ -250,9 +255,17 @@ __global__ __launch_bounds__(256) void sinkhorn_sweep_rows_kernel(const float* _
                 for (int e = 0; e < 4; ++e) sum += __expf(x[r][k][e] + vv[k][e] - mx);
             sum = wave_sum(sum) + __expf(dcol - mx);
             ur[r] = la - (mx + __logf(sum));
+            if (abl & 1) ur[r] = la - mx;
             if (lane == 0 && row0 + r < M) u[(int64_t)b * ldu + row0 + r] = ur[r];
         }
         // online column partials with the new u
+        if (abl & 2) {      // profiling: skip the column half (keep x alive)
+#pragma unroll
+            for (int k = 0; k < CPL; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cm[k][e] = fmaxf(cm[k][e], x[0][k][e] + ur[0]);
+            continue;
+        }
 #pragma unroll
         for (int k = 0; k < CPL; ++k)
 #pragma unroll
@@ -397,7 +410,7 @@ void launch_sweep(const float* S, int64_t lds, int B, int m, int n, const float*
 
 extern "C" size_t og_sinkhorn_workspace_bytes(int32_t batch, int32_t m, int32_t n) {
     if (batch <= 0 || m <= 0 || n <= 0 || n > 4096) return 0;
-    const int cpt = sk_cpt(n), R = sk_rows_variant(n) ? 4 * SK_RW : 16 / cpt, RB = (m + R - 1) / R;
+    const int cpt = sk_cpt(n), R = sk_rows_variant(n) ? 4 * sk_rw() : 16 / cpt, RB = (m + R - 1) / R;
     const int64_t ldu = og_round_up(m + 1, 4), ldv = og_round_up(n + 1, 4), ldp = og_round_up(n, 4);
     const int64_t floats = (int64_t)batch * (ldu + 2 * ldv) + 4 + 2 * (int64_t)batch * RB * ldp;
     return (size_t)floats * sizeof(float);
@@ -417,20 +430,33 @@ int og_launch_sinkhorn(const float* S, int64_t lds, const float* zdev, float dus
     // u = v = 0 (optimal_transport.py:22)
     hipError_t e = hipMemsetAsync(w.u, 0, sizeof(float) * (size_t)B * (w.ldu + 2 * (size_t)w.ldv), st);
     if (e != hipSuccess) return (int)e;
+    static const int sk_abl = [] { const char* e = getenv("OG_SINKHORN_ABLATE"); return e ? atoi(e) : 0; }();
     int cur = 0;
     for (int it = 0; it < iters; ++it) {
         if (sk_rows_variant(n)) {
             const dim3 grid(w.RB, B), block(256);
+#define OG_SWEEP_ROWS_RW(CPL, RG, RW)                                                                                   \
+    hipLaunchKernelGGL((sinkhorn_sweep_rows_kernel<CPL, RG, RW>), grid, block, sizeof(float) * 4 * 2 * 256 * CPL, st, S,        \
+                       lds, m, n, zdev, dustbin, inv_reg, la, w.v[cur], w.ldv, w.u, w.ldu, w.pm, w.ps, w.ldp, w.RB, sk_abl)
 #define OG_SWEEP_ROWS(CPL, RG)                                                                                          \
-    hipLaunchKernelGGL((sinkhorn_sweep_rows_kernel<CPL, RG, SK_RW>), grid, block, sizeof(float) * 4 * 2 * 256 * CPL, st, S,     \
-                       lds, m, n, zdev, dustbin, inv_reg, la, w.v[cur], w.ldv, w.u, w.ldu, w.pm, w.ps, w.ldp, w.RB)
+    do {                                                                                                                \
+        if (sk_rw() == 4) OG_SWEEP_ROWS_RW(CPL, RG, 4);                                                                 \
+        else if (sk_rw() == 16) OG_SWEEP_ROWS_RW(CPL, RG, 16);                                                          \
+        else OG_SWEEP_ROWS_RW(CPL, RG, 8);                                                                              \
+    } while (0)
+            static const int sk_rg = [] { const char* e = getenv("OG_SINKHORN_RG"); return e ? atoi(e) : 2; }();
             switch (sk_cpl(n)) {
                 case 1: OG_SWEEP_ROWS(1, 4); break;
                 case 2: OG_SWEEP_ROWS(2, 4); break;
-                case 4: OG_SWEEP_ROWS(4, 4); break;
+                case 4:
+                    if (sk_rg == 1) OG_SWEEP_ROWS(4, 1);
+                    else if (sk_rg == 2) OG_SWEEP_ROWS(4, 2);
+                    else OG_SWEEP_ROWS(4, 4);
+                    break;
                 default: OG_SWEEP_ROWS(8, 2); break;
             }
 #undef OG_SWEEP_ROWS
+#undef OG_SWEEP_ROWS_RW
         } else
         switch (w.CPT) {
             case 1: launch_sweep<1>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, w.v[cur], w, st); break;

@@ -90,10 +90,11 @@ def gemm_nt_f16x3(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor]
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int) -> torch.Tensor:
     """Multi-head softmax attention on token-major fp32 tensors q [Z,nq,D], k,v [Z,nk,D]; head h owns
-    channels h*d..(h+1)*d-1.  q must already carry the d^-1/2 scale.  Operands are converted to the
-    kernel's split-f16 planes on the device; the result planes are merged back to fp32."""
+    channels h*d..(h+1)*d-1.  q must already carry the d^-1/2 scale (the log2(e) factor of the kernel's
+    base-2 softmax is applied here).  Operands are converted to the kernel's split-f16 planes on the
+    device; the result planes are merged back to fp32."""
     lib = _lib.load()
-    q, k, v = _req(q, "q"), _req(k, "k"), _req(v, "v")
+    q, k, v = _req(q * 1.4426950408889634, "q"), _req(k, "k"), _req(v, "v")
     Z, nq, D = q.shape
     nk = k.shape[1]
     (qh, ql), (kh, kl), (vh, vl) = split_f16(q), split_f16(k), split_f16(v)

@@ -52,7 +52,8 @@ def forward_from_packed(model, data, dtype=torch.float64):
     if not model.no_descriptors:
         x0, x1 = x0 + d0, x1 + d1
 
-    def attn(q, k, v):      # q pre-scaled
+    def attn(q, k, v):      # q pre-scaled by d^-1/2 * log2(e): softmax in base 2
+        q = q * math.log(2.0)
         B, nq, _ = q.shape
         d = D // H
         qh = q.view(B, nq, H, d).transpose(1, 2)
