@@ -49,12 +49,17 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a) {
     constexpr int NCH = DH / 16;                  // 16-wide k chunks of the QKᵀ contraction
     constexpr int KW = DH + 8;                    // K LDS row (halves): 16 B pad -> conflict-free b128
     constexpr int VW = KV_TILE + 4;               // Vᵀ LDS row (halves): 8 B pad -> conflict-free b64
-    constexpr int D4 = DH / 4;                    // float4 per row
+    constexpr int D4 = DH / 4;                    // 4-wide dv groups per row
+    constexpr int KSZ = KV_TILE * KW;             // halves per K plane buffer
+    constexpr int VSZ = DHP * VW;                 // halves per Vᵀ plane buffer
 
-    __shared__ __attribute__((aligned(16))) _Float16 Kh[KV_TILE * KW];
-    __shared__ __attribute__((aligned(16))) _Float16 Kl[KV_TILE * KW];
-    __shared__ __attribute__((aligned(16))) _Float16 Vh[DHP * VW];
-    __shared__ __attribute__((aligned(16))) _Float16 Vl[DHP * VW];
+    // Double-buffered tiles: K_t / V_t live in buffer t&1.  One array (a second __shared__ object makes
+    // hipcc serialise LDS traffic with outstanding global loads).
+    __shared__ __attribute__((aligned(16))) _Float16 smem[2 * (2 * KSZ + 2 * VSZ)];
+    auto Kh = [&](int b) { return smem + b * (2 * KSZ + 2 * VSZ); };
+    auto Kl = [&](int b) { return smem + b * (2 * KSZ + 2 * VSZ) + KSZ; };
+    auto Vh = [&](int b) { return smem + b * (2 * KSZ + 2 * VSZ) + 2 * KSZ; };
+    auto Vl = [&](int b) { return smem + b * (2 * KSZ + 2 * VSZ) + 2 * KSZ + VSZ; };
 
     const int z = blockIdx.z, h = blockIdx.y;
     const int gsel = z < a.split ? 0 : 1;
@@ -68,11 +73,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
 
-    if (DH < 32) {   // zero the padding rows of Vᵀ once; staging never touches them
-        for (int i = tid; i < (DHP - DH) * VW; i += 256) {
-            Vh[DH * VW + i] = (_Float16)0.f;
-            Vl[DH * VW + i] = (_Float16)0.f;
-        }
+    if (DH < 32) {   // zero the padding rows of Vᵀ once (both buffers); staging never touches them
+        for (int i = tid; i < (DHP - DH) * VW; i += 256)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) { Vh(b)[DH * VW + i] = (_Float16)0.f; Vl(b)[DH * VW + i] = (_Float16)0.f; }
     }
 
     // ---- Q fragments (B operand): lane (query l31, k-group hi) holds Q[q][16c + 8hi + e] ----
@@ -95,47 +99,91 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) { oh[d][r] = 0.f; ol[d][r] = 0.f; }
     float m_run = OG_NEG_INF, l_run = 0.f;
 
-    // staging maps: K as 16-byte chunks (8 halves), V as 4 keys x 4 dv register transposes
+    // ---- staging: K as 16-byte chunks, V as 4 keys x 4 dv register transposes; a tile travels
+    //      global -> registers (issued one tile ahead) -> LDS ----
     constexpr int C8 = DH / 8;                       // chunks per K row
     constexpr int K_KEYS_PER_PASS = 256 / C8;
     constexpr int K_PASSES = (KV_TILE + K_KEYS_PER_PASS - 1) / K_KEYS_PER_PASS;
     const int k_c8 = tid % C8, k_key = tid / C8;
     const int v_dg = tid % D4, v_kg = tid / D4;
     const bool v_active = v_kg < KV_TILE / 4;
-
-    const int ntiles = (nk + KV_TILE - 1) / KV_TILE;
-    for (int kt = 0; kt < ntiles; ++kt) {
+    f16x8 rkh[K_PASSES], rkl[K_PASSES];
+    f16x4 rvh[4], rvl[4];
+    auto load_tile = [&](int kt) {
         const int key0 = kt * KV_TILE;
-        // ---- stage K (row-major [key][d]) and Vᵀ ([dv][key]), hi and lo planes ----
 #pragma unroll
         for (int p = 0; p < K_PASSES; ++p) {
             const int key = k_key + p * K_KEYS_PER_PASS;
             if (key < KV_TILE) {
-                int gk = key0 + key; if (gk >= nk) gk = nk - 1;      // clamp (masked below)
+                int gk = key0 + key; if (gk >= nk) gk = nk - 1;      // clamp (masked in the softmax)
                 const int64_t go = (kv_row0 + gk) * a.ldk + h * DH + 8 * k_c8;
-                *reinterpret_cast<f16x8*>(&Kh[key * KW + 8 * k_c8]) = *reinterpret_cast<const f16x8*>(a.kh + go);
-                *reinterpret_cast<f16x8*>(&Kl[key * KW + 8 * k_c8]) = *reinterpret_cast<const f16x8*>(a.kl + go);
+                rkh[p] = *reinterpret_cast<const f16x8*>(a.kh + go);
+                rkl[p] = *reinterpret_cast<const f16x8*>(a.kl + go);
             }
         }
         if (v_active) {
-            f16x4 xh[4], xl[4];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 int gk = key0 + 4 * v_kg + kk; if (gk >= nk) gk = nk - 1;
                 const int64_t go = (kv_row0 + gk) * a.ldv + h * DH + 4 * v_dg;
-                xh[kk] = *reinterpret_cast<const f16x4*>(a.vh + go);
-                xl[kk] = *reinterpret_cast<const f16x4*>(a.vl + go);
+                rvh[kk] = *reinterpret_cast<const f16x4*>(a.vh + go);
+                rvl[kk] = *reinterpret_cast<const f16x4*>(a.vl + go);
             }
+        }
+    };
+    auto store_tile = [&](int b) {
+#pragma unroll
+        for (int p = 0; p < K_PASSES; ++p) {
+            const int key = k_key + p * K_KEYS_PER_PASS;
+            if (key < KV_TILE) {
+                *reinterpret_cast<f16x8*>(Kh(b) + key * KW + 8 * k_c8) = rkh[p];
+                *reinterpret_cast<f16x8*>(Kl(b) + key * KW + 8 * k_c8) = rkl[p];
+            }
+        }
+        if (v_active) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {       // dv = 4*v_dg + e : 4 consecutive keys
                 f16x4 th, tl;
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) { th[kk] = xh[kk][e]; tl[kk] = xl[kk][e]; }
-                *reinterpret_cast<f16x4*>(&Vh[(4 * v_dg + e) * VW + 4 * v_kg]) = th;
-                *reinterpret_cast<f16x4*>(&Vl[(4 * v_dg + e) * VW + 4 * v_kg]) = tl;
+                for (int kk = 0; kk < 4; ++kk) { th[kk] = rvh[kk][e]; tl[kk] = rvl[kk][e]; }
+                *reinterpret_cast<f16x4*>(Vh(b) + (4 * v_dg + e) * VW + 4 * v_kg) = th;
+                *reinterpret_cast<f16x4*>(Vl(b) + (4 * v_dg + e) * VW + 4 * v_kg) = tl;
             }
         }
-        __syncthreads();
+    };
+    // Oᵀ += Vᵀ_b Pᵀ  (P fragments of the tile staged in buffer b)
+    f16x8 pf[2][2], pl[2][2];
+    auto pv = [&](int b) {
+#pragma unroll
+        for (int d = 0; d < NDV; ++d)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int off = (d * 32 + l31) * VW + kb * 32 + 16 * t + 4 * hi;
+                    const f16x4 h0 = *reinterpret_cast<const f16x4*>(Vh(b) + off);
+                    const f16x4 h1 = *reinterpret_cast<const f16x4*>(Vh(b) + off + 8);
+                    const f16x4 l0 = *reinterpret_cast<const f16x4*>(Vl(b) + off);
+                    const f16x4 l1 = *reinterpret_cast<const f16x4*>(Vl(b) + off + 8);
+                    f16x8 vh, vl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { vh[e] = h0[e]; vh[4 + e] = h1[e]; vl[e] = l0[e]; vl[4 + e] = l1[e]; }
+                    oh[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pf[kb][t], oh[d], 0, 0, 0);
+                    ol[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, pf[kb][t], ol[d], 0, 0, 0);
+                    ol[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[kb][t], ol[d], 0, 0, 0);
+                }
+    };
+
+    const int ntiles = (nk + KV_TILE - 1) / KV_TILE;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    // Software pipeline per tile t (buffer t&1):  issue the global loads of tile t+1 | QKᵀ(t) on the matrix
+    // pipe | PV(t-1) on the matrix pipe while the VALU runs softmax(t) | barrier | registers -> LDS | barrier
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int b = kt & 1;
+        const int key0 = kt * KV_TILE;
+        if (kt + 1 < ntiles) load_tile(kt + 1);
 
         // ---- Sᵀ = K Qᵀ for the two 32-key blocks ----
         float s[2][16];
@@ -146,8 +194,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a) {
             for (int r = 0; r < 16; ++r) { shh[r] = 0.f; sx[r] = 0.f; }
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                const f16x8 kh = *reinterpret_cast<const f16x8*>(&Kh[(kb * 32 + l31) * KW + 16 * c + 8 * hi]);
-                const f16x8 kl = *reinterpret_cast<const f16x8*>(&Kl[(kb * 32 + l31) * KW + 16 * c + 8 * hi]);
+                const f16x8 kh = *reinterpret_cast<const f16x8*>(Kh(b) + (kb * 32 + l31) * KW + 16 * c + 8 * hi);
+                const f16x8 kl = *reinterpret_cast<const f16x8*>(Kl(b) + (kb * 32 + l31) * KW + 16 * c + 8 * hi);
                 shh = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[c], shh, 0, 0, 0);
                 sx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[c], sx, 0, 0, 0);
                 sx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[c], sx, 0, 0, 0);
@@ -164,6 +212,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a) {
             }
         }
 
+        // ---- PV of the PREVIOUS tile: independent of Sᵀ(t), keeps the matrix pipe busy under the softmax ----
+        if (kt > 0) pv(b ^ 1);
+
         // ---- online softmax over keys, base 2 (this lane: 32 of the tile's 64 keys of ONE query) ----
         float mt = s[0][0];
 #pragma unroll
@@ -179,10 +230,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a) {
 #pragma unroll
             for (int d = 0; d < NDV; ++d)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { oh[d][r] *= alpha; ol[d][r] *= alpha; }
+                for (int r = 0; r < 16; ++r) { oh[d][r] *= alpha; ol[d][r] *= alpha; }   // after PV(t-1): O is complete up to t-1
         }
         float psum = 0.f;
-        f16x8 pf[2][2], pl[2][2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -196,27 +246,13 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a) {
             }
         l_run += psum;
 
-        // ---- Oᵀ += Vᵀ Pᵀ ----
-#pragma unroll
-        for (int d = 0; d < NDV; ++d)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int off = (d * 32 + l31) * VW + kb * 32 + 16 * t + 4 * hi;
-                    const f16x4 h0 = *reinterpret_cast<const f16x4*>(&Vh[off]);
-                    const f16x4 h1 = *reinterpret_cast<const f16x4*>(&Vh[off + 8]);
-                    const f16x4 l0 = *reinterpret_cast<const f16x4*>(&Vl[off]);
-                    const f16x4 l1 = *reinterpret_cast<const f16x4*>(&Vl[off + 8]);
-                    f16x8 vh, vl;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { vh[e] = h0[e]; vh[4 + e] = h1[e]; vl[e] = l0[e]; vl[4 + e] = l1[e]; }
-                    oh[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pf[kb][t], oh[d], 0, 0, 0);
-                    ol[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, pf[kb][t], ol[d], 0, 0, 0);
-                    ol[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[kb][t], ol[d], 0, 0, 0);
-                }
-        __syncthreads();
+        __syncthreads();                                  // every wave is done with K(t) and V(t-1)
+        if (kt + 1 < ntiles) {
+            store_tile(b ^ 1);                            // K(t+1), V(t+1) replace K(t-1), V(t-1)
+            __syncthreads();
+        }
     }
+    pv((ntiles - 1) & 1);                                 // the last tile's PV
 
     // ---- normalise and store O[q][h*DH + dv] ----
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
