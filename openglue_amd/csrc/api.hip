@@ -103,7 +103,7 @@ int check_shape(const og_shape* s) {
     if (s->num_hidden < 0 || s->num_hidden > OG_MAX_HIDDEN) return OG_E_SHAPE;
     for (int i = 0; i < s->num_hidden; ++i)
         if (s->hidden[i] <= 0 || og_round_up(s->hidden[i], 64) > 2 * s->desc_dim) return OG_E_SHAPE;
-    if (s->n > 4096) return OG_E_SHAPE;                 // Sinkhorn register tile (sinkhorn.hip)
+    if (s->n > 8192) return OG_E_SHAPE;                 // Sinkhorn sweep geometry (sinkhorn.hip)
     if (s->sinkhorn_iters < 0 || !(s->sinkhorn_reg > 0.f)) return OG_E_SHAPE;
     if (s->flags & ~(OG_FLAG_RESIDUAL | OG_FLAG_USE_OFFSET | OG_FLAG_NO_DESCRIPTORS)) return OG_E_FLAG;
     return 0;

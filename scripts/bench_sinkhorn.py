@@ -4,7 +4,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from openglue_amd import _lib
 lib = _lib.load(); dev = torch.device("cuda:0")
-B, m, n, iters = 32, 1024, 1024, 100
+B, m, n, iters = [int(v) for v in os.environ.get('OG_SK_SHAPE', '32,1024,1024,100').split(',')]
 S = (torch.randn(B, m, n, generator=torch.Generator().manual_seed(0)) * 4).to(dev)
 ws = torch.empty(lib.og_sinkhorn_workspace_bytes(B, m, n), device=dev, dtype=torch.uint8)
 out = torch.empty(B, m + 1, n + 1, device=dev)
@@ -23,4 +23,4 @@ if os.environ.get("OG_CAL"):
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 20 * 1e3
         print(f"calibration torch {name}: {us:.1f} us for {S.numel()*4/1e6:.0f} MB read -> {S.numel()*4/us/1e6:.2f} TB/s read side")
-print(f"rw={os.environ.get('OG_SINKHORN_RW','8')} rg={os.environ.get('OG_SINKHORN_RG','4')} ablate={os.environ.get('OG_SINKHORN_ABLATE','0')}: {ms:.3f} ms per 100 iterations = {ms*10:.1f} us/iter; finite={bool(torch.isfinite(out).all())}")
+print(f"shape {B}x{m}x{n} ablate={os.environ.get('OG_SINKHORN_ABLATE','0')}: {ms:.3f} ms per 100 iterations = {ms*1e3/iters:.1f} us/iter ({B*m*n*4/(ms*1e3/iters)/1e6:.2f} TB/s of S); finite={bool(torch.isfinite(out).all())}")

@@ -1,3 +1,3 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out
-{ for rg in 1 2; do for rw in 4 8 16; do OG_SINKHORN_RG=$rg OG_SINKHORN_RW=$rw timeout 300 python scripts/bench_sinkhorn.py; done; done; } 2>&1 | grep -v "amdgpu.ids" | tee gpurun_out/sk_ab.log
+{ timeout 300 python -m pytest tests -m gpu -q -k "sinkhorn" -p no:cacheprovider | tail -3; for sh in 32,1024,1024,100 32,2048,2048,50 8,4096,4096,50; do OG_SK_SHAPE=$sh timeout 300 python scripts/bench_sinkhorn.py; done; } 2>&1 | grep -v "amdgpu.ids" | tee gpurun_out/sk_ab.log

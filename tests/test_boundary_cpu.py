@@ -106,7 +106,7 @@ def test_error_behaviour():
     assert lib.og_check_shape(C.byref(s)) == 0
     s.desc_dim = 100
     assert lib.og_check_shape(C.byref(s)) == -2 and lib.og_workspace_bytes(C.byref(s)) == 0
-    s = model._shape(1, 16, 5000)
+    s = model._shape(1, 16, 9000)
     assert lib.og_check_shape(C.byref(s)) == -2
     s = model._shape(1, 16, 16); s.flags = 64
     assert lib.og_check_shape(C.byref(s)) == -4
