@@ -61,11 +61,19 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a) {
     auto Vh = [&](int b) { return smem + b * (2 * KSZ + 2 * VSZ) + 2 * KSZ; };
     auto Vl = [&](int b) { return smem + b * (2 * KSZ + 2 * VSZ) + 2 * KSZ + VSZ; };
 
-    const int z = blockIdx.z, h = blockIdx.y;
+    // XCD-aware block mapping: workgroup b is dispatched to XCD b % 8 and every XCD has its own L2.  All
+    // query tiles of one (problem, head) share the same K/V (512 KB at 1024 keys), so they are placed on ONE
+    // XCD; with the natural (x = tile) order the eight tiles land on eight XCDs and K/V is fetched from
+    // HBM / Infinity Cache eight times (measured: 743 MB per launch instead of ~250 MB).
+    const int id = blockIdx.x;
+    const int xcd = id & 7, local = id >> 3;
+    const int grp = (local / a.qtiles) * 8 + xcd;          // (problem, head) group
+    if (grp >= a.nz * a.num_heads) return;
+    const int z = grp / a.num_heads, h = grp - z * a.num_heads;
     const int gsel = z < a.split ? 0 : 1;
     const int zz = gsel ? z - a.split : z;
     const int nq = a.nq[gsel], nk = a.nk[gsel];
-    const int q0 = blockIdx.x * Q_TILE;
+    const int q0 = (local % a.qtiles) * Q_TILE;
     if (q0 >= nq) return;
     const int64_t q_row0 = a.q_base[gsel] + (int64_t)zz * a.q_step[gsel];
     const int64_t kv_row0 = a.kv_base[gsel] + (int64_t)zz * a.kv_step[gsel];
@@ -296,11 +304,14 @@ int og_launch_attention(const AttnArgs& a, hipStream_t stream) {
         if (a.nq[g] <= 0 || a.nk[g] <= 0) return OG_E_INVALID;
         if (a.nq[g] > nqmax) nqmax = a.nq[g];
     }
-    dim3 grid((nqmax + Q_TILE - 1) / Q_TILE, a.num_heads, a.nz), block(256);
+    AttnArgs a2 = a;
+    a2.qtiles = (nqmax + Q_TILE - 1) / Q_TILE;
+    const int groups8 = (a.nz * a.num_heads + 7) / 8 * 8;
+    dim3 grid(groups8 * a2.qtiles), block(256);
     switch (a.dh) {
-        case 16: hipLaunchKernelGGL(attention_kernel<16>, grid, block, 0, stream, a); break;
-        case 32: hipLaunchKernelGGL(attention_kernel<32>, grid, block, 0, stream, a); break;
-        case 64: hipLaunchKernelGGL(attention_kernel<64>, grid, block, 0, stream, a); break;
+        case 16: hipLaunchKernelGGL(attention_kernel<16>, grid, block, 0, stream, a2); break;
+        case 32: hipLaunchKernelGGL(attention_kernel<32>, grid, block, 0, stream, a2); break;
+        case 64: hipLaunchKernelGGL(attention_kernel<64>, grid, block, 0, stream, a2); break;
         default: return OG_E_SHAPE;
     }
     return og_launch_status();

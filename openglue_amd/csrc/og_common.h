@@ -80,6 +80,7 @@ struct AttnArgs {
     int split;                // problems z < split use geometry A, the others geometry B
     int64_t q_base[2], q_step[2], kv_base[2], kv_step[2];
     int nq[2], nk[2];
+    int qtiles;               // set by the launcher: query tiles per (problem, head)
 };
 int og_launch_attention(const AttnArgs& a, hipStream_t stream);
 
