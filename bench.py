@@ -102,12 +102,64 @@ def cpu_baseline(cfg, sd, cfg_kw, m, n, budget_s=20.0):
             "sample": f"{reps} x 1 pair of the same workload (B=1, torch-CPU oracle, {best_t} of {ncpu} host threads), {dt * 1e3:.0f} ms/pair"}
 
 
+def bench_ragged(args, world, rank, dev):
+    """BASELINE configs[4]: 128 pairs with 512-2048 keypoints per image, cost-balanced over the ranks; pairs
+    are bucketed by exact shape (openglue_amd/ragged.py), i.e. every pair is its own launch sequence."""
+    from openglue_amd.ragged import match_ragged
+    kw = dict(syn.CONFIGS["C2"]); kw.pop("kpts"); kw.pop("batch")
+    total = (args.batch or 16) * world
+    lens = syn.ragged_lengths(total, 512, 2048, seed=0)
+    costs = [sharding.pair_cost(m, n) for m, n in lens]
+    mine = sharding.shard_pairs(total, world, costs)[rank]
+    cfg = syn.make_config(**kw)
+    sd = syn.make_state_dict(cfg, seed=0)
+    model = SuperGlue(cfg).eval(); model.load_state_dict(sd, strict=True); model.to(dev)
+    pairs = []
+    for i in mine:
+        p = syn.make_pair(lens[i][0], lens[i][1], 256, 1, seed=i)
+        p = {k: v.to(dev) for k, v in p.items()}
+        p["image0_size"] = list(syn.IMAGE_WH); p["image1_size"] = list(syn.IMAGE_WH)
+        pairs.append(p)
+
+    def step():
+        return match_ragged(model, pairs, MATCH_THRESHOLD, both_sides=False)
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        line = {"metric": "image-pairs/sec (C5 ragged 512-2048 kpts)", "value": round(total * args.steps / dt, 2), "unit": "image-pairs/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"BASELINE configs[4]: {total} ragged pairs, 512-2048 kpts/image, 256-dim, 9 stages, 100 Sinkhorn iters, "
+                                       "bucketed by exact shape (one launch sequence per pair), LPT cost-balanced over ranks",
+                           "mean_kpts": round(sum(a + b for a, b in lens) / (2 * total), 1)},
+                "roofline": None, "cpu_baseline": None,
+                "valid_matches_per_pair": round(sum(int((r["matches0"] >= 0).sum()) for r in res) / max(1, len(res)), 1)}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="C2", choices=sorted(syn.CONFIGS))
+    ap.add_argument("--config", default="C2", choices=sorted(syn.CONFIGS) + ["C5"])
     ap.add_argument("--batch", type=int, default=None, help="pairs per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -126,6 +178,8 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if args.config == "C5":
+        return bench_ragged(args, world, rank, dev)
     kw = dict(syn.CONFIGS[args.config])
     (m, n), B = kw.pop("kpts"), kw.pop("batch")
     if args.batch:

@@ -335,3 +335,27 @@ def test_larger_baseline_configs(gpu_device, cfg_name, B):
     assert err < TOL_SCORES
     ndiff, unexplained, _ = _index_agreement(out["matches0"][:1].cpu(), s[:1].cpu(), sd, cfg, one)
     assert unexplained == 0, (ndiff, unexplained)
+
+
+def test_ragged_pairs_equal_per_pair_oracle(gpu_device):
+    """BASELINE configs[4] semantics at small scale: every pair has its own (m, n); the result must equal the
+    per-pair (B=1) oracle, whatever the bucketing."""
+    from openglue_amd.ragged import bucket_by_shape, match_ragged
+    cfg = syn.make_config(descriptor_dim=128, num_stages=2, num_heads=4, num_iters=10, side_info_size=1)
+    sd = syn.make_state_dict(cfg, seed=0)
+    model = _build(cfg, sd, gpu_device)
+    lens = [(70, 91), (64, 64), (70, 91), (129, 33), (64, 64)]
+    pairs_cpu = []
+    for i, (m, n) in enumerate(lens):
+        p = syn.make_pair(m, n, 128, 1, seed=100 + i)
+        p["image0_size"] = list(syn.IMAGE_WH); p["image1_size"] = list(syn.IMAGE_WH)
+        pairs_cpu.append(p)
+    assert [len(v) for v in bucket_by_shape(pairs_cpu).values()] == [2, 2, 1]
+    res = match_ragged(model, [to_device(p, gpu_device) for p in pairs_cpu], MATCH_THRESHOLD)
+    for p, r, (m, n) in zip(pairs_cpu, res, lens):
+        one = {k: (v[None] if torch.is_tensor(v) else v) for k, v in p.items()}
+        with torch.no_grad():
+            ref = orc.match_pairs(sd, cfg, one, MATCH_THRESHOLD)
+        assert r["scores"].shape == (m + 1, n + 1)
+        assert (r["scores"].cpu() - ref["scores"][0]).abs().max() < TOL_SCORES
+        assert torch.equal(r["matches0"].cpu(), ref["matches0"][0])
