@@ -233,13 +233,22 @@ def main():
             "sinkhorn": (counts["sinkhorn_bytes"] * B, 1e9, "hbm", PEAK_HBM_GBS, "GB/s",
                          "sinkhorn_sweep + sinkhorn_combine (stage time incl. launch gaps; one sweep of S per iteration)"),
         }
+        # HBM traffic per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+        # corrected as MI355X_MICROARCH.md prescribes); only valid for the configuration it was measured on (C2, B=32)
+        traffic = {}
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic_c2.json")
+        if args.config == "C2" and B == 32 and os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            traffic = {"gemm_f16x3": tj.get("gemm_f16x3"), "gemm_f32": tj.get("gemm_f32"), "attention": tj.get("attention"),
+                       "sinkhorn": {"hbm_bytes_per_launch": (tj["sinkhorn_sweep"]["hbm_bytes_per_launch"] + tj["sinkhorn_combine"]["hbm_bytes_per_launch"]) * kw["num_iters"]}}
         roofs = {}
         for k, (work, scale, bound, peak, unit, kern) in per_step.items():
             ms = stages[k]
             ach = work / (ms * 1e-3) / scale if ms > 0 else 0.0
             nl = max(1, launches[k])
             roofs[k] = {"kernel": kern, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
-                        "frac": round(ach / peak, 4), "traffic": None, "class_ms_per_step": round(ms, 3),
+                        "frac": round(ach / peak, 4),
+                        "traffic": (traffic.get(k) or {}).get("hbm_bytes_per_launch"), "class_ms_per_step": round(ms, 3),
                         "launches_per_step": launches[k], "avg_launch_ms": round(ms / nl, 4),
                         "algorithmic_work_per_launch": round(work / nl / scale, 6)}
         dominant = max(per_step, key=lambda k: stages[k])
