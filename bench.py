@@ -103,9 +103,8 @@ def cpu_baseline(cfg, sd, cfg_kw, m, n, budget_s=20.0):
 
 
 def bench_ragged(args, world, rank, dev):
-    """BASELINE configs[4]: 128 pairs with 512-2048 keypoints per image, cost-balanced over the ranks; pairs
-    are bucketed by exact shape (openglue_amd/ragged.py), i.e. every pair is its own launch sequence."""
-    from openglue_amd.ragged import match_ragged
+    """BASELINE configs[4]: 128 pairs with 512-2048 keypoints per image, cost-balanced over the ranks, through the
+    token-packed ragged path (SuperGlue.match_ragged -> og_forward_ragged)."""
     kw = dict(syn.CONFIGS["C2"]); kw.pop("kpts"); kw.pop("batch")
     total = (args.batch or 16) * world
     lens = syn.ragged_lengths(total, 512, 2048, seed=0)
@@ -122,7 +121,7 @@ def bench_ragged(args, world, rank, dev):
         pairs.append(p)
 
     def step():
-        return match_ragged(model, pairs, MATCH_THRESHOLD, both_sides=False)
+        return model.match_ragged(pairs, MATCH_THRESHOLD, both_sides=False)
     for _ in range(args.warmup):
         step()
     if world > 1:
@@ -144,7 +143,7 @@ def bench_ragged(args, world, rank, dev):
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": f"BASELINE configs[4]: {total} ragged pairs, 512-2048 kpts/image, 256-dim, 9 stages, 100 Sinkhorn iters, "
-                                       "bucketed by exact shape (one launch sequence per pair), LPT cost-balanced over ranks",
+                                       "token-packed ragged kernels (og_forward_ragged), LPT cost-balanced over ranks",
                            "mean_kpts": round(sum(a + b for a, b in lens) / (2 * total), 1)},
                 "roofline": None, "cpu_baseline": None,
                 "valid_matches_per_pair": round(sum(int((r["matches0"] >= 0).sum()) for r in res) / max(1, len(res)), 1)}

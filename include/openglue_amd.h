@@ -156,6 +156,16 @@ int og_packed_layout(const og_shape* shape, og_packed_layout_t* layout);
 int og_forward(const og_shape* shape, const og_inputs* in, const void* packed_dev,
                void* workspace_dev, const og_outputs* out, void* stream);
 
+/* Ragged batch (BASELINE config 5): pair b has lens0[b] keypoints in image 0 and lens1[b] in image 1
+ * (host arrays, batch <= OG_MAX_RAGGED; shape->m / shape->n are the maxima).  Every tensor is PACKED without
+ * padding in pair order: keypoints0 [sum m_b][2], descriptors0 [sum m_b][D], ..., scores = the
+ * [m_b+1][n_b+1] blocks one after the other, matches0 / matching_scores0 [sum m_b], matches1 [sum n_b].
+ * The result of pair b equals og_forward on that pair alone (the reference has no masks: SURVEY.md 3.5).
+ * context_descriptors{0,1} are not produced (must be NULL). */
+#define OG_MAX_RAGGED 64
+int og_forward_ragged(const og_shape* shape, const int32_t* lens0, const int32_t* lens1, const og_inputs* in,
+                      const void* packed_dev, void* workspace_dev, const og_outputs* out, void* stream);
+
 /* Profiling variant of og_forward (bench.py): same work, but every launch group is bracketed by HIP
  * events recorded on `stream`; the call SYNCHRONISES the stream and returns the summed elapsed
  * milliseconds and the number of bracketed launch groups per kernel class.  GEMM and attention are

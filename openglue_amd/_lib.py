@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("OPENGLUE_AMD_LIB") or os.path.join(HERE, "lib", "libo
 OG_ABI_VERSION = 1
 OG_FLAG_RESIDUAL, OG_FLAG_USE_OFFSET, OG_FLAG_NO_DESCRIPTORS = 1, 2, 4
 OG_MAX_HIDDEN = 8
+OG_MAX_RAGGED = 64
 OG_STAGES = ("encoder_input", "gemm_f32", "attention", "sinkhorn", "matches", "gemm_f16x3")
 
 _ERRORS = {-1: "OG_E_INVALID (null pointer / bad size)", -2: "OG_E_SHAPE (unsupported shape)",
@@ -79,6 +80,8 @@ SYMBOLS = {
     "og_packed_layout": (C.c_int, [C.POINTER(og_shape), C.POINTER(og_packed_layout_t)]),
     "og_pack_weights": (C.c_int, [C.POINTER(og_shape), C.POINTER(og_params), _vp]),
     "og_forward": (C.c_int, [C.POINTER(og_shape), C.POINTER(og_inputs), _vp, _vp, C.POINTER(og_outputs), _vp]),
+    "og_forward_ragged": (C.c_int, [C.POINTER(og_shape), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(og_inputs), _vp, _vp,
+                                    C.POINTER(og_outputs), _vp]),
     "og_forward_profiled": (C.c_int, [C.POINTER(og_shape), C.POINTER(og_inputs), _vp, _vp, C.POINTER(og_outputs), _vp,
                                       C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "og_gemm_nt": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _i32,

@@ -292,7 +292,7 @@ struct Scope {
 };
 
 int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_dev, void* workspace_dev,
-                 const og_outputs* outp, void* stream, Profiler* prof) {
+                 const og_outputs* outp, void* stream, Profiler* prof, const RaggedDesc* rag = nullptr) {
     if (!shape || !in || !packed_dev || !workspace_dev || !outp) return OG_E_INVALID;
     if (int e = check_shape(shape)) return e;
     og_clear_status();
@@ -311,7 +311,9 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
     const float* pk = (const float*)packed_dev;
     float* ws = (float*)workspace_dev;
     const int D = s.desc_dim, D2 = 2 * D, D3 = 3 * D, B = s.batch, m = s.m, n = s.n;
-    const int64_t T0 = (int64_t)B * m, T1 = (int64_t)B * n, T = T0 + T1;
+    // uniform batch: B sets of m (n) tokens; ragged batch: packed sets, m and n are the maxima
+    const int64_t T0 = rag ? rag->off0[B] : (int64_t)B * m, T1 = rag ? rag->off1[B] : (int64_t)B * n, T = T0 + T1;
+    if (rag && (outp->context_descriptors0 || outp->context_descriptors1)) return OG_E_INVALID;
     float* X32 = ws + W.x32; float* G = ws + W.g; float* Sb = ws + W.sbuf;
     _Float16* XOh = (_Float16*)(ws + W.xoh); _Float16* XOl = (_Float16*)(ws + W.xol);      // [T][2D]: x | O
     _Float16* QKVh = (_Float16*)(ws + W.qkvh); _Float16* QKVl = (_Float16*)(ws + W.qkvl);  // [T][3D]: q | k | v
@@ -371,8 +373,9 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
     // ---- 2. attentional GNN (attention_gnn.py:84-93) ----
     const int dh = D / s.num_heads;
     auto attention = [&](int nz, int split, int64_t qb0, int64_t qs0, int nq0, int64_t kb0, int64_t ks0, int nk0,
-                         int64_t qb1, int64_t qs1, int nq1, int64_t kb1, int64_t ks1, int nk1) -> int {
+                         int64_t qb1, int64_t qs1, int nq1, int64_t kb1, int64_t ks1, int nk1, int rag_mode) -> int {
         AttnArgs a{};
+        a.rag = rag; a.rag_mode = rag_mode;
         a.qh = QKVh; a.ql = QKVl; a.ldq = D3; a.kh = QKVh + D; a.kl = QKVl + D; a.ldk = D3;
         a.vh = QKVh + D2; a.vl = QKVl + D2; a.ldv = D3; a.oh = XOh + D; a.ol = XOl + D; a.ldo = D2;
         a.nz = nz; a.num_heads = s.num_heads; a.dh = dh; a.split = split;
@@ -393,7 +396,7 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
         // self layer 2l: both images through the same weights (attention_gnn.py:63-66)
         const float* lw = pk + L.layer0 + (int64_t)(2 * l) * L.layer_stride;
         if ((rc = gemmh(XOh, XOl, D2, lw, L.o_wqkv_h, L.o_wqkv_l, 0, D, T, D3, D, lw + L.o_bqkv, 0, nullptr, nullptr, QKVh, QKVl, D3))) return rc;
-        if ((rc = attention(2 * B, B, 0, m, m, 0, m, m, T0, n, n, T0, n, n))) return rc;
+        if ((rc = attention(2 * B, B, 0, m, m, 0, m, m, T0, n, n, T0, n, n, 1))) return rc;
         if ((rc = mlp(lw, 0, T))) return rc;
         // cross layer 2l+1: image 0 first, then image 1 against the UPDATED image 0 (attention_gnn.py:74-77)
         lw = pk + L.layer0 + (int64_t)(2 * l + 1) * L.layer_stride;
@@ -404,8 +407,8 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
                             nullptr, QKVh + qr0 * D3, QKVl + qr0 * D3, D3))) return rc;
             if ((rc = gemmh(XOh + kr0 * D2, XOl + kr0 * D2, D2, lw, L.o_wqkv_h, L.o_wqkv_l, D, D, kR, D2, D, lw + L.o_bqkv + D, 0, nullptr,
                             nullptr, QKVh + kr0 * D3 + D, QKVl + kr0 * D3 + D, D3))) return rc;
-            if (side == 0) rc = attention(B, B, 0, m, m, T0, n, n, 0, 0, 0, 0, 0, 0);
-            else rc = attention(B, B, T0, n, n, 0, m, m, 0, 0, 0, 0, 0, 0);
+            if (side == 0) rc = attention(B, B, 0, m, m, T0, n, n, 0, 0, 0, 0, 0, 0, 2);
+            else rc = attention(B, B, T0, n, n, 0, m, m, 0, 0, 0, 0, 0, 0, 3);
             if (rc) return rc;
             if ((rc = mlp(lw, qr0, qR))) return rc;
         }
@@ -432,6 +435,8 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
         g.A = G; g.lda = D; g.strideA = (int64_t)m * D; g.B = G + T0 * D; g.ldb = D; g.strideB = (int64_t)n * D;
         g.C = Sb; g.ldc = W.lds; g.strideC = (int64_t)m * W.lds; g.M = m; g.N = n; g.K = D; g.batch = B;
         g.scale = (float)pow((double)D, -0.5); g.ct_rows = 1;
+        g.rag = rag;                       // ragged: pair z multiplies rows off0[z].. of G by rows T0 + off1[z].. of G
+        if (rag) g.B = G;
         Scope sc(prof, OG_STAGE_GEMM);
         if ((rc = og_launch_gemm(g, st))) return rc;
     }
@@ -440,14 +445,14 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
     {
         Scope sc(prof, OG_STAGE_SINKHORN);
         if ((rc = og_launch_sinkhorn(Sb, W.lds, pk + L.dustbin, 0.f, B, m, n, s.sinkhorn_iters, s.sinkhorn_reg, outp->scores,
-                                     ws + W.sink, st))) return rc;
+                                     ws + W.sink, st, rag))) return rc;
     }
 
     // ---- 6. mutual-NN matches (matching_module.py:174-187) ----
     if (outp->matches0) {
         Scope sc(prof, OG_STAGE_MATCHES);
         if ((rc = og_launch_matches(outp->scores, B, m, n, s.match_threshold, outp->matches0, outp->matching_scores0,
-                                    outp->matches1, outp->matching_scores1, ws + W.match, st))) return rc;
+                                    outp->matches1, outp->matching_scores1, ws + W.match, st, rag))) return rc;
     }
     return 0;
 }
@@ -457,6 +462,23 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
 extern "C" int og_forward(const og_shape* shape, const og_inputs* in, const void* packed_dev, void* workspace_dev,
                           const og_outputs* outp, void* stream) {
     return forward_impl(shape, in, packed_dev, workspace_dev, outp, stream, nullptr);
+}
+
+extern "C" int og_forward_ragged(const og_shape* shape, const int32_t* lens0, const int32_t* lens1, const og_inputs* in,
+                                 const void* packed_dev, void* workspace_dev, const og_outputs* outp, void* stream) {
+    if (!shape || !lens0 || !lens1) return OG_E_INVALID;
+    if (shape->batch <= 0 || shape->batch > OG_MAX_RAGGED) return OG_E_SHAPE;
+    RaggedDesc rd;
+    rd.B = shape->batch;
+    rd.off0[0] = rd.off1[0] = 0;
+    rd.soff[0] = 0;
+    for (int b = 0; b < rd.B; ++b) {
+        if (lens0[b] <= 0 || lens1[b] <= 0 || lens0[b] > shape->m || lens1[b] > shape->n) return OG_E_SHAPE;
+        rd.off0[b + 1] = rd.off0[b] + lens0[b];
+        rd.off1[b + 1] = rd.off1[b] + lens1[b];
+        rd.soff[b + 1] = rd.soff[b] + (int64_t)(lens0[b] + 1) * (lens1[b] + 1);
+    }
+    return forward_impl(shape, in, packed_dev, workspace_dev, outp, stream, nullptr, &rd);
 }
 
 extern "C" int og_forward_profiled(const og_shape* shape, const og_inputs* in, const void* packed_dev, void* workspace_dev,

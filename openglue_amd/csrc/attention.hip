@@ -43,7 +43,7 @@ __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
 }
 
 template <int DH>
-__global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a, RaggedDesc rd) {
     constexpr int DHP = DH < 32 ? 32 : DH;        // Vᵀ rows padded to a full 32-row MFMA tile
     constexpr int NDV = DHP / 32;                 // output row blocks
     constexpr int NCH = DH / 16;                  // 16-wide k chunks of the QKᵀ contraction
@@ -72,11 +72,21 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a) {
     const int z = grp / a.num_heads, h = grp - z * a.num_heads;
     const int gsel = z < a.split ? 0 : 1;
     const int zz = gsel ? z - a.split : z;
-    const int nq = a.nq[gsel], nk = a.nk[gsel];
+    int nq = a.nq[gsel], nk = a.nk[gsel];
+    int64_t q_row0 = a.q_base[gsel] + (int64_t)zz * a.q_step[gsel];
+    int64_t kv_row0 = a.kv_base[gsel] + (int64_t)zz * a.kv_step[gsel];
+    if (rd.B > 0) {          // ragged batch: per-pair row ranges of the packed token matrix
+        const int T0 = rd.off0[rd.B];
+        const int b = z < rd.B ? z : z - rd.B;
+        const int r0 = rd.off0[b], m_b = rd.off0[b + 1] - r0;
+        const int r1 = T0 + rd.off1[b], n_b = rd.off1[b + 1] - rd.off1[b];
+        const bool q_is0 = a.rag_mode == 1 ? z < rd.B : a.rag_mode == 2;
+        const bool kv_is0 = a.rag_mode == 1 ? q_is0 : !q_is0;
+        q_row0 = q_is0 ? r0 : r1; nq = q_is0 ? m_b : n_b;
+        kv_row0 = kv_is0 ? r0 : r1; nk = kv_is0 ? m_b : n_b;
+    }
     const int q0 = (local % a.qtiles) * Q_TILE;
     if (q0 >= nq) return;
-    const int64_t q_row0 = a.q_base[gsel] + (int64_t)zz * a.q_step[gsel];
-    const int64_t kv_row0 = a.kv_base[gsel] + (int64_t)zz * a.kv_step[gsel];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -306,12 +316,16 @@ int og_launch_attention(const AttnArgs& a, hipStream_t stream) {
     }
     AttnArgs a2 = a;
     a2.qtiles = (nqmax + Q_TILE - 1) / Q_TILE;
+    RaggedDesc rd;
+    rd.B = 0;
+    if (a.rag) rd = *a.rag;
+    a2.rag = nullptr;
     const int groups8 = (a.nz * a.num_heads + 7) / 8 * 8;
     dim3 grid(groups8 * a2.qtiles), block(256);
     switch (a.dh) {
-        case 16: hipLaunchKernelGGL(attention_kernel<16>, grid, block, 0, stream, a2); break;
-        case 32: hipLaunchKernelGGL(attention_kernel<32>, grid, block, 0, stream, a2); break;
-        case 64: hipLaunchKernelGGL(attention_kernel<64>, grid, block, 0, stream, a2); break;
+        case 16: hipLaunchKernelGGL(attention_kernel<16>, grid, block, 0, stream, a2, rd); break;
+        case 32: hipLaunchKernelGGL(attention_kernel<32>, grid, block, 0, stream, a2, rd); break;
+        case 64: hipLaunchKernelGGL(attention_kernel<64>, grid, block, 0, stream, a2, rd); break;
         default: return OG_E_SHAPE;
     }
     return og_launch_status();

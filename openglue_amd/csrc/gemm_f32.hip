@@ -25,7 +25,7 @@ constexpr int BK = 32;
 constexpr int LDSW = BK + 4;   // padded LDS row, floats
 
 template <int BN>
-__global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g, int tiles_m, int tiles_n, RaggedDesc rd) {
     constexpr int TN = BN / 64;            // MFMA tiles per wave along N
     constexpr int BROWS = BN / 32;         // staging passes for B
     __shared__ __attribute__((aligned(16))) float As[BM * LDSW];
@@ -41,6 +41,13 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g, int tiles_
 
     const float* __restrict__ A = g.A + (int64_t)z * g.strideA;
     const float* __restrict__ B = g.B + (int64_t)z * g.strideB;
+    if (rd.B > 0) {          // ragged: problem z = pair z, operands are row ranges of the packed token matrix
+        g.M = rd.off0[z + 1] - rd.off0[z];
+        g.N = rd.off1[z + 1] - rd.off1[z];
+        if (m0 >= g.M || n0 >= g.N) return;
+        A = g.A + (int64_t)rd.off0[z] * g.lda;
+        B = g.B + (int64_t)(rd.off0[rd.B] + rd.off1[z]) * g.ldb;
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -153,12 +160,17 @@ int og_launch_gemm(const GemmArgs& a, hipStream_t stream) {
     if ((a.strideA & 3) || (a.strideB & 3)) return OG_E_ALIGN;
     const int tiles_m = (a.M + BM - 1) / BM;
     const int tiles_m8 = (tiles_m + 7) / 8 * 8;
+    RaggedDesc rd;
+    rd.B = 0;
+    if (a.rag) rd = *a.rag;
+    GemmArgs k = a;
+    k.rag = nullptr;
     if (a.N > 64) {
         const int tiles_n = (a.N + 127) / 128;
         hipLaunchKernelGGL(gemm_nt_f32_kernel<128>, dim3(tiles_m8 * tiles_n, a.batch), dim3(256), 0, stream,
-                           a, tiles_m, tiles_n);
+                           k, tiles_m, tiles_n, rd);
     } else {
-        hipLaunchKernelGGL(gemm_nt_f32_kernel<64>, dim3(tiles_m8, a.batch), dim3(256), 0, stream, a, tiles_m, 1);
+        hipLaunchKernelGGL(gemm_nt_f32_kernel<64>, dim3(tiles_m8, a.batch), dim3(256), 0, stream, k, tiles_m, 1, rd);
     }
     return og_launch_status();
 }
@@ -177,6 +189,6 @@ extern "C" int og_gemm_nt(const float* A, int64_t lda, int64_t strideA, const fl
     g.res = res; g.ldr = ldr; g.strideR = (int64_t)M * ldr;
     g.alpha = alpha; g.scale = scale;
     g.Ct = nullptr; g.ldct = 0; g.strideCt = 0; g.ct_rows = 1;
-    g.Ch = nullptr; g.Cl = nullptr; g.ldch = 0;
+    g.Ch = nullptr; g.Cl = nullptr; g.ldch = 0; g.rag = nullptr;
     return og_launch_gemm(g, (hipStream_t)stream);
 }

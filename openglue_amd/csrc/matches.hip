@@ -37,12 +37,15 @@ __device__ __forceinline__ float unorderable(unsigned int k) {
 
 // one wave per row i < m
 __global__ __launch_bounds__(256) void row_argmax_kernel(const float* __restrict__ scores, int M, int N,
-                                                         int* __restrict__ idx0, float* __restrict__ max0) {
+                                                         int* __restrict__ idx0, float* __restrict__ max0, RaggedDesc rd) {
     const int b = blockIdx.y;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
+    const int Mmax = M;                          // workspace stride
+    int64_t so = (int64_t)b * (M + 1) * (N + 1);
+    if (rd.B > 0) { M = rd.off0[b + 1] - rd.off0[b]; N = rd.off1[b + 1] - rd.off1[b]; so = rd.soff[b]; }
     if (row >= M) return;
-    const float* sp = scores + ((int64_t)b * (M + 1) + row) * (N + 1);
+    const float* sp = scores + so + (int64_t)row * (N + 1);
     float best = OG_NEG_INF;
     int bi = 0x7FFFFFFF;
     for (int j = lane; j < N; j += 64) {
@@ -55,18 +58,21 @@ __global__ __launch_bounds__(256) void row_argmax_kernel(const float* __restrict
         const int oi = __shfl_xor(bi, o, 64);
         if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
     }
-    if (lane == 0) { idx0[(int64_t)b * M + row] = bi; max0[(int64_t)b * M + row] = best; }
+    if (lane == 0) { idx0[(int64_t)b * Mmax + row] = bi; max0[(int64_t)b * Mmax + row] = best; }
 }
 
 // grid (ceil(n/256), ceil(m/64), B): thread = one column over a 64-row slab, then one 64-bit atomicMax
 __global__ __launch_bounds__(256) void col_argmax_kernel(const float* __restrict__ scores, int M, int N,
-                                                         unsigned long long* __restrict__ colbest) {
+                                                         unsigned long long* __restrict__ colbest, RaggedDesc rd) {
     const int b = blockIdx.z;
     const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= N) return;
+    const int Nmax = N;
+    int64_t so = (int64_t)b * (M + 1) * (N + 1);
+    if (rd.B > 0) { M = rd.off0[b + 1] - rd.off0[b]; N = rd.off1[b + 1] - rd.off1[b]; so = rd.soff[b]; }
     const int i0 = blockIdx.y * 64;
+    if (j >= N || i0 >= M) return;
     const int i1 = min(i0 + 64, M);
-    const float* sp = scores + (int64_t)b * (M + 1) * (N + 1) + j;
+    const float* sp = scores + so + j;
     float best = sp[(int64_t)i0 * (N + 1)];
     int bi = i0;
     for (int i = i0 + 1; i < i1; ++i) {
@@ -74,32 +80,35 @@ __global__ __launch_bounds__(256) void col_argmax_kernel(const float* __restrict
         if (v > best) { best = v; bi = i; }
     }
     const unsigned long long key = ((unsigned long long)orderable(best) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)bi);
-    atomicMax(colbest + (int64_t)b * N + j, key);
+    atomicMax(colbest + (int64_t)b * Nmax + j, key);
 }
 
 __global__ __launch_bounds__(256) void mutual_kernel(int M, int N, float thr, const int* __restrict__ idx0,
                                                      const float* __restrict__ max0,
                                                      const unsigned long long* __restrict__ colbest,
                                                      int64_t* __restrict__ matches0, float* __restrict__ ms0,
-                                                     int64_t* __restrict__ matches1, float* __restrict__ ms1) {
+                                                     int64_t* __restrict__ matches1, float* __restrict__ ms1, RaggedDesc rd) {
     const int b = blockIdx.y;
     const int t = blockIdx.x * 256 + threadIdx.x;
+    const int Mmax = M, Nmax = N;                    // workspace strides
+    int64_t o0 = (int64_t)b * M, o1 = (int64_t)b * N;  // output offsets (packed per pair when ragged)
+    if (rd.B > 0) { M = rd.off0[b + 1] - rd.off0[b]; N = rd.off1[b + 1] - rd.off1[b]; o0 = rd.off0[b]; o1 = rd.off1[b]; }
     if (t < M) {
-        const int j = idx0[(int64_t)b * M + t];
-        const int i1 = (int)(0xFFFFFFFFu - (unsigned)(colbest[(int64_t)b * N + j] & 0xFFFFFFFFull));
+        const int j = idx0[(int64_t)b * Mmax + t];
+        const int i1 = (int)(0xFFFFFFFFu - (unsigned)(colbest[(int64_t)b * Nmax + j] & 0xFFFFFFFFull));
         const bool mutual = i1 == t;
-        const float s = mutual ? expf(max0[(int64_t)b * M + t]) : 0.f;
+        const float s = mutual ? expf(max0[(int64_t)b * Mmax + t]) : 0.f;
         const bool valid = mutual && s > thr;
-        matches0[(int64_t)b * M + t] = valid ? (int64_t)j : (int64_t)-1;
-        ms0[(int64_t)b * M + t] = s;
+        matches0[o0 + t] = valid ? (int64_t)j : (int64_t)-1;
+        ms0[o0 + t] = s;
     }
     if (matches1 && t < N) {
-        const int i = (int)(0xFFFFFFFFu - (unsigned)(colbest[(int64_t)b * N + t] & 0xFFFFFFFFull));
-        const bool mutual = idx0[(int64_t)b * M + i] == t;          // then mutual0[i] holds as well
-        const float s = mutual ? expf(max0[(int64_t)b * M + i]) : 0.f;
+        const int i = (int)(0xFFFFFFFFu - (unsigned)(colbest[(int64_t)b * Nmax + t] & 0xFFFFFFFFull));
+        const bool mutual = idx0[(int64_t)b * Mmax + i] == t;          // then mutual0[i] holds as well
+        const float s = mutual ? expf(max0[(int64_t)b * Mmax + i]) : 0.f;
         const bool valid = mutual && s > thr;
-        matches1[(int64_t)b * N + t] = valid ? (int64_t)i : (int64_t)-1;
-        ms1[(int64_t)b * N + t] = s;
+        matches1[o1 + t] = valid ? (int64_t)i : (int64_t)-1;
+        ms1[o1 + t] = s;
     }
 }
 
@@ -133,18 +142,21 @@ extern "C" size_t og_matches_workspace_bytes(int32_t batch, int32_t m, int32_t n
 }
 
 int og_launch_matches(const float* scores, int B, int m, int n, float thr, int64_t* matches0, float* ms0,
-                      int64_t* matches1, float* ms1, void* workspace, hipStream_t st) {
+                      int64_t* matches1, float* ms1, void* workspace, hipStream_t st, const RaggedDesc* rag) {
+    RaggedDesc rd;
+    rd.B = 0;
+    if (rag) { if (rag->B != B) return OG_E_INVALID; rd = *rag; }
     if (!scores || !matches0 || !ms0 || !workspace || B <= 0 || m <= 0 || n <= 0) return OG_E_INVALID;
     if ((matches1 == nullptr) != (ms1 == nullptr)) return OG_E_INVALID;
     if ((uintptr_t)workspace & 15) return OG_E_ALIGN;
     const MatchWs w = mw_layout(workspace, B, m, n);
     hipError_t e = hipMemsetAsync(w.colbest, 0, sizeof(unsigned long long) * (size_t)B * n, st);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(row_argmax_kernel, dim3((m + 3) / 4, B), dim3(256), 0, st, scores, m, n, w.idx0, w.max0);
-    hipLaunchKernelGGL(col_argmax_kernel, dim3((n + 255) / 256, (m + 63) / 64, B), dim3(256), 0, st, scores, m, n, w.colbest);
+    hipLaunchKernelGGL(row_argmax_kernel, dim3((m + 3) / 4, B), dim3(256), 0, st, scores, m, n, w.idx0, w.max0, rd);
+    hipLaunchKernelGGL(col_argmax_kernel, dim3((n + 255) / 256, (m + 63) / 64, B), dim3(256), 0, st, scores, m, n, w.colbest, rd);
     const int mx = m > n ? m : n;
     hipLaunchKernelGGL(mutual_kernel, dim3((mx + 255) / 256, B), dim3(256), 0, st, m, n, thr, w.idx0, w.max0, w.colbest,
-                       matches0, ms0, matches1, ms1);
+                       matches0, ms0, matches1, ms1, rd);
     return og_launch_status();
 }
 
@@ -153,7 +165,7 @@ extern "C" int og_extract_matches(const float* scores, int32_t batch, int32_t m,
                                   float* matching_scores1, void* workspace_dev, void* stream) {
     og_clear_status();
     return og_launch_matches(scores, batch, m, n, match_threshold, matches0, matching_scores0, matches1,
-                             matching_scores1, workspace_dev, (hipStream_t)stream);
+                             matching_scores1, workspace_dev, (hipStream_t)stream, nullptr);
 }
 
 int og_launch_encoder_input(const float* kpts, const float* side, int64_t tokens, int s, float wx, float wy,

@@ -40,6 +40,16 @@ static inline int og_launch_status() {
 
 static inline int64_t og_round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
+// Ragged batches: every pair b has its own (m_b, n_b).  Tokens are PACKED (no padding): image-0 sets at rows
+// off0[b] .. off0[b+1], image-1 sets at rows T0 + off1[b] ..; the descriptor travels to the kernels by value
+// (kernarg), so no device-side table and no host->device copy is needed.  B == 0 means "uniform batch".
+struct RaggedDesc {                    // OG_MAX_RAGGED: include/openglue_amd.h
+    int B;
+    int off0[OG_MAX_RAGGED + 1];       // prefix sums of m_b
+    int off1[OG_MAX_RAGGED + 1];       // prefix sums of n_b
+    int64_t soff[OG_MAX_RAGGED + 1];   // float offsets of the [m_b+1][n_b+1] blocks in the packed scores output
+};
+
 // ---- internal launchers shared between api.hip and the per-stage entry points ----
 struct GemmArgs {
     const float* A; int64_t lda, strideA;
@@ -53,6 +63,8 @@ struct GemmArgs {
     float scale;
     float* Ct; int64_t ldct, strideCt; int ct_rows;   // optional transposed copy: Ct[row / ct_rows][col][row % ct_rows]
     _Float16* Ch; _Float16* Cl; int64_t ldch;         // optional split-f16 copy (hi, lo*2^11 planes), batch == 1 only
+    const RaggedDesc* rag;                            // host pointer or null: batched problem z = pair z of a ragged batch
+                                                      // (A rows off0[z].., B rows T0 + off1[z].., M = m_z, N = n_z)
 };
 int og_launch_gemm(const GemmArgs& a, hipStream_t stream);
 
@@ -81,12 +93,16 @@ struct AttnArgs {
     int64_t q_base[2], q_step[2], kv_base[2], kv_step[2];
     int nq[2], nk[2];
     int qtiles;               // set by the launcher: query tiles per (problem, head)
+    const RaggedDesc* rag;    // host pointer or null; with rag_mode: 1 = self (z < B image 0, else image 1),
+    int rag_mode;             // 2 = cross, queries of image 0 attend image 1, 3 = cross, image 1 attends image 0
 };
 int og_launch_attention(const AttnArgs& a, hipStream_t stream);
 
+// m, n are the (maximum) sizes; with `rag` pair b uses m_b, n_b, S stays at stride m*lds per pair, scores are packed
 int og_launch_sinkhorn(const float* S, int64_t lds, const float* dustbin_dev /*or null*/, float dustbin_host, int batch, int m, int n, int iters,
-                       float reg, float* scores, void* workspace, hipStream_t stream);
+                       float reg, float* scores, void* workspace, hipStream_t stream, const RaggedDesc* rag = nullptr);
 int og_launch_matches(const float* scores, int batch, int m, int n, float thr, int64_t* matches0,
-                      float* ms0, int64_t* matches1, float* ms1, void* workspace, hipStream_t stream);
+                      float* ms0, int64_t* matches1, float* ms1, void* workspace, hipStream_t stream,
+                      const RaggedDesc* rag = nullptr);
 int og_launch_encoder_input(const float* kpts, const float* side, int64_t tokens, int s, float wx, float wy,
                             float* out /*[tokens][32]*/, hipStream_t stream);

@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) void sinkhorn_sweep_kernel(const float* __rest
                                                              const float* __restrict__ zdev, float zhost, float inv_reg,
                                                              float la, const float* __restrict__ v_in, int ldv,
                                                              float* __restrict__ u, int ldu, float* __restrict__ pm,
-                                                             float* __restrict__ ps, int ldp, int RB) {
+                                                             float* __restrict__ ps, int ldp, int RB, int64_t strideS,
+                                                             RaggedDesc rd) {
     constexpr int NRS = 4 / WPR;                 // row streams
     constexpr int RW = SK_ROWS / NRS;            // rows per stream
     constexpr int NCW = 256 * CPL;               // columns per wave
@@ -94,6 +95,13 @@ __global__ __launch_bounds__(256) void sinkhorn_sweep_kernel(const float* __rest
     float* xch = sm + NRS * 2 * NCB;             // [2 parity][NRS][RG][WPR][2]: row (max, sum) exchange between column parts
 
     const int b = blockIdx.y, rb = blockIdx.x;
+    if (rd.B > 0) {                              // ragged: this pair's own size; la = norm = -log(m_b + n_b)
+        M = rd.off0[b + 1] - rd.off0[b];
+        N = rd.off1[b + 1] - rd.off1[b];
+        if (rb * SK_ROWS >= M) return;           // whole block: no barrier is skipped by a subset of waves
+        la = -__logf((float)(M + N));
+    }
+    S += (int64_t)b * strideS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cp = wave % WPR, rs = wave / WPR;
     const int cbase = cp * NCW + 4 * lane;
@@ -120,7 +128,7 @@ __global__ __launch_bounds__(256) void sinkhorn_sweep_kernel(const float* __rest
 #pragma unroll
         for (int r = 0; r < RG; ++r) {
             const int row = row0 + r;
-            const float* sp = S + ((int64_t)b * M + row) * lds;
+            const float* sp = S + (int64_t)row * lds;
 #pragma unroll
             for (int k = 0; k < CPL; ++k) {
                 const int c0 = cbase + 256 * k;
@@ -252,9 +260,18 @@ __global__ __launch_bounds__(256) void sinkhorn_combine_kernel(int M, int N, con
                                                                float* __restrict__ v_out, int ldv,
                                                                float* __restrict__ u, int ldu,
                                                                const float* __restrict__ pm,
-                                                               const float* __restrict__ ps, int ldp, int RB) {
+                                                               const float* __restrict__ ps, int ldp, int RB, RaggedDesc rd) {
     __shared__ float sm[4];
     const int b = blockIdx.y, tid = threadIdx.x;
+    int RBv = RB;                                // row blocks that hold valid partials for this pair
+    if (rd.B > 0) {
+        M = rd.off0[b + 1] - rd.off0[b];
+        N = rd.off1[b + 1] - rd.off1[b];
+        if ((int)blockIdx.x * 256 > N) return;
+        RBv = (M + SK_ROWS - 1) / SK_ROWS;
+        const float norm = -__logf((float)(M + N));
+        lb = norm; la_bin = norm + __logf((float)N); lb_bin = norm + __logf((float)M);
+    }
     const float zr = (zdev ? zdev[0] : zhost) * inv_reg;
     const float* vb = v_in + (int64_t)b * ldv;
     // dustbin row: u_M = log a_M - (z + LSE_{j<=N} v_j)
@@ -275,11 +292,11 @@ __global__ __launch_bounds__(256) void sinkhorn_combine_kernel(int M, int N, con
         // chunks of 8 row blocks: 16 independent loads in flight per thread (the naive dependent
         // loop is latency-bound), online (max, sum) merge per chunk
         float cs = 1.f;                          // exp(zr + uM - cm)
-        for (int rb0 = 0; rb0 < RB; rb0 += 8) {
+        for (int rb0 = 0; rb0 < RBv; rb0 += 8) {
             float pmv[8], psv[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const bool ok = rb0 + q < RB;
+                const bool ok = rb0 + q < RBv;
                 pmv[q] = ok ? pmb[(int64_t)(rb0 + q) * ldp] : OG_NEG_INF;
                 psv[q] = ok ? psb[(int64_t)(rb0 + q) * ldp] : 0.f;
             }
@@ -293,7 +310,7 @@ __global__ __launch_bounds__(256) void sinkhorn_combine_kernel(int M, int N, con
         }
         v_out[(int64_t)b * ldv + j] = lb - (cm + __logf(cs));
     }
-    if (blockIdx.x == gridDim.x - 1) {
+    if ((int)blockIdx.x == N / 256) {          // the block that owns column N
         // dustbin column: v_N = log b_N - (z + LSE_{i<=M} u_i), with the new u (u_M from above)
         const float* ub = u + (int64_t)b * ldu;
         float um = uM;
@@ -312,17 +329,25 @@ __global__ __launch_bounds__(256) void sinkhorn_scores_kernel(const float* __res
                                                               float inv_reg, float norm,
                                                               const float* __restrict__ u, int ldu,
                                                               const float* __restrict__ v, int ldv,
-                                                              float* __restrict__ scores) {
+                                                              float* __restrict__ scores, int64_t strideS, RaggedDesc rd) {
     const int b = blockIdx.y;
+    int64_t so = (int64_t)b * (M + 1) * (N + 1);
+    if (rd.B > 0) {
+        M = rd.off0[b + 1] - rd.off0[b];
+        N = rd.off1[b + 1] - rd.off1[b];
+        norm = -__logf((float)(M + N));
+        so = rd.soff[b];
+    }
+    S += (int64_t)b * strideS;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row > M) return;
     const float zr = (zdev ? zdev[0] : zhost) * inv_reg;
     const float ui = u[(int64_t)b * ldu + row];
     const float* vb = v + (int64_t)b * ldv;
-    float* out = scores + ((int64_t)b * (M + 1) + row) * (N + 1);
+    float* out = scores + so + (int64_t)row * (N + 1);
     if (row < M) {
-        const float* sp = S + ((int64_t)b * M + row) * lds;
+        const float* sp = S + (int64_t)row * lds;
         for (int j = lane; j < N; j += 64) out[j] = ((sp[j] * inv_reg + ui) + vb[j]) - norm;
     } else {
         for (int j = lane; j < N; j += 64) out[j] = ((zr + ui) + vb[j]) - norm;
@@ -332,11 +357,11 @@ __global__ __launch_bounds__(256) void sinkhorn_scores_kernel(const float* __res
 
 template <int CPL, int RG, int WPR>
 void launch_sweep(const float* S, int64_t lds, int B, int m, int n, const float* zdev, float zhost, float inv_reg, float la,
-                  const float* v_in, const SinkhornWs& w, hipStream_t st) {
+                  const float* v_in, const SinkhornWs& w, hipStream_t st, const RaggedDesc& rd) {
     constexpr int NRS = 4 / WPR;
     const size_t shmem = sizeof(float) * ((size_t)NRS * 2 * 256 * CPL * WPR + 2 * NRS * RG * WPR * 2);
     hipLaunchKernelGGL((sinkhorn_sweep_kernel<CPL, RG, WPR>), dim3(w.RB, B), dim3(256), shmem, st, S, lds, m, n, zdev, zhost,
-                       inv_reg, la, v_in, w.ldv, w.u, w.ldu, w.pm, w.ps, w.ldp, w.RB);
+                       inv_reg, la, v_in, w.ldv, w.u, w.ldu, w.pm, w.ps, w.ldp, w.RB, (int64_t)m * lds, rd);
 }
 
 }  // namespace
@@ -350,7 +375,10 @@ extern "C" size_t og_sinkhorn_workspace_bytes(int32_t batch, int32_t m, int32_t 
 }
 
 int og_launch_sinkhorn(const float* S, int64_t lds, const float* zdev, float dustbin, int B, int m, int n, int iters, float reg,
-                       float* scores, void* workspace, hipStream_t st) {
+                       float* scores, void* workspace, hipStream_t st, const RaggedDesc* rag) {
+    RaggedDesc rd;
+    rd.B = 0;
+    if (rag) { if (rag->B != B) return OG_E_INVALID; rd = *rag; }
     if (!S || !scores || !workspace || B <= 0 || m <= 0 || n <= 0 || iters < 0 || !(reg > 0.f)) return OG_E_INVALID;
     if (n > 8192) return OG_E_SHAPE;
     if ((lds & 3) || ((uintptr_t)S & 15) || ((uintptr_t)workspace & 15)) return OG_E_ALIGN;
@@ -367,23 +395,23 @@ int og_launch_sinkhorn(const float* S, int64_t lds, const float* zdev, float dus
     int cur = 0;
     for (int it = 0; it < iters; ++it) {
         const float* vin = w.v[cur];
-        if (g.CPL == 1) launch_sweep<1, 4, 1>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st);
-        else if (g.CPL == 2) launch_sweep<2, 4, 1>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st);
-        else if (g.CPL == 8) launch_sweep<8, 1, 4>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st);
-        else if (g.WPR == 1) launch_sweep<4, 2, 1>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st);
-        else if (g.WPR == 2) launch_sweep<4, 2, 2>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st);
-        else launch_sweep<4, 2, 4>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st);
+        if (g.CPL == 1) launch_sweep<1, 4, 1>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd);
+        else if (g.CPL == 2) launch_sweep<2, 4, 1>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd);
+        else if (g.CPL == 8) launch_sweep<8, 1, 4>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd);
+        else if (g.WPR == 1) launch_sweep<4, 2, 1>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd);
+        else if (g.WPR == 2) launch_sweep<4, 2, 2>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd);
+        else launch_sweep<4, 2, 4>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd);
         hipLaunchKernelGGL(sinkhorn_combine_kernel, dim3((n + 1 + 255) / 256, B), dim3(256), 0, st, m, n, zdev, dustbin, inv_reg, la_bin,
-                           lb, lb_bin, w.v[cur], w.v[cur ^ 1], w.ldv, w.u, w.ldu, w.pm, w.ps, w.ldp, w.RB);
+                           lb, lb_bin, w.v[cur], w.v[cur ^ 1], w.ldv, w.u, w.ldu, w.pm, w.ps, w.ldp, w.RB, rd);
         cur ^= 1;
     }
     hipLaunchKernelGGL(sinkhorn_scores_kernel, dim3((m + 1 + 3) / 4, B), dim3(256), 0, st, S, lds, m, n, zdev, dustbin, inv_reg,
-                       (float)norm, w.u, w.ldu, w.v[cur], w.ldv, scores);
+                       (float)norm, w.u, w.ldu, w.v[cur], w.ldv, scores, (int64_t)m * lds, rd);
     return og_launch_status();
 }
 
 extern "C" int og_sinkhorn(const float* S, int64_t lds, float dustbin, int32_t batch, int32_t m, int32_t n,
                            int32_t iters, float reg, float* scores, void* workspace_dev, void* stream) {
     og_clear_status();
-    return og_launch_sinkhorn(S, lds, nullptr, dustbin, batch, m, n, iters, reg, scores, workspace_dev, (hipStream_t)stream);
+    return og_launch_sinkhorn(S, lds, nullptr, dustbin, batch, m, n, iters, reg, scores, workspace_dev, (hipStream_t)stream, nullptr);
 }

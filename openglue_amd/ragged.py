@@ -3,10 +3,12 @@
 The reference has no mask argument anywhere on the path: its loaders make batches
 rectangular by truncation or by zero "virtual keypoints" that DO take part in attention and Sinkhorn, so
 the only unambiguous semantics for a truly ragged batch is "every pair on its own, with its own (m, n)".
-That is what this module implements: pairs are bucketed by EXACT shape, every bucket goes through the
-batched HIP path once, and the results are scattered back in job order -- bit-identical to running each
-pair alone.  (Token-packed kernels with per-pair length descriptors are the planned replacement; see
-DESIGN.md §8.)
+Two implementations with identical results:
+  * `SuperGlue.match_ragged` (openglue_amd/superglue.py -> og_forward_ragged): token-PACKED tensors and a
+    per-pair length descriptor handed to every kernel -- one launch sequence for the whole batch.  This is
+    the fast path.
+  * `match_ragged` below: pairs bucketed by EXACT shape, every bucket through the uniform batched path,
+    results scattered back in job order.  Kept as the independent cross-check for the packed kernels.
 """
 from __future__ import annotations
 

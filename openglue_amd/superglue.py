@@ -227,6 +227,63 @@ class SuperGlue(nn.Module):
         return out
 
     @torch.no_grad()
+    def match_ragged(self, pairs, match_threshold: float = 0.2, both_sides: bool = True) -> List[Dict[str, torch.Tensor]]:
+        """Ragged batch (BASELINE config 5): `pairs[i]` is an UN-batched data dict (keypoints0 [m_i, 2],
+        local_descriptors0 [m_i, D], side_info0 [m_i, s], ... on the GPU; image sizes taken from pairs[0]).  All pairs
+        go through ONE og_forward_ragged call on token-packed tensors (chunks of 64 pairs); the result of every pair
+        equals running it alone, which is the only semantics the mask-free reference defines.
+        Returns one dict per pair: 'scores' [m_i+1, n_i+1], 'matches0' [m_i], 'matching_scores0' [m_i] (+ side 1)."""
+        if self.training:
+            raise RuntimeError("openglue_amd.SuperGlue implements the eval()/inference path only; call .eval()")
+        lib = _lib.load()
+        results: List[Dict[str, torch.Tensor]] = []
+        for c0 in range(0, len(pairs), _lib.OG_MAX_RAGGED):
+            chunk = pairs[c0:c0 + _lib.OG_MAX_RAGGED]
+            B = len(chunk)
+            names = ("keypoints0", "keypoints1", "local_descriptors0", "local_descriptors1", "side_info0", "side_info1")
+            for p in chunk:
+                for k in names:
+                    if not isinstance(p[k], torch.Tensor) or not p[k].is_cuda:
+                        raise RuntimeError(f"pairs[*]['{k}'] must be a tensor on the MI355X; openglue_amd has no CPU fallback")
+            t = {k: torch.cat([p[k].detach().to(torch.float32) for p in chunk], 0).contiguous() for k in names}
+            dev = t["keypoints0"].device
+            l0 = [int(p["keypoints0"].shape[0]) for p in chunk]
+            l1 = [int(p["keypoints1"].shape[0]) for p in chunk]
+            shape = self._shape(B, max(l0), max(l1), match_threshold)
+            _lib.check(lib.og_check_shape(C.byref(shape)), "og_check_shape")
+            n_scores = sum((a + 1) * (b + 1) for a, b in zip(l0, l1))
+            with torch.cuda.device(dev):
+                packed = self._pack(dev)
+                ws = torch.empty(lib.og_workspace_bytes(C.byref(shape)), device=dev, dtype=torch.uint8)
+                scores = torch.empty(n_scores, device=dev, dtype=torch.float32)
+                m0 = torch.empty(sum(l0), device=dev, dtype=torch.int64)
+                s0 = torch.empty(sum(l0), device=dev, dtype=torch.float32)
+                m1 = torch.empty(sum(l1), device=dev, dtype=torch.int64) if both_sides else None
+                s1 = torch.empty(sum(l1), device=dev, dtype=torch.float32) if both_sides else None
+                s_ = self.side_info_size
+                inp = _lib.og_inputs(t["keypoints0"].data_ptr(), t["keypoints1"].data_ptr(), t["local_descriptors0"].data_ptr(),
+                                     t["local_descriptors1"].data_ptr(), t["side_info0"].data_ptr() if s_ else None,
+                                     t["side_info1"].data_ptr() if s_ else None)
+                inp.image0_wh[0], inp.image0_wh[1] = _get_wh(chunk[0], 0)
+                inp.image1_wh[0], inp.image1_wh[1] = _get_wh(chunk[0], 1)
+                o = _lib.og_outputs(scores.data_ptr(), None, None, m0.data_ptr(), s0.data_ptr(),
+                                    m1.data_ptr() if both_sides else None, s1.data_ptr() if both_sides else None)
+                a0 = (C.c_int32 * B)(*l0)
+                a1 = (C.c_int32 * B)(*l1)
+                rc = lib.og_forward_ragged(C.byref(shape), a0, a1, C.byref(inp), packed.data_ptr(), ws.data_ptr(), C.byref(o),
+                                           torch.cuda.current_stream(dev).cuda_stream)
+                _lib.check(rc, "og_forward_ragged")
+            so = o0 = o1 = 0
+            for a, b in zip(l0, l1):
+                r = {"scores": scores[so:so + (a + 1) * (b + 1)].view(a + 1, b + 1), "matches0": m0[o0:o0 + a],
+                     "matching_scores0": s0[o0:o0 + a]}
+                if both_sides:
+                    r["matches1"], r["matching_scores1"] = m1[o1:o1 + b], s1[o1:o1 + b]
+                results.append(r)
+                so += (a + 1) * (b + 1); o0 += a; o1 += b
+        return results
+
+    @torch.no_grad()
     def forward(self, data: Mapping) -> Dict[str, torch.Tensor]:
         """Same contract as the reference SuperGlue.forward (superglue.py:29-72)."""
         return self._run(data, want_matches=False, match_threshold=0.0, both_sides=False)

@@ -337,6 +337,27 @@ def test_larger_baseline_configs(gpu_device, cfg_name, B):
     assert unexplained == 0, (ndiff, unexplained)
 
 
+def test_ragged_packed_wide_range(gpu_device):
+    """Packed ragged kernels on a spread of sizes that crosses the Sinkhorn / attention tile geometries
+    (1..2 column parts, partial last key tile, m < 32), against the uniform path run per pair."""
+    cfg = syn.make_config(descriptor_dim=64, num_stages=1, num_heads=4, num_iters=7, side_info_size=1)
+    sd = syn.make_state_dict(cfg, seed=0)
+    model = _build(cfg, sd, gpu_device)
+    lens = [(5, 1100), (300, 40), (1025, 1030), (64, 64), (130, 257), (1, 1), (777, 512)]
+    pairs = []
+    for i, (m, n) in enumerate(lens):
+        p = to_device(syn.make_pair(m, n, 64, 1, seed=300 + i), gpu_device)
+        p["image0_size"] = list(syn.IMAGE_WH); p["image1_size"] = list(syn.IMAGE_WH)
+        pairs.append(p)
+    packed = model.match_ragged(pairs, MATCH_THRESHOLD)
+    for p, q, (m, n) in zip(pairs, packed, lens):
+        one = {k: (v[None] if torch.is_tensor(v) else v) for k, v in p.items()}
+        ref = model.match(one, MATCH_THRESHOLD)
+        assert q["scores"].shape == (m + 1, n + 1)
+        assert (q["scores"] - ref["scores"][0]).abs().max() < 1e-4, (m, n)
+        assert torch.equal(q["matches0"], ref["matches0"][0]) and torch.equal(q["matches1"], ref["matches1"][0]), (m, n)
+
+
 def test_ragged_pairs_equal_per_pair_oracle(gpu_device):
     """BASELINE configs[4] semantics at small scale: every pair has its own (m, n); the result must equal the
     per-pair (B=1) oracle, whatever the bucketing."""
@@ -351,8 +372,13 @@ def test_ragged_pairs_equal_per_pair_oracle(gpu_device):
         p["image0_size"] = list(syn.IMAGE_WH); p["image1_size"] = list(syn.IMAGE_WH)
         pairs_cpu.append(p)
     assert [len(v) for v in bucket_by_shape(pairs_cpu).values()] == [2, 2, 1]
-    res = match_ragged(model, [to_device(p, gpu_device) for p in pairs_cpu], MATCH_THRESHOLD)
-    for p, r, (m, n) in zip(pairs_cpu, res, lens):
+    dev_pairs = [to_device(p, gpu_device) for p in pairs_cpu]
+    res = match_ragged(model, dev_pairs, MATCH_THRESHOLD)
+    packed = model.match_ragged(dev_pairs, MATCH_THRESHOLD)          # token-packed kernels (og_forward_ragged)
+    for r, q in zip(res, packed):
+        assert (r["scores"] - q["scores"]).abs().max() < 1e-4
+        assert torch.equal(r["matches0"], q["matches0"]) and torch.equal(r["matches1"], q["matches1"])
+    for p, r, (m, n) in zip(pairs_cpu, packed, lens):
         one = {k: (v[None] if torch.is_tensor(v) else v) for k, v in p.items()}
         with torch.no_grad():
             ref = orc.match_pairs(sd, cfg, one, MATCH_THRESHOLD)
