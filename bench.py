@@ -102,7 +102,7 @@ def cpu_baseline(cfg, sd, cfg_kw, m, n, budget_s=20.0):
             "sample": f"{reps} x 1 pair of the same workload (B=1, torch-CPU oracle, {best_t} of {ncpu} host threads), {dt * 1e3:.0f} ms/pair"}
 
 
-def bench_ragged(args, world, rank, dev):
+def bench_ragged(args, world, rank, dev, dist_on=False):
     """BASELINE configs[4]: 128 pairs with 512-2048 keypoints per image, cost-balanced over the ranks, through the
     token-packed ragged path (SuperGlue.match_ragged -> og_forward_ragged)."""
     kw = dict(syn.CONFIGS["C2"]); kw.pop("kpts"); kw.pop("batch")
@@ -121,20 +121,28 @@ def bench_ragged(args, world, rank, dev):
         pairs.append(p)
 
     def step():
-        return model.match_ragged(pairs, MATCH_THRESHOLD, both_sides=False)
+        res = model.match_ragged(pairs, MATCH_THRESHOLD, both_sides=False)
+        if dist_on:   # the one collective: match lists to rank 0, padded to the longest keypoint set (2048)
+            width = 2048
+            m0 = torch.full((len(res), width), -1, dtype=torch.int64, device=dev)
+            s0 = torch.zeros((len(res), width), dtype=torch.float32, device=dev)
+            for i, r in enumerate(res):
+                m0[i, :r["matches0"].numel()] = r["matches0"]; s0[i, :r["matches0"].numel()] = r["matching_scores0"]
+            sharding.gather_matches({"matches0": m0, "matching_scores0": s0}, mine, total, dst=0, always_collective=True)
+        return res
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
@@ -148,7 +156,7 @@ def bench_ragged(args, world, rank, dev):
                 "roofline": None, "cpu_baseline": None,
                 "valid_matches_per_pair": round(sum(int((r["matches0"] >= 0).sum()) for r in res) / max(1, len(res)), 1)}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
@@ -172,13 +180,15 @@ def main():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    dist_on = world > 1 or os.environ.get("OG_BENCH_FORCE_DIST") == "1"    # the latter: smoke-test the RCCL path on one GPU
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     if args.config == "C5":
-        return bench_ragged(args, world, rank, dev)
+        return bench_ragged(args, world, rank, dev, dist_on)
     kw = dict(syn.CONFIGS[args.config])
     (m, n), B = kw.pop("kpts"), kw.pop("batch")
     if args.batch:
@@ -193,23 +203,23 @@ def main():
 
     def step():
         out = model.match(data, MATCH_THRESHOLD, both_sides=True)
-        if world > 1:
-            sharding.gather_matches(out, pair_ids, world * B, dst=0)
+        if dist_on:
+            sharding.gather_matches(out, pair_ids, world * B, dst=0, always_collective=True)
         return out
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
@@ -272,7 +282,7 @@ def main():
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -56,12 +56,12 @@ def take_pairs(data: Mapping, idx: Sequence[int]) -> Dict:
 
 
 def gather_matches(local: Mapping[str, torch.Tensor], pair_ids: Sequence[int], num_pairs: int, dst: int = 0,
-                   group=None) -> Optional[Dict[str, torch.Tensor]]:
+                   group=None, always_collective: bool = False) -> Optional[Dict[str, torch.Tensor]]:
     """The one collective: every rank contributes matches0 [b, m] (int64) and matching_scores0 [b, m]
     (fp32) of its shard; rank `dst` returns them re-assembled in job order [num_pairs, m]; others None.
     Shards are padded to the largest shard so a single fixed-size gather suffices."""
     m0, s0 = local["matches0"], local["matching_scores0"]
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not always_collective):
         order = torch.as_tensor(list(pair_ids), dtype=torch.long, device=m0.device)
         out_m = torch.full((num_pairs, m0.shape[1]), -1, dtype=torch.int64, device=m0.device)
         out_s = torch.zeros((num_pairs, m0.shape[1]), dtype=torch.float32, device=m0.device)
@@ -70,26 +70,30 @@ def gather_matches(local: Mapping[str, torch.Tensor], pair_ids: Sequence[int], n
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     cap = (num_pairs + world - 1) // world
     width = m0.shape[1]
-    # one packed fp32 payload per rank: [cap, 1 + 2*width] = pair id | matches (exact in fp32 below 2^24) | scores
     if width >= (1 << 24) or num_pairs >= (1 << 24):
         raise ValueError("index does not fit the packed fp32 payload")
-    payload = torch.full((cap, 1 + 2 * width), -1.0, dtype=torch.float32, device=m0.device)
     b = m0.shape[0]
-    if b:
-        payload[:b, 0] = torch.as_tensor(list(pair_ids), dtype=torch.float32, device=m0.device)
-        payload[:b, 1:1 + width] = m0.to(torch.float32)
-        payload[:b, 1 + width:] = s0
+    ids = torch.as_tensor(list(pair_ids), dtype=torch.long, device=m0.device)
+    # one packed fp32 payload per rank: [cap, 1 + 2*width] = pair id | matches (exact in fp32 below 2^24) | scores
+    if b == cap:                                   # the common case (equal shards): a single fused concatenation
+        payload = torch.cat([ids.to(torch.float32)[:, None], m0.to(torch.float32), s0], dim=1)
+    else:
+        payload = torch.full((cap, 1 + 2 * width), -1.0, dtype=torch.float32, device=m0.device)
+        if b:
+            payload[:b, 0] = ids.to(torch.float32)
+            payload[:b, 1:1 + width] = m0.to(torch.float32)
+            payload[:b, 1 + width:] = s0
     bufs = [torch.empty_like(payload) for _ in range(world)] if rank == dst else None
     dist.gather(payload, bufs, dst=dst, group=group)
     if rank != dst:
         return None
     allp = torch.cat(bufs, 0)
-    ids = allp[:, 0].to(torch.long)
-    keep = ids >= 0
+    gid = allp[:, 0].to(torch.long)
+    keep = gid >= 0
     out_m = torch.full((num_pairs, width), -1, dtype=torch.int64, device=m0.device)
     out_s = torch.zeros((num_pairs, width), dtype=torch.float32, device=m0.device)
-    out_m[ids[keep]] = allp[keep, 1:1 + width].to(torch.int64)
-    out_s[ids[keep]] = allp[keep, 1 + width:]
+    out_m[gid[keep]] = allp[keep, 1:1 + width].to(torch.int64)
+    out_s[gid[keep]] = allp[keep, 1 + width:]
     return {"matches0": out_m, "matching_scores0": out_s}
 
 
