@@ -121,10 +121,10 @@ __global__ __launch_bounds__(256) void sinkhorn_sweep_kernel(const float* __rest
 
     const int srow0 = rb * SK_ROWS + rs * RW;
     int parity = 0;
-#pragma unroll 1
-    for (int g0 = 0; g0 < RW; g0 += RG) {        // same trip count in every wave (barrier inside when WPR > 1)
-        const int row0 = srow0 + g0;
-        float x[RG][CPL][4];
+    // raw rows of the NEXT group are fetched before the current group is processed (register double buffer):
+    // the sweep is bound by bytes in flight, not by arithmetic
+    f32x4 nx[RG][CPL];
+    auto fetch = [&](int row0) {
 #pragma unroll
         for (int r = 0; r < RG; ++r) {
             const int row = row0 + r;
@@ -132,16 +132,25 @@ __global__ __launch_bounds__(256) void sinkhorn_sweep_kernel(const float* __rest
 #pragma unroll
             for (int k = 0; k < CPL; ++k) {
                 const int c0 = cbase + 256 * k;
-                if (row < M && c0 < N) {
-                    const f32x4 t = *reinterpret_cast<const f32x4*>(sp + c0);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) x[r][k][e] = (c0 + e < N) ? t[e] * inv_reg : OG_NEG_INF;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) x[r][k][e] = OG_NEG_INF;
-                }
+                if (row < M && c0 < N) nx[r][k] = *reinterpret_cast<const f32x4*>(sp + c0);
+                else nx[r][k] = f32x4{OG_NEG_INF, OG_NEG_INF, OG_NEG_INF, OG_NEG_INF};
             }
         }
+    };
+    fetch(srow0);
+#pragma unroll 1
+    for (int g0 = 0; g0 < RW; g0 += RG) {        // same trip count in every wave (barrier inside when WPR > 1)
+        const int row0 = srow0 + g0;
+        float x[RG][CPL][4];
+#pragma unroll
+        for (int r = 0; r < RG; ++r)
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                const int c0 = cbase + 256 * k;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[r][k][e] = (c0 + e < N) ? nx[r][k][e] * inv_reg : OG_NEG_INF;
+            }
+        if (g0 + RG < RW) fetch(row0 + RG);
         // ---- row log-sum-exp -> u of the RG rows ----
         float mx[RG], sum[RG];
 #pragma unroll
