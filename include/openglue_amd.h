@@ -225,6 +225,26 @@ int og_extract_matches(const float* scores, int32_t batch, int32_t m, int32_t n,
                        int64_t* matches0, float* matching_scores0, int64_t* matches1,
                        float* matching_scores1, void* workspace_dev, void* stream);
 
+/* ---- the steps either side of the matcher in OpenGlue's inference loop ---- */
+
+/* models/features/utils.py:54-65 prepare_features_output + models/laf_converter.py: lafs [tokens][2][3],
+ * responses [tokens] -> keypoints [tokens][2] (LAF centre) and side_info [tokens][s].
+ * method: 0 'none' (s=1), 1 'scale' (2), 2 'rotation' (3), 3 'scale_rotation' (4), 4 'affine' (6);
+ * log_response: response -> log(response + 0.1).  LAF scale as kornia.feature.laf.get_laf_scale. */
+int og_prepare_features(const float* lafs, const float* responses, int64_t tokens, int32_t method, int32_t log_response,
+                        float* keypoints, float* side_info, void* stream);
+
+/* inference.py:192-209: order-preserving compaction of the valid matches of a batch.
+ * matches0 / matching_scores0 [B][m]; lafs0 [B][m][2][3], lafs1 [B][n][2][3] (both may be NULL).
+ * Outputs sized for the worst case (B*m rows): matching_idxs [K][2] (keypoint index in image 0, in image 1),
+ * batch_indexes [K], confidence [K], mlafs0/mlafs1 [K][2][3], keypoints0/1 [K][2]; K is written to count_dev.
+ * workspace: og_compact_workspace_bytes. */
+size_t og_compact_workspace_bytes(int32_t batch, int32_t m);
+int og_compact_matches(const int64_t* matches0, const float* matching_scores0, const float* lafs0, const float* lafs1,
+                       int32_t batch, int32_t m, int32_t n, int64_t* matching_idxs, int64_t* batch_indexes,
+                       float* confidence, float* mlafs0, float* mlafs1, float* keypoints0, float* keypoints1,
+                       int32_t* count_dev, void* workspace_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

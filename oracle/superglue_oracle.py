@@ -237,3 +237,54 @@ def ambiguous_rows(scores64: torch.Tensor, gap: float = 1e-4) -> Tuple[torch.Ten
     t0 = inner.topk(2, dim=2).values
     t1 = inner.topk(2, dim=1).values
     return (t0[..., 0] - t0[..., 1]) < gap, (t1[:, 0] - t1[:, 1]) < gap
+
+
+# ---------------------------------------------------------------------------------------------------
+# The steps either side of the matcher.  kornia is NOT installed here and not vendored
+# in the reference, so get_laf_scale / get_laf_center are restated from kornia's published source
+# (kornia/feature/laf.py, requirements.txt:5 `kornia>=0.6.1`): parity for these two helpers is pinned to the
+# published algorithm only, not to an execution of kornia.
+def get_laf_scale(lafs: torch.Tensor) -> torch.Tensor:
+    """kornia.feature.laf.get_laf_scale: sqrt(|det(A) + 1e-10|) of the 2x2 affine part, shape [B, N, 1, 1]."""
+    det = lafs[..., 0:1, 0:1] * lafs[..., 1:2, 1:2] - lafs[..., 1:2, 0:1] * lafs[..., 0:1, 1:2] + 1e-10
+    return det.abs().sqrt()
+
+
+def laf_side_info(lafs: torch.Tensor, method: str) -> torch.Tensor:
+    """models/laf_converter.py:22-128: 'none' | 'scale' | 'rotation' | 'scale_rotation' | 'affine'."""
+    B, N = lafs.shape[:2]
+    scale = get_laf_scale(lafs).squeeze(-1)                                   # [B, N, 1]
+    log_scale = torch.log(scale)                                              # LAF2LogScale (:22-36) -- [B, N, 1]
+    rot = torch.flip(lafs[..., 0, :-1], dims=(-1,)) / scale                   # LAF2SinCosOrientation (:39-55)
+    aff = torch.flatten(lafs[..., :-1], start_dim=2) / scale                  # LAF2AffineGeom (:58-72)
+    parts = {"none": [], "scale": [log_scale], "rotation": [rot], "scale_rotation": [log_scale, rot],
+             "affine": [log_scale, aff]}
+    if method.lower() not in parts:
+        raise NameError("Unexpected name for the method: {}".format(method))
+    p = parts[method.lower()]
+    return torch.cat(p, dim=-1) if p else lafs.new_empty(B, N, 0)
+
+
+def prepare_features_output(lafs, responses, desc, method="none", permute_desc=False, log_response=False):
+    """models/features/utils.py:54-65."""
+    kpts = lafs[:, :, :, -1]
+    responses = responses.unsqueeze(-1)
+    if log_response:
+        responses = (responses + 0.1).log()
+    return {"keypoints": kpts, "side_info": torch.cat([responses, laf_side_info(lafs, method)], dim=-1),
+            "local_descriptors": desc.permute(0, 2, 1) if permute_desc else desc}
+
+
+def compact_matches(matches0: torch.Tensor, matching_scores0: torch.Tensor, lafs0=None, lafs1=None):
+    """inference.py:192-209: boolean-mask compaction of the valid matches (row-major over pair, keypoint)."""
+    B, M = matches0.shape
+    mask0 = matches0 != -1
+    arange0 = torch.arange(M)[None].expand(B, -1)
+    batch_idxs0 = torch.arange(B)[:, None].expand(-1, M)[mask0]
+    idx0, idx1 = arange0[mask0], matches0[mask0]
+    out = {"original_matching_idxs": torch.stack([idx0, idx1], dim=-1), "batch_indexes": batch_idxs0,
+           "confidence": matching_scores0[mask0]}
+    if lafs0 is not None:
+        ml0, ml1 = lafs0[batch_idxs0, idx0][None], lafs1[batch_idxs0, idx1][None]
+        out.update(lafs0=ml0, lafs1=ml1, keypoints0=ml0[0][..., 2], keypoints1=ml1[0][..., 2])   # kornia get_laf_center
+    return out

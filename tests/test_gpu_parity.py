@@ -388,3 +388,44 @@ def test_ragged_pairs_equal_per_pair_oracle(gpu_device):
         assert r["scores"].shape == (m + 1, n + 1)
         assert (r["scores"].cpu() - ref["scores"][0]).abs().max() < TOL_SCORES
         assert torch.equal(r["matches0"].cpu(), ref["matches0"][0])
+
+
+# ----------------------------------------------------------------------------- steps either side of the path (f1, f3)
+@pytest.mark.parametrize("method", ["none", "scale", "rotation", "scale_rotation", "affine"])
+def test_prepare_features_output(gpu_device, method):
+    from openglue_amd import features
+    g = torch.Generator().manual_seed(len(method))
+    B, N, D = 2, 333, 32
+    A = torch.randn(B, N, 2, 2, generator=g) + 2.0 * torch.eye(2)          # affine shapes, some with negative determinant
+    lafs = torch.cat([A, torch.rand(B, N, 2, 1, generator=g) * 900], dim=-1)
+    resp = torch.rand(B, N, generator=g)
+    desc = torch.randn(B, N, D, generator=g)
+    for log_response in (False, True):
+        want = orc.prepare_features_output(lafs, resp, desc, method, log_response=log_response)
+        got = features.prepare_features_output(lafs.to(gpu_device), resp.to(gpu_device), desc.to(gpu_device), method,
+                                               log_response=log_response)
+        assert got["side_info"].shape[-1] == features.side_info_size(method)
+        assert torch.equal(got["keypoints"].cpu(), want["keypoints"])
+        # thin frames (det ~ 0) make 1/scale ill-conditioned: judge both fp32 results against float64
+        truth = orc.prepare_features_output(lafs.double(), resp.double(), desc, method, log_response=log_response)["side_info"]
+        err_gpu = (got["side_info"].cpu().double() - truth).abs()
+        err_cpu = (want["side_info"].double() - truth).abs()
+        assert (err_gpu <= 4.0 * err_cpu + 2e-6 * truth.abs() + 1e-6).all()
+
+
+def test_compact_matches(gpu_device):
+    from openglue_amd import features
+    g = torch.Generator().manual_seed(3)
+    B, M, N = 3, 700, 650
+    m0 = torch.randint(0, N, (B, M), generator=g)
+    m0[torch.rand(B, M, generator=g) < 0.45] = -1
+    m0[1] = -1                                                   # a pair without any match
+    ms0 = torch.rand(B, M, generator=g)
+    lafs0, lafs1 = torch.randn(B, M, 2, 3, generator=g), torch.randn(B, N, 2, 3, generator=g)
+    want = orc.compact_matches(m0, ms0, lafs0, lafs1)
+    got = features.compact_matches(m0.to(gpu_device), ms0.to(gpu_device), lafs0.to(gpu_device), lafs1.to(gpu_device))
+    assert set(got) == set(want)
+    for k in want:
+        assert torch.equal(got[k].cpu(), want[k]), k
+    none = features.compact_matches(torch.full((2, 5), -1, device=gpu_device), torch.zeros(2, 5, device=gpu_device))
+    assert none["confidence"].numel() == 0
