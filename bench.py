@@ -277,6 +277,19 @@ def main():
             "algorithmic": {"gflop_per_pair": round(counts["total_flops"] / 1e9, 2), "sinkhorn_gb_per_pair": round(counts["sinkhorn_bytes"] / 1e9, 3)},
             "valid_matches_per_pair": round(float((out["matches0"] >= 0).sum().item()) / B, 1),
         }
+        # the same step fed from pinned HOST buffers (H2D of keypoints/descriptors/side-info included, synchronous with
+        # the step: the boundary hands over device tensors, so this is informational and never `value`)
+        host = {k: v.cpu().pin_memory() for k, v in data.items() if torch.is_tensor(v)}
+        def step_h2d():
+            d = {k: v.to(dev, non_blocking=True) for k, v in host.items()}
+            d["image0_size"], d["image1_size"] = data["image0_size"], data["image1_size"]
+            return model.match(d, MATCH_THRESHOLD, both_sides=True)
+        step_h2d(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_h2d()
+        torch.cuda.synchronize()
+        line["value_incl_h2d"] = round(B * args.steps / (time.perf_counter() - t0), 2)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, sd, kw, m, n)
         else:

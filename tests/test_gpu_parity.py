@@ -429,3 +429,22 @@ def test_compact_matches(gpu_device):
         assert torch.equal(got[k].cpu(), want[k]), k
     none = features.compact_matches(torch.full((2, 5), -1, device=gpu_device), torch.zeros(2, 5, device=gpu_device))
     assert none["confidence"].numel() == 0
+
+
+def test_hipgraph_replay_equals_eager(gpu_device):
+    """The whole launch sequence captured into a hipGraph (launch-bound small shapes) gives identical results."""
+    from openglue_amd.graph import GraphedMatcher
+    z, cfg, sd, data = load_case("c1")
+    model = _build(cfg, sd, gpu_device)
+    d0 = to_device(data, gpu_device)
+    eager = {k: v.clone() for k, v in model.match(d0, MATCH_THRESHOLD).items()}
+    gm = GraphedMatcher(model, d0, MATCH_THRESHOLD)
+    out = gm(d0)
+    for k in eager:
+        assert torch.equal(out[k], eager[k]), k
+    # new inputs through the same graph
+    d1 = to_device(syn.make_batch(1, 64, 64, 64, 1, seed=77), gpu_device)
+    want = {k: v.clone() for k, v in model.match(d1, MATCH_THRESHOLD).items()}
+    out = gm(d1)
+    for k in want:
+        assert torch.equal(out[k], want[k]), k
