@@ -448,3 +448,28 @@ def test_hipgraph_replay_equals_eager(gpu_device):
     out = gm(d1)
     for k in want:
         assert torch.equal(out[k], want[k]), k
+
+
+@pytest.mark.parametrize("m,n,kw", [
+    (1, 1, dict(descriptor_dim=64, num_stages=1, num_heads=4, num_iters=2)),
+    (3, 200, dict(descriptor_dim=64, num_stages=2, num_heads=2, num_iters=4, side_info_size=3)),
+    (129, 2, dict(descriptor_dim=128, num_stages=1, num_heads=8, num_iters=5, side_info_size=0 + 1)),
+    (70, 90, dict(descriptor_dim=512, num_stages=1, num_heads=8, num_iters=5, hidden_layers_sizes=(64, 256))),
+    (40, 40, dict(descriptor_dim=256, num_stages=0, num_heads=4, num_iters=3)),
+])
+def test_forward_edge_shapes(gpu_device, m, n, kw):
+    """Degenerate and unusual shapes through the whole path: single keypoints, strongly non-square pairs, 8 heads,
+    512-d descriptors with a non-default encoder, zero GNN stages."""
+    cfg = syn.make_config(**kw)
+    sd = syn.make_state_dict(cfg, seed=1)
+    model = _build(cfg, sd, gpu_device)
+    data = syn.make_batch(2, m, n, cfg["descriptor_dim"], cfg["positional_encoding"]["side_info_size"], seed=5)
+    out = {k: v.cpu() for k, v in model.match(to_device(data, gpu_device), MATCH_THRESHOLD).items()}
+    with torch.no_grad():
+        ref = orc.match_pairs(sd, cfg, data, MATCH_THRESHOLD)
+    err = (out["scores"] - ref["scores"]).abs().max().item()
+    assert err < TOL_SCORES, err
+    assert (out["context_descriptors0"] - ref["context_descriptors0"]).abs().max() < TOL_SCORES
+    amb_r, _ = orc.ambiguous_rows(ref["scores"].double(), 1e-3) if m > 1 and n > 1 else (torch.zeros(2, m, dtype=torch.bool), None)
+    diff = (out["matches0"] != ref["matches0"]) & ~amb_r
+    assert int(diff.sum()) == 0
