@@ -105,7 +105,7 @@ int check_shape(const og_shape* s) {
         if (s->hidden[i] <= 0 || og_round_up(s->hidden[i], 64) > 2 * s->desc_dim) return OG_E_SHAPE;
     if (s->n > 8192) return OG_E_SHAPE;                 // Sinkhorn sweep geometry (sinkhorn.hip)
     if (s->sinkhorn_iters < 0 || !(s->sinkhorn_reg > 0.f)) return OG_E_SHAPE;
-    if (s->flags & ~(OG_FLAG_RESIDUAL | OG_FLAG_USE_OFFSET | OG_FLAG_NO_DESCRIPTORS)) return OG_E_FLAG;
+    if (s->flags & ~(OG_FLAG_RESIDUAL | OG_FLAG_USE_OFFSET | OG_FLAG_NO_DESCRIPTORS | OG_FLAG_SIREN_ENCODER)) return OG_E_FLAG;
     return 0;
 }
 
@@ -189,9 +189,13 @@ extern "C" int og_pack_weights(const og_shape* shape, const og_params* P, void* 
                 b[o] = (float)bb;
             }
             if (i < s.num_hidden) {
-                const og_bn& bn = P->enc_bn[i];
-                if (!bn.weight || !bn.bias || !bn.running_mean || !bn.running_var) return OG_E_INVALID;
-                bn_affine(bn, out_real, g, c);
+                if (s.flags & OG_FLAG_SIREN_ENCODER) {       // no BatchNorm between the layers: identity fold
+                    g.assign(out_real, 1.0); c.assign(out_real, 0.0);
+                } else {
+                    const og_bn& bn = P->enc_bn[i];
+                    if (!bn.weight || !bn.bias || !bn.running_mean || !bn.running_var) return OG_E_INVALID;
+                    bn_affine(bn, out_real, g, c);
+                }
             }
             in_real = out_real;
         }
@@ -359,7 +363,8 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
             const float* Wi = pk + L.enc_w[i]; const float* bi = pk + L.enc_b[i];
             if (i + 1 < L.n_enc) {
                 float* dst = (i & 1) ? Eb : Ea;
-                if ((rc = gemm(cur, ldcur, Wi, L.enc_k[i], dst, L.enc_maxw, T, L.enc_out[i], L.enc_k[i], bi, 1, nullptr, 0, nullptr, nullptr, 0))) return rc;
+                const int act = (s.flags & OG_FLAG_SIREN_ENCODER) ? 2 : 1;      // sin(30 x) or ReLU (+ folded BatchNorm)
+                if ((rc = gemm(cur, ldcur, Wi, L.enc_k[i], dst, L.enc_maxw, T, L.enc_out[i], L.enc_k[i], bi, act, nullptr, 0, nullptr, nullptr, 0))) return rc;
                 cur = dst; ldcur = L.enc_maxw;
             } else {
                 const bool nd = s.flags & OG_FLAG_NO_DESCRIPTORS;

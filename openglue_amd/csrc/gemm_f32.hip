@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g, int tiles_
                 const int row = m0 + wm * 64 + i * 32 + mfma32_row(r, lane);
                 if (row >= g.M) continue;
                 float v = acc[i][j][r] + bias;
-                if (g.relu) v = fmaxf(v, 0.f);
+                if (g.relu == 1) v = fmaxf(v, 0.f);
+                else if (g.relu == 2) v = sinf(30.f * v);      // Siren activation (reference models/utils.py:29)
                 if (R) {
                     const float rr = R[(int64_t)row * g.ldr + col];
                     v = g.alpha ? al * v + (1.f - al) * rr : v + rr;

@@ -57,7 +57,7 @@ struct GemmArgs {
     float* C; int64_t ldc, strideC;
     int M, N, K, batch;
     const float* bias;        // [N] or null
-    int relu;
+    int relu;                 // activation: 0 none, 1 ReLU, 2 sin(30 v)
     const float* res; int64_t ldr, strideR;   // residual / mix source, rows like C
     const float* alpha;       // [N] or null: v = alpha*v + (1-alpha)*res
     float scale;

@@ -25,7 +25,7 @@ import torch.nn as nn
 
 from . import _lib
 
-_ENCODERS = ("FeedForwardNet",)          # FeedForwardNetSiren: SURVEY.md §8 f4 ("next")
+_ENCODERS = ("FeedForwardNet", "FeedForwardNetSiren")
 _ATTENTIONS = ("softmax",)               # linear / FAVOR: SURVEY.md §8 f4 ("next")
 
 
@@ -35,6 +35,16 @@ def _mlp_container(*sizes: int) -> nn.Sequential:
     layers: List[nn.Module] = []
     for i in range(1, len(sizes) - 1):
         layers += [nn.Conv1d(sizes[i - 1], sizes[i], kernel_size=1), nn.ReLU(inplace=True), nn.BatchNorm1d(sizes[i])]
+    layers.append(nn.Conv1d(sizes[-2], sizes[-1], kernel_size=1))
+    return nn.Sequential(*layers)
+
+
+def _siren_container(*sizes: int) -> nn.Sequential:
+    """Same child indices as the reference FeedForwardNetSiren (models/utils.py:32-45): conv 2i, Sine 2i+1, last conv.
+    (The reference's special sine_init only matters for training from scratch; weights are loaded here.)"""
+    layers: List[nn.Module] = []
+    for i in range(1, len(sizes) - 1):
+        layers += [nn.Conv1d(sizes[i - 1], sizes[i], kernel_size=1), nn.Identity()]
     layers.append(nn.Conv1d(sizes[-2], sizes[-1], kernel_size=1))
     return nn.Sequential(*layers)
 
@@ -81,7 +91,9 @@ class SuperGlue(nn.Module):
         self.no_descriptors = bool(config.get("no_descriptors", False))
 
         # ---- parameter tree with the reference's names ----
-        self.positional_encoding = _Holder(encoder=_mlp_container(2 + self.side_info_size, *self.hidden, D))
+        self.siren = enc_name == "FeedForwardNetSiren"
+        make_enc = _siren_container if self.siren else _mlp_container
+        self.positional_encoding = _Holder(encoder=make_enc(2 + self.side_info_size, *self.hidden, D))
         layers = nn.ModuleList()
         for _ in range(2 * self.num_stages):       # even = self, odd = cross (attention_gnn.py:84-89)
             mha = _Holder(in_proj_q=nn.Conv1d(D, D, 1), in_proj_k=nn.Conv1d(D, D, 1),
@@ -112,7 +124,8 @@ class SuperGlue(nn.Module):
         s.sinkhorn_iters = int(self.config["otp"]["num_iters"])
         s.sinkhorn_reg = float(self.config["otp"]["reg"])
         s.flags = ((_lib.OG_FLAG_RESIDUAL if self.residual else 0) | (_lib.OG_FLAG_USE_OFFSET if self.use_offset else 0)
-                   | (_lib.OG_FLAG_NO_DESCRIPTORS if self.no_descriptors else 0))
+                   | (_lib.OG_FLAG_NO_DESCRIPTORS if self.no_descriptors else 0)
+                   | (_lib.OG_FLAG_SIREN_ENCODER if self.siren else 0))
         s.match_threshold = float(match_threshold)
         return s
 
@@ -149,9 +162,12 @@ class SuperGlue(nn.Module):
         P = _lib.og_params()
         enc = self.positional_encoding.encoder
         for i in range(len(self.hidden) + 1):
-            P.enc_conv[i] = conv(enc[3 * i])
-            if i < len(self.hidden):
-                P.enc_bn[i] = bn(enc[3 * i + 2])
+            if self.siren:
+                P.enc_conv[i] = conv(enc[2 * i])
+            else:
+                P.enc_conv[i] = conv(enc[3 * i])
+                if i < len(self.hidden):
+                    P.enc_bn[i] = bn(enc[3 * i + 2])
         LayerArr = _lib.og_layer_params * max(1, 2 * self.num_stages)
         layer_arr = LayerArr()
         for l, holder in enumerate(self.attention_gnn.layers):

@@ -41,7 +41,8 @@ def make_config(descriptor_dim: int = 256, num_stages: int = 9, num_heads: int =
                 num_iters: int = 100, side_info_size: int = 1, reg: float = 1.0,
                 residual: bool = True, use_offset: bool = False, no_descriptors: bool = False,
                 dustbin_score_init: float = 1.0,
-                hidden_layers_sizes: Sequence[int] = (32, 64, 128), **_unused) -> dict:
+                hidden_layers_sizes: Sequence[int] = (32, 64, 128), encoder_name: str = "FeedForwardNet",
+                **_unused) -> dict:
     """The `superglue:` config block with the keys SuperGlue.__init__ reads
     (reference models/superglue/superglue.py:16-27, config/config.yaml:42-55) plus the keys
     MatchingTrainingModule injects (models/matching_module.py:35-43)."""
@@ -50,7 +51,7 @@ def make_config(descriptor_dim: int = 256, num_stages: int = 9, num_heads: int =
         "positional_encoding": {
             "output_size": descriptor_dim,
             "side_info_size": side_info_size,
-            "encoder_name": "FeedForwardNet",
+            "encoder_name": encoder_name,
             "hidden_layers_sizes": list(hidden_layers_sizes),
         },
         "attention_gnn": {
@@ -90,13 +91,18 @@ def state_dict_spec(config: dict) -> "OrderedDict[str, tuple]":
     if config.get("residual", False):
         spec["mix_coefs"] = ((D, 1), "mix", 0)
     spec["dustbin_score"] = ((), "dustbin", 0)
-    # FeedForwardNet = [Conv1d, ReLU, BatchNorm1d] * (n-1) + Conv1d  -> Sequential indices 0,(1),2, 3,(4),5, ...
-    idx = 0
-    for i in range(1, len(sizes) - 1):
-        conv(f"positional_encoding.encoder.{idx}", sizes[i], sizes[i - 1])
-        bn(f"positional_encoding.encoder.{idx + 2}", sizes[i])
-        idx += 3
-    conv(f"positional_encoding.encoder.{idx}", sizes[-1], sizes[-2])
+    if pe.get("encoder_name", "FeedForwardNet") == "FeedForwardNetSiren":
+        # FeedForwardNetSiren = [Conv1d, Sine] * (n-1) + Conv1d (models/utils.py:32-45) -> conv indices 0, 2, 4, ...
+        for i in range(1, len(sizes)):
+            conv(f"positional_encoding.encoder.{2 * (i - 1)}", sizes[i], sizes[i - 1])
+    else:
+        # FeedForwardNet = [Conv1d, ReLU, BatchNorm1d] * (n-1) + Conv1d  -> Sequential indices 0,(1),2, 3,(4),5, ...
+        idx = 0
+        for i in range(1, len(sizes) - 1):
+            conv(f"positional_encoding.encoder.{idx}", sizes[i], sizes[i - 1])
+            bn(f"positional_encoding.encoder.{idx + 2}", sizes[i])
+            idx += 3
+        conv(f"positional_encoding.encoder.{idx}", sizes[-1], sizes[-2])
     for l in range(2 * L):
         p = f"attention_gnn.layers.{l}.module"
         for name in ("in_proj_q", "in_proj_k", "in_proj_v", "out_proj"):

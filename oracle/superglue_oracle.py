@@ -60,6 +60,14 @@ def feed_forward(x: torch.Tensor, sd, prefix: str, n_conv: int) -> torch.Tensor:
     return conv1x1(x, sd, f"{prefix}.{3 * (n_conv - 1)}")
 
 
+def feed_forward_siren(x: torch.Tensor, sd, prefix: str, n_conv: int) -> torch.Tensor:
+    """FeedForwardNetSiren: [Conv1d, Sine] * (n_conv-1) + Conv1d, Sine(x) = sin(30 x), no BatchNorm
+    (models/utils.py:23-45).  Sequential indices: conv 2i, sine 2i+1."""
+    for i in range(n_conv - 1):
+        x = torch.sin(30 * conv1x1(x, sd, f"{prefix}.{2 * i}"))
+    return conv1x1(x, sd, f"{prefix}.{2 * (n_conv - 1)}")
+
+
 def normalize_keypoints(kpts: torch.Tensor, width: float, height: float) -> torch.Tensor:
     """superglue.py:74-78: 2*k / [W-1, H-1] - 1."""
     return 2 * kpts / torch.tensor([width - 1, height - 1], dtype=kpts.dtype) - 1.0
@@ -68,7 +76,8 @@ def normalize_keypoints(kpts: torch.Tensor, width: float, height: float) -> torc
 def keypoint_encoder(kpts_n: torch.Tensor, side: torch.Tensor, sd, config) -> torch.Tensor:
     """MLPPositionalEncoding.forward, positional_encoding.py:16-19: cat([xy, side_info]) -> MLP."""
     n_conv = len(config["positional_encoding"]["hidden_layers_sizes"]) + 1
-    return feed_forward(torch.cat([kpts_n, side], dim=-1), sd, "positional_encoding.encoder", n_conv)
+    ff = feed_forward_siren if config["positional_encoding"].get("encoder_name") == "FeedForwardNetSiren" else feed_forward
+    return ff(torch.cat([kpts_n, side], dim=-1), sd, "positional_encoding.encoder", n_conv)
 
 
 def softmax_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int,

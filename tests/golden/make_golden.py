@@ -42,6 +42,8 @@ CASES = {
                    residual=False, use_offset=True, reg=0.5, dustbin_score_init=0.3), 96, 130, 2, 3, "full"),
     "nodesc": (dict(descriptor_dim=64, num_stages=1, num_heads=4, num_iters=5, side_info_size=1,
                     no_descriptors=True), 70, 33, 1, 4, "full"),
+    "siren": (dict(descriptor_dim=64, num_stages=1, num_heads=4, num_iters=5, side_info_size=2,
+                   encoder_name="FeedForwardNetSiren", hidden_layers_sizes=(32, 64)), 80, 75, 2, 6, "full"),
     "c2": (dict(syn.CONFIGS["C2"]), 1024, 1024, 2, 5, "sub8"),
 }
 

@@ -43,7 +43,7 @@ def forward_from_packed(model, data, dtype=torch.float64):
             W, b = mat(L.enc_w[i], L.enc_out[i], L.enc_k[i]), vec(L.enc_b[i], L.enc_out[i])
             x = x @ W.T + b
             if i + 1 < L.n_enc:
-                x = torch.relu(x)
+                x = torch.sin(30 * x) if model.siren else torch.relu(x)
         return x
 
     d0, d1 = data["local_descriptors0"].to(dtype), data["local_descriptors1"].to(dtype)
