@@ -43,6 +43,7 @@ extern "C" {
 #define OG_FLAG_RESIDUAL        1
 #define OG_FLAG_USE_OFFSET      2
 #define OG_FLAG_NO_DESCRIPTORS  4
+#define OG_FLAG_LINEAR_ATTENTION 16  /* attention_gnn.attention = 'linear': elu+1 linear attention (attention.py:22-40) instead of softmax */
 #define OG_FLAG_SIREN_ENCODER   8   /* positional_encoding.encoder_name = FeedForwardNetSiren: [Conv, sin(30x)]*h + Conv,
                                        no BatchNorm (models/utils.py:23-45); og_params.enc_bn is ignored */
 

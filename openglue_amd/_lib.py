@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OPENGLUE_AMD_LIB") or os.path.join(HERE, "lib", "libopenglue_amd.so")   # override: A/B builds
 
 OG_ABI_VERSION = 1
-OG_FLAG_RESIDUAL, OG_FLAG_USE_OFFSET, OG_FLAG_NO_DESCRIPTORS, OG_FLAG_SIREN_ENCODER = 1, 2, 4, 8
+OG_FLAG_RESIDUAL, OG_FLAG_USE_OFFSET, OG_FLAG_NO_DESCRIPTORS, OG_FLAG_SIREN_ENCODER, OG_FLAG_LINEAR_ATTENTION = 1, 2, 4, 8, 16
 OG_MAX_HIDDEN = 8
 OG_MAX_RAGGED = 64
 OG_STAGES = ("encoder_input", "gemm_f32", "attention", "sinkhorn", "matches", "gemm_f16x3")

@@ -105,7 +105,7 @@ int check_shape(const og_shape* s) {
         if (s->hidden[i] <= 0 || og_round_up(s->hidden[i], 64) > 2 * s->desc_dim) return OG_E_SHAPE;
     if (s->n > 8192) return OG_E_SHAPE;                 // Sinkhorn sweep geometry (sinkhorn.hip)
     if (s->sinkhorn_iters < 0 || !(s->sinkhorn_reg > 0.f)) return OG_E_SHAPE;
-    if (s->flags & ~(OG_FLAG_RESIDUAL | OG_FLAG_USE_OFFSET | OG_FLAG_NO_DESCRIPTORS | OG_FLAG_SIREN_ENCODER)) return OG_E_FLAG;
+    if (s->flags & ~(OG_FLAG_RESIDUAL | OG_FLAG_USE_OFFSET | OG_FLAG_NO_DESCRIPTORS | OG_FLAG_SIREN_ENCODER | OG_FLAG_LINEAR_ATTENTION)) return OG_E_FLAG;
     return 0;
 }
 
@@ -203,8 +203,9 @@ extern "C" int og_pack_weights(const og_shape* shape, const og_params* P, void* 
 
     // ---- GNN layers ----
     const int dh = D / s.num_heads;
-    // attention.py:12 `* embed_dim ** -0.5`, times log2(e): the attention kernel's softmax is base 2
-    const double qscale = 1.4426950408889634 / sqrt((double)dh);
+    // attention.py:12 `* embed_dim ** -0.5`, times log2(e): the attention kernel's softmax is base 2.
+    // Linear attention (attention.py:22-40) has no scale.
+    const double qscale = (s.flags & OG_FLAG_LINEAR_ATTENTION) ? 1.0 : 1.4426950408889634 / sqrt((double)dh);
     const bool offset = s.flags & OG_FLAG_USE_OFFSET;
     std::vector<double> Wm((size_t)D2 * D), prod((size_t)D2 * D), g, c;
     for (int l = 0; l < 2 * s.num_stages; ++l) {
@@ -387,7 +388,7 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
         a.q_base[0] = qb0; a.q_step[0] = qs0; a.nq[0] = nq0; a.kv_base[0] = kb0; a.kv_step[0] = ks0; a.nk[0] = nk0;
         a.q_base[1] = qb1; a.q_step[1] = qs1; a.nq[1] = nq1; a.kv_base[1] = kb1; a.kv_step[1] = ks1; a.nk[1] = nk1;
         Scope sc(prof, OG_STAGE_ATTENTION);
-        return og_launch_attention(a, st);
+        return (s.flags & OG_FLAG_LINEAR_ATTENTION) ? og_launch_linear_attention(a, st) : og_launch_attention(a, st);
     };
     // message MLP on token rows [r0, r0+R):  h = relu([x;O] W0'^T + b0') ; x += h W3'^T + b3'  (x kept in fp32 AND as planes)
     auto mlp = [&](const float* lw, int64_t r0, int64_t R) -> int {

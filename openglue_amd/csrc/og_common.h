@@ -97,6 +97,7 @@ struct AttnArgs {
     int rag_mode;             // 2 = cross, queries of image 0 attend image 1, 3 = cross, image 1 attends image 0
 };
 int og_launch_attention(const AttnArgs& a, hipStream_t stream);
+int og_launch_linear_attention(const AttnArgs& a, hipStream_t stream);   // attention = 'linear' (elu+1 feature map)
 
 // m, n are the (maximum) sizes; with `rag` pair b uses m_b, n_b, S stays at stride m*lds per pair, scores are packed
 int og_launch_sinkhorn(const float* S, int64_t lds, const float* dustbin_dev /*or null*/, float dustbin_host, int batch, int m, int n, int iters,

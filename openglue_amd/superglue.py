@@ -26,7 +26,7 @@ import torch.nn as nn
 from . import _lib
 
 _ENCODERS = ("FeedForwardNet", "FeedForwardNetSiren")
-_ATTENTIONS = ("softmax",)               # linear / FAVOR: SURVEY.md §8 f4 ("next")
+_ATTENTIONS = ("softmax", "linear")      # FAVOR variants: out of scope ('favor_softmax' is unreachable upstream)
 
 
 def _mlp_container(*sizes: int) -> nn.Sequential:
@@ -87,6 +87,7 @@ class SuperGlue(nn.Module):
         self.side_info_size = int(pe.get("side_info_size", 1))
         self.num_stages, self.num_heads = int(gnn["num_stages"]), int(gnn["num_heads"])
         self.use_offset = bool(gnn.get("use_offset", False))
+        self.linear_attention = attn == "linear"
         self.residual = bool(config.get("residual", False))
         self.no_descriptors = bool(config.get("no_descriptors", False))
 
@@ -125,7 +126,8 @@ class SuperGlue(nn.Module):
         s.sinkhorn_reg = float(self.config["otp"]["reg"])
         s.flags = ((_lib.OG_FLAG_RESIDUAL if self.residual else 0) | (_lib.OG_FLAG_USE_OFFSET if self.use_offset else 0)
                    | (_lib.OG_FLAG_NO_DESCRIPTORS if self.no_descriptors else 0)
-                   | (_lib.OG_FLAG_SIREN_ENCODER if self.siren else 0))
+                   | (_lib.OG_FLAG_SIREN_ENCODER if self.siren else 0)
+                   | (_lib.OG_FLAG_LINEAR_ATTENTION if self.linear_attention else 0))
         s.match_threshold = float(match_threshold)
         return s
 

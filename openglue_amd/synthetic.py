@@ -42,7 +42,7 @@ def make_config(descriptor_dim: int = 256, num_stages: int = 9, num_heads: int =
                 residual: bool = True, use_offset: bool = False, no_descriptors: bool = False,
                 dustbin_score_init: float = 1.0,
                 hidden_layers_sizes: Sequence[int] = (32, 64, 128), encoder_name: str = "FeedForwardNet",
-                **_unused) -> dict:
+                attention: str = "softmax", **_unused) -> dict:
     """The `superglue:` config block with the keys SuperGlue.__init__ reads
     (reference models/superglue/superglue.py:16-27, config/config.yaml:42-55) plus the keys
     MatchingTrainingModule injects (models/matching_module.py:35-43)."""
@@ -58,7 +58,7 @@ def make_config(descriptor_dim: int = 256, num_stages: int = 9, num_heads: int =
             "num_stages": num_stages,
             "embed_dim": descriptor_dim,
             "num_heads": num_heads,
-            "attention": "softmax",
+            "attention": attention,
             "use_offset": use_offset,
         },
         "dustbin_score_init": dustbin_score_init,

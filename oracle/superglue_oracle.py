@@ -104,14 +104,28 @@ def softmax_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_hea
     return o.transpose(1, 2).reshape(B, nq, D)
 
 
+def linear_attention_elu(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int) -> torch.Tensor:
+    """attention.py:22-40: q' = elu(q)+1+eps, k' = elu(k)+1+eps (eps = 1e-6), kv = K'^T V per head,
+    out = (Q' kv) / (Q' sum_keys k').  No d^-1/2 scale."""
+    B, nq, D = q.shape
+    d = D // num_heads
+    qh = F.elu(q.view(B, nq, num_heads, d).transpose(1, 2)) + 1 + 1e-6          # [B,H,nq,d]
+    kh = F.elu(k.view(B, -1, num_heads, d).transpose(1, 2)) + 1 + 1e-6
+    vh = v.view(B, -1, num_heads, d).transpose(1, 2)
+    kv = kh.transpose(-1, -2) @ vh                                               # [B,H,d,d]
+    o = (qh @ kv) / (qh @ kh.sum(2, keepdim=True).transpose(-1, -2))
+    return o.transpose(1, 2).reshape(B, nq, D)
+
+
 def message_passing(xq: torch.Tensor, xkv: torch.Tensor, sd, prefix: str, num_heads: int,
-                    use_offset: bool, attn_operand_dtype=None) -> torch.Tensor:
+                    use_offset: bool, attn_operand_dtype=None, attention: str = "softmax") -> torch.Tensor:
     """ResidualAttentionMessagePropagation.forward, attention_gnn.py:43-55, with
     MultiheadAttention.forward :22-32 inlined:  q + fc(cat[q, out_proj(MHA(q, kv, kv))])."""
     q = conv1x1(xq, sd, prefix + ".mha.in_proj_q")
     k = conv1x1(xkv, sd, prefix + ".mha.in_proj_k")
     v = conv1x1(xkv, sd, prefix + ".mha.in_proj_v")
-    msg = conv1x1(softmax_attention(q, k, v, num_heads, attn_operand_dtype), sd, prefix + ".mha.out_proj")
+    att = linear_attention_elu(q, k, v, num_heads) if attention == "linear" else softmax_attention(q, k, v, num_heads, attn_operand_dtype)
+    msg = conv1x1(att, sd, prefix + ".mha.out_proj")
     y = torch.cat([xq - msg, msg], dim=-1) if use_offset else torch.cat([xq, msg], dim=-1)
     return xq + feed_forward(y, sd, prefix + ".fc", 2)
 
@@ -122,12 +136,15 @@ def attentional_gnn(x0: torch.Tensor, x1: torch.Tensor, sd, config, attn_operand
     UPDATED image-0 descriptors."""
     g = config["attention_gnn"]
     H, off = g["num_heads"], g.get("use_offset", False)
+    att = g.get("attention", "softmax")
+    if att not in ("softmax", "linear"):
+        raise ValueError(f"oracle: attention {att} not restated")
     for l in range(g["num_stages"]):
         ps, pc = f"attention_gnn.layers.{2 * l}.module", f"attention_gnn.layers.{2 * l + 1}.module"
-        x0 = message_passing(x0, x0, sd, ps, H, off, attn_operand_dtype)
-        x1 = message_passing(x1, x1, sd, ps, H, off, attn_operand_dtype)
-        x0 = message_passing(x0, x1, sd, pc, H, off, attn_operand_dtype)
-        x1 = message_passing(x1, x0, sd, pc, H, off, attn_operand_dtype)
+        x0 = message_passing(x0, x0, sd, ps, H, off, attn_operand_dtype, att)
+        x1 = message_passing(x1, x1, sd, ps, H, off, attn_operand_dtype, att)
+        x0 = message_passing(x0, x1, sd, pc, H, off, attn_operand_dtype, att)
+        x1 = message_passing(x1, x0, sd, pc, H, off, attn_operand_dtype, att)
     return x0, x1
 
 

@@ -44,6 +44,8 @@ CASES = {
                     no_descriptors=True), 70, 33, 1, 4, "full"),
     "siren": (dict(descriptor_dim=64, num_stages=1, num_heads=4, num_iters=5, side_info_size=2,
                    encoder_name="FeedForwardNetSiren", hidden_layers_sizes=(32, 64)), 80, 75, 2, 6, "full"),
+    "linear": (dict(descriptor_dim=128, num_stages=2, num_heads=4, num_iters=8, side_info_size=1, attention="linear"),
+               150, 97, 2, 7, "full"),
     "c2": (dict(syn.CONFIGS["C2"]), 1024, 1024, 2, 5, "sub8"),
 }
 

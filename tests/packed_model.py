@@ -53,6 +53,8 @@ def forward_from_packed(model, data, dtype=torch.float64):
         x0, x1 = x0 + d0, x1 + d1
 
     def attn(q, k, v):      # q pre-scaled by d^-1/2 * log2(e): softmax in base 2
+        if model.linear_attention:
+            return orc.linear_attention_elu(q, k, v, H)
         q = q * math.log(2.0)
         B, nq, _ = q.shape
         d = D // H

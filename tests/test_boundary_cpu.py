@@ -61,7 +61,7 @@ def test_state_dict_equals_live_reference():
     assert {k: tuple(v.shape) for k, v in a.items()} == {k: tuple(v.shape) for k, v in b.items()}
 
 
-@pytest.mark.parametrize("name", ["c1", "flags", "nodesc", "mid", "siren"])
+@pytest.mark.parametrize("name", ["c1", "flags", "nodesc", "mid", "siren", "linear"])
 def test_pack_weights_algebra_against_oracle(name):
     """og_pack_weights (BN folds, out_proj -> fc.0 fold, q pre-scale, padding) evaluated on the CPU in
     float64 must reproduce the oracle: proves the packed blob og_forward consumes is right."""

@@ -213,7 +213,7 @@ def _index_agreement(got_matches0, scores_gpu, sd, cfg, data):
     return int(diff.sum()), 0, o64
 
 
-@pytest.mark.parametrize("name", ["c1", "mid", "flags", "nodesc", "siren"])
+@pytest.mark.parametrize("name", ["c1", "mid", "flags", "nodesc", "siren", "linear"])
 def test_forward_against_reference_fixture(gpu_device, name):
     z, cfg, sd, data = load_case(name)
     model = _build(cfg, sd, gpu_device)
