@@ -1,3 +1,3 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out
-{ timeout 600 python -m pytest tests -m gpu -q -k "forward_against" -p no:cacheprovider -rA 2>&1 | grep -E "^\[|passed|failed|Error|assert|^E " | head -30; } 2>&1 | grep -v amdgpu.ids | tee gpurun_out/misc.log
+{ timeout 600 python scripts/bench_streams.py; } 2>&1 | grep -v amdgpu.ids | tee gpurun_out/misc.log
