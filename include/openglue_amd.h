@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define OG_ABI_VERSION 1
+#define OG_ABI_VERSION 2
 
 #define OG_E_INVALID   (-1)  /* NULL pointer / non-positive size                         */
 #define OG_E_SHAPE     (-2)  /* unsupported shape (see og_check_shape)                   */
@@ -147,7 +147,7 @@ typedef struct og_packed_layout_t {
     int32_t n_enc;
     int32_t enc_k[OG_MAX_HIDDEN + 1], enc_out[OG_MAX_HIDDEN + 1];
     int64_t enc_w[OG_MAX_HIDDEN + 1], enc_b[OG_MAX_HIDDEN + 1];
-    int64_t layer0, layer_stride, o_wqkv_h, o_wqkv_l, o_bqkv, o_w0_h, o_w0_l, o_b0, o_w3_h, o_w3_l, o_b3;
+    int64_t layer0, layer_stride, o_wqkv, o_bqkv, o_w0, o_b0, o_w3, o_b3;   /* o_w*: hl32 rows of 2K halves */
     int64_t wp, bp, alpha, dustbin, total;
 } og_packed_layout_t;
 int og_packed_layout(const og_shape* shape, og_packed_layout_t* layout);
@@ -194,16 +194,22 @@ int og_gemm_nt(const float* A, int64_t lda, int64_t strideA, const float* B, int
                float scale, void* stream);
 
 /* Split-f16 representation used inside the GNN: x = hi + lo * 2^-11 with hi, lo IEEE binary16
- * (|x| < 65504).  og_split_f16 converts n (multiple of 4) fp32 values into the two planes. */
+ * (|x| < 65504), stored either as two planes or in the "hl32" row format the GEMM consumes: one row of
+ * 2K halves per token, hi and lo interleaved in groups of 32 channels
+ * [hi 0..31 | lo 0..31 | hi 32..63 | lo 32..63 | ...] so that a 32-channel k-slab is one 128-byte line.
+ * og_split_f16 converts n (multiple of 4) fp32 values into two planes; og_split_f16_hl converts
+ * x [rows][cols] (row stride ldx, cols % 32 == 0) into hl32 rows (row stride ldo >= 2*cols halves). */
 int og_split_f16(const float* x, int64_t n, void* hi, void* lo, void* stream);
+int og_split_f16_hl(const float* x, int64_t rows, int32_t cols, int64_t ldx, void* out, int64_t ldo, void* stream);
 
-/* C = epilogue(A * B^T) with A [M][K], B [N][K] given as split-f16 planes (leading dimensions in
- * elements, multiples of 8): 3 f16 MFMAs per product, fp32 accumulate, fp32-class accuracy.
- * v = acc + bias[col]; relu; + res[row][col] (fp32, ldr); written as fp32 (C32, may be NULL) and/or as
- * split planes (Ch/Cl, may be NULL).  N % 4 == 0. */
-int og_gemm_nt_f16x3(const void* Ah, const void* Al, int64_t lda, const void* Bh, const void* Bl, int64_t ldb,
-                     int32_t M, int32_t N, int32_t K, const float* bias, int32_t relu, const float* res,
-                     int64_t ldr, float* C32, int64_t ldc, void* Ch, void* Cl, int64_t ldch, void* stream);
+/* C = epilogue(A * B^T) with A [M][K], B [N][K] in the hl32 row format (lda, ldb: row strides in halves,
+ * multiples of 8, >= 2K; K % 32 == 0): 3 f16 MFMAs per product, fp32 accumulate, fp32-class accuracy.
+ * v = acc + bias[col]; relu; + res[row][col] (fp32, ldr); written as fp32 (C32, may be NULL) and/or in
+ * split-f16 form: c_hl == 0 -> two planes Ch/Cl with leading dimension ldch; c_hl != 0 -> hl32 rows at Ch
+ * (row stride ldch halves, Cl ignored, N % 32 == 0).  N % 4 == 0. */
+int og_gemm_nt_f16x3(const void* A, int64_t lda, const void* B, int64_t ldb, int32_t M, int32_t N, int32_t K,
+                     const float* bias, int32_t relu, const float* res, int64_t ldr, float* C32, int64_t ldc,
+                     void* Ch, void* Cl, int64_t ldch, int32_t c_hl, void* stream);
 
 /* softmax attention (attention.py:8-19) for `batch` independent problems and H heads, operands and
  * result as split-f16 planes: q [batch][nq][ldq] (columns h*dh.. of row i = head h, PRE-SCALED by

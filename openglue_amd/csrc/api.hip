@@ -16,8 +16,8 @@ struct PackedLayout {
     int enc_out[OG_MAX_HIDDEN + 1];             // padded output width of layer i
     int64_t enc_w[OG_MAX_HIDDEN + 1], enc_b[OG_MAX_HIDDEN + 1];
     int64_t layer0, layer_stride;               // per GNN layer block
-    // offsets inside a layer block (float units; an f16 plane of n elements takes n/2 floats)
-    int64_t o_wqkv_h, o_wqkv_l, o_bqkv, o_w0_h, o_w0_l, o_b0, o_w3_h, o_w3_l, o_b3;
+    // offsets inside a layer block (float units); weights in the hl32 row format: [N][2K] halves = N*K floats
+    int64_t o_wqkv, o_bqkv, o_w0, o_b0, o_w3, o_b3;
     int64_t wp, bp, alpha, dustbin;
     int64_t total;                              // floats
     int enc_maxw;                               // widest padded hidden activation
@@ -41,14 +41,11 @@ PackedLayout packed_layout(const og_shape& s) {
         k = out;
     }
     int64_t lo = 0;
-    L.o_wqkv_h = lo; lo = al64(lo + 3 * D * D / 2);
-    L.o_wqkv_l = lo; lo = al64(lo + 3 * D * D / 2);
+    L.o_wqkv = lo; lo = al64(lo + 3 * D * D);
     L.o_bqkv = lo; lo = al64(lo + 3 * D);
-    L.o_w0_h = lo; lo = al64(lo + 4 * D * D / 2);
-    L.o_w0_l = lo; lo = al64(lo + 4 * D * D / 2);
+    L.o_w0 = lo; lo = al64(lo + 4 * D * D);
     L.o_b0 = lo; lo = al64(lo + 2 * D);
-    L.o_w3_h = lo; lo = al64(lo + 2 * D * D / 2);
-    L.o_w3_l = lo; lo = al64(lo + 2 * D * D / 2);
+    L.o_w3 = lo; lo = al64(lo + 2 * D * D);
     L.o_b3 = lo; lo = al64(lo + D);
     L.layer_stride = lo;
     L.layer0 = off; off += lo * 2 * s.num_stages;
@@ -61,8 +58,8 @@ PackedLayout packed_layout(const og_shape& s) {
 }
 
 struct WorkspaceLayout {
-    // float offsets; f16 planes take half a float per element
-    int64_t x32, xoh, xol, qkvh, qkvl, hh, hl, g, ei, ea, eb, sbuf, sink, match, total;
+    // float offsets; f16 planes take half a float per element, hl32 rows one float per element
+    int64_t x32, xo, qkvh, qkvl, h, g, ei, ea, eb, sbuf, sink, match, total;
     int64_t lds;
 };
 
@@ -74,12 +71,10 @@ WorkspaceLayout workspace_layout(const og_shape& s) {
     const PackedLayout PL = packed_layout(s);
     const int64_t ew = PL.enc_maxw > 0 ? PL.enc_maxw : 64;
     W.x32 = off; off = al64(off + T * D);
-    W.xoh = off; off = al64(off + T * D);          // [T][2D] halves
-    W.xol = off; off = al64(off + T * D);
+    W.xo = off; off = al64(off + T * 2 * D);       // [T] hl32 rows of [x | O]: 4D halves each
     W.qkvh = off; off = al64(off + T * 3 * D / 2); // [T][3D] halves
     W.qkvl = off; off = al64(off + T * 3 * D / 2);
-    W.hh = off; off = al64(off + T * D);           // [T][2D] halves
-    W.hl = off; off = al64(off + T * D);
+    W.h = off; off = al64(off + T * 2 * D);        // [T] hl32 rows of the 2D hidden activations
     W.g = off; off = al64(off + T * D);
     W.ei = off; off = al64(off + T * 32);
     W.ea = off; off = al64(off + T * ew);
@@ -109,11 +104,12 @@ int check_shape(const og_shape* s) {
     return 0;
 }
 
-// w -> (hi, lo) f16 planes with w = hi + lo * 2^-11 (gemm_f16x3.hip)
-inline void put_split(_Float16* h, _Float16* l, int64_t i, double w) {
+// w -> (hi, lo) with w = hi + lo * 2^-11, element (row, col) of an hl32 weight matrix with K columns (og_common.h)
+inline void put_split(_Float16* W, int64_t row, int col, int K, double w) {
     const _Float16 hi = (_Float16)w;
-    h[i] = hi;
-    l[i] = (_Float16)((w - (double)hi) * 2048.0);
+    _Float16* d = W + row * 2 * K + og_hl_col(col);
+    d[0] = hi;
+    d[32] = (_Float16)((w - (double)hi) * 2048.0);
 }
 
 // BatchNorm (eval) as y*g + c
@@ -147,9 +143,9 @@ extern "C" int og_packed_layout(const og_shape* shape, og_packed_layout_t* o) {
     o->n_enc = L.n_enc;
     for (int i = 0; i < L.n_enc; ++i) { o->enc_k[i] = L.enc_k[i]; o->enc_out[i] = L.enc_out[i]; o->enc_w[i] = L.enc_w[i]; o->enc_b[i] = L.enc_b[i]; }
     o->layer0 = L.layer0; o->layer_stride = L.layer_stride;
-    o->o_wqkv_h = L.o_wqkv_h; o->o_wqkv_l = L.o_wqkv_l; o->o_bqkv = L.o_bqkv;
-    o->o_w0_h = L.o_w0_h; o->o_w0_l = L.o_w0_l; o->o_b0 = L.o_b0;
-    o->o_w3_h = L.o_w3_h; o->o_w3_l = L.o_w3_l; o->o_b3 = L.o_b3;
+    o->o_wqkv = L.o_wqkv; o->o_bqkv = L.o_bqkv;
+    o->o_w0 = L.o_w0; o->o_b0 = L.o_b0;
+    o->o_w3 = L.o_w3; o->o_b3 = L.o_b3;
     o->wp = L.wp; o->bp = L.bp; o->alpha = L.alpha; o->dustbin = L.dustbin; o->total = L.total;
     return 0;
 }
@@ -212,25 +208,26 @@ extern "C" int og_pack_weights(const og_shape* shape, const og_params* P, void* 
         if (!P->layers) return OG_E_INVALID;
         const og_layer_params& lp = P->layers[l];
         float* base = out + L.layer0 + (int64_t)l * L.layer_stride;
-        _Float16* Wqkv_h = (_Float16*)(base + L.o_wqkv_h); _Float16* Wqkv_l = (_Float16*)(base + L.o_wqkv_l);
+        _Float16* Wqkv = (_Float16*)(base + L.o_wqkv);
         float* bqkv = base + L.o_bqkv;
         const og_conv* proj[3] = {&lp.in_proj_q, &lp.in_proj_k, &lp.in_proj_v};
         for (int p = 0; p < 3; ++p) {
             if (!proj[p]->weight || !proj[p]->bias) return OG_E_INVALID;
             const double sc = p == 0 ? qscale : 1.0;
-            for (int64_t i = 0; i < (int64_t)D * D; ++i) put_split(Wqkv_h, Wqkv_l, (int64_t)p * D * D + i, proj[p]->weight[i] * sc);
+            for (int o = 0; o < D; ++o)
+                for (int k = 0; k < D; ++k) put_split(Wqkv, (int64_t)p * D + o, k, D, proj[p]->weight[(int64_t)o * D + k] * sc);
             for (int i = 0; i < D; ++i) bqkv[p * D + i] = (float)(proj[p]->bias[i] * sc);
         }
         // fc.0 on y = [x ; msg] (or [x - msg ; msg] with use_offset, attention_gnn.py:51-54), msg = Wo O + bo:
         //   W0 y = W0a x + Wm (Wo O + bo),  Wm = W0b (- W0a)   ->  [W0a | Wm Wo] [x ; O] + (b0 + Wm bo)
         if (!lp.fc0.weight || !lp.fc0.bias || !lp.out_proj.weight || !lp.out_proj.bias || !lp.fc3.weight || !lp.fc3.bias)
             return OG_E_INVALID;
-        _Float16* W0_h = (_Float16*)(base + L.o_w0_h); _Float16* W0_l = (_Float16*)(base + L.o_w0_l);
+        _Float16* W0 = (_Float16*)(base + L.o_w0);
         float* b0 = base + L.o_b0;
         for (int o = 0; o < D2; ++o)
             for (int k = 0; k < D; ++k) {
                 const double wa = lp.fc0.weight[(int64_t)o * D2 + k], wb = lp.fc0.weight[(int64_t)o * D2 + D + k];
-                put_split(W0_h, W0_l, (int64_t)o * D2 + k, wa);
+                put_split(W0, o, k, D2, wa);
                 Wm[(size_t)o * D + k] = offset ? wb - wa : wb;
             }
         std::fill(prod.begin(), prod.end(), 0.0);
@@ -243,19 +240,19 @@ extern "C" int og_pack_weights(const og_shape* shape, const og_params* P, void* 
                 for (int j = 0; j < D; ++j) pr[j] += w * (double)wo[j];
                 bb += w * (double)lp.out_proj.bias[k];
             }
-            for (int j = 0; j < D; ++j) put_split(W0_h, W0_l, (int64_t)o * D2 + D + j, pr[j]);
+            for (int j = 0; j < D; ++j) put_split(W0, o, D + j, D2, pr[j]);
             b0[o] = (float)bb;
         }
         // fc.3 with BN(2D) folded in
         if (!lp.fc_bn.weight || !lp.fc_bn.bias || !lp.fc_bn.running_mean || !lp.fc_bn.running_var) return OG_E_INVALID;
         bn_affine(lp.fc_bn, D2, g, c);
-        _Float16* W3_h = (_Float16*)(base + L.o_w3_h); _Float16* W3_l = (_Float16*)(base + L.o_w3_l);
+        _Float16* W3 = (_Float16*)(base + L.o_w3);
         float* b3 = base + L.o_b3;
         for (int o = 0; o < D; ++o) {
             double bb = lp.fc3.bias[o];
             for (int k = 0; k < D2; ++k) {
                 const double w = lp.fc3.weight[(int64_t)o * D2 + k];
-                put_split(W3_h, W3_l, (int64_t)o * D2 + k, w * g[k]);
+                put_split(W3, o, k, D2, w * g[k]);
                 bb += w * c[k];
             }
             b3[o] = (float)bb;
@@ -320,31 +317,32 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
     const int64_t T0 = rag ? rag->off0[B] : (int64_t)B * m, T1 = rag ? rag->off1[B] : (int64_t)B * n, T = T0 + T1;
     if (rag && (outp->context_descriptors0 || outp->context_descriptors1)) return OG_E_INVALID;
     float* X32 = ws + W.x32; float* G = ws + W.g; float* Sb = ws + W.sbuf;
-    _Float16* XOh = (_Float16*)(ws + W.xoh); _Float16* XOl = (_Float16*)(ws + W.xol);      // [T][2D]: x | O
-    _Float16* QKVh = (_Float16*)(ws + W.qkvh); _Float16* QKVl = (_Float16*)(ws + W.qkvl);  // [T][3D]: q | k | v
-    _Float16* Hh = (_Float16*)(ws + W.hh); _Float16* Hl = (_Float16*)(ws + W.hl);          // [T][2D]
+    const int D4 = 4 * D;
+    _Float16* XO = (_Float16*)(ws + W.xo);             // [T] hl32 rows of [x | O]: 4D halves, x in the first 2D, O in the last 2D
+    _Float16* QKVh = (_Float16*)(ws + W.qkvh); _Float16* QKVl = (_Float16*)(ws + W.qkvl);  // planes [T][3D]: q | k | v
+    _Float16* Hb = (_Float16*)(ws + W.h);              // [T] hl32 rows of the hidden activations (4D halves)
     int rc;
 
     // exact-fp32 GEMM (encoder, final projection, score matrix)
     auto gemm = [&](const float* A, int64_t lda, const float* Bm, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
-                    const float* bias, int relu, const float* res, int64_t ldr, _Float16* Ch, _Float16* Cl, int64_t ldch) -> int {
+                    const float* bias, int relu, const float* res, int64_t ldr, _Float16* Chl, int64_t ldch) -> int {
         GemmArgs g{};
         g.A = A; g.lda = lda; g.strideA = 0; g.B = Bm; g.ldb = ldb; g.strideB = 0; g.C = C; g.ldc = ldc; g.strideC = 0;
         g.M = (int)M; g.N = N; g.K = K; g.batch = 1; g.bias = bias; g.relu = relu; g.res = res; g.ldr = ldr; g.strideR = 0;
         g.alpha = nullptr; g.scale = 1.f; g.Ct = nullptr; g.ldct = 0; g.strideCt = 0; g.ct_rows = 1;
-        g.Ch = Ch; g.Cl = Cl; g.ldch = ldch;
+        g.Ch = Chl; g.Cl = Chl ? Chl + 32 : nullptr; g.ldch = ldch; g.c_hl = 1;      // hl32 copy for the f16x3 consumers
         Scope sc(prof, OG_STAGE_GEMM);
         return og_launch_gemm(g, st);
     };
-    // split-f16 GEMM (the GNN's 1x1 convolutions): planes in, planes and/or fp32 out
-    auto gemmh = [&](const _Float16* Ah, const _Float16* Al, int64_t lda, const float* wbase, int64_t o_h, int64_t o_l,
-                     int64_t wrow0, int64_t ldb, int64_t M, int N, int K, const float* bias, int relu, const float* res,
-                     float* C32, _Float16* Ch, _Float16* Cl, int64_t ldch) -> int {
+    // split-f16 GEMM (the GNN's 1x1 convolutions): hl32 rows in; fp32 and/or hl32 rows (c_hl) or planes out
+    auto gemmh = [&](const _Float16* A, const float* wbase, int64_t o_w, int64_t wrow0, int64_t M, int N, int K,
+                     const float* bias, int relu, const float* res, float* C32, _Float16* Ch, _Float16* Cl, int64_t ldch,
+                     int c_hl) -> int {
         GemmHArgs g{};
-        g.Ah = Ah; g.Al = Al; g.lda = lda;
-        g.Bh = (const _Float16*)(wbase + o_h) + wrow0 * ldb; g.Bl = (const _Float16*)(wbase + o_l) + wrow0 * ldb; g.ldb = ldb;
+        g.A = A; g.lda = D4;
+        g.B = (const _Float16*)(wbase + o_w) + wrow0 * 2 * K; g.ldb = 2 * K;
         g.M = (int)M; g.N = N; g.K = K; g.bias = bias; g.relu = relu; g.res = res; g.ldr = D;
-        g.C32 = C32; g.ldc = D; g.Ch = Ch; g.Cl = Cl; g.ldch = ldch;
+        g.C32 = C32; g.ldc = D; g.Ch = Ch; g.Cl = Cl; g.ldch = ldch; g.c_hl = c_hl;
         Scope sc(prof, OG_STAGE_GEMM_F16X3);
         return og_launch_gemm_f16x3(g, st);
     };
@@ -365,13 +363,13 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
             if (i + 1 < L.n_enc) {
                 float* dst = (i & 1) ? Eb : Ea;
                 const int act = (s.flags & OG_FLAG_SIREN_ENCODER) ? 2 : 1;      // sin(30 x) or ReLU (+ folded BatchNorm)
-                if ((rc = gemm(cur, ldcur, Wi, L.enc_k[i], dst, L.enc_maxw, T, L.enc_out[i], L.enc_k[i], bi, act, nullptr, 0, nullptr, nullptr, 0))) return rc;
+                if ((rc = gemm(cur, ldcur, Wi, L.enc_k[i], dst, L.enc_maxw, T, L.enc_out[i], L.enc_k[i], bi, act, nullptr, 0, nullptr, 0))) return rc;
                 cur = dst; ldcur = L.enc_maxw;
             } else {
                 const bool nd = s.flags & OG_FLAG_NO_DESCRIPTORS;
-                if ((rc = gemm(cur, ldcur, Wi, L.enc_k[i], X32, D, T0, D, L.enc_k[i], bi, 0, nd ? nullptr : in->descriptors0, D, XOh, XOl, D2))) return rc;
+                if ((rc = gemm(cur, ldcur, Wi, L.enc_k[i], X32, D, T0, D, L.enc_k[i], bi, 0, nd ? nullptr : in->descriptors0, D, XO, D4))) return rc;
                 if ((rc = gemm(cur + T0 * ldcur, ldcur, Wi, L.enc_k[i], X32 + T0 * D, D, T1, D, L.enc_k[i], bi, 0,
-                               nd ? nullptr : in->descriptors1, D, XOh + T0 * D2, XOl + T0 * D2, D2))) return rc;
+                               nd ? nullptr : in->descriptors1, D, XO + T0 * D4, D4))) return rc;
             }
         }
     }
@@ -383,7 +381,8 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
         AttnArgs a{};
         a.rag = rag; a.rag_mode = rag_mode;
         a.qh = QKVh; a.ql = QKVl; a.ldq = D3; a.kh = QKVh + D; a.kl = QKVl + D; a.ldk = D3;
-        a.vh = QKVh + D2; a.vl = QKVl + D2; a.ldv = D3; a.oh = XOh + D; a.ol = XOl + D; a.ldo = D2;
+        a.vh = QKVh + D2; a.vl = QKVl + D2; a.ldv = D3;
+        a.oh = XO + D2; a.ol = XO + D2 + 32; a.ldo = D4; a.o_hl = 1;        // O = channels D..2D-1 of the [x | O] rows
         a.nz = nz; a.num_heads = s.num_heads; a.dh = dh; a.split = split;
         a.q_base[0] = qb0; a.q_step[0] = qs0; a.nq[0] = nq0; a.kv_base[0] = kb0; a.kv_step[0] = ks0; a.nk[0] = nk0;
         a.q_base[1] = qb1; a.q_step[1] = qs1; a.nq[1] = nq1; a.kv_base[1] = kb1; a.kv_step[1] = ks1; a.nk[1] = nk1;
@@ -392,16 +391,14 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
     };
     // message MLP on token rows [r0, r0+R):  h = relu([x;O] W0'^T + b0') ; x += h W3'^T + b3'  (x kept in fp32 AND as planes)
     auto mlp = [&](const float* lw, int64_t r0, int64_t R) -> int {
-        int e = gemmh(XOh + r0 * D2, XOl + r0 * D2, D2, lw, L.o_w0_h, L.o_w0_l, 0, D2, R, D2, D2, lw + L.o_b0, 1, nullptr,
-                      nullptr, Hh + r0 * D2, Hl + r0 * D2, D2);
+        int e = gemmh(XO + r0 * D4, lw, L.o_w0, 0, R, D2, D2, lw + L.o_b0, 1, nullptr, nullptr, Hb + r0 * D4, nullptr, D4, 1);
         if (e) return e;
-        return gemmh(Hh + r0 * D2, Hl + r0 * D2, D2, lw, L.o_w3_h, L.o_w3_l, 0, D2, R, D, D2, lw + L.o_b3, 0, X32 + r0 * D,
-                     X32 + r0 * D, XOh + r0 * D2, XOl + r0 * D2, D2);
+        return gemmh(Hb + r0 * D4, lw, L.o_w3, 0, R, D, D2, lw + L.o_b3, 0, X32 + r0 * D, X32 + r0 * D, XO + r0 * D4, nullptr, D4, 1);
     };
     for (int l = 0; l < s.num_stages; ++l) {
         // self layer 2l: both images through the same weights (attention_gnn.py:63-66)
         const float* lw = pk + L.layer0 + (int64_t)(2 * l) * L.layer_stride;
-        if ((rc = gemmh(XOh, XOl, D2, lw, L.o_wqkv_h, L.o_wqkv_l, 0, D, T, D3, D, lw + L.o_bqkv, 0, nullptr, nullptr, QKVh, QKVl, D3))) return rc;
+        if ((rc = gemmh(XO, lw, L.o_wqkv, 0, T, D3, D, lw + L.o_bqkv, 0, nullptr, nullptr, QKVh, QKVl, D3, 0))) return rc;
         if ((rc = attention(2 * B, B, 0, m, m, 0, m, m, T0, n, n, T0, n, n, 1))) return rc;
         if ((rc = mlp(lw, 0, T))) return rc;
         // cross layer 2l+1: image 0 first, then image 1 against the UPDATED image 0 (attention_gnn.py:74-77)
@@ -409,10 +406,10 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
         for (int side = 0; side < 2; ++side) {
             const int64_t qr0 = side ? T0 : 0, qR = side ? T1 : T0;       // query rows
             const int64_t kr0 = side ? 0 : T0, kR = side ? T0 : T1;       // key/value rows
-            if ((rc = gemmh(XOh + qr0 * D2, XOl + qr0 * D2, D2, lw, L.o_wqkv_h, L.o_wqkv_l, 0, D, qR, D, D, lw + L.o_bqkv, 0, nullptr,
-                            nullptr, QKVh + qr0 * D3, QKVl + qr0 * D3, D3))) return rc;
-            if ((rc = gemmh(XOh + kr0 * D2, XOl + kr0 * D2, D2, lw, L.o_wqkv_h, L.o_wqkv_l, D, D, kR, D2, D, lw + L.o_bqkv + D, 0, nullptr,
-                            nullptr, QKVh + kr0 * D3 + D, QKVl + kr0 * D3 + D, D3))) return rc;
+            if ((rc = gemmh(XO + qr0 * D4, lw, L.o_wqkv, 0, qR, D, D, lw + L.o_bqkv, 0, nullptr, nullptr, QKVh + qr0 * D3,
+                            QKVl + qr0 * D3, D3, 0))) return rc;
+            if ((rc = gemmh(XO + kr0 * D4, lw, L.o_wqkv, D, kR, D2, D, lw + L.o_bqkv + D, 0, nullptr, nullptr, QKVh + kr0 * D3 + D,
+                            QKVl + kr0 * D3 + D, D3, 0))) return rc;
             if (side == 0) rc = attention(B, B, 0, m, m, T0, n, n, 0, 0, 0, 0, 0, 0, 2);
             else rc = attention(B, B, T0, n, n, 0, m, m, 0, 0, 0, 0, 0, 0, 3);
             if (rc) return rc;

@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a, RaggedDes
     const float inv = 1.f / l_tot;
     const int qi = q0 + wave * 32 + l31;
     if (qi < nq) {
-        const int64_t oo = (q_row0 + qi) * a.ldo + h * DH;
+        const int64_t orow = (q_row0 + qi) * a.ldo;
 #pragma unroll
         for (int d = 0; d < NDV; ++d)
 #pragma unroll
@@ -292,8 +292,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a, RaggedDes
                         split_f16(o, th, tl);
                         vh[e] = th; vl[e] = tl;
                     }
-                    *reinterpret_cast<f16x4*>(a.oh + oo + dv) = vh;
-                    *reinterpret_cast<f16x4*>(a.ol + oo + dv) = vl;
+                    const int64_t oo = orow + (a.o_hl ? og_hl_col(h * DH + dv) : (int64_t)(h * DH + dv));
+                    *reinterpret_cast<f16x4*>(a.oh + oo) = vh;
+                    *reinterpret_cast<f16x4*>(a.ol + oo) = vl;
                 }
             }
     }
@@ -339,7 +340,7 @@ extern "C" int og_attention(const void* qh, const void* ql, int64_t ldq, const v
     a.qh = (const _Float16*)qh; a.ql = (const _Float16*)ql; a.ldq = ldq;
     a.kh = (const _Float16*)kh; a.kl = (const _Float16*)kl; a.ldk = ldk;
     a.vh = (const _Float16*)vh; a.vl = (const _Float16*)vl; a.ldv = ldv;
-    a.oh = (_Float16*)oh; a.ol = (_Float16*)ol; a.ldo = ldo;
+    a.oh = (_Float16*)oh; a.ol = (_Float16*)ol; a.ldo = ldo; a.o_hl = 0;
     a.nz = batch; a.num_heads = num_heads; a.dh = dh; a.split = batch;
     a.q_base[0] = 0; a.q_step[0] = nq; a.kv_base[0] = 0; a.kv_step[0] = nk;
     a.nq[0] = nq; a.nk[0] = nk;

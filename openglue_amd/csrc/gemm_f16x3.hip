@@ -10,15 +10,15 @@
 // with fp32 accumulation in two accumulators: measured error equals the fp32 GEMM's.
 // Operand range: |x| < 65504 (f16); activations of this network are O(10).
 //
-// Planes are produced by the PRODUCER's epilogue (this kernel, the attention kernel, the fp32 GEMM of the
-// encoder) and weights are split once at pack time, so no conversion happens on the load path: tiles go
-// global -> registers -> LDS as 16-byte chunks.
+// The (hi, lo) pairs are produced by the PRODUCER's epilogue (this kernel, the attention kernel, the fp32 GEMM
+// of the encoder) and weights are split once at pack time, so no conversion happens on the load path.
+// Both operands arrive in the hl32 row format (og_common.h): hi and lo of a 32-channel group share one
+// 128-byte line.
 //
 // MFMA orientation: D[outch][token] = W · Xᵀ  (A operand = weight tile, B operand = token tile), so a lane
 // owns ONE token (column l&31) and, per 4-register group, FOUR CONSECUTIVE output channels: bias, residual
-// and all stores (fp32 float4 / f16x4 planes) are vectorised along the channel axis.
-// v_mfma_f32_32x32x16_f16; block tile 128 tokens x OC channels x 32 k, 4 waves as 2x2; LDS rows of 40
-// halves (80 B) keep every 16-lane ds_read_b128 group on 16 distinct 4-bank slots.
+// and all stores are vectorised along the channel axis.
+// v_mfma_f32_32x32x16_f16; block tile 128 tokens x OC channels x 32 k, 4 waves as 2x2.
 #include <stdlib.h>
 
 #include "og_common.h"
@@ -27,10 +27,15 @@ namespace {
 
 constexpr int TOK = 128;
 constexpr int BKH = 32;          // k per tile (halves)
-constexpr int LW = BKH + 8;      // padded LDS row (halves)
 constexpr float LO_INV = 1.f / 2048.f;
 constexpr float LO_SCALE = 2048.f;
 constexpr int EPI_SLAB = 64 * 144;   // per-wave epilogue scratch: 64 rows x (128 B + 16 B pad)
+
+// Compile-time ablations of the LDS-DMA kernel (scripts/build_ablation.sh; results are wrong by construction):
+// 1 = no global stores, 2 = every block reads token tile 0 (operands L2-resident), 4 = no MFMA.
+#ifndef OG_GEMM_ABL
+#define OG_GEMM_ABL 0
+#endif
 
 // Epilogue.  After the MFMAs a lane owns ONE token and 4 consecutive channels per register group; storing
 // that directly means 8-byte pieces scattered over 32 rows per instruction (measured: 113 of 210 us of the
@@ -69,8 +74,41 @@ __device__ __forceinline__ void gemm_f16x3_epilogue(const GemmHArgs& g, f32x16 (
             }
     }
 
+    // ---- hl32 rows: per 32-channel group one pass through a [64 tok][hi 64 B | lo 64 B] slab, stored as whole
+    //      128-byte lines (8 lanes x 16 B per token) ----
+    if (g.Ch && g.c_hl) {
+        constexpr int ROWB = 128 + 16;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f16x4 th, tl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = acc0[i][j][4 * q + e];
+                        const _Float16 h = (_Float16)v;
+                        th[e] = h;
+                        tl[e] = (_Float16)((v - (float)h) * LO_SCALE);
+                    }
+                    char* d = slab + (j * 32 + l31) * ROWB + (8 * q + 4 * hi) * 2;
+                    *reinterpret_cast<f16x4*>(d) = th;
+                    *reinterpret_cast<f16x4*>(d + 64) = tl;
+                }
+            const int oc = oc0 + i * 32;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int r = it * 8 + (lane >> 3), c = lane & 7;
+                const f16x8 t = *reinterpret_cast<const f16x8*>(slab + r * ROWB + c * 16);
+                const int tok = tok0 + r;
+                if (tok < g.M && oc < g.N && !((OG_GEMM_ABL & 1) && tok >= 0))
+                    *reinterpret_cast<f16x8*>(g.Ch + (int64_t)tok * g.ldch + og_hl_col(oc) + c * 8) = t;
+            }
+        }
+    }
     // ---- split-f16 planes: two passes (hi, lo) through a [64 tok][OCW halves] slab ----
-    if (g.Ch) {
+    if (g.Ch && !g.c_hl) {
         constexpr int ROWB = OCW * 2 + 16;              // padded LDS row (bytes), 16-byte aligned
         constexpr int CPR = OCW * 2 / 16;               // 16-byte chunks per row
         constexpr int RPI = 64 / CPR;                   // rows per store instruction
@@ -97,7 +135,7 @@ __device__ __forceinline__ void gemm_f16x3_epilogue(const GemmHArgs& g, f32x16 (
                 const int r = it * RPI + lane / CPR, c = lane % CPR;
                 const f16x8 t = *reinterpret_cast<const f16x8*>(slab + r * ROWB + c * 16);
                 const int tok = tok0 + r, oc = oc0 + c * 8;
-                if (tok < g.M && oc < g.N) *reinterpret_cast<f16x8*>(dst + (int64_t)tok * g.ldch + oc) = t;
+                if (tok < g.M && oc < g.N && !((OG_GEMM_ABL & 1) && tok >= 0)) *reinterpret_cast<f16x8*>(dst + (int64_t)tok * g.ldch + oc) = t;
             }
         }
     }
@@ -120,158 +158,37 @@ __device__ __forceinline__ void gemm_f16x3_epilogue(const GemmHArgs& g, f32x16 (
                 const int r = it * 8 + (lane >> 3), c = lane & 7;
                 const f32x4 t = *reinterpret_cast<const f32x4*>(slab + r * ROWB + c * 16);
                 const int tok = tok0 + r, oc = oc0 + i * 32 + c * 4;
-                if (tok < g.M && oc < g.N) *reinterpret_cast<f32x4*>(g.C32 + (int64_t)tok * g.ldc + oc) = t;
+                if (tok < g.M && oc < g.N && !((OG_GEMM_ABL & 1) && tok >= 0)) *reinterpret_cast<f32x4*>(g.C32 + (int64_t)tok * g.ldc + oc) = t;
             }
         }
     }
 }
 
-template <int OC>
-__global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmHArgs g, int tiles_m, int tiles_n) {
-    constexpr int TI = OC / 64;            // MFMA tiles per wave along channels
-    constexpr int WP = OC / 64;            // staging passes for W (64 rows per pass)
-    constexpr int STG = (2 * TOK + 2 * OC) * LW * 2;                      // staging bytes
-    constexpr int EPI = 4 * EPI_SLAB;                                     // epilogue slabs (4 waves)
-    __shared__ __attribute__((aligned(16))) char smem[STG > EPI ? STG : EPI];
-    _Float16* Xh = reinterpret_cast<_Float16*>(smem);
-    _Float16* Xl = Xh + TOK * LW;
-    _Float16* Wh = Xl + TOK * LW;
-    _Float16* Wl = Wh + OC * LW;
-
-    const int id = blockIdx.x;
-    const int xcd = id & 7, local = id >> 3;
-    const int tm = (local / tiles_n) * 8 + xcd;       // all channel tiles of a token tile on one XCD
-    const int tn = local % tiles_n;
-    if (tm >= tiles_m) return;
-    const int t0 = tm * TOK, n0 = tn * OC;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wt = wave >> 1, wo = wave & 1;
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int srow = tid >> 2, sc8 = (tid & 3) * 8;   // staging: row within a 64-row pass, k offset (halves)
-
-    f16x8 rxh[2], rxl[2], rwh[WP], rwl[WP];
-    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    auto load_tiles = [&](int k0) {
-        const int kk = k0 + sc8;
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int row = t0 + srow + 64 * p;
-            if (row < g.M && kk < g.K) {
-                rxh[p] = *reinterpret_cast<const f16x8*>(g.Ah + (int64_t)row * g.lda + kk);
-                rxl[p] = *reinterpret_cast<const f16x8*>(g.Al + (int64_t)row * g.lda + kk);
-            } else { rxh[p] = zero8; rxl[p] = zero8; }
-        }
-#pragma unroll
-        for (int p = 0; p < WP; ++p) {
-            const int row = n0 + srow + 64 * p;
-            if (row < g.N && kk < g.K) {
-                rwh[p] = *reinterpret_cast<const f16x8*>(g.Bh + (int64_t)row * g.ldb + kk);
-                rwl[p] = *reinterpret_cast<const f16x8*>(g.Bl + (int64_t)row * g.ldb + kk);
-            } else { rwh[p] = zero8; rwl[p] = zero8; }
-        }
-    };
-    auto store_tiles = [&]() {
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            *reinterpret_cast<f16x8*>(&Xh[(srow + 64 * p) * LW + sc8]) = rxh[p];
-            *reinterpret_cast<f16x8*>(&Xl[(srow + 64 * p) * LW + sc8]) = rxl[p];
-        }
-#pragma unroll
-        for (int p = 0; p < WP; ++p) {
-            *reinterpret_cast<f16x8*>(&Wh[(srow + 64 * p) * LW + sc8]) = rwh[p];
-            *reinterpret_cast<f16x8*>(&Wl[(srow + 64 * p) * LW + sc8]) = rwl[p];
-        }
-    };
-
-    f32x16 acc0[TI][2], acc1[TI][2];
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc0[i][j][r] = 0.f; acc1[i][j][r] = 0.f; }
-
-    const int x_off = (wt * 64 + l31) * LW + 8 * hi;
-    const int w_off = (wo * (OC / 2) + l31) * LW + 8 * hi;
-
-    const int nk = (g.K + BKH - 1) / BKH;
-    load_tiles(0);
-    for (int kt = 0; kt < nk; ++kt) {
-        store_tiles();
-        __syncthreads();
-        if (kt + 1 < nk && !(g.ablate & 4)) load_tiles((kt + 1) * BKH);
-#pragma unroll
-        for (int ks = 0; ks < BKH / 16; ++ks) {
-            f16x8 wh[TI], wl[TI], xh[2], xl[2];
-#pragma unroll
-            for (int i = 0; i < TI; ++i) {
-                wh[i] = *reinterpret_cast<const f16x8*>(&Wh[w_off + i * 32 * LW + 16 * ks]);
-                wl[i] = *reinterpret_cast<const f16x8*>(&Wl[w_off + i * 32 * LW + 16 * ks]);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                xh[j] = *reinterpret_cast<const f16x8*>(&Xh[x_off + j * 32 * LW + 16 * ks]);
-                xl[j] = *reinterpret_cast<const f16x8*>(&Xl[x_off + j * 32 * LW + 16 * ks]);
-            }
-            if (g.ablate & 2) {          // keep the fragment reads alive, skip the matrix pipe
-#pragma unroll
-                for (int i = 0; i < TI; ++i) asm volatile("" ::"v"(wh[i]), "v"(wl[i]));
-#pragma unroll
-                for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(xh[j]), "v"(xl[j]));
-                continue;
-            }
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i], xh[j], acc0[i][j], 0, 0, 0);
-                    acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i], xl[j], acc1[i][j], 0, 0, 0);
-                    acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[i], xh[j], acc1[i][j], 0, 0, 0);
-                }
-        }
-        __syncthreads();
-    }
-    if (g.ablate & 1) {                  // no epilogue: keep the accumulators alive with a never-taken store
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) t += acc0[i][j][r] + acc1[i][j][r];
-        if (t == 1.2345e30f && g.C32) g.C32[0] = t;
-        return;
-    }
-
-    gemm_f16x3_epilogue<OC, TI>(g, acc0, acc1, t0, n0, wt, wo, lane, smem + wave * EPI_SLAB);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Variant 2: the same tile and MFMA schedule, but operands reach LDS by LDS-DMA (global_load_lds, 16 B per
-// lane, no staging registers) into an NS-deep ring, so NS-1 k-tiles of loads are in flight: the activation
-// panel is streamed from HBM / Infinity Cache (1-2 us latency) while one k-tile of MFMAs lasts ~0.35 us, so
-// the one-tile-deep register prefetch of variant 1 leaves the matrix pipe idle ~80 % of the time.
-// LDS rows are unpadded (64 B = 4 chunks of 16 B; an LDS-DMA writes wave-uniform base + lane*16), bank
-// conflicts are avoided by an XOR swizzle applied on the SOURCE address and again on the fragment read:
-// chunk c of tile row r lives at chunk position c ^ ((r >> 2) & 3).
-// Waits are counted by hand: s_waitcnt vmcnt(N) + raw s_barrier (a __syncthreads() would drain the ring).
+// Operands reach LDS by LDS-DMA (global_load_lds, 16 B per lane, no staging registers) into a 2-deep ring; two
+// blocks per CU.  A stage is one 32-channel k-slab: in the hl32 row format (og_common.h) that is ONE full
+// 128-byte line per row (64 B hi + 64 B lo).  [Measured on MI355X, scripts/probes/l2_bandwidth.hip: fetching
+// 64-byte row pieces caps the L2->LDS path at 18 TB/s, full lines reach 35 TB/s; with separate hi/lo planes
+// this kernel was bound by exactly that.]
+// LDS rows are unpadded (an LDS-DMA writes wave-uniform base + lane*16); bank conflicts are avoided by an XOR
+// swizzle applied on the SOURCE address and again on the fragment read: 16-byte chunk c (0-3 hi, 4-7 lo) of
+// tile row r lives at chunk position c ^ ((r >> 1) & 7), which puts the 16 lanes of a ds_read_b128 group on 16
+// distinct 4-bank slots.  Waits are counted by hand: s_waitcnt vmcnt(N) + raw s_barrier.
 typedef __attribute__((address_space(3))) void og_lds_void;
 typedef __attribute__((address_space(1))) const void og_glb_void;
 
 template <int OC, int NS>
-__global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void gemm_nt_f16x3_glds_kernel(GemmHArgs g, int tiles_m, int tiles_n) {
-    constexpr int TI = OC / 64;
-    constexpr int XB = TOK * 64;               // bytes of one X plane per stage
-    constexpr int WB = OC * 64;
-    constexpr int STAGE = 2 * XB + 2 * WB;
-    constexpr int PIECES = STAGE / 1024;       // 1 KiB = 16 rows x 64 B per wave-instruction
-    constexpr int PPW = PIECES / 4;            // pieces per wave per stage
+__global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void gemm_nt_f16x3_kernel(GemmHArgs g, int tiles_m, int tiles_n) {
+    constexpr int TI = OC / 64;                // MFMA tiles per wave along channels
+    constexpr int XB = TOK * 128;              // bytes of the token tile per stage (hi|lo rows)
+    constexpr int WB = OC * 128;
+    constexpr int STAGE = XB + WB;
+    constexpr int WPC = OC / 32;               // W pieces per wave per stage (1 KiB = 8 rows x 128 B each)
+    constexpr int PPW = 4 + WPC;               // DMA instructions per wave per stage
     __shared__ __attribute__((aligned(16))) char smem[NS * STAGE > 4 * EPI_SLAB ? NS * STAGE : 4 * EPI_SLAB];
 
     const int id = blockIdx.x;
     const int xcd = id & 7, local = id >> 3;
-    const int tm = (local / tiles_n) * 8 + xcd;
+    const int tm = (local / tiles_n) * 8 + xcd;       // all channel tiles of a token tile on one XCD
     const int tn = local % tiles_n;
     if (tm >= tiles_m) return;
     const int t0 = tm * TOK, n0 = tn * OC;
@@ -281,44 +198,35 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void gemm_nt_f16x3_glds_ker
     const int wt = wave >> 1, wo = wave & 1;
     const int l31 = lane & 31, hi = lane >> 5;
 
-    // ---- this wave's DMA pieces (1 KiB = 16 rows x 64 B each): rows [32w, 32w+32) of both X planes and rows
-    //      [w*OC/4, (w+1)*OC/4) of both W planes -> 4 + OC/32 pieces per wave per stage ----
-    constexpr int WPC = OC / 64;                           // W pieces per plane per wave
-    static_assert(PPW == 4 + 2 * WPC, "piece accounting");
+    // ---- this wave's DMA pieces: rows [32w, 32w+32) of the token tile, rows [w*OC/4, (w+1)*OC/4) of the W tile ----
     const char* src[PPW];
     {
-        const int rl = lane >> 2;                          // row inside the 16-row piece
-        const int cl = (lane & 3) ^ ((lane >> 4) & 3);     // logical chunk fetched into physical chunk lane&3
+        const int rl = lane >> 3;                          // row inside the 8-row piece
+        const int pc = lane & 7;                           // physical chunk this lane fills
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
+        for (int h = 0; h < 4; ++h) {
+            const int rt = wave * 32 + h * 8 + rl;         // tile row
+            int row = t0 + rt; if (row >= g.M) row = g.M - 1;
+            if (OG_GEMM_ABL & 2) row = rt;
+            src[h] = reinterpret_cast<const char*>(g.A + (int64_t)row * g.lda) + (pc ^ ((rt >> 1) & 7)) * 16;
+        }
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                int row = t0 + wave * 32 + h * 16 + rl; if (row >= g.M) row = g.M - 1;
-                src[pl * 2 + h] = reinterpret_cast<const char*>((pl ? g.Al : g.Ah) + (int64_t)row * g.lda) + cl * 16;
-            }
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-            for (int h = 0; h < WPC; ++h) {
-                int row = n0 + wave * (OC / 4) + h * 16 + rl; if (row >= g.N) row = g.N - 1;
-                src[4 + pl * WPC + h] = reinterpret_cast<const char*>((pl ? g.Bl : g.Bh) + (int64_t)row * g.ldb) + cl * 16;
-            }
+        for (int h = 0; h < WPC; ++h) {
+            const int rt = wave * (OC / 4) + h * 8 + rl;
+            int row = n0 + rt; if (row >= g.N) row = g.N - 1;
+            src[4 + h] = reinterpret_cast<const char*>(g.B + (int64_t)row * g.ldb) + (pc ^ ((rt >> 1) & 7)) * 16;
+        }
     }
     auto issue_stage = [&](int kt) {
         char* sbase = smem + (kt % NS) * STAGE;
-        const int64_t koff = (int64_t)kt * 64;
+        const int64_t koff = (int64_t)kt * 128;
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
+        for (int h = 0; h < 4; ++h)
+            __builtin_amdgcn_global_load_lds((og_glb_void*)(src[h] + koff), (og_lds_void*)(sbase + (wave * 32 + h * 8) * 128), 16, 0, 0);
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
-                __builtin_amdgcn_global_load_lds((og_glb_void*)(src[pl * 2 + h] + koff),
-                                                 (og_lds_void*)(sbase + pl * XB + (wave * 32 + h * 16) * 64), 16, 0, 0);
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-            for (int h = 0; h < WPC; ++h)
-                __builtin_amdgcn_global_load_lds((og_glb_void*)(src[4 + pl * WPC + h] + koff),
-                                                 (og_lds_void*)(sbase + 2 * XB + pl * WB + (wave * (OC / 4) + h * 16) * 64), 16, 0, 0);
+        for (int h = 0; h < WPC; ++h)
+            __builtin_amdgcn_global_load_lds((og_glb_void*)(src[4 + h] + koff),
+                                             (og_lds_void*)(sbase + XB + (wave * (OC / 4) + h * 8) * 128), 16, 0, 0);
     };
 
     f32x16 acc0[TI][2], acc1[TI][2];
@@ -329,9 +237,9 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void gemm_nt_f16x3_glds_ker
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc0[i][j][r] = 0.f; acc1[i][j][r] = 0.f; }
 
-    const int swz = (l31 >> 2) & 3;
-    const int x_row = (wt * 64 + l31) * 64;            // byte offset of this lane's X row (j = 0)
-    const int w_row = (wo * (OC / 2) + l31) * 64;
+    const int swz = (l31 >> 1) & 7;                    // tile rows differ from l31 by multiples of 16 only
+    const int x_row = (wt * 64 + l31) * 128;           // byte offset of this lane's token row (j = 0)
+    const int w_row = XB + (wo * (OC / 2) + l31) * 128;
 
     const int nk = g.K / BKH;
     const int pre = nk < NS - 1 ? nk : NS - 1;
@@ -347,18 +255,24 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void gemm_nt_f16x3_glds_ker
         const char* sb = smem + (kt % NS) * STAGE;
 #pragma unroll
         for (int ks = 0; ks < BKH / 16; ++ks) {
-            const int coff = ((2 * ks + hi) ^ swz) * 16;
+            const int ch = ((2 * ks + hi) ^ swz) * 16;  // hi chunk; its lo partner is chunk + 4 -> byte offset ^ 64
             f16x8 wh[TI], wl[TI], xh[2], xl[2];
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
-                wh[i] = *reinterpret_cast<const f16x8*>(sb + 2 * XB + w_row + i * 32 * 64 + coff);
-                wl[i] = *reinterpret_cast<const f16x8*>(sb + 2 * XB + WB + w_row + i * 32 * 64 + coff);
+                wh[i] = *reinterpret_cast<const f16x8*>(sb + w_row + i * 32 * 128 + ch);
+                wl[i] = *reinterpret_cast<const f16x8*>(sb + w_row + i * 32 * 128 + (ch ^ 64));
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                xh[j] = *reinterpret_cast<const f16x8*>(sb + x_row + j * 32 * 64 + coff);
-                xl[j] = *reinterpret_cast<const f16x8*>(sb + XB + x_row + j * 32 * 64 + coff);
+                xh[j] = *reinterpret_cast<const f16x8*>(sb + x_row + j * 32 * 128 + ch);
+                xl[j] = *reinterpret_cast<const f16x8*>(sb + x_row + j * 32 * 128 + (ch ^ 64));
             }
+#if OG_GEMM_ABL & 4
+#pragma unroll
+            for (int i = 0; i < TI; ++i) asm volatile("" ::"v"(wh[i]), "v"(wl[i]));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(xh[j]), "v"(xl[j]));
+#else
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -367,6 +281,7 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void gemm_nt_f16x3_glds_ker
                     acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i], xl[j], acc1[i][j], 0, 0, 0);
                     acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[i], xh[j], acc1[i][j], 0, 0, 0);
                 }
+#endif
         }
     }
 
@@ -391,38 +306,46 @@ __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict_
     *reinterpret_cast<f16x4*>(l + 4 * i) = vl;
 }
 
+// x [rows][cols] fp32 -> hl32 rows (test helper / conversions outside the GEMMs)
+__global__ __launch_bounds__(256) void split_f16_hl_kernel(const float* __restrict__ x, int64_t rows, int cols, int64_t ldx,
+                                                           _Float16* __restrict__ out, int64_t ldo) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int c4 = cols / 4;
+    if (i >= rows * c4) return;
+    const int64_t r = i / c4; const int c = (int)(i % c4) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + c);
+    f16x4 vh, vl;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const _Float16 t = (_Float16)v[e];
+        vh[e] = t;
+        vl[e] = (_Float16)((v[e] - (float)t) * LO_SCALE);
+    }
+    _Float16* d = out + r * ldo + og_hl_col(c);
+    *reinterpret_cast<f16x4*>(d) = vh;
+    *reinterpret_cast<f16x4*>(d + 32) = vl;
+}
+
 }  // namespace
 
-int og_launch_gemm_f16x3(const GemmHArgs& a_in, hipStream_t stream) {
-    const GemmHArgs& a0 = a_in;
-    if (!a0.Ah || !a0.Al || !a0.Bh || !a0.Bl || a0.M <= 0 || a0.N <= 0 || a0.K <= 0) return OG_E_INVALID;
-    if (!a0.C32 && !a0.Ch) return OG_E_INVALID;
-    if ((a0.Ch == nullptr) != (a0.Cl == nullptr)) return OG_E_INVALID;
-    if ((a0.lda & 7) || (a0.ldb & 7) || (a0.K & 7) || (a0.N & 3)) return OG_E_ALIGN;
-    if (((uintptr_t)a0.Ah & 15) || ((uintptr_t)a0.Al & 15) || ((uintptr_t)a0.Bh & 15) || ((uintptr_t)a0.Bl & 15)) return OG_E_ALIGN;
-    if (a0.C32 && (((uintptr_t)a0.C32 & 15) || (a0.ldc & 3))) return OG_E_ALIGN;
-    if (a0.Ch && (((uintptr_t)a0.Ch & 7) || ((uintptr_t)a0.Cl & 7) || (a0.ldch & 3))) return OG_E_ALIGN;
-    if (a0.res && (((uintptr_t)a0.res & 15) || (a0.ldr & 3))) return OG_E_ALIGN;
-    if (a0.bias && ((uintptr_t)a0.bias & 15)) return OG_E_ALIGN;
-    static const int variant = [] { const char* e = getenv("OG_GEMM_VARIANT"); return e ? atoi(e) : 4; }();
-    static const int ablate = [] { const char* e = getenv("OG_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
-    GemmHArgs a = a_in;
-    a.ablate = ablate;
+int og_launch_gemm_f16x3(const GemmHArgs& a, hipStream_t stream) {
+    if (!a.A || !a.B || a.M <= 0 || a.N <= 0 || a.K <= 0) return OG_E_INVALID;
+    if (!a.C32 && !a.Ch) return OG_E_INVALID;
+    if (a.Ch && !a.c_hl && !a.Cl) return OG_E_INVALID;
+    if ((a.K % BKH) || (a.N & 3) || (a.lda & 7) || (a.ldb & 7) || a.lda < 2 * (int64_t)a.K || a.ldb < 2 * (int64_t)a.K) return OG_E_ALIGN;
+    if (((uintptr_t)a.A & 15) || ((uintptr_t)a.B & 15)) return OG_E_ALIGN;
+    if (a.C32 && (((uintptr_t)a.C32 & 15) || (a.ldc & 3))) return OG_E_ALIGN;
+    if (a.Ch && a.c_hl && (((uintptr_t)a.Ch & 15) || (a.ldch & 7) || (a.N & 31))) return OG_E_ALIGN;
+    if (a.Ch && !a.c_hl && (((uintptr_t)a.Ch & 7) || ((uintptr_t)a.Cl & 7) || (a.ldch & 3))) return OG_E_ALIGN;
+    if (a.res && (((uintptr_t)a.res & 15) || (a.ldr & 3))) return OG_E_ALIGN;
+    if (a.bias && ((uintptr_t)a.bias & 15)) return OG_E_ALIGN;
     const int tiles_m = (a.M + TOK - 1) / TOK;
     const int tiles_m8 = (tiles_m + 7) / 8 * 8;
-    if (variant >= 2 && a.N > 64 && a.K % BKH == 0) {
+    if (a.N > 64) {
         const int tiles_n = (a.N + 127) / 128;
-        if (variant == 4)
-            hipLaunchKernelGGL((gemm_nt_f16x3_glds_kernel<128, 2>), dim3(tiles_m8 * tiles_n), dim3(256), 0, stream, a, tiles_m, tiles_n);
-        else if (variant == 3)
-            hipLaunchKernelGGL((gemm_nt_f16x3_glds_kernel<128, 3>), dim3(tiles_m8 * tiles_n), dim3(256), 0, stream, a, tiles_m, tiles_n);
-        else
-            hipLaunchKernelGGL((gemm_nt_f16x3_glds_kernel<128, 4>), dim3(tiles_m8 * tiles_n), dim3(256), 0, stream, a, tiles_m, tiles_n);
-    } else if (a.N > 64) {
-        const int tiles_n = (a.N + 127) / 128;
-        hipLaunchKernelGGL(gemm_nt_f16x3_kernel<128>, dim3(tiles_m8 * tiles_n), dim3(256), 0, stream, a, tiles_m, tiles_n);
+        hipLaunchKernelGGL((gemm_nt_f16x3_kernel<128, 2>), dim3(tiles_m8 * tiles_n), dim3(256), 0, stream, a, tiles_m, tiles_n);
     } else {
-        hipLaunchKernelGGL(gemm_nt_f16x3_kernel<64>, dim3(tiles_m8), dim3(256), 0, stream, a, tiles_m, 1);
+        hipLaunchKernelGGL((gemm_nt_f16x3_kernel<64, 2>), dim3(tiles_m8), dim3(256), 0, stream, a, tiles_m, 1);
     }
     return og_launch_status();
 }
@@ -436,19 +359,33 @@ int og_launch_split_f16(const float* x, int64_t n, void* hi, void* lo, hipStream
     return og_launch_status();
 }
 
+int og_launch_split_f16_hl(const float* x, int64_t rows, int cols, int64_t ldx, void* out, int64_t ldo, hipStream_t stream) {
+    if (!x || !out || rows <= 0 || cols <= 0) return OG_E_INVALID;
+    if ((cols & 31) || (ldx & 3) || (ldo & 3) || ldo < 2 * (int64_t)cols || ((uintptr_t)x & 15) || ((uintptr_t)out & 7)) return OG_E_ALIGN;
+    const int64_t n4 = rows * (cols / 4);
+    hipLaunchKernelGGL(split_f16_hl_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, x, rows, cols, ldx,
+                       (_Float16*)out, ldo);
+    return og_launch_status();
+}
+
 extern "C" int og_split_f16(const float* x, int64_t n, void* hi, void* lo, void* stream) {
     og_clear_status();
     return og_launch_split_f16(x, n, hi, lo, (hipStream_t)stream);
 }
 
-extern "C" int og_gemm_nt_f16x3(const void* Ah, const void* Al, int64_t lda, const void* Bh, const void* Bl, int64_t ldb,
-                                int32_t M, int32_t N, int32_t K, const float* bias, int32_t relu, const float* res,
-                                int64_t ldr, float* C32, int64_t ldc, void* Ch, void* Cl, int64_t ldch, void* stream) {
+extern "C" int og_split_f16_hl(const float* x, int64_t rows, int32_t cols, int64_t ldx, void* out, int64_t ldo, void* stream) {
+    og_clear_status();
+    return og_launch_split_f16_hl(x, rows, cols, ldx, out, ldo, (hipStream_t)stream);
+}
+
+extern "C" int og_gemm_nt_f16x3(const void* A, int64_t lda, const void* B, int64_t ldb, int32_t M, int32_t N, int32_t K,
+                                const float* bias, int32_t relu, const float* res, int64_t ldr, float* C32, int64_t ldc,
+                                void* Ch, void* Cl, int64_t ldch, int32_t c_hl, void* stream) {
     og_clear_status();
     GemmHArgs g{};
-    g.Ah = (const _Float16*)Ah; g.Al = (const _Float16*)Al; g.lda = lda;
-    g.Bh = (const _Float16*)Bh; g.Bl = (const _Float16*)Bl; g.ldb = ldb;
+    g.A = (const _Float16*)A; g.lda = lda; g.B = (const _Float16*)B; g.ldb = ldb;
     g.M = M; g.N = N; g.K = K; g.bias = bias; g.relu = relu; g.res = res; g.ldr = ldr;
-    g.C32 = C32; g.ldc = ldc; g.Ch = (_Float16*)Ch; g.Cl = (_Float16*)Cl; g.ldch = ldch;
+    g.C32 = C32; g.ldc = ldc; g.Ch = (_Float16*)Ch; g.Cl = c_hl ? (Ch ? (_Float16*)Ch + 32 : nullptr) : (_Float16*)Cl;
+    g.ldch = ldch; g.c_hl = c_hl ? 1 : 0;
     return og_launch_gemm_f16x3(g, (hipStream_t)stream);
 }

@@ -140,8 +140,9 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g, int tiles_
                 C[(int64_t)row * g.ldc + col] = v;
                 if (g.Ch) {     // split-f16 copy for the f16x3 consumers (x = hi + lo * 2^-11)
                     const _Float16 h = (_Float16)v;
-                    g.Ch[(int64_t)row * g.ldch + col] = h;
-                    g.Cl[(int64_t)row * g.ldch + col] = (_Float16)((v - (float)h) * 2048.f);
+                    const int64_t o = (int64_t)row * g.ldch + (g.c_hl ? og_hl_col(col) : (int64_t)col);
+                    g.Ch[o] = h;
+                    g.Cl[o] = (_Float16)((v - (float)h) * 2048.f);
                 }
                 if (g.Ct) {
                     const int bz = row / g.ct_rows, ri = row - bz * g.ct_rows;
@@ -190,6 +191,6 @@ extern "C" int og_gemm_nt(const float* A, int64_t lda, int64_t strideA, const fl
     g.res = res; g.ldr = ldr; g.strideR = (int64_t)M * ldr;
     g.alpha = alpha; g.scale = scale;
     g.Ct = nullptr; g.ldct = 0; g.strideCt = 0; g.ct_rows = 1;
-    g.Ch = nullptr; g.Cl = nullptr; g.ldch = 0; g.rag = nullptr;
+    g.Ch = nullptr; g.Cl = nullptr; g.ldch = 0; g.c_hl = 0; g.rag = nullptr;
     return og_launch_gemm(g, (hipStream_t)stream);
 }

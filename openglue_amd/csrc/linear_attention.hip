@@ -98,13 +98,15 @@ __global__ __launch_bounds__(256) void linear_attention_kernel(AttnArgs a, Ragge
             for (int i = 0; i < DVQ; ++i) o[i] += qq * kv[d][dq * DVQ + i];
         }
         if (q0 + qi < nq) {
-            const int64_t oo = (q_row0 + q0 + qi) * a.ldo + h * DH + dq * DVQ;
+            const int64_t orow = (q_row0 + q0 + qi) * a.ldo;
 #pragma unroll
             for (int i = 0; i < DVQ; ++i) {
                 const float v = o[i] / nrm;
                 const _Float16 hi = (_Float16)v;
-                a.oh[oo + i] = hi;
-                a.ol[oo + i] = (_Float16)((v - (float)hi) * LO_SCALE);
+                const int c = h * DH + dq * DVQ + i;
+                const int64_t oo = orow + (a.o_hl ? og_hl_col(c) : (int64_t)c);
+                a.oh[oo] = hi;
+                a.ol[oo] = (_Float16)((v - (float)hi) * LO_SCALE);
             }
         }
         __syncthreads();

@@ -40,6 +40,13 @@ static inline int og_launch_status() {
 
 static inline int64_t og_round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
+// "hl32" operand format of the split-f16 GEMM (gemm_f16x3.hip): the hi and lo halves of a row live in ONE
+// row of 2K halves, interleaved in groups of 32 channels -- [hi 0..31 | lo 0..31 | hi 32..63 | lo 32..63 | ...]
+// -- so that the 32-channel k-slab a GEMM stage consumes is one full 128-byte cache line (64 B hi + 64 B lo).
+// Column c of the hi part sits at og_hl_col(c), its lo partner 32 halves further.  Vector accesses of 4 or 8
+// halves at aligned columns never straddle a group.
+__host__ __device__ __forceinline__ int64_t og_hl_col(int c) { return ((int64_t)(c >> 5) << 6) + (c & 31); }
+
 // Ragged batches: every pair b has its own (m_b, n_b).  Tokens are PACKED (no padding): image-0 sets at rows
 // off0[b] .. off0[b+1], image-1 sets at rows T0 + off1[b] ..; the descriptor travels to the kernels by value
 // (kernarg), so no device-side table and no host->device copy is needed.  B == 0 means "uniform batch".
@@ -62,31 +69,34 @@ struct GemmArgs {
     const float* alpha;       // [N] or null: v = alpha*v + (1-alpha)*res
     float scale;
     float* Ct; int64_t ldct, strideCt; int ct_rows;   // optional transposed copy: Ct[row / ct_rows][col][row % ct_rows]
-    _Float16* Ch; _Float16* Cl; int64_t ldch;         // optional split-f16 copy (hi, lo*2^11 planes), batch == 1 only
+    _Float16* Ch; _Float16* Cl; int64_t ldch;         // optional split-f16 copy (hi, lo*2^11), batch == 1 only
+    int c_hl;                                         //   1: hl32 row format (Cl == Ch + 32, ldch = row stride), 0: two planes
     const RaggedDesc* rag;                            // host pointer or null: batched problem z = pair z of a ragged batch
                                                       // (A rows off0[z].., B rows T0 + off1[z].., M = m_z, N = n_z)
 };
 int og_launch_gemm(const GemmArgs& a, hipStream_t stream);
 
-// split-f16 GEMM (gemm_f16x3.hip): tokens A [M][K] and weights B [N][K] as (hi, lo) f16 planes
+// split-f16 GEMM (gemm_f16x3.hip): tokens A [M][K] and weights B [N][K], both in the hl32 row format
 struct GemmHArgs {
-    const _Float16* Ah; const _Float16* Al; int64_t lda;
-    const _Float16* Bh; const _Float16* Bl; int64_t ldb;
+    const _Float16* A; int64_t lda;           // row stride in halves (>= 2K)
+    const _Float16* B; int64_t ldb;
     int M, N, K;
     const float* bias; int relu;
     const float* res; int64_t ldr;            // fp32 residual [M][N] (may alias C32)
     float* C32; int64_t ldc;                  // optional fp32 output
-    _Float16* Ch; _Float16* Cl; int64_t ldch; // optional split-f16 output planes
-    int ablate;                               // profiling only (OG_GEMM_ABLATE): 1 = no epilogue, 2 = no MFMA, 4 = no global loads in the k loop
+    _Float16* Ch; _Float16* Cl; int64_t ldch; // optional split-f16 output: two planes, or
+    int c_hl;                                 //   1: hl32 rows (Cl == Ch + 32, ldch = row stride in halves)
 };
 int og_launch_gemm_f16x3(const GemmHArgs& a, hipStream_t stream);
 int og_launch_split_f16(const float* x, int64_t n, void* hi, void* lo, hipStream_t stream);
+int og_launch_split_f16_hl(const float* x, int64_t rows, int cols, int64_t ldx, void* out, int64_t ldo, hipStream_t stream);
 
 struct AttnArgs {
     const _Float16* qh; const _Float16* ql; int64_t ldq;     // leading dimensions in halves
     const _Float16* kh; const _Float16* kl; int64_t ldk;
     const _Float16* vh; const _Float16* vl; int64_t ldv;
     _Float16* oh; _Float16* ol; int64_t ldo;
+    int o_hl;                 // 1: output rows in the hl32 format (ol == oh + 32), 0: two planes
     // problem z in [0, nz): rows of q/out start at q_row0(z), rows of k/v at kv_row0(z)
     int nz, num_heads, dh;
     int split;                // problems z < split use geometry A, the others geometry B

@@ -65,27 +65,55 @@ def merge_f16(hi: torch.Tensor, lo: torch.Tensor) -> torch.Tensor:
     return hi.float() + lo.float() * (1.0 / 2048.0)
 
 
+def split_f16_hl(x: torch.Tensor) -> torch.Tensor:
+    """fp32 [rows, cols] (cols % 32 == 0) -> float16 [rows, 2*cols] in the GEMM's hl32 row format: hi and
+    lo interleaved in groups of 32 channels, so a 32-channel k-slab is one 128-byte line."""
+    lib = _lib.load()
+    x = _req(x, "x")
+    rows, cols = x.shape
+    out = torch.empty(rows, 2 * cols, device=x.device, dtype=torch.float16)
+    _lib.check(lib.og_split_f16_hl(x.data_ptr(), rows, cols, cols, out.data_ptr(), 2 * cols, _stream()), "og_split_f16_hl")
+    return out
+
+
+def merge_f16_hl(t: torch.Tensor) -> torch.Tensor:
+    """Inverse of split_f16_hl (plain torch; for tests and debugging only)."""
+    rows, c2 = t.shape
+    g = t.view(rows, c2 // 64, 2, 32).float()
+    return (g[:, :, 0] + g[:, :, 1] * (1.0 / 2048.0)).reshape(rows, c2 // 2)
+
+
 def gemm_nt_f16x3(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False,
-                  res: Optional[torch.Tensor] = None, want_planes: bool = False):
-    """epilogue(a @ b^T) through the split-f16 3-pass MFMA kernel: a [M,K], b [N,K] fp32 are split on the
-    device first.  Returns the fp32 result, plus the (hi, lo) output planes if want_planes."""
+                  res: Optional[torch.Tensor] = None, want: Optional[str] = None):
+    """epilogue(a @ b^T) through the split-f16 3-pass MFMA kernel: a [M,K], b [N,K] fp32 are converted to
+    hl32 rows on the device first.  Returns the fp32 result; with want='planes' also the (hi, lo) output
+    planes, with want='hl' also the hl32 output rows."""
     lib = _lib.load()
     a, b = _req(a, "a"), _req(b, "b")
     M, K = a.shape
     N = b.shape[0]
-    ah, al = split_f16(a)
-    bh, bl = split_f16(b)
+    a_hl, b_hl = split_f16_hl(a), split_f16_hl(b)
     out = torch.empty(M, N, device=a.device, dtype=torch.float32)
     ch = cl = None
-    if want_planes:
+    ldch = N
+    if want == "planes":
         ch = torch.empty(M, N, device=a.device, dtype=torch.float16)
         cl = torch.empty(M, N, device=a.device, dtype=torch.float16)
+    elif want == "hl":
+        ch = torch.empty(M, 2 * N, device=a.device, dtype=torch.float16)
+        ldch = 2 * N
+    elif want is not None:
+        raise ValueError(want)
     if bias is not None: bias = _req(bias, "bias")
     if res is not None: res = _req(res, "res")
-    rc = lib.og_gemm_nt_f16x3(ah.data_ptr(), al.data_ptr(), K, bh.data_ptr(), bl.data_ptr(), K, M, N, K, _ptr(bias),
-                              int(relu), _ptr(res), N, out.data_ptr(), N, _ptr(ch), _ptr(cl), N, _stream())
+    rc = lib.og_gemm_nt_f16x3(a_hl.data_ptr(), 2 * K, b_hl.data_ptr(), 2 * K, M, N, K, _ptr(bias), int(relu), _ptr(res), N,
+                              out.data_ptr(), N, _ptr(ch), _ptr(cl), ldch, int(want == "hl"), _stream())
     _lib.check(rc, "og_gemm_nt_f16x3")
-    return (out, ch, cl) if want_planes else out
+    if want == "planes":
+        return out, ch, cl
+    if want == "hl":
+        return out, ch
+    return out
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int) -> torch.Tensor:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the split-f16 GEMM kernel on the C2 shapes (T = 65536 tokens).
-OG_GEMM_VARIANT selects the kernel variant (read once by the library)."""
+OPENGLUE_AMD_LIB selects an experiment build (scripts/build_ablation.sh)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from openglue_amd import _lib, ops
@@ -10,17 +10,17 @@ dev = torch.device("cuda:0")
 T = 65536
 shapes = [("qkv", T, 768, 256), ("fc0", T, 512, 512), ("fc3", T, 256, 512), ("q_cross", T // 2, 256, 256), ("kv_cross", T // 2, 512, 256)]
 g = torch.Generator().manual_seed(0)
-print("variant", os.environ.get("OG_GEMM_VARIANT", "1"))
 tot = 0.0
 for name, M, N, K in shapes:
     a = torch.randn(M, K, generator=g).to(dev); b = (torch.randn(N, K, generator=g) * 0.05).to(dev)
-    ah, al = ops.split_f16(a); bh, bl = ops.split_f16(b)
+    a_hl, b_hl = ops.split_f16_hl(a), ops.split_f16_hl(b)
     bias = torch.randn(N, generator=g).to(dev)
-    ch = torch.empty(M, N, device=dev, dtype=torch.float16); cl = torch.empty_like(ch)
+    planes = name in ('qkv', 'q_cross', 'kv_cross')       # as in og_forward: q/k/v leave as planes, the MLP as hl32 rows
+    ch = torch.empty(M, N if planes else 2 * N, device=dev, dtype=torch.float16); cl = torch.empty_like(ch) if planes else None
     st = torch.cuda.current_stream().cuda_stream
     def run():
-        rc = lib.og_gemm_nt_f16x3(ah.data_ptr(), al.data_ptr(), K, bh.data_ptr(), bl.data_ptr(), K, M, N, K, bias.data_ptr(), 1, None, N,
-                                  None, N, ch.data_ptr(), cl.data_ptr(), N, st)
+        rc = lib.og_gemm_nt_f16x3(a_hl.data_ptr(), 2 * K, b_hl.data_ptr(), 2 * K, M, N, K, bias.data_ptr(), 1, None, N,
+                                  None, N, ch.data_ptr(), cl.data_ptr() if planes else None, N if planes else 2 * N, 0 if planes else 1, st)
         assert rc == 0, rc
     for _ in range(3): run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -30,7 +30,8 @@ for name, M, N, K in shapes:
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / reps * 1e3
     ref = torch.relu(a[:256].double() @ b.double().T + bias.double())
-    err = (ops.merge_f16(ch[:256], cl[:256]).double() - ref).abs().max().item()
+    got = ops.merge_f16(ch[:256], cl[:256]) if planes else ops.merge_f16_hl(ch[:256])
+    err = (got.double() - ref).abs().max().item()
     tf = 2.0 * M * N * K / us / 1e6
     print(f"{name:9s} M={M} N={N} K={K}: {us:8.1f} us  {tf:7.1f} TF algorithmic ({3 * tf:7.1f} TF f16 MFMA executed)  err {err:.1e}")
     tot += us

@@ -25,10 +25,9 @@ def forward_from_packed(model, data, dtype=torch.float64):
     blob = torch.from_numpy(raw).to(dtype)
     half = torch.from_numpy(raw.view("float16").copy()).to(dtype)       # same bytes viewed as f16 (2 per float slot)
 
-    def planes(off_h, off_l, r, c):     # w = hi + lo * 2^-11 (gemm_f16x3.hip)
-        h = half[2 * off_h:2 * off_h + r * c].view(r, c)
-        l = half[2 * off_l:2 * off_l + r * c].view(r, c)
-        return h + l / 2048.0
+    def planes(off, r, c):     # hl32 rows (gemm_f16x3.hip): [r][c/32][hi 32 | lo 32], w = hi + lo * 2^-11
+        g = half[2 * off:2 * off + 2 * r * c].view(r, c // 32, 2, 32)
+        return (g[:, :, 0] + g[:, :, 1] / 2048.0).reshape(r, c)
 
     D, H, s = model.descriptor_dim, model.num_heads, model.side_info_size
     mat = lambda off, r, c: blob[off:off + r * c].view(r, c)
@@ -66,12 +65,12 @@ def forward_from_packed(model, data, dtype=torch.float64):
 
     def prop(l, xq, xkv):
         base = L.layer0 + l * L.layer_stride
-        Wqkv, bqkv = planes(base + L.o_wqkv_h, base + L.o_wqkv_l, 3 * D, D), vec(base + L.o_bqkv, 3 * D)
+        Wqkv, bqkv = planes(base + L.o_wqkv, 3 * D, D), vec(base + L.o_bqkv, 3 * D)
         q = xq @ Wqkv[:D].T + bqkv[:D]
         kv = xkv @ Wqkv[D:].T + bqkv[D:]
         o = attn(q, kv[..., :D], kv[..., D:])
-        h = torch.relu(torch.cat([xq, o], -1) @ planes(base + L.o_w0_h, base + L.o_w0_l, 2 * D, 2 * D).T + vec(base + L.o_b0, 2 * D))
-        return xq + h @ planes(base + L.o_w3_h, base + L.o_w3_l, D, 2 * D).T + vec(base + L.o_b3, D)
+        h = torch.relu(torch.cat([xq, o], -1) @ planes(base + L.o_w0, 2 * D, 2 * D).T + vec(base + L.o_b0, 2 * D))
+        return xq + h @ planes(base + L.o_w3, D, 2 * D).T + vec(base + L.o_b3, D)
 
     for l in range(model.num_stages):
         x0, x1 = prop(2 * l, x0, x0), prop(2 * l, x1, x1)

@@ -68,11 +68,14 @@ def test_gemm_nt_f16x3_fp32_class_accuracy(gpu_device, M, N, K):
     err = (out.double() - ref).abs().max().item()
     print(f"[f16x3 {M}x{N}x{K}] err {err:.2e} (fp32 CPU GEMM err {fp32_err:.2e})")
     assert err < max(2.0 * fp32_err, 1e-6)
-    out, ch, cl = ops.gemm_nt_f16x3(dev(a), dev(b), bias=dev(bias), relu=True, res=dev(res), want_planes=True)
+    out, ch, cl = ops.gemm_nt_f16x3(dev(a), dev(b), bias=dev(bias), relu=True, res=dev(res), want="planes")
     want = torch.relu(ref + bias.double()) + res.double()
     assert (out.cpu().double() - want).abs().max() < max(2.0 * fp32_err, 1e-6)
     merged = ops.merge_f16(ch, cl).cpu()
     assert (merged.double() - want).abs().max() < max(2.0 * fp32_err, 1e-6) + 1e-6 * want.abs().max()
+    out2, chl = ops.gemm_nt_f16x3(dev(a), dev(b), bias=dev(bias), relu=True, res=dev(res), want="hl")     # hl32 output rows
+    assert torch.equal(out2, out)
+    assert torch.equal(ops.merge_f16_hl(chl).cpu(), merged)
 
 
 def test_split_f16_roundtrip(gpu_device):
@@ -81,6 +84,11 @@ def test_split_f16_roundtrip(gpu_device):
     hi, lo = ops.split_f16(x.to(gpu_device))
     back = ops.merge_f16(hi, lo).cpu()
     assert ((back - x).abs() <= 2.0 ** -21 * x.abs() + 1e-9).all()
+    x2 = x.view(125, 32)                                   # the same values as hl32 rows
+    hl = ops.split_f16_hl(x2.to(gpu_device))
+    assert hl.shape == (125, 64)
+    assert torch.equal(hl[:, :32].cpu(), hi.view(125, 32).cpu()) and torch.equal(hl[:, 32:].cpu(), lo.view(125, 32).cpu())
+    assert torch.equal(ops.merge_f16_hl(hl).cpu(), back.view(125, 32))
 
 
 # ----------------------------------------------------------------------------- attention
