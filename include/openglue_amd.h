@@ -136,12 +136,12 @@ size_t og_workspace_bytes(const og_shape* shape);
 int og_pack_weights(const og_shape* shape, const og_params* params, void* packed_host);
 
 /* Introspection of the packed blob (offsets in floats).  All matrices are [out][in] row-major; the
- * GNN matrices are stored as two f16 planes (suffix _h, _l; w = h + l * 2^-11; an f16 plane of n
- * elements occupies n/2 floats), everything else as fp32.
+ * GNN matrices are stored as split-f16 hl32 rows of 256 * w (see og_split_f16_hl / og_gemm_nt_f16x3 below:
+ * [out][2*in] halves = out*in floats), everything else as fp32.
  *   enc_w[i] [enc_out[i]][enc_k[i]], enc_b[i] [enc_out[i]]   keypoint-encoder conv i, zero-padded (k: 32 | out: mult. of 64),
  *                                                            BatchNorm i-1 folded in
- *   layer l at layer0 + l*layer_stride:  wqkv_{h,l} [3D][D] (q rows pre-scaled by (D/H)^-1/2 * log2 e), bqkv [3D],
- *                                        w0_{h,l} [2D][2D] = [W0a | Wm*Wo], b0 [2D], w3_{h,l} [D][2D] (BN folded), b3 [D]
+ *   layer l at layer0 + l*layer_stride:  wqkv [3D][D] (q rows pre-scaled by (D/H)^-1/2 * log2 e), bqkv [3D],
+ *                                        w0 [2D][2D] = [W0a | Wm*Wo], b0 [2D], w3 [D][2D] (BN folded), b3 [D]
  *   wp [D][D], bp [D], alpha [D] = sigmoid(mix_coefs), dustbin [1] */
 typedef struct og_packed_layout_t {
     int32_t n_enc;
@@ -193,8 +193,8 @@ int og_gemm_nt(const float* A, int64_t lda, int64_t strideA, const float* B, int
                const float* bias, int32_t relu, const float* res, int64_t ldr, const float* alpha,
                float scale, void* stream);
 
-/* Split-f16 representation used inside the GNN: x = hi + lo * 2^-11 with hi, lo IEEE binary16
- * (|x| < 65504), stored either as two planes or in the "hl32" row format the GEMM consumes: one row of
+/* Split-f16 representation used inside the GNN: x = hi + lo with hi = f16(x), lo = f16(x - hi), both IEEE
+ * binary16 (|x| < 65504; lo may be subnormal, the matrix cores honour it), stored either as two planes or in the "hl32" row format the GEMM consumes: one row of
  * 2K halves per token, hi and lo interleaved in groups of 32 channels
  * [hi 0..31 | lo 0..31 | hi 32..63 | lo 32..63 | ...] so that a 32-channel k-slab is one 128-byte line.
  * og_split_f16 converts n (multiple of 4) fp32 values into two planes; og_split_f16_hl converts
@@ -204,11 +204,12 @@ int og_split_f16_hl(const float* x, int64_t rows, int32_t cols, int64_t ldx, voi
 
 /* C = epilogue(A * B^T) with A [M][K], B [N][K] in the hl32 row format (lda, ldb: row strides in halves,
  * multiples of 8, >= 2K; K % 32 == 0): 3 f16 MFMAs per product, fp32 accumulate, fp32-class accuracy.
- * v = acc + bias[col]; relu; + res[row][col] (fp32, ldr); written as fp32 (C32, may be NULL) and/or in
+ * v = acc * scale + bias[col] (scale undoes a power-of-two pre-scale of B: og_pack_weights stores 256 * W so
+ * that the lo parts of small weights stay normal numbers); relu; + res[row][col] (fp32, ldr); written as fp32 (C32, may be NULL) and/or in
  * split-f16 form: c_hl == 0 -> two planes Ch/Cl with leading dimension ldch; c_hl != 0 -> hl32 rows at Ch
  * (row stride ldch halves, Cl ignored, N % 32 == 0).  N % 4 == 0. */
 int og_gemm_nt_f16x3(const void* A, int64_t lda, const void* B, int64_t ldb, int32_t M, int32_t N, int32_t K,
-                     const float* bias, int32_t relu, const float* res, int64_t ldr, float* C32, int64_t ldc,
+                     float scale, const float* bias, int32_t relu, const float* res, int64_t ldr, float* C32, int64_t ldc,
                      void* Ch, void* Cl, int64_t ldch, int32_t c_hl, void* stream);
 
 /* softmax attention (attention.py:8-19) for `batch` independent problems and H heads, operands and

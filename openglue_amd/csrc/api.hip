@@ -104,12 +104,13 @@ int check_shape(const og_shape* s) {
     return 0;
 }
 
-// w -> (hi, lo) with w = hi + lo * 2^-11, element (row, col) of an hl32 weight matrix with K columns (og_common.h)
+// w -> (hi, lo) of w * OG_W_SCALE, element (row, col) of an hl32 weight matrix with K columns (og_common.h)
 inline void put_split(_Float16* W, int64_t row, int col, int K, double w) {
+    w *= OG_W_SCALE;
     const _Float16 hi = (_Float16)w;
     _Float16* d = W + row * 2 * K + og_hl_col(col);
     d[0] = hi;
-    d[32] = (_Float16)((w - (double)hi) * 2048.0);
+    d[32] = (_Float16)(w - (double)hi);
 }
 
 // BatchNorm (eval) as y*g + c
@@ -341,7 +342,7 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
         GemmHArgs g{};
         g.A = A; g.lda = D4;
         g.B = (const _Float16*)(wbase + o_w) + wrow0 * 2 * K; g.ldb = 2 * K;
-        g.M = (int)M; g.N = N; g.K = K; g.bias = bias; g.relu = relu; g.res = res; g.ldr = D;
+        g.M = (int)M; g.N = N; g.K = K; g.scale = (float)(1.0 / OG_W_SCALE); g.bias = bias; g.relu = relu; g.res = res; g.ldr = D;
         g.C32 = C32; g.ldc = D; g.Ch = Ch; g.Cl = Cl; g.ldch = ldch; g.c_hl = c_hl;
         Scope sc(prof, OG_STAGE_GEMM_F16X3);
         return og_launch_gemm_f16x3(g, st);

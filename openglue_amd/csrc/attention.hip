@@ -7,10 +7,10 @@
 //
 // Precision (DESIGN.md "attention numerics"): the parity bar is 1e-3 on the final log-scores and
 // plain f16 operands miss it on small problems (logit error dominates).  Q, K and V are therefore
-// split x = hi + lo * 2^-11 with hi, lo both f16 (lo is pre-scaled by 2^11 so it never lands in the
-// f16 subnormal range); QKᵀ = Qh·Kh + 2^-11 (Qh·Kl + Ql·Kh) and PV = Ph·Vh + 2^-11 (Ph·Vl + Pl·Vh)
-// (3 MFMAs each), all with f32 accumulation: every product carries ~22 mantissa bits.  (Rounding P
-// alone to f16 already costs 1.2e-3 on the `flags` golden case.)
+// split x = hi + lo with hi, lo both f16 (og_common.h: lo at its true scale, subnormals are honoured by the
+// matrix cores); QKᵀ = Qh·Kh + Qh·Kl + Ql·Kh and PV = Ph·Vh + Ph·Vl + Pl·Vh (3 MFMAs each into ONE f32
+// accumulator): every product carries ~22 mantissa bits.  (Rounding P alone to f16 already costs 1.2e-3
+// on the `flags` golden case.)
 //
 // MFMA bookkeeping (v_mfma_f32_32x32x16_f16, lane l holds 8 k-values of row/col l&31, k-group l>>5):
 //   Sᵀ[key][query] = K · Qᵀ   (A = K tile, B = Qᵀ)  -> lane owns ONE query column (l&31) and 16 keys
@@ -33,14 +33,7 @@ namespace {
 
 constexpr int KV_TILE = 64;
 constexpr int Q_TILE = 128;
-constexpr float LO_SCALE = 2048.f;           // 2^11
-constexpr float LO_INV = 1.f / 2048.f;
 constexpr float RESCALE_THR = 11.f;          // base-2 exponent headroom before the running max is advanced
-
-__device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
-    hi = (_Float16)x;
-    lo = (_Float16)((x - (float)hi) * LO_SCALE);
-}
 
 template <int DH>
 __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a, RaggedDesc rd) {
@@ -110,11 +103,11 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a, RaggedDes
         }
     }
 
-    f32x16 oh[NDV], ol[NDV];
+    f32x16 oacc[NDV];
 #pragma unroll
     for (int d = 0; d < NDV; ++d)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { oh[d][r] = 0.f; ol[d][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
     float m_run = OG_NEG_INF, l_run = 0.f;
 
     // ---- staging: K as 16-byte chunks, V as 4 keys x 4 dv register transposes; a tile travels
@@ -186,9 +179,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a, RaggedDes
                     f16x8 vh, vl;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { vh[e] = h0[e]; vh[4 + e] = h1[e]; vl[e] = l0[e]; vl[4 + e] = l1[e]; }
-                    oh[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pf[kb][t], oh[d], 0, 0, 0);
-                    ol[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, pf[kb][t], ol[d], 0, 0, 0);
-                    ol[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[kb][t], ol[d], 0, 0, 0);
+                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, pf[kb][t], oacc[d], 0, 0, 0);
+                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[kb][t], oacc[d], 0, 0, 0);
+                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pf[kb][t], oacc[d], 0, 0, 0);
                 }
     };
 
@@ -207,26 +200,26 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a, RaggedDes
         float s[2][16];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            f32x16 shh, sx;
+            f32x16 sacc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { shh[r] = 0.f; sx[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const f16x8 kh = *reinterpret_cast<const f16x8*>(Kh(b) + (kb * 32 + l31) * KW + 16 * c + 8 * hi);
                 const f16x8 kl = *reinterpret_cast<const f16x8*>(Kl(b) + (kb * 32 + l31) * KW + 16 * c + 8 * hi);
-                shh = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[c], shh, 0, 0, 0);
-                sx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[c], sx, 0, 0, 0);
-                sx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[c], sx, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[c], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[c], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[c], sacc, 0, 0, 0);
             }
             if (key0 + KV_TILE > nk) {                  // only the last tile can hold padded keys (block-uniform)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = key0 + kb * 32 + mfma32_row(r, lane);
-                    s[kb][r] = key < nk ? shh[r] + sx[r] * LO_INV : OG_NEG_INF;
+                    s[kb][r] = key < nk ? sacc[r] : OG_NEG_INF;
                 }
             } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s[kb][r] = shh[r] + sx[r] * LO_INV;
+                for (int r = 0; r < 16; ++r) s[kb][r] = sacc[r];
             }
         }
 
@@ -248,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a, RaggedDes
 #pragma unroll
             for (int d = 0; d < NDV; ++d)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { oh[d][r] *= alpha; ol[d][r] *= alpha; }   // after PV(t-1): O is complete up to t-1
+                for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;   // after PV(t-1): O is complete up to t-1
         }
         float psum = 0.f;
 #pragma unroll
@@ -258,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a, RaggedDes
                 const float p = __builtin_amdgcn_exp2f(s[kb][r] - m_run);    // <= 2^RESCALE_THR
                 psum += p;
                 _Float16 th, tl;
-                split_f16(p, th, tl);
+                og_split(p, th, tl);
                 pf[kb][r >> 3][r & 7] = th;
                 pl[kb][r >> 3][r & 7] = tl;
             }
@@ -287,9 +280,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a, RaggedDes
                     f16x4 vh, vl;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float o = (oh[d][4 * g4 + e] + ol[d][4 * g4 + e] * LO_INV) * inv;
+                        float o = oacc[d][4 * g4 + e] * inv;
+                        asm("" : "+v"(o));          // one materialised product for both halves of og_split (og_common.h)
                         _Float16 th, tl;
-                        split_f16(o, th, tl);
+                        og_split(o, th, tl);
                         vh[e] = th; vl[e] = tl;
                     }
                     const int64_t oo = orow + (a.o_hl ? og_hl_col(h * DH + dv) : (int64_t)(h * DH + dv));

@@ -4,10 +4,9 @@
 // Used for the 1x1 convolutions inside the attentional GNN (reference attention_gnn.py:16-20, 41:
 // in_proj_q/k/v, fc.0, fc.3 -- 98 % of the GEMM FLOPs of the path).  fp32 MFMA runs at 1/16 of the f16
 // rate and the parity bar (1e-3 on log-scores) rules out plain f16/bf16 operands, so
-// every operand is carried as TWO f16 planes  x = hi + lo * 2^-11  (lo pre-scaled by 2^11: it has the
-// magnitude of x, never an f16 subnormal) and
-//        X Wᵀ  =  Xh Whᵀ  +  2^-11 (Xh Wlᵀ + Xl Whᵀ)            (the lo*lo term is 2^-22 relative: dropped)
-// with fp32 accumulation in two accumulators: measured error equals the fp32 GEMM's.
+// every operand is carried as TWO f16 numbers  x = hi + lo  (og_common.h: lo at its true scale) and
+//        X Wᵀ  =  Xh Whᵀ + Xh Wlᵀ + Xl Whᵀ                        (the lo*lo term is 2^-22 relative: dropped)
+// with fp32 accumulation in ONE accumulator: measured error equals the fp32 GEMM's.
 // Operand range: |x| < 65504 (f16); activations of this network are O(10).
 //
 // The (hi, lo) pairs are produced by the PRODUCER's epilogue (this kernel, the attention kernel, the fp32 GEMM
@@ -27,8 +26,6 @@ namespace {
 
 constexpr int TOK = 128;
 constexpr int BKH = 32;          // k per tile (halves)
-constexpr float LO_INV = 1.f / 2048.f;
-constexpr float LO_SCALE = 2048.f;
 constexpr int EPI_SLAB = 64 * 144;   // per-wave epilogue scratch: 64 rows x (128 B + 16 B pad)
 
 // Compile-time ablations of the LDS-DMA kernel (scripts/build_ablation.sh; results are wrong by construction):
@@ -44,14 +41,15 @@ constexpr int EPI_SLAB = 64 * 144;   // per-wave epilogue scratch: 64 rows x (12
 // `slab` = this wave's private LDS scratch (EPI_SLAB bytes), free once all waves passed the last
 // k-tile barrier.  No block barrier is needed: a wave only re-reads what it wrote itself.
 template <int OC, int TI>
-__device__ __forceinline__ void gemm_f16x3_epilogue(const GemmHArgs& g, f32x16 (&acc0)[TI][2], f32x16 (&acc1)[TI][2], int t0,
+__device__ __forceinline__ void gemm_f16x3_epilogue(const GemmHArgs& g, f32x16 (&acc0)[TI][2], int t0,
                                                     int n0, int wt, int wo, int lane, char* slab) {
+#pragma clang fp contract(off)                  // og_split: hi and lo must see the same rounded value (og_common.h)
     constexpr int OCW = OC / 2;                 // channels of a wave tile
     const int l31 = lane & 31, hi = lane >> 5;
     const int tok0 = t0 + wt * 64;              // first token of the wave tile
     const int oc0 = n0 + wo * OCW;              // first channel of the wave tile
 
-    // finish the arithmetic in registers: v = acc0 + acc1 * 2^-11 + bias (+relu) (+res)
+    // finish the arithmetic in registers: v = acc * scale + bias (+relu) (+res)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int tok = tok0 + j * 32 + l31;
@@ -62,7 +60,7 @@ __device__ __forceinline__ void gemm_f16x3_epilogue(const GemmHArgs& g, f32x16 (
                 const int oc = oc0 + i * 32 + 8 * q + 4 * hi;
                 f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc0[i][j][4 * q + e] + acc1[i][j][4 * q + e] * LO_INV;
+                for (int e = 0; e < 4; ++e) v[e] = acc0[i][j][4 * q + e] * g.scale;
                 if (g.bias && oc < g.N) v += *reinterpret_cast<const f32x4*>(g.bias + oc);
                 if (g.relu) {
 #pragma unroll
@@ -87,10 +85,9 @@ __device__ __forceinline__ void gemm_f16x3_epilogue(const GemmHArgs& g, f32x16 (
                     f16x4 th, tl;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float v = acc0[i][j][4 * q + e];
-                        const _Float16 h = (_Float16)v;
-                        th[e] = h;
-                        tl[e] = (_Float16)((v - (float)h) * LO_SCALE);
+                        _Float16 h, l;
+                        og_split(acc0[i][j][4 * q + e], h, l);
+                        th[e] = h; tl[e] = l;
                     }
                     char* d = slab + (j * 32 + l31) * ROWB + (8 * q + 4 * hi) * 2;
                     *reinterpret_cast<f16x4*>(d) = th;
@@ -123,9 +120,9 @@ __device__ __forceinline__ void gemm_f16x3_epilogue(const GemmHArgs& g, f32x16 (
                         f16x4 t;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float v = acc0[i][j][4 * q + e];
-                            const _Float16 h = (_Float16)v;
-                            t[e] = pass == 0 ? h : (_Float16)((v - (float)h) * LO_SCALE);
+                            _Float16 h, l;
+                            og_split(acc0[i][j][4 * q + e], h, l);
+                            t[e] = pass == 0 ? h : l;
                         }
                         *reinterpret_cast<f16x4*>(slab + (j * 32 + l31) * ROWB + (i * 32 + 8 * q + 4 * hi) * 2) = t;
                     }
@@ -229,13 +226,13 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void gemm_nt_f16x3_kernel(G
                                              (og_lds_void*)(sbase + XB + (wave * (OC / 4) + h * 8) * 128), 16, 0, 0);
     };
 
-    f32x16 acc0[TI][2], acc1[TI][2];
+    f32x16 acc[TI][2];
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc0[i][j][r] = 0.f; acc1[i][j][r] = 0.f; }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int swz = (l31 >> 1) & 7;                    // tile rows differ from l31 by multiples of 16 only
     const int x_row = (wt * 64 + l31) * 128;           // byte offset of this lane's token row (j = 0)
@@ -273,20 +270,25 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void gemm_nt_f16x3_kernel(G
 #pragma unroll
             for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(xh[j]), "v"(xl[j]));
 #else
+            // pass-major order: consecutive MFMAs write different accumulators
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i], xh[j], acc0[i][j], 0, 0, 0);
-                    acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i], xl[j], acc1[i][j], 0, 0, 0);
-                    acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[i], xh[j], acc1[i][j], 0, 0, 0);
-                }
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[i], xh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i], xl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i], xh[j], acc[i][j], 0, 0, 0);
 #endif
         }
     }
 
     __builtin_amdgcn_s_barrier();      // every wave is past its last fragment reads: the ring is free
-    gemm_f16x3_epilogue<OC, TI>(g, acc0, acc1, t0, n0, wt, wo, lane, smem + wave * EPI_SLAB);
+    gemm_f16x3_epilogue<OC, TI>(g, acc, t0, n0, wt, wo, lane, smem + wave * EPI_SLAB);
 }
 
 // x -> (hi, lo) planes, elementwise (test helper and weight/activation conversion outside the GEMMs)
@@ -298,9 +300,9 @@ __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict_
     f16x4 vh, vl;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const _Float16 t = (_Float16)v[e];
-        vh[e] = t;
-        vl[e] = (_Float16)((v[e] - (float)t) * LO_SCALE);
+        _Float16 h, l;
+        og_split(v[e], h, l);
+        vh[e] = h; vl[e] = l;
     }
     *reinterpret_cast<f16x4*>(h + 4 * i) = vh;
     *reinterpret_cast<f16x4*>(l + 4 * i) = vl;
@@ -317,9 +319,9 @@ __global__ __launch_bounds__(256) void split_f16_hl_kernel(const float* __restri
     f16x4 vh, vl;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const _Float16 t = (_Float16)v[e];
-        vh[e] = t;
-        vl[e] = (_Float16)((v[e] - (float)t) * LO_SCALE);
+        _Float16 h, l;
+        og_split(v[e], h, l);
+        vh[e] = h; vl[e] = l;
     }
     _Float16* d = out + r * ldo + og_hl_col(c);
     *reinterpret_cast<f16x4*>(d) = vh;
@@ -379,12 +381,12 @@ extern "C" int og_split_f16_hl(const float* x, int64_t rows, int32_t cols, int64
 }
 
 extern "C" int og_gemm_nt_f16x3(const void* A, int64_t lda, const void* B, int64_t ldb, int32_t M, int32_t N, int32_t K,
-                                const float* bias, int32_t relu, const float* res, int64_t ldr, float* C32, int64_t ldc,
+                                float scale, const float* bias, int32_t relu, const float* res, int64_t ldr, float* C32, int64_t ldc,
                                 void* Ch, void* Cl, int64_t ldch, int32_t c_hl, void* stream) {
     og_clear_status();
     GemmHArgs g{};
     g.A = (const _Float16*)A; g.lda = lda; g.B = (const _Float16*)B; g.ldb = ldb;
-    g.M = M; g.N = N; g.K = K; g.bias = bias; g.relu = relu; g.res = res; g.ldr = ldr;
+    g.M = M; g.N = N; g.K = K; g.scale = scale; g.bias = bias; g.relu = relu; g.res = res; g.ldr = ldr;
     g.C32 = C32; g.ldc = ldc; g.Ch = (_Float16*)Ch; g.Cl = c_hl ? (Ch ? (_Float16*)Ch + 32 : nullptr) : (_Float16*)Cl;
     g.ldch = ldch; g.c_hl = c_hl ? 1 : 0;
     return og_launch_gemm_f16x3(g, (hipStream_t)stream);

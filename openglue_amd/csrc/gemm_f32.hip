@@ -119,6 +119,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g, int tiles_
     const float* R = g.res ? g.res + (int64_t)z * g.strideR : nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
+#pragma clang fp contract(off)                  // og_split: hi and lo must see the same rounded value (og_common.h)
         const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
         if (col >= g.N) continue;
         const float bias = g.bias ? g.bias[col] : 0.f;
@@ -138,11 +139,9 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g, int tiles_
                 }
                 v *= g.scale;
                 C[(int64_t)row * g.ldc + col] = v;
-                if (g.Ch) {     // split-f16 copy for the f16x3 consumers (x = hi + lo * 2^-11)
-                    const _Float16 h = (_Float16)v;
+                if (g.Ch) {     // split-f16 copy for the f16x3 consumers (x = hi + lo)
                     const int64_t o = (int64_t)row * g.ldch + (g.c_hl ? og_hl_col(col) : (int64_t)col);
-                    g.Ch[o] = h;
-                    g.Cl[o] = (_Float16)((v - (float)h) * 2048.f);
+                    og_split(v, g.Ch[o], g.Cl[o]);
                 }
                 if (g.Ct) {
                     const int bz = row / g.ct_rows, ri = row - bz * g.ct_rows;

@@ -4,15 +4,13 @@
 //     kv[dk][dv] = sum_keys k'[key][dk] v[key][dv],  ksum[dk] = sum_keys k'[key][dk]
 //     out[q][dv] = (q'[q] . kv[:, dv]) / (q'[q] . ksum)
 // One workgroup per (problem, head): phase 1 reduces all keys into the d x d matrix kv (fp32 FMAs, operands
-// rebuilt from the split-f16 planes: hi + lo * 2^-11), phase 2 streams the queries.  The work is O(N d^2)
+// rebuilt from the split-f16 planes: hi + lo), phase 2 streams the queries.  The work is O(N d^2)
 // (8 MFLOP per head at 1024 keys, d = 64), i.e. negligible next to the GEMMs; plain VALU, no matrix cores.
 // Same problem descriptors / plane I/O as attention.hip.
 #include "og_common.h"
 
 namespace {
 
-constexpr float LO_INV = 1.f / 2048.f;
-constexpr float LO_SCALE = 2048.f;
 constexpr float ELU_EPS = 1e-6f;
 
 __device__ __forceinline__ float elu1(float x) { return (x > 0.f ? x : expm1f(x)) + 1.f + ELU_EPS; }   // F.elu(x) + 1 + eps
@@ -56,8 +54,8 @@ __global__ __launch_bounds__(256) void linear_attention_kernel(AttnArgs a, Ragge
             float kx = 0.f, vx = 0.f;
             if (k0 + r < nk) {
                 const int64_t ko = (kv_row0 + k0 + r) * a.ldk + h * DH + c, vo = (kv_row0 + k0 + r) * a.ldv + h * DH + c;
-                kx = elu1((float)a.kh[ko] + (float)a.kl[ko] * LO_INV);
-                vx = (float)a.vh[vo] + (float)a.vl[vo] * LO_INV;
+                kx = elu1((float)a.kh[ko] + (float)a.kl[ko]);
+                vx = (float)a.vh[vo] + (float)a.vl[vo];
             }
             ks[r][c] = kx; vs[r][c] = vx;               // rows beyond nk: k' = 0 contributes nothing
         }
@@ -82,7 +80,7 @@ __global__ __launch_bounds__(256) void linear_attention_kernel(AttnArgs a, Ragge
             float qx = 0.f;
             if (q0 + r < nq) {
                 const int64_t qo = (q_row0 + q0 + r) * a.ldq + h * DH + c;
-                qx = elu1((float)a.qh[qo] + (float)a.ql[qo] * LO_INV);
+                qx = elu1((float)a.qh[qo] + (float)a.ql[qo]);
             }
             ks[r][c] = qx;
         }
@@ -102,11 +100,9 @@ __global__ __launch_bounds__(256) void linear_attention_kernel(AttnArgs a, Ragge
 #pragma unroll
             for (int i = 0; i < DVQ; ++i) {
                 const float v = o[i] / nrm;
-                const _Float16 hi = (_Float16)v;
                 const int c = h * DH + dq * DVQ + i;
                 const int64_t oo = orow + (a.o_hl ? og_hl_col(c) : (int64_t)c);
-                a.oh[oo] = hi;
-                a.ol[oo] = (_Float16)((v - (float)hi) * LO_SCALE);
+                og_split(v, a.oh[oo], a.ol[oo]);
             }
         }
         __syncthreads();

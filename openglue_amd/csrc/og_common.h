@@ -40,6 +40,23 @@ static inline int og_launch_status() {
 
 static inline int64_t og_round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
+// Split-f16 operands: x = hi + lo with hi = f16(x), lo = f16(x - hi), both IEEE binary16 (|x| < 65504).  lo is kept
+// at its TRUE scale (about 2^-11 |x|), so the three MFMA passes  Ah·Bh + Ah·Bl + Al·Bh  accumulate into ONE fp32
+// accumulator.  For |x| < 2^-3 lo is an f16 subnormal; v_mfma_f32_32x32x16_f16 honours subnormal inputs
+// (scripts/probes/mfma_denorm.hip, profiles/r01_probe_mfma_denorm.log), so the representation error is
+// <= max(2^-22 |x|, 2^-25).  Weights are additionally pre-scaled by OG_W_SCALE at pack time (exact) so that their
+// lo parts are normal numbers; the GEMM epilogue multiplies the accumulator by 1/OG_W_SCALE.
+#define OG_W_SCALE 256.0
+// CALLERS: if x is the result of a multiply, pin it first (`asm("" : "+v"(x))`, or compute it under `#pragma clang fp
+// contract(off)` and check the ISA for v_fma_mix).  The compiler may otherwise fuse that multiply into ONE of the two
+// conversions (v_fma_mixlo_f16: single rounding) while the other uses the separately rounded fp32 product
+// (v_cvt_pk_f16_f32); the two his can differ by an ulp and hi + lo is then off by 2^-11 |x| (seen on the attention
+// output; tests/test_gpu_parity.py::test_attention_vs_oracle catches it).
+__device__ __forceinline__ void og_split(float x, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)x;
+    lo = (_Float16)(x - (float)hi);
+}
+
 // "hl32" operand format of the split-f16 GEMM (gemm_f16x3.hip): the hi and lo halves of a row live in ONE
 // row of 2K halves, interleaved in groups of 32 channels -- [hi 0..31 | lo 0..31 | hi 32..63 | lo 32..63 | ...]
 // -- so that the 32-channel k-slab a GEMM stage consumes is one full 128-byte cache line (64 B hi + 64 B lo).
@@ -69,7 +86,7 @@ struct GemmArgs {
     const float* alpha;       // [N] or null: v = alpha*v + (1-alpha)*res
     float scale;
     float* Ct; int64_t ldct, strideCt; int ct_rows;   // optional transposed copy: Ct[row / ct_rows][col][row % ct_rows]
-    _Float16* Ch; _Float16* Cl; int64_t ldch;         // optional split-f16 copy (hi, lo*2^11), batch == 1 only
+    _Float16* Ch; _Float16* Cl; int64_t ldch;         // optional split-f16 copy (hi, lo), batch == 1 only
     int c_hl;                                         //   1: hl32 row format (Cl == Ch + 32, ldch = row stride), 0: two planes
     const RaggedDesc* rag;                            // host pointer or null: batched problem z = pair z of a ragged batch
                                                       // (A rows off0[z].., B rows T0 + off1[z].., M = m_z, N = n_z)
@@ -81,6 +98,7 @@ struct GemmHArgs {
     const _Float16* A; int64_t lda;           // row stride in halves (>= 2K)
     const _Float16* B; int64_t ldb;
     int M, N, K;
+    float scale;                              // v = acc * scale + bias (undoes a power-of-two pre-scale of B)
     const float* bias; int relu;
     const float* res; int64_t ldr;            // fp32 residual [M][N] (may alias C32)
     float* C32; int64_t ldc;                  // optional fp32 output

@@ -49,7 +49,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
 
 
 def split_f16(x: torch.Tensor):
-    """fp32 tensor -> (hi, lo) float16 planes with x = hi + lo * 2^-11 (the GNN's operand format)."""
+    """fp32 tensor -> (hi, lo) float16 planes with x = hi + lo, lo = f16(x - hi) (the GNN's operand format)."""
     lib = _lib.load()
     x = _req(x, "x")
     if x.numel() % 4:
@@ -62,7 +62,7 @@ def split_f16(x: torch.Tensor):
 
 def merge_f16(hi: torch.Tensor, lo: torch.Tensor) -> torch.Tensor:
     """Inverse of split_f16 (plain torch; for tests and debugging only)."""
-    return hi.float() + lo.float() * (1.0 / 2048.0)
+    return hi.float() + lo.float()
 
 
 def split_f16_hl(x: torch.Tensor) -> torch.Tensor:
@@ -80,19 +80,20 @@ def merge_f16_hl(t: torch.Tensor) -> torch.Tensor:
     """Inverse of split_f16_hl (plain torch; for tests and debugging only)."""
     rows, c2 = t.shape
     g = t.view(rows, c2 // 64, 2, 32).float()
-    return (g[:, :, 0] + g[:, :, 1] * (1.0 / 2048.0)).reshape(rows, c2 // 2)
+    return (g[:, :, 0] + g[:, :, 1]).reshape(rows, c2 // 2)
 
 
 def gemm_nt_f16x3(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False,
                   res: Optional[torch.Tensor] = None, want: Optional[str] = None):
     """epilogue(a @ b^T) through the split-f16 3-pass MFMA kernel: a [M,K], b [N,K] fp32 are converted to
-    hl32 rows on the device first.  Returns the fp32 result; with want='planes' also the (hi, lo) output
+    hl32 rows on the device first (b pre-scaled by 256, like the packed weights, so its lo parts are normal
+    f16 numbers).  Returns the fp32 result; with want='planes' also the (hi, lo) output
     planes, with want='hl' also the hl32 output rows."""
     lib = _lib.load()
     a, b = _req(a, "a"), _req(b, "b")
     M, K = a.shape
     N = b.shape[0]
-    a_hl, b_hl = split_f16_hl(a), split_f16_hl(b)
+    a_hl, b_hl = split_f16_hl(a), split_f16_hl(b * 256.0)
     out = torch.empty(M, N, device=a.device, dtype=torch.float32)
     ch = cl = None
     ldch = N
@@ -106,7 +107,7 @@ def gemm_nt_f16x3(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor]
         raise ValueError(want)
     if bias is not None: bias = _req(bias, "bias")
     if res is not None: res = _req(res, "res")
-    rc = lib.og_gemm_nt_f16x3(a_hl.data_ptr(), 2 * K, b_hl.data_ptr(), 2 * K, M, N, K, _ptr(bias), int(relu), _ptr(res), N,
+    rc = lib.og_gemm_nt_f16x3(a_hl.data_ptr(), 2 * K, b_hl.data_ptr(), 2 * K, M, N, K, 1.0 / 256.0, _ptr(bias), int(relu), _ptr(res), N,
                               out.data_ptr(), N, _ptr(ch), _ptr(cl), ldch, int(want == "hl"), _stream())
     _lib.check(rc, "og_gemm_nt_f16x3")
     if want == "planes":

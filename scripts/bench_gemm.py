@@ -13,13 +13,13 @@ g = torch.Generator().manual_seed(0)
 tot = 0.0
 for name, M, N, K in shapes:
     a = torch.randn(M, K, generator=g).to(dev); b = (torch.randn(N, K, generator=g) * 0.05).to(dev)
-    a_hl, b_hl = ops.split_f16_hl(a), ops.split_f16_hl(b)
+    a_hl, b_hl = ops.split_f16_hl(a), ops.split_f16_hl(b * 256.0)
     bias = torch.randn(N, generator=g).to(dev)
     planes = name in ('qkv', 'q_cross', 'kv_cross')       # as in og_forward: q/k/v leave as planes, the MLP as hl32 rows
     ch = torch.empty(M, N if planes else 2 * N, device=dev, dtype=torch.float16); cl = torch.empty_like(ch) if planes else None
     st = torch.cuda.current_stream().cuda_stream
     def run():
-        rc = lib.og_gemm_nt_f16x3(a_hl.data_ptr(), 2 * K, b_hl.data_ptr(), 2 * K, M, N, K, bias.data_ptr(), 1, None, N,
+        rc = lib.og_gemm_nt_f16x3(a_hl.data_ptr(), 2 * K, b_hl.data_ptr(), 2 * K, M, N, K, 1.0 / 256.0, bias.data_ptr(), 1, None, N,
                                   None, N, ch.data_ptr(), cl.data_ptr() if planes else None, N if planes else 2 * N, 0 if planes else 1, st)
         assert rc == 0, rc
     for _ in range(3): run()

@@ -1,0 +1,8 @@
+#!/bin/bash
+# quick GPU check: all gpu tests, GEMM/attention microbenches (+ ablation builds if present), one bench line
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
+timeout 900 python -m pytest tests -m gpu -q -x -p no:cacheprovider 2>&1 | tail -8 | tee gpurun_out/pytest_gpu.log
+{ timeout 120 python scripts/bench_gemm.py | sed 's/^/abl=0  /'
+  for f in openglue_amd/lib/libog_gabl_*.so; do [ -e "$f" ] || continue; n=${f##*_}; n=${n%.so}; OPENGLUE_AMD_LIB=$PWD/$f timeout 120 python scripts/bench_gemm.py | sed "s/^/abl=$n  /"; done; } 2>&1 | grep -v "amdgpu.ids" | tee gpurun_out/gemm_ablate.log
+timeout 120 python scripts/bench_attention.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/attn.log
+timeout 300 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | tee gpurun_out/bench_quick.json | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['stages_ms'])"

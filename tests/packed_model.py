@@ -25,9 +25,9 @@ def forward_from_packed(model, data, dtype=torch.float64):
     blob = torch.from_numpy(raw).to(dtype)
     half = torch.from_numpy(raw.view("float16").copy()).to(dtype)       # same bytes viewed as f16 (2 per float slot)
 
-    def planes(off, r, c):     # hl32 rows (gemm_f16x3.hip): [r][c/32][hi 32 | lo 32], w = hi + lo * 2^-11
+    def planes(off, r, c):     # hl32 rows (gemm_f16x3.hip): [r][c/32][hi 32 | lo 32] of 256 * w (OG_W_SCALE)
         g = half[2 * off:2 * off + 2 * r * c].view(r, c // 32, 2, 32)
-        return (g[:, :, 0] + g[:, :, 1] / 2048.0).reshape(r, c)
+        return (g[:, :, 0] + g[:, :, 1]).reshape(r, c) / 256.0
 
     D, H, s = model.descriptor_dim, model.num_heads, model.side_info_size
     mat = lambda off, r, c: blob[off:off + r * c].view(r, c)

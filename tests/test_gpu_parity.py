@@ -83,7 +83,7 @@ def test_split_f16_roundtrip(gpu_device):
     x = torch.cat([_rand(g, 1000, scale=s) for s in (1e-3, 1.0, 50.0, 3000.0)])
     hi, lo = ops.split_f16(x.to(gpu_device))
     back = ops.merge_f16(hi, lo).cpu()
-    assert ((back - x).abs() <= 2.0 ** -21 * x.abs() + 1e-9).all()
+    assert ((back - x).abs() <= 2.0 ** -21 * x.abs() + 2.0 ** -25).all()      # lo may be an f16 subnormal (spacing 2^-24)
     x2 = x.view(125, 32)                                   # the same values as hl32 rows
     hl = ops.split_f16_hl(x2.to(gpu_device))
     assert hl.shape == (125, 64)
