@@ -29,7 +29,8 @@ constexpr int BKH = 32;          // k per tile (halves)
 constexpr int EPI_SLAB = 64 * 144;   // per-wave epilogue scratch: 64 rows x (128 B + 16 B pad)
 
 // Compile-time ablations of the LDS-DMA kernel (scripts/build_ablation.sh; results are wrong by construction):
-// 1 = no global stores, 2 = every block reads token tile 0 (operands L2-resident), 4 = no MFMA.
+// 1 = no global stores, 2 = every block reads token tile 0 (operands L2-resident), 4 = no MFMA,
+// 8 = (256-tile kernel) no LDS-DMA after the first two stages, 16 = (256-tile kernel) no fragment reads after the first.
 #ifndef OG_GEMM_ABL
 #define OG_GEMM_ABL 0
 #endif
@@ -40,14 +41,13 @@ constexpr int EPI_SLAB = 64 * 144;   // per-wave epilogue scratch: 64 rows x (12
 // writes whole rows: 16 B per lane, 128-byte (or 64-byte) contiguous row segments.
 // `slab` = this wave's private LDS scratch (EPI_SLAB bytes), free once all waves passed the last
 // k-tile barrier.  No block barrier is needed: a wave only re-reads what it wrote itself.
-template <int OC, int TI>
-__device__ __forceinline__ void gemm_f16x3_epilogue(const GemmHArgs& g, f32x16 (&acc0)[TI][2], int t0,
-                                                    int n0, int wt, int wo, int lane, char* slab) {
+// acc0: the wave's 64 token x TI*32 channel tile starting at (tok0, oc0).
+template <int TI>
+__device__ __forceinline__ void gemm_f16x3_epilogue(const GemmHArgs& g, f32x16 (&acc0)[TI][2], int tok0, int oc0, int lane,
+                                                    char* slab) {
 #pragma clang fp contract(off)                  // og_split: hi and lo must see the same rounded value (og_common.h)
-    constexpr int OCW = OC / 2;                 // channels of a wave tile
+    constexpr int OCW = TI * 32;                // channels of a wave tile
     const int l31 = lane & 31, hi = lane >> 5;
-    const int tok0 = t0 + wt * 64;              // first token of the wave tile
-    const int oc0 = n0 + wo * OCW;              // first channel of the wave tile
 
     // finish the arithmetic in registers: v = acc * scale + bias (+relu) (+res)
 #pragma unroll
@@ -288,7 +288,166 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void gemm_nt_f16x3_kernel(G
     }
 
     __builtin_amdgcn_s_barrier();      // every wave is past its last fragment reads: the ring is free
-    gemm_f16x3_epilogue<OC, TI>(g, acc, t0, n0, wt, wo, lane, smem + wave * EPI_SLAB);
+    gemm_f16x3_epilogue<TI>(g, acc, t0 + wt * 64, n0 + wo * (OC / 2), lane, smem + wave * EPI_SLAB);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Large-tile variant for the big GEMMs of the GNN: 256 tokens x 256 channels per block, 8 waves as 2 (tokens) x 4
+// (channels), wave tile 128 x 64 = 2 x 4 MFMA tiles (128 accumulator registers), one block per CU.
+// Why: the 128 x 128 kernel above is bound by its operand traffic, not by the matrix pipe (ablation: 62 us of
+// global->LDS->register traffic + 41 us of MFMA for fc.0 at C2, barely overlapped).  Here a k-step
+// moves the same 64 KB through LDS for 4x the MFMA work of a 128 x 128 step (half the L2->LDS bytes and 3/4 of
+// the LDS fragment reads per MFMA), and a k-step holds 2 x 48 MFMAs per SIMD (~1.3 us), which covers the latency
+// of the one-stage-ahead LDS-DMA prefetch.
+constexpr int BIG = 256;
+
+__global__ __launch_bounds__(512) void gemm_nt_f16x3_big_kernel(GemmHArgs g, int tiles_m, int tiles_n) {
+    constexpr int NS = 2;
+    constexpr int XB = BIG * 128;              // bytes of the token tile per stage
+    constexpr int STAGE = 2 * XB;              // token tile + weight tile
+    __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
+    static_assert(NS * STAGE >= 8 * EPI_SLAB, "epilogue slabs must fit in the ring");
+
+    const int id = blockIdx.x;
+    const int xcd = id & 7, local = id >> 3;
+    const int tm = (local / tiles_n) * 8 + xcd;       // all channel tiles of a token tile on one XCD
+    const int tn = local % tiles_n;
+    if (tm >= tiles_m) return;
+    const int t0 = tm * BIG, n0 = tn * BIG;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wt = wave >> 2, wo = wave & 3;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    // ---- DMA pieces (1 KiB = 8 rows x 128 B): wave w fills rows [32w, 32w+32) of the token tile and of the W tile ----
+    const char* src[8];
+    {
+        const int rl = lane >> 3, pc = lane & 7;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int rt = wave * 32 + h * 8 + rl;
+            const int sw = (pc ^ ((rt >> 1) & 7)) * 16;
+            int row = t0 + rt; if (row >= g.M) row = g.M - 1;
+            src[h] = reinterpret_cast<const char*>(g.A + (int64_t)row * g.lda) + sw;
+            row = n0 + rt; if (row >= g.N) row = g.N - 1;
+            src[4 + h] = reinterpret_cast<const char*>(g.B + (int64_t)row * g.ldb) + sw;
+        }
+    }
+    auto issue_stage = [&](int kt) {
+        char* sbase = smem + (kt % NS) * STAGE + wave * 32 * 128;
+        const int64_t koff = (int64_t)kt * 128;
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+            __builtin_amdgcn_global_load_lds((og_glb_void*)(src[h] + koff), (og_lds_void*)(sbase + h * 8 * 128), 16, 0, 0);
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+            __builtin_amdgcn_global_load_lds((og_glb_void*)(src[4 + h] + koff), (og_lds_void*)(sbase + XB + h * 8 * 128), 16, 0, 0);
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int swz = (l31 >> 1) & 7;
+    const int x_row = (wt * 128 + l31) * 128;
+    const int w_row = XB + (wo * 64 + l31) * 128;
+
+    // Fragment pipeline.  A k-step is 8 groups (2 k16 halves x 4 token tiles) of 6 MFMAs; the LDS reads of group
+    // g+1 are issued BEFORE the MFMAs of group g (double-buffered fragment registers), so the matrix pipe never waits
+    // for a full LDS round trip.  The stage hand-over (wait for the DMA of stage kt+1, barrier, DMA of stage kt+2,
+    // first fragments of stage kt+1) sits in front of the LAST group of stage kt, whose MFMAs cover it.
+    // The fragment reads and their waits are inline asm: hipcc's own waitcnt insertion drains the LDS queue
+    // (lgkmcnt(0)) in front of every second group here, which serialises the read of group g+1 with the MFMAs of
+    // group g.  LDS returns data in order, so "all but the N newest reads" is what s_waitcnt lgkmcnt(N) waits for;
+    // the "+v" operands tie each wait to the registers it releases.
+    f16x8 wh[2][2], wl[2][2], xh[2], xl[2];
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    auto lds_read = [&](f16x8& dst, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr)); };
+    auto read_w = [&](unsigned sb, int ks, int buf) {
+        const unsigned a = sb + w_row + (((2 * ks + hi) ^ swz) * 16);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            lds_read(wh[buf][i], a + i * 32 * 128);
+            lds_read(wl[buf][i], (a + i * 32 * 128) ^ 64);
+        }
+    };
+    auto read_x = [&](unsigned sb, int ks, int j, int buf) {
+        const unsigned a = sb + x_row + j * 32 * 128 + (((2 * ks + hi) ^ swz) * 16);
+        lds_read(xh[buf], a);
+        lds_read(xl[buf], a ^ 64);
+    };
+    // frees the fragments of (w buffer wb, x buffer xb) while `newer` younger reads may stay in flight
+    auto wait_frags = [&](int wb, int xb, int newer) {
+        if (newer == 0)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wh[wb][0]), "+v"(wl[wb][0]), "+v"(wh[wb][1]), "+v"(wl[wb][1]), "+v"(xh[xb]), "+v"(xl[xb]));
+        else if (newer == 2)
+            asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(wh[wb][0]), "+v"(wl[wb][0]), "+v"(wh[wb][1]), "+v"(wl[wb][1]), "+v"(xh[xb]), "+v"(xl[xb]));
+        else
+            asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(wh[wb][0]), "+v"(wl[wb][0]), "+v"(wh[wb][1]), "+v"(wl[wb][1]), "+v"(xh[xb]), "+v"(xl[xb]));
+    };
+
+    const int nk = g.K / BKH;
+    issue_stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (nk > 1) issue_stage(1);
+    read_x(lds0, 0, 0, 0);
+    read_w(lds0, 0, 0);
+    if (OG_GEMM_ABL & 16) { read_x(lds0, 0, 1, 1); read_w(lds0, 1, 1); }
+    for (int kt = 0; kt < nk; ++kt) {
+        const unsigned sb = lds0 + (kt % NS) * STAGE;
+        const unsigned sbn = lds0 + ((kt + 1) % NS) * STAGE;
+#pragma unroll
+        for (int grp = 0; grp < 8; ++grp) {
+            const int ks = grp >> 2, j = grp & 3;
+            if (grp < 7) {
+                const int ks1 = (grp + 1) >> 2, j1 = (grp + 1) & 3;
+                if (!(OG_GEMM_ABL & 16)) {
+                    read_x(sb, ks1, j1, (grp + 1) & 1);
+                    if (j1 == 0) read_w(sb, ks1, ks1 & 1);
+                    wait_frags(ks & 1, grp & 1, j1 == 0 ? 6 : 2);
+                }
+            } else {
+                wait_frags(ks & 1, grp & 1, 0);                                // all my reads of stage kt are done
+                if (kt + 1 < nk) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // my DMA pieces of stage kt+1 landed
+                    __builtin_amdgcn_s_barrier();
+                    if (kt + 2 < nk && !(OG_GEMM_ABL & 8)) issue_stage(kt + 2);   // overwrites the slot of stage kt
+                    if (!(OG_GEMM_ABL & 16)) { read_x(sbn, 0, 0, 0); read_w(sbn, 0, 0); }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#if OG_GEMM_ABL & 4
+            asm volatile("" ::"v"(wh[ks & 1][0]), "v"(wl[ks & 1][0]), "v"(wh[ks & 1][1]), "v"(wl[ks & 1][1]), "v"(xh[grp & 1]), "v"(xl[grp & 1]));
+#else
+            // pass-major: consecutive MFMAs write different accumulators
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks & 1][0], xh[grp & 1], acc[0][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks & 1][1], xh[grp & 1], acc[1][j], 0, 0, 0);
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks & 1][0], xl[grp & 1], acc[0][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks & 1][1], xl[grp & 1], acc[1][j], 0, 0, 0);
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks & 1][0], xh[grp & 1], acc[0][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks & 1][1], xh[grp & 1], acc[1][j], 0, 0, 0);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    __builtin_amdgcn_s_barrier();      // the ring is free: per-wave epilogue slabs
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        f32x16 part[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) part[i][j] = acc[i][2 * half + j];
+        gemm_f16x3_epilogue<2>(g, part, t0 + wt * 128 + half * 64, n0 + wo * 64, lane, smem + wave * EPI_SLAB);
+    }
 }
 
 // x -> (hi, lo) planes, elementwise (test helper and weight/activation conversion outside the GEMMs)
@@ -341,6 +500,16 @@ int og_launch_gemm_f16x3(const GemmHArgs& a, hipStream_t stream) {
     if (a.Ch && !a.c_hl && (((uintptr_t)a.Ch & 7) || ((uintptr_t)a.Cl & 7) || (a.ldch & 3))) return OG_E_ALIGN;
     if (a.res && (((uintptr_t)a.res & 15) || (a.ldr & 3))) return OG_E_ALIGN;
     if (a.bias && ((uintptr_t)a.bias & 15)) return OG_E_ALIGN;
+    static const int force = [] { const char* e = getenv("OG_GEMM_TILE"); return e ? atoi(e) : 0; }();   // experiments: 128 / 256
+    {   // large tiles when they still give (nearly) every CU a block
+        const int tiles_m = (a.M + BIG - 1) / BIG, tiles_n = (a.N + BIG - 1) / BIG;
+        const bool fits = a.N % BIG == 0 && (int64_t)tiles_m * tiles_n >= 192;
+        if (force == 256 ? a.N >= BIG : (fits && force != 128)) {
+            const int tiles_m8 = (tiles_m + 7) / 8 * 8;
+            hipLaunchKernelGGL(gemm_nt_f16x3_big_kernel, dim3(tiles_m8 * tiles_n), dim3(512), 0, stream, a, tiles_m, tiles_n);
+            return og_launch_status();
+        }
+    }
     const int tiles_m = (a.M + TOK - 1) / TOK;
     const int tiles_m8 = (tiles_m + 7) / 8 * 8;
     if (a.N > 64) {

@@ -55,7 +55,8 @@ def test_gemm_nt_batched_scores_shape(gpu_device):
     assert (out.double() - ref).abs().max() < 1e-5
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 192, 96), (77, 64, 64), (1000, 768, 256), (4099, 512, 512)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 192, 96), (77, 64, 64), (1000, 768, 256), (4099, 512, 512),
+                                   (49999, 256, 64), (24700, 512, 256)])     # the last two take the 256x256-tile kernel
 def test_gemm_nt_f16x3_fp32_class_accuracy(gpu_device, M, N, K):
     """The split-f16 3-pass GEMM must be as accurate as an fp32 GEMM (both measured against float64)."""
     g = torch.Generator().manual_seed(M * 3 + K)
