@@ -17,23 +17,50 @@
 //                               per 32-key block: softmax statistics are lane-local + one xor-32 exchange.
 //   Oᵀ[dv][query]  = Vᵀ · Pᵀ   (A = Vᵀ, B = Pᵀ)    -> same query column per lane, so the exp'd Sᵀ
 //                               registers ARE the B operand: register 8t+e of key block kb is key
-//                               kb*32 + 16t + 8(e>>2) + 4(l>>5) + (e&3); Vᵀ is staged in LDS as [dv][key]
-//                               so those keys are two 8-byte reads.  (The k order inside an MFMA is free
-//                               as long as A and B agree.)
+//                               kb*32 + 16t + 8(e>>2) + 4(l>>5) + (e&3); V is staged in LDS row-major [key][dv]
+//                               like K and the A fragments are two ds_read_b64_tr_b16 (hardware 4x16 transpose)
+//                               each.  (The k order inside an MFMA is free as long as A and B agree.)
 // Q is expected PRE-SCALED by d^-1/2 * log2(e) (folded into the packed q-projection weights): the
 // softmax then runs in the base-2 domain, p = 2^(s - m) is one v_exp_f32 with no extra multiply.
 // The running max is only advanced (and O, l rescaled) when some row's max grew by more than 2^11
-// in the current tile ("deferred rescale"): p stays <= 2^11, exactly representable in the f16 hi plane,
-// and the 64-register rescale of O leaves the common path.
+// in the current tile ("deferred rescale"): p stays <= 2^11, well inside f16 range, and the rescale of O
+// leaves the common path.  The QKᵀ accumulator is initialised with -m_run, so in the common path the
+// exponent arguments s - m_run come straight from the matrix pipe (no per-element subtract).
 // I/O: q, k, v arrive as f16 (hi, lo) PLANES written by the producing GEMM's epilogue and O leaves as planes
 // (it is the A operand of the fc.0 GEMM), so no conversion sits on the load path of either kernel.
+#include <type_traits>
+
 #include "og_common.h"
 
 namespace {
 
+typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+typedef __attribute__((address_space(3))) s16x4 og_lds_s16x4;
+
 constexpr int KV_TILE = 64;
 constexpr int Q_TILE = 128;
 constexpr float RESCALE_THR = 11.f;          // base-2 exponent headroom before the running max is advanced
+
+// Experiment builds only (scripts/build_ablation.sh attn_trace -DOG_ATTN_TRACE=1): per-segment shader-cycle stamps of
+// all four waves of two workgroups, read back by og_debug_attn_trace().  The sched_barriers around the stamps
+// perturb the schedule; compare the traced build's kernel time with the normal one before trusting a breakdown.
+#ifndef OG_ATTN_TRACE
+#define OG_ATTN_TRACE 0
+#endif
+#ifndef OG_ATTN_DBG
+#define OG_ATTN_DBG 0      // debugging: 1 = P split in C++ instead of the 3-instruction asm
+#endif
+#if OG_ATTN_TRACE
+__device__ unsigned og_attn_trace_buf[2][4][16][8];
+#define OG_TP(i)                                                                                         \
+    do {                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        if (tsel >= 0) tp[i] = (unsigned)__builtin_amdgcn_s_memtime();   /* SMEM: costs an lgkmcnt(0) at the stamp */        \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+    } while (0)
+#else
+#define OG_TP(i) do {} while (0)
+#endif
 
 template <int DH>
 __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a, RaggedDesc rd) {
@@ -41,10 +68,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a, RaggedDes
     constexpr int NDV = DHP / 32;                 // output row blocks
     constexpr int NCH = DH / 16;                  // 16-wide k chunks of the QKᵀ contraction
     constexpr int KW = DH + 8;                    // K LDS row (halves): 16 B pad -> conflict-free b128
-    constexpr int VW = KV_TILE + 4;               // Vᵀ LDS row (halves): 8 B pad -> conflict-free b64
-    constexpr int D4 = DH / 4;                    // 4-wide dv groups per row
+    constexpr int VP = DHP + 8;                   // V LDS row (halves), row-major [key][dv] like K: conflict-free b128 stores and
+                                                  // conflict-free ds_read_b64_tr_b16 gathers (4 rows x 32 B per 16-lane group)
     constexpr int KSZ = KV_TILE * KW;             // halves per K plane buffer
-    constexpr int VSZ = DHP * VW;                 // halves per Vᵀ plane buffer
+    constexpr int VSZ = KV_TILE * VP;             // halves per V plane buffer
 
     // Double-buffered tiles: K_t / V_t live in buffer t&1.  One array (a second __shared__ object makes
     // hipcc serialise LDS traffic with outstanding global loads).
@@ -84,10 +111,12 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a, RaggedDes
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
 
-    if (DH < 32) {   // zero the padding rows of Vᵀ once (both buffers); staging never touches them
-        for (int i = tid; i < (DHP - DH) * VW; i += 256)
+    if (DH < 32) {   // zero the padding columns DH..31 of V once (both buffers); staging never touches them
+        for (int i = tid; i < KV_TILE * (DHP - DH); i += 256) {
+            const int o = (i / (DHP - DH)) * VP + DH + i % (DHP - DH);
 #pragma unroll
-            for (int b = 0; b < 2; ++b) { Vh(b)[DH * VW + i] = (_Float16)0.f; Vl(b)[DH * VW + i] = (_Float16)0.f; }
+            for (int b = 0; b < 2; ++b) { Vh(b)[o] = (_Float16)0.f; Vl(b)[o] = (_Float16)0.f; }
+        }
     }
 
     // ---- Q fragments (B operand): lane (query l31, k-group hi) holds Q[q][16c + 8hi + e] ----
@@ -108,105 +137,151 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a, RaggedDes
     for (int d = 0; d < NDV; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
-    float m_run = OG_NEG_INF, l_run = 0.f;
+    float m_run = 0.f, l_run = 0.f;              // m_run: any finite start; the first tile replaces it (kt == 0 below)
 
-    // ---- staging: K as 16-byte chunks, V as 4 keys x 4 dv register transposes; a tile travels
-    //      global -> registers (issued one tile ahead) -> LDS ----
+    // ---- staging: K and V as 16-byte chunks; a tile travels
+    //      (V is staged row-major exactly like K and transposed by the LDS read, ds_read_b64_tr_b16)
+    //      global -> registers (issued one tile ahead) -> LDS.  Addresses: one per-lane byte offset computed once,
+    //      the tile base is wave-uniform (scalar) arithmetic; only the last, partial tile clamps its rows. ----
     constexpr int C8 = DH / 8;                       // chunks per K row
     constexpr int K_KEYS_PER_PASS = 256 / C8;
     constexpr int K_PASSES = (KV_TILE + K_KEYS_PER_PASS - 1) / K_KEYS_PER_PASS;
     const int k_c8 = tid % C8, k_key = tid / C8;
-    const int v_dg = tid % D4, v_kg = tid / D4;
-    const bool v_active = v_kg < KV_TILE / 4;
-    f16x8 rkh[K_PASSES], rkl[K_PASSES];
-    f16x4 rvh[4], rvl[4];
+    f16x8 rkh[K_PASSES], rkl[K_PASSES], rvh[K_PASSES], rvl[K_PASSES];
+    const unsigned k_off = (unsigned)(k_key * (int)a.ldk + 8 * k_c8) * 2u;                  // bytes inside a tile
+    const unsigned v_off = (unsigned)(k_key * (int)a.ldv + 8 * k_c8) * 2u;
+    const int64_t k_tile0 = (kv_row0 * a.ldk + h * DH) * 2, v_tile0 = (kv_row0 * a.ldv + h * DH) * 2;   // bytes, uniform
     auto load_tile = [&](int kt) {
         const int key0 = kt * KV_TILE;
+        const char* kbh = reinterpret_cast<const char*>(a.kh) + k_tile0 + (int64_t)key0 * a.ldk * 2;
+        const char* kbl = reinterpret_cast<const char*>(a.kl) + k_tile0 + (int64_t)key0 * a.ldk * 2;
+        const char* vbh = reinterpret_cast<const char*>(a.vh) + v_tile0 + (int64_t)key0 * a.ldv * 2;
+        const char* vbl = reinterpret_cast<const char*>(a.vl) + v_tile0 + (int64_t)key0 * a.ldv * 2;
+        if (key0 + KV_TILE <= nk) {                  // full tile (block-uniform): no clamping
 #pragma unroll
-        for (int p = 0; p < K_PASSES; ++p) {
-            const int key = k_key + p * K_KEYS_PER_PASS;
-            if (key < KV_TILE) {
-                int gk = key0 + key; if (gk >= nk) gk = nk - 1;      // clamp (masked in the softmax)
-                const int64_t go = (kv_row0 + gk) * a.ldk + h * DH + 8 * k_c8;
-                rkh[p] = *reinterpret_cast<const f16x8*>(a.kh + go);
-                rkl[p] = *reinterpret_cast<const f16x8*>(a.kl + go);
+            for (int p = 0; p < K_PASSES; ++p) {
+                if (k_key + p * K_KEYS_PER_PASS < KV_TILE) {
+                    const unsigned o = k_off + (unsigned)(p * K_KEYS_PER_PASS * (int)a.ldk) * 2u;
+                    rkh[p] = *reinterpret_cast<const f16x8*>(kbh + o);
+                    rkl[p] = *reinterpret_cast<const f16x8*>(kbl + o);
+                    const unsigned ov = v_off + (unsigned)(p * K_KEYS_PER_PASS * (int)a.ldv) * 2u;
+                    rvh[p] = *reinterpret_cast<const f16x8*>(vbh + ov);
+                    rvl[p] = *reinterpret_cast<const f16x8*>(vbl + ov);
+                }
             }
-        }
-        if (v_active) {
+        } else {                                     // last, partial tile: rows past nk are clamped (masked in the softmax)
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                int gk = key0 + 4 * v_kg + kk; if (gk >= nk) gk = nk - 1;
-                const int64_t go = (kv_row0 + gk) * a.ldv + h * DH + 4 * v_dg;
-                rvh[kk] = *reinterpret_cast<const f16x4*>(a.vh + go);
-                rvl[kk] = *reinterpret_cast<const f16x4*>(a.vl + go);
+            for (int p = 0; p < K_PASSES; ++p) {
+                const int key = k_key + p * K_KEYS_PER_PASS;
+                if (key < KV_TILE) {
+                    int gk = key0 + key; if (gk >= nk) gk = nk - 1;
+                    const int64_t go = (kv_row0 + gk) * a.ldk + h * DH + 8 * k_c8;
+                    rkh[p] = *reinterpret_cast<const f16x8*>(a.kh + go);
+                    rkl[p] = *reinterpret_cast<const f16x8*>(a.kl + go);
+                    const int64_t gv = (kv_row0 + gk) * a.ldv + h * DH + 8 * k_c8;
+                    rvh[p] = *reinterpret_cast<const f16x8*>(a.vh + gv);
+                    rvl[p] = *reinterpret_cast<const f16x8*>(a.vl + gv);
+                }
             }
         }
     };
-    auto store_tile = [&](int b) {
+    // LDS offsets of this lane (halves), identical for both buffers; the buffer is a compile-time constant at every use
+    // (the tile loop is unrolled by two) so all LDS addresses are one VGPR + an immediate.
+    const int ks_off = k_key * KW + 8 * k_c8;            // K staging store
+    const int vs_off = k_key * VP + 8 * k_c8;            // V staging store
+    const int kf_off = l31 * KW + 8 * hi;                // K fragment read (key block kb, chunk c: + kb*32*KW + 16c)
+    // V fragment gather: each 16-lane group fetches one [4 keys][16 dv] block, lane i of the group supplies the address
+    // of the 8-byte chunk (key i>>2, dv 4(i&3)..) and receives column dv i of the 4 keys (scripts/probes/ds_read_tr.hip).
+    // Groups: lanes 0-15 dv 0-15, 16-31 dv 16-31 (k-half hi = 0), 32-63 the same for hi = 1 (keys + 4).
+    const int vf_off = (4 * hi + ((lane & 15) >> 2)) * VP + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    auto store_tile = [&](auto BUF) {
+        constexpr int b = decltype(BUF)::value;
 #pragma unroll
         for (int p = 0; p < K_PASSES; ++p) {
-            const int key = k_key + p * K_KEYS_PER_PASS;
-            if (key < KV_TILE) {
-                *reinterpret_cast<f16x8*>(Kh(b) + key * KW + 8 * k_c8) = rkh[p];
-                *reinterpret_cast<f16x8*>(Kl(b) + key * KW + 8 * k_c8) = rkl[p];
+            if (k_key + p * K_KEYS_PER_PASS < KV_TILE) {
+                *reinterpret_cast<f16x8*>(Kh(b) + ks_off + p * K_KEYS_PER_PASS * KW) = rkh[p];
+                *reinterpret_cast<f16x8*>(Kl(b) + ks_off + p * K_KEYS_PER_PASS * KW) = rkl[p];
             }
         }
-        if (v_active) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {       // dv = 4*v_dg + e : 4 consecutive keys
-                f16x4 th, tl;
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) { th[kk] = rvh[kk][e]; tl[kk] = rvl[kk][e]; }
-                *reinterpret_cast<f16x4*>(Vh(b) + (4 * v_dg + e) * VW + 4 * v_kg) = th;
-                *reinterpret_cast<f16x4*>(Vl(b) + (4 * v_dg + e) * VW + 4 * v_kg) = tl;
+        for (int p = 0; p < K_PASSES; ++p) {
+            if (k_key + p * K_KEYS_PER_PASS < KV_TILE) {
+                *reinterpret_cast<f16x8*>(Vh(b) + vs_off + p * K_KEYS_PER_PASS * VP) = rvh[p];
+                *reinterpret_cast<f16x8*>(Vl(b) + vs_off + p * K_KEYS_PER_PASS * VP) = rvl[p];
             }
         }
     };
     // Oᵀ += Vᵀ_b Pᵀ  (P fragments of the tile staged in buffer b)
     f16x8 pf[2][2], pl[2][2];
-    auto pv = [&](int b) {
+    auto pv = [&](auto BUF) {
+        constexpr int b = decltype(BUF)::value;
 #pragma unroll
         for (int d = 0; d < NDV; ++d)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const int off = (d * 32 + l31) * VW + kb * 32 + 16 * t + 4 * hi;
-                    const f16x4 h0 = *reinterpret_cast<const f16x4*>(Vh(b) + off);
-                    const f16x4 h1 = *reinterpret_cast<const f16x4*>(Vh(b) + off + 8);
-                    const f16x4 l0 = *reinterpret_cast<const f16x4*>(Vl(b) + off);
-                    const f16x4 l1 = *reinterpret_cast<const f16x4*>(Vl(b) + off + 8);
-                    f16x8 vh, vl;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { vh[e] = h0[e]; vh[4 + e] = h1[e]; vl[e] = l0[e]; vl[4 + e] = l1[e]; }
+                    // A operand element e of lane (dv, hi): key kb*32 + 16t + 8(e>>2) + 4hi + (e&3) -> two transposing reads
+                    const int off = vf_off + (kb * 32 + 16 * t) * VP + d * 32;
+                    const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((og_lds_s16x4*)(Vh(b) + off));
+                    const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((og_lds_s16x4*)(Vh(b) + off + 8 * VP));
+                    const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((og_lds_s16x4*)(Vl(b) + off));
+                    const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((og_lds_s16x4*)(Vl(b) + off + 8 * VP));
+                    const f16x8 vh = __builtin_bit_cast(f16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+                    const f16x8 vl = __builtin_bit_cast(f16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
                     oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, pf[kb][t], oacc[d], 0, 0, 0);
                     oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[kb][t], oacc[d], 0, 0, 0);
                     oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pf[kb][t], oacc[d], 0, 0, 0);
                 }
     };
+    // Four fp32 p -> two packed (hi, lo) f16 pairs, 3 instructions per pair: hi = RNE pack; lo = f16(p - hi) by the
+    // mixed-precision FMA (f32 p * 1.0 - f16 hi, one rounding) written straight into the low / high half of the result
+    // (bit-identical to og_split: scripts/probes/split_asm.hip).  ONE asm block with a fixed internal order, because
+    // the compiler's hazard recognizer does not look inside inline asm: gfx950 needs a wait state between a
+    // transcendental op (the v_exp_f32 that produced p) and a VALU reading its result, and between an op_sel partial
+    // register write (mixlo) and the next access of that register (mixhi) -- hence the leading s_nop and the A/B
+    // interleave.  (Without them the dh = 16 / 32 instantiations read stale p: 1.5e-3 errors on a few outputs.)
+    auto split_quad = [&](float p0, float p1, float p2, float p3, unsigned& ha, unsigned& la, unsigned& hb, unsigned& lb) {
+        asm("s_nop 0\n\t"
+            "v_cvt_pk_f16_f32 %0, %4, %5\n\t"
+            "v_cvt_pk_f16_f32 %2, %6, %7\n\t"
+            "v_fma_mixlo_f16 %1, %4, 1.0, -%0 op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixlo_f16 %3, %6, 1.0, -%2 op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixhi_f16 %1, %5, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixhi_f16 %3, %7, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+            : "=&v"(ha), "=&v"(la), "=&v"(hb), "=&v"(lb)
+            : "v"(p0), "v"(p1), "v"(p2), "v"(p3));
+    };
 
     const int ntiles = (nk + KV_TILE - 1) / KV_TILE;
+#if OG_ATTN_TRACE
+    const int tsel = blockIdx.x == 8 * 40 ? 0 : blockIdx.x == 8 * 41 + 3 ? 1 : -1;     // two workgroups somewhere in the middle
+    unsigned tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     load_tile(0);
-    store_tile(0);
+    store_tile(std::integral_constant<int, 0>{});
     __syncthreads();
     // Software pipeline per tile t (buffer t&1):  issue the global loads of tile t+1 | QKᵀ(t) on the matrix
     // pipe | PV(t-1) on the matrix pipe while the VALU runs softmax(t) | barrier | registers -> LDS | barrier
-    for (int kt = 0; kt < ntiles; ++kt) {
-        const int b = kt & 1;
+    auto tile_step = [&](int kt, auto BUF) {
+        constexpr int b = decltype(BUF)::value;
         const int key0 = kt * KV_TILE;
+        OG_TP(0);
         if (kt + 1 < ntiles) load_tile(kt + 1);
+        OG_TP(1);
 
-        // ---- Sᵀ = K Qᵀ for the two 32-key blocks ----
+        // ---- S' = K Qᵀ - m_run for the two 32-key blocks: the accumulator starts at -m_run, so the exponent
+        //      arguments of the common (no-rescale) path come straight out of the matrix pipe ----
         float s[2][16];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             f32x16 sacc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+            for (int r = 0; r < 16; ++r) sacc[r] = -m_run;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                const f16x8 kh = *reinterpret_cast<const f16x8*>(Kh(b) + (kb * 32 + l31) * KW + 16 * c + 8 * hi);
-                const f16x8 kl = *reinterpret_cast<const f16x8*>(Kl(b) + (kb * 32 + l31) * KW + 16 * c + 8 * hi);
+                const f16x8 kh = *reinterpret_cast<const f16x8*>(Kh(b) + kf_off + kb * 32 * KW + 16 * c);
+                const f16x8 kl = *reinterpret_cast<const f16x8*>(Kl(b) + kf_off + kb * 32 * KW + 16 * c);
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[c], sacc, 0, 0, 0);
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[c], sacc, 0, 0, 0);
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[c], sacc, 0, 0, 0);
@@ -223,8 +298,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a, RaggedDes
             }
         }
 
-        // ---- PV of the PREVIOUS tile: independent of Sᵀ(t), keeps the matrix pipe busy under the softmax ----
-        if (kt > 0) pv(b ^ 1);
+        OG_TP(2);
+        // ---- PV of the PREVIOUS tile: independent of S(t), keeps the matrix pipe busy under the softmax ----
+        if (kt > 0) pv(std::integral_constant<int, b ^ 1>{});
+        OG_TP(3);
 
         // ---- online softmax over keys, base 2 (this lane: 32 of the tile's 64 keys of ONE query) ----
         float mt = s[0][0];
@@ -232,38 +309,69 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a, RaggedDes
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[kb][r]);
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        const float m_new = fmaxf(m_run, mt);            // finite: every tile holds >= 1 valid key
-        if (__any(m_new - m_run > RESCALE_THR)) {        // wave-uniform; first tile: inf > THR
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // rows that did not grow: 2^0 = 1
-            l_run *= alpha;
-            m_run = m_new;
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));          // max of s - m_run over the tile; finite: every tile holds >= 1 valid key
+        if (kt == 0 || __any(mt > RESCALE_THR)) {        // wave-uniform; rare after the first tile
+            const float delta = kt == 0 ? mt : fmaxf(mt, 0.f);       // new running max = m_run + delta
+            m_run += delta;
+            if (kt > 0) {                                // after PV(t-1): O and l are complete up to t-1 (first tile: both still 0)
+                const float alpha = __builtin_amdgcn_exp2f(-delta);  // rows that did not grow: 2^0 = 1
+                l_run *= alpha;
 #pragma unroll
-            for (int d = 0; d < NDV; ++d)
+                for (int d = 0; d < NDV; ++d)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;   // after PV(t-1): O is complete up to t-1
+                    for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+            }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kb][r] -= delta;
         }
         float psum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(s[kb][r] - m_run);    // <= 2^RESCALE_THR
-                psum += p;
-                _Float16 th, tl;
-                og_split(p, th, tl);
-                pf[kb][r >> 3][r & 7] = th;
-                pl[kb][r >> 3][r & 7] = tl;
+            for (int r = 0; r < 16; r += 4) {
+                const float p0 = __builtin_amdgcn_exp2f(s[kb][r]);       // <= 2^RESCALE_THR
+                const float p1 = __builtin_amdgcn_exp2f(s[kb][r + 1]);
+                const float p2 = __builtin_amdgcn_exp2f(s[kb][r + 2]);
+                const float p3 = __builtin_amdgcn_exp2f(s[kb][r + 3]);
+                psum += (p0 + p1) + (p2 + p3);
+                unsigned ha, la, hb, lb;
+#if OG_ATTN_DBG & 1
+                auto pack = [](_Float16 x, _Float16 y) { return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16); };
+                { _Float16 h0_, l0_, h1_, l1_; og_split(p0, h0_, l0_); og_split(p1, h1_, l1_); ha = pack(h0_, h1_); la = pack(l0_, l1_);
+                  og_split(p2, h0_, l0_); og_split(p3, h1_, l1_); hb = pack(h0_, h1_); lb = pack(l0_, l1_); }
+#else
+                split_quad(p0, p1, p2, p3, ha, la, hb, lb);
+#endif
+                unsigned* pfw = reinterpret_cast<unsigned*>(&pf[kb][r >> 3]);
+                unsigned* plw = reinterpret_cast<unsigned*>(&pl[kb][r >> 3]);
+                pfw[(r & 7) >> 1] = ha; pfw[((r & 7) >> 1) + 1] = hb;
+                plw[(r & 7) >> 1] = la; plw[((r & 7) >> 1) + 1] = lb;
             }
         l_run += psum;
 
+        OG_TP(4);
         __syncthreads();                                  // every wave is done with K(t) and V(t-1)
+        OG_TP(5);
         if (kt + 1 < ntiles) {
-            store_tile(b ^ 1);                            // K(t+1), V(t+1) replace K(t-1), V(t-1)
+            store_tile(std::integral_constant<int, b ^ 1>{});   // K(t+1), V(t+1) replace K(t-1), V(t-1)
+            OG_TP(6);
             __syncthreads();
         }
+        OG_TP(7);
+#if OG_ATTN_TRACE
+        if (tsel >= 0 && lane == 0 && kt < 16)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) og_attn_trace_buf[tsel][wave][kt][i] = tp[i];
+#endif
+    };
+    for (int kt = 0; kt < ntiles; kt += 2) {
+        tile_step(kt, std::integral_constant<int, 0>{});
+        if (kt + 1 < ntiles) tile_step(kt + 1, std::integral_constant<int, 1>{});
     }
-    pv((ntiles - 1) & 1);                                 // the last tile's PV
+    if ((ntiles - 1) & 1) pv(std::integral_constant<int, 1>{});   // the last tile's PV
+    else pv(std::integral_constant<int, 0>{});
 
     // ---- normalise and store O[q][h*DH + dv] ----
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -325,6 +433,13 @@ int og_launch_attention(const AttnArgs& a, hipStream_t stream) {
     }
     return og_launch_status();
 }
+
+#if OG_ATTN_TRACE
+extern "C" int og_debug_attn_trace(void* host_dst, size_t bytes) {
+    if (bytes > sizeof(og_attn_trace_buf)) bytes = sizeof(og_attn_trace_buf);
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(og_attn_trace_buf), bytes);
+}
+#endif
 
 extern "C" int og_attention(const void* qh, const void* ql, int64_t ldq, const void* kh, const void* kl, int64_t ldk,
                             const void* vh, const void* vl, int64_t ldv, void* oh, void* ol, int64_t ldo, int32_t batch,

@@ -97,7 +97,8 @@ def _attn_ref(q, k, v, H):
     return orc.softmax_attention(q.double(), k.double(), v.double(), H)     # applies d^-1/2 itself
 
 
-@pytest.mark.parametrize("H,dh,nq,nk", [(4, 16, 50, 70), (4, 32, 129, 64), (4, 64, 300, 257), (2, 64, 128, 1024), (1, 32, 1, 1)])
+@pytest.mark.parametrize("H,dh,nq,nk", [(4, 16, 50, 70), (4, 32, 129, 64), (4, 64, 300, 257), (2, 64, 128, 1024), (1, 32, 1, 1),
+                                        (4, 32, 300, 257), (4, 16, 300, 257), (2, 32, 40, 65)])    # several key tiles at every head size
 def test_attention_vs_oracle(gpu_device, H, dh, nq, nk):
     g = torch.Generator().manual_seed(H * 100 + dh + nq)
     D = H * dh
