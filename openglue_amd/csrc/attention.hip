@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a, RaggedDes
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
 
-    if (DH < 32) {   // zero the padding columns DH..31 of V once (both buffers); staging never touches them
+    if constexpr (DH < 32) {   // zero the padding columns DH..31 of V once (both buffers); staging never touches them
         for (int i = tid; i < KV_TILE * (DHP - DH); i += 256) {
             const int o = (i / (DHP - DH)) * VP + DH + i % (DHP - DH);
 #pragma unroll

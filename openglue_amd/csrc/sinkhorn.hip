@@ -17,6 +17,8 @@
 // The kernel is bandwidth/latency-bound (removing half of its arithmetic changes its time by 7 %), so the
 // geometry is chosen for bytes in flight: 32 rows per workgroup, 2 rows per group, <= 1024 columns per wave.
 // Numerics: max-subtracted LSEs like torch.logsumexp, fp32, v_exp_f32 / v_log_f32.
+#include <stdlib.h>
+
 #include "og_common.h"
 
 namespace {
@@ -332,6 +334,217 @@ __global__ __launch_bounds__(256) void sinkhorn_combine_kernel(int M, int N, con
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Dual-stabilised iterations (every iteration after the first).
+// After one max-subtracted iteration the plan entries  P_ij = exp(S~_ij + u_i + v_j)  are <= max(a_i, b_j) < 1 and stay so
+// under every later half-update (a row update makes the row sums a_i, a column update the column sums b_j), so the
+// log-sum-exps can use the CURRENT duals as their reference instead of a running maximum:
+//     rowsum_i = sum_j P_ij            u_i += log a_i - log rowsum_i
+//     colsum_j = sum_i P_ij f_i        v_j += log b_j - log colsum_j,     f_i = a_i / rowsum_i  (the row's own correction)
+// No overflow is possible (all terms <= 1), underflow only zeroes entries below 2^-126, and a row (column) sum cannot
+// vanish: it was a_i (b_j) one half-step earlier and the other side moved it by at most a factor (m+n).
+// Same recursion as optimal_transport.py:24-26 in exact arithmetic; in fp32 the two forms differ by rounding (~1e-6).
+// Work per element: one fma, one add, one v_exp_f32, one add for the row pass and ONE fma for the column pass (the
+// exponentials of the row pass are reused), against ~18 VALU + 2.5 exp of the max-subtracted sweep, which is VALU-bound
+// at 1024 keypoints (27 us of VALU for 22 us of HBM time).  Everything is kept in base 2 inside the kernels
+// (v_exp_f32 / v_log_f32); u and v stay in natural units in memory.
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+template <int CPL, int RG, int WPR>
+__global__ __launch_bounds__(256) void sinkhorn_sweep_fast_kernel(const float* __restrict__ S, int64_t lds, int M, int N,
+                                                                  const float* __restrict__ zdev, float zhost, float inv_reg,
+                                                                  float la, const float* __restrict__ v_in, int ldv,
+                                                                  float* __restrict__ u, int ldu, float* __restrict__ ps,
+                                                                  int ldp, int RB, int64_t strideS, RaggedDesc rd) {
+    constexpr int NRS = 4 / WPR;                 // row streams
+    constexpr int RW = SK_ROWS / NRS;            // rows per stream
+    constexpr int NCW = 256 * CPL;               // columns per wave
+    constexpr int NCB = NCW * WPR;               // columns per block
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* xch = sm + NRS * NCB;                 // [2 parity][NRS][RG][WPR]: row sums exchanged between column parts
+
+    const int b = blockIdx.y, rb = blockIdx.x;
+    if (rd.B > 0) {
+        M = rd.off0[b + 1] - rd.off0[b];
+        N = rd.off1[b + 1] - rd.off1[b];
+        if (rb * SK_ROWS >= M) return;
+        la = -__logf((float)(M + N));
+    }
+    S += (int64_t)b * strideS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cp = wave % WPR, rs = wave / WPR;
+    const int cbase = cp * NCW + 4 * lane;
+    const float c2 = inv_reg * LOG2E;
+    const float zr2 = (zdev ? zdev[0] : zhost) * c2;
+    const float* vb = v_in + (int64_t)b * ldv;
+    float* ub = u + (int64_t)b * ldu;
+    const float dcol2 = zr2 + vb[N] * LOG2E;     // dustbin column entry of every row (without u)
+    const float la2 = la * LOG2E;
+
+    float vv[CPL][4], cs[CPL][4];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        const int c0 = cbase + 256 * k;
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if (c0 < N) t = *reinterpret_cast<const f32x4*>(vb + c0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { vv[k][e] = t[e] * LOG2E; cs[k][e] = 0.f; }
+    }
+
+    const int srow0 = rb * SK_ROWS + rs * RW;
+    int parity = 0;
+    f32x4 nx[RG][CPL];
+    float nu[RG];                                // u of the next group's rows
+    auto fetch = [&](int row0) {
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+            const int row = row0 + r;
+            const float* sp = S + (int64_t)row * lds;
+            nu[r] = row < M ? ub[row] : 0.f;
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                const int c0 = cbase + 256 * k;
+                if (row < M && c0 < N) nx[r][k] = *reinterpret_cast<const f32x4*>(sp + c0);
+                else nx[r][k] = f32x4{OG_NEG_INF, OG_NEG_INF, OG_NEG_INF, OG_NEG_INF};
+            }
+        }
+    };
+    fetch(srow0);
+#pragma unroll 1
+    for (int g0 = 0; g0 < RW; g0 += RG) {
+        const int row0 = srow0 + g0;
+        float p[RG][CPL][4], uo[RG], sum[RG];
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+            uo[r] = nu[r] * LOG2E;
+            float s_ = 0.f;
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                const int c0 = cbase + 256 * k;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xs = (c0 + e < N) ? nx[r][k][e] : OG_NEG_INF;      // exp2(-inf) = 0
+                    p[r][k][e] = __builtin_amdgcn_exp2f(__builtin_fmaf(xs, c2, vv[k][e]) + uo[r]);
+                    s_ += p[r][k][e];
+                }
+            }
+            sum[r] = s_;
+        }
+        if (g0 + RG < RW) fetch(row0 + RG);
+#pragma unroll
+        for (int r = 0; r < RG; ++r) sum[r] = wave_sum(sum[r]);
+        if (WPR > 1) {
+            float* xs = xch + ((parity * NRS + rs) * RG) * WPR;
+            if (lane == 0) {
+#pragma unroll
+                for (int r = 0; r < RG; ++r) xs[r * WPR + cp] = sum[r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < RG; ++r) {
+                float st = 0.f;
+#pragma unroll
+                for (int w = 0; w < WPR; ++w) st += xs[r * WPR + w];
+                sum[r] = st;
+            }
+            parity ^= 1;
+        }
+        float f[RG];
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+            const float rowsum = sum[r] + __builtin_amdgcn_exp2f(dcol2 + uo[r]);
+            const float un = uo[r] + la2 - __builtin_amdgcn_logf(rowsum);           // v_log_f32 = log2
+            f[r] = __builtin_amdgcn_exp2f(un - uo[r]);
+            if (cp == 0 && lane == 0 && row0 + r < M) ub[row0 + r] = un * LN2;
+        }
+#pragma unroll
+        for (int k = 0; k < CPL; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int r = 0; r < RG; ++r) cs[k][e] = __builtin_fmaf(p[r][k][e], f[r], cs[k][e]);
+    }
+
+    float* psb = ps + ((int64_t)b * RB + rb) * ldp;
+    if (NRS == 1) {
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            const int c0 = cbase + 256 * k;
+            if (c0 < N) *reinterpret_cast<f32x4*>(psb + c0) = f32x4{cs[k][0], cs[k][1], cs[k][2], cs[k][3]};
+        }
+        return;
+    }
+    float* smm = sm + (size_t)rs * NCB;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        const int c0 = cbase + 256 * k;
+        *reinterpret_cast<f32x4*>(smm + c0) = f32x4{cs[k][0], cs[k][1], cs[k][2], cs[k][3]};
+    }
+    __syncthreads();
+    for (int c0 = 4 * tid; c0 < N; c0 += 1024) {
+        f32x4 acc = *reinterpret_cast<const f32x4*>(sm + c0);
+#pragma unroll
+        for (int w = 1; w < NRS; ++w) acc += *reinterpret_cast<const f32x4*>(sm + (size_t)w * NCB + c0);
+        *reinterpret_cast<f32x4*>(psb + c0) = acc;       // columns >= N inside the float4: never read
+    }
+}
+
+// Combine of a dual-stabilised iteration: dustbin-row u, all v from the per-row-block partial column sums.
+__global__ __launch_bounds__(256) void sinkhorn_combine_fast_kernel(int M, int N, const float* __restrict__ zdev, float zhost,
+                                                                    float inv_reg, float la_bin, float lb, float lb_bin,
+                                                                    const float* __restrict__ v_in, float* __restrict__ v_out,
+                                                                    int ldv, float* __restrict__ u, int ldu,
+                                                                    const float* __restrict__ ps, int ldp, int RB, RaggedDesc rd) {
+    __shared__ float sm[4];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    int RBv = RB;
+    if (rd.B > 0) {
+        M = rd.off0[b + 1] - rd.off0[b];
+        N = rd.off1[b + 1] - rd.off1[b];
+        if ((int)blockIdx.x * 256 > N) return;
+        RBv = (M + SK_ROWS - 1) / SK_ROWS;
+        const float norm = -__logf((float)(M + N));
+        lb = norm; la_bin = norm + __logf((float)N); lb_bin = norm + __logf((float)M);
+    }
+    const float zr2 = (zdev ? zdev[0] : zhost) * inv_reg * LOG2E;
+    const float* vb = v_in + (int64_t)b * ldv;
+    float* ub = u + (int64_t)b * ldu;
+    // dustbin row: u_M = log a_M - (z + LSE_{j<=N} v_j) from the old v alone (every block of the pair recomputes it; a
+    // form relative to the old u_M would race with the block that publishes the new one).  1025 terms: max-subtracted.
+    float m = OG_NEG_INF;
+    for (int j = tid; j <= N; j += 256) m = fmaxf(m, vb[j]);
+    m = block_max(m, sm) * LOG2E;
+    float s = 0.f;
+    for (int j = tid; j <= N; j += 256) s += __builtin_amdgcn_exp2f(vb[j] * LOG2E - m);
+    s = block_sum(s, sm);
+    const float uM = la_bin * LOG2E - (zr2 + m + __builtin_amdgcn_logf(s));      // base 2
+    if (blockIdx.x == 0 && tid == 0) ub[M] = uM * LN2;
+
+    const int j = blockIdx.x * 256 + tid;
+    if (j < N) {
+        const float* psb = ps + (int64_t)b * RB * ldp + j;
+        const float vo = vb[j] * LOG2E;
+        float cs = __builtin_amdgcn_exp2f(zr2 + vo + uM);          // dustbin row entry of column j with the new u_M
+        for (int rb0 = 0; rb0 < RBv; rb0 += 8) {
+            float t[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[q] = rb0 + q < RBv ? psb[(int64_t)(rb0 + q) * ldp] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) cs += t[q];
+        }
+        v_out[(int64_t)b * ldv + j] = (vo + lb * LOG2E - __builtin_amdgcn_logf(cs)) * LN2;
+    }
+    if ((int)blockIdx.x == N / 256) {          // the block that owns column N
+        // dustbin column: v_N += log b_N - log sum_{i<=M} P_iN with the new u (u_M from above)
+        const float vNo = vb[N] * LOG2E;
+        float us = 0.f;
+        for (int i = tid; i < M; i += 256) us += __builtin_amdgcn_exp2f(zr2 + vNo + ub[i] * LOG2E);
+        us = block_sum(us, sm) + __builtin_amdgcn_exp2f(zr2 + vNo + uM);
+        if (tid == 0) v_out[(int64_t)b * ldv + N] = (vNo + lb_bin * LOG2E - __builtin_amdgcn_logf(us)) * LN2;
+    }
+}
+
 // scores[b][i][j] = ((S~_ij + u_i) + v_j) - norm   (same association as optimal_transport.py:28, superglue.py:111)
 __global__ __launch_bounds__(256) void sinkhorn_scores_kernel(const float* __restrict__ S, int64_t lds, int M, int N,
                                                               const float* __restrict__ zdev, float zhost,
@@ -373,6 +586,15 @@ void launch_sweep(const float* S, int64_t lds, int B, int m, int n, const float*
                        inv_reg, la, v_in, w.ldv, w.u, w.ldu, w.pm, w.ps, w.ldp, w.RB, (int64_t)m * lds, rd);
 }
 
+template <int CPL, int RG, int WPR>
+void launch_sweep_fast(const float* S, int64_t lds, int B, int m, int n, const float* zdev, float zhost, float inv_reg, float la,
+                       const float* v_in, const SinkhornWs& w, hipStream_t st, const RaggedDesc& rd) {
+    constexpr int NRS = 4 / WPR;
+    const size_t shmem = sizeof(float) * ((size_t)NRS * 256 * CPL * WPR + 2 * NRS * RG * WPR);
+    hipLaunchKernelGGL((sinkhorn_sweep_fast_kernel<CPL, RG, WPR>), dim3(w.RB, B), dim3(256), shmem, st, S, lds, m, n, zdev, zhost,
+                       inv_reg, la, v_in, w.ldv, w.u, w.ldu, w.ps, w.ldp, w.RB, (int64_t)m * lds, rd);
+}
+
 }  // namespace
 
 extern "C" size_t og_sinkhorn_workspace_bytes(int32_t batch, int32_t m, int32_t n) {
@@ -402,8 +624,21 @@ int og_launch_sinkhorn(const float* S, int64_t lds, const float* zdev, float dus
     if (e != hipSuccess) return (int)e;
     const SinkhornGeom g = sk_geom(n);
     int cur = 0;
+    static const bool robust_only = [] { const char* e = getenv("OG_SINKHORN_ROBUST"); return e && atoi(e) != 0; }();   // experiments
     for (int it = 0; it < iters; ++it) {
         const float* vin = w.v[cur];
+        if (it > 0 && !robust_only) {     // dual-stabilised form: valid once one max-subtracted iteration has been done
+            if (g.CPL == 1) launch_sweep_fast<1, 4, 1>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd);
+            else if (g.CPL == 2) launch_sweep_fast<2, 4, 1>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd);
+            else if (g.CPL == 8) launch_sweep_fast<8, 1, 4>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd);
+            else if (g.WPR == 1) launch_sweep_fast<4, 2, 1>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd);
+            else if (g.WPR == 2) launch_sweep_fast<4, 2, 2>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd);
+            else launch_sweep_fast<4, 2, 4>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd);
+            hipLaunchKernelGGL(sinkhorn_combine_fast_kernel, dim3((n + 1 + 255) / 256, B), dim3(256), 0, st, m, n, zdev, dustbin,
+                               inv_reg, la_bin, lb, lb_bin, w.v[cur], w.v[cur ^ 1], w.ldv, w.u, w.ldu, w.ps, w.ldp, w.RB, rd);
+            cur ^= 1;
+            continue;
+        }
         if (g.CPL == 1) launch_sweep<1, 4, 1>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd);
         else if (g.CPL == 2) launch_sweep<2, 4, 1>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd);
         else if (g.CPL == 8) launch_sweep<8, 1, 4>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd);
