@@ -1,6 +1,7 @@
 // C-ABI entry points: shape checks, host-side weight packing, workspace layout and the launch
 // sequence of the whole hot path (og_forward).  See include/openglue_amd.h for the contract.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -337,12 +338,12 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
     };
     // split-f16 GEMM (the GNN's 1x1 convolutions): hl32 rows in; fp32 and/or hl32 rows (c_hl) or planes out
     auto gemmh = [&](const _Float16* A, const float* wbase, int64_t o_w, int64_t wrow0, int64_t M, int N, int K,
-                     const float* bias, int relu, const float* res, float* C32, _Float16* Ch, _Float16* Cl, int64_t ldch,
+                     const float* bias, int relu, const _Float16* res_hl, float* C32, _Float16* Ch, _Float16* Cl, int64_t ldch,
                      int c_hl) -> int {
         GemmHArgs g{};
         g.A = A; g.lda = D4;
         g.B = (const _Float16*)(wbase + o_w) + wrow0 * 2 * K; g.ldb = 2 * K;
-        g.M = (int)M; g.N = N; g.K = K; g.scale = (float)(1.0 / OG_W_SCALE); g.bias = bias; g.relu = relu; g.res = res; g.ldr = D;
+        g.M = (int)M; g.N = N; g.K = K; g.scale = (float)(1.0 / OG_W_SCALE); g.bias = bias; g.relu = relu; g.res = nullptr; g.ldr = D; g.res_hl = res_hl; g.ldrh = D4;
         g.C32 = C32; g.ldc = D; g.Ch = Ch; g.Cl = Cl; g.ldch = ldch; g.c_hl = c_hl;
         Scope sc(prof, OG_STAGE_GEMM_F16X3);
         return og_launch_gemm_f16x3(g, st);
@@ -391,30 +392,38 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
         return (s.flags & OG_FLAG_LINEAR_ATTENTION) ? og_launch_linear_attention(a, st) : og_launch_attention(a, st);
     };
     // message MLP on token rows [r0, r0+R):  h = relu([x;O] W0'^T + b0') ; x += h W3'^T + b3'  (x kept in fp32 AND as planes)
-    auto mlp = [&](const float* lw, int64_t r0, int64_t R) -> int {
+    // message MLP on token rows [r0, r0+R):  h = relu([x;O] W0'^T + b0') ; x += h W3'^T + b3'.  x lives as hl32 (hi, lo)
+    // rows between the layers (the residual is read from them: 2^-22 relative per layer); only the last update of a row
+    // also writes the fp32 copy the final projection reads.
+    auto mlp = [&](const float* lw, int64_t r0, int64_t R, bool last) -> int {
         int e = gemmh(XO + r0 * D4, lw, L.o_w0, 0, R, D2, D2, lw + L.o_b0, 1, nullptr, nullptr, Hb + r0 * D4, nullptr, D4, 1);
         if (e) return e;
-        return gemmh(Hb + r0 * D4, lw, L.o_w3, 0, R, D, D2, lw + L.o_b3, 0, X32 + r0 * D, X32 + r0 * D, XO + r0 * D4, nullptr, D4, 1);
+        return gemmh(Hb + r0 * D4, lw, L.o_w3, 0, R, D, D2, lw + L.o_b3, 0, XO + r0 * D4, last ? X32 + r0 * D : nullptr,
+                     XO + r0 * D4, nullptr, D4, 1);
     };
     for (int l = 0; l < s.num_stages; ++l) {
         // self layer 2l: both images through the same weights (attention_gnn.py:63-66)
         const float* lw = pk + L.layer0 + (int64_t)(2 * l) * L.layer_stride;
         if ((rc = gemmh(XO, lw, L.o_wqkv, 0, T, D3, D, lw + L.o_bqkv, 0, nullptr, nullptr, QKVh, QKVl, D3, 0))) return rc;
         if ((rc = attention(2 * B, B, 0, m, m, 0, m, m, T0, n, n, T0, n, n, 1))) return rc;
-        if ((rc = mlp(lw, 0, T))) return rc;
+        if ((rc = mlp(lw, 0, T, false))) return rc;
         // cross layer 2l+1: image 0 first, then image 1 against the UPDATED image 0 (attention_gnn.py:74-77)
         lw = pk + L.layer0 + (int64_t)(2 * l + 1) * L.layer_stride;
         for (int side = 0; side < 2; ++side) {
             const int64_t qr0 = side ? T0 : 0, qR = side ? T1 : T0;       // query rows
-            const int64_t kr0 = side ? 0 : T0, kR = side ? T0 : T1;       // key/value rows
-            if ((rc = gemmh(XO + qr0 * D4, lw, L.o_wqkv, 0, qR, D, D, lw + L.o_bqkv, 0, nullptr, nullptr, QKVh + qr0 * D3,
-                            QKVl + qr0 * D3, D3, 0))) return rc;
-            if ((rc = gemmh(XO + kr0 * D4, lw, L.o_wqkv, D, kR, D2, D, lw + L.o_bqkv + D, 0, nullptr, nullptr, QKVh + kr0 * D3 + D,
-                            QKVl + kr0 * D3 + D, D3, 0))) return rc;
+            if (side == 0) {
+                // image 1 is still untouched: its k, v (for this half) and its q (for the second half) in ONE launch
+                if ((rc = gemmh(XO + T0 * D4, lw, L.o_wqkv, 0, T1, D3, D, lw + L.o_bqkv, 0, nullptr, nullptr, QKVh + T0 * D3,
+                                QKVl + T0 * D3, D3, 0))) return rc;
+                if ((rc = gemmh(XO, lw, L.o_wqkv, 0, T0, D, D, lw + L.o_bqkv, 0, nullptr, nullptr, QKVh, QKVl, D3, 0))) return rc;
+            } else {
+                // k, v of the UPDATED image 0
+                if ((rc = gemmh(XO, lw, L.o_wqkv, D, T0, D2, D, lw + L.o_bqkv + D, 0, nullptr, nullptr, QKVh + D, QKVl + D, D3, 0))) return rc;
+            }
             if (side == 0) rc = attention(B, B, 0, m, m, T0, n, n, 0, 0, 0, 0, 0, 0, 2);
             else rc = attention(B, B, T0, n, n, 0, m, m, 0, 0, 0, 0, 0, 0, 3);
             if (rc) return rc;
-            if ((rc = mlp(lw, qr0, qR))) return rc;
+            if ((rc = mlp(lw, qr0, qR, l + 1 == s.num_stages))) return rc;
         }
     }
 

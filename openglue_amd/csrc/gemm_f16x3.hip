@@ -67,6 +67,12 @@ __device__ __forceinline__ void gemm_f16x3_epilogue(const GemmHArgs& g, f32x16 (
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
                 if (g.res && tok < g.M && oc < g.N) v += *reinterpret_cast<const f32x4*>(g.res + (int64_t)tok * g.ldr + oc);
+                if (g.res_hl && tok < g.M && oc < g.N) {         // residual carried as (hi, lo): 2^-22 relative
+                    const _Float16* rp = g.res_hl + (int64_t)tok * g.ldrh + og_hl_col(oc);
+                    const f16x4 rh = *reinterpret_cast<const f16x4*>(rp), rl = *reinterpret_cast<const f16x4*>(rp + 32);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)rh[e] + (float)rl[e];
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc0[i][j][4 * q + e] = v[e];
             }
@@ -499,6 +505,7 @@ int og_launch_gemm_f16x3(const GemmHArgs& a, hipStream_t stream) {
     if (a.Ch && a.c_hl && (((uintptr_t)a.Ch & 15) || (a.ldch & 7) || (a.N & 31))) return OG_E_ALIGN;
     if (a.Ch && !a.c_hl && (((uintptr_t)a.Ch & 7) || ((uintptr_t)a.Cl & 7) || (a.ldch & 3))) return OG_E_ALIGN;
     if (a.res && (((uintptr_t)a.res & 15) || (a.ldr & 3))) return OG_E_ALIGN;
+    if (a.res_hl && (a.res || ((uintptr_t)a.res_hl & 15) || (a.ldrh & 7) || (a.N & 31))) return OG_E_ALIGN;
     if (a.bias && ((uintptr_t)a.bias & 15)) return OG_E_ALIGN;
     static const int force = [] { const char* e = getenv("OG_GEMM_TILE"); return e ? atoi(e) : 0; }();   // experiments: 128 / 256
     {   // large tiles when they still give (nearly) every CU a block

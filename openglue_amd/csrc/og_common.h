@@ -100,7 +100,8 @@ struct GemmHArgs {
     int M, N, K;
     float scale;                              // v = acc * scale + bias (undoes a power-of-two pre-scale of B)
     const float* bias; int relu;
-    const float* res; int64_t ldr;            // fp32 residual [M][N] (may alias C32)
+    const float* res; int64_t ldr;            // fp32 residual [M][N] (may alias C32), or
+    const _Float16* res_hl; int64_t ldrh;     //   split-f16 residual in hl32 rows (may alias Ch when c_hl): v += hi + lo
     float* C32; int64_t ldc;                  // optional fp32 output
     _Float16* Ch; _Float16* Cl; int64_t ldch; // optional split-f16 output: two planes, or
     int c_hl;                                 //   1: hl32 rows (Cl == Ch + 32, ldch = row stride in halves)
