@@ -356,7 +356,11 @@ __global__ __launch_bounds__(256) void sinkhorn_sweep_fast_kernel(const float* _
                                                                   const float* __restrict__ zdev, float zhost, float inv_reg,
                                                                   float la, const float* __restrict__ v_in, int ldv,
                                                                   float* __restrict__ u, int ldu, float* __restrict__ ps,
-                                                                  int ldp, int RB, int64_t strideS, RaggedDesc rd) {
+                                                                  int ldp, int RB, int64_t strideS, float in_scale,
+                                                                  float out_scale, RaggedDesc rd) {
+    // u, v in memory: base-2 units between two dual-stabilised iterations (no per-iteration unit conversion: at
+    // convergence the increments vanish and the duals stop moving, instead of random-walking by an ulp per round trip);
+    // in_scale = log2(e) when the previous iteration left natural units, out_scale = ln 2 on the last iteration.
     constexpr int NRS = 4 / WPR;                 // row streams
     constexpr int RW = SK_ROWS / NRS;            // rows per stream
     constexpr int NCW = 256 * CPL;               // columns per wave
@@ -379,7 +383,7 @@ __global__ __launch_bounds__(256) void sinkhorn_sweep_fast_kernel(const float* _
     const float zr2 = (zdev ? zdev[0] : zhost) * c2;
     const float* vb = v_in + (int64_t)b * ldv;
     float* ub = u + (int64_t)b * ldu;
-    const float dcol2 = zr2 + vb[N] * LOG2E;     // dustbin column entry of every row (without u)
+    const float dcol2 = zr2 + vb[N] * in_scale;  // dustbin column entry of every row (without u)
     const float la2 = la * LOG2E;
 
     float vv[CPL][4], cs[CPL][4];
@@ -389,7 +393,7 @@ __global__ __launch_bounds__(256) void sinkhorn_sweep_fast_kernel(const float* _
         f32x4 t = {0.f, 0.f, 0.f, 0.f};
         if (c0 < N) t = *reinterpret_cast<const f32x4*>(vb + c0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { vv[k][e] = t[e] * LOG2E; cs[k][e] = 0.f; }
+        for (int e = 0; e < 4; ++e) { vv[k][e] = t[e] * in_scale; cs[k][e] = 0.f; }
     }
 
     const int srow0 = rb * SK_ROWS + rs * RW;
@@ -417,7 +421,7 @@ __global__ __launch_bounds__(256) void sinkhorn_sweep_fast_kernel(const float* _
         float p[RG][CPL][4], uo[RG], sum[RG];
 #pragma unroll
         for (int r = 0; r < RG; ++r) {
-            uo[r] = nu[r] * LOG2E;
+            uo[r] = nu[r] * in_scale;
             float s_ = 0.f;
 #pragma unroll
             for (int k = 0; k < CPL; ++k) {
@@ -456,7 +460,7 @@ __global__ __launch_bounds__(256) void sinkhorn_sweep_fast_kernel(const float* _
             const float rowsum = sum[r] + __builtin_amdgcn_exp2f(dcol2 + uo[r]);
             const float un = uo[r] + la2 - __builtin_amdgcn_logf(rowsum);           // v_log_f32 = log2
             f[r] = __builtin_amdgcn_exp2f(un - uo[r]);
-            if (cp == 0 && lane == 0 && row0 + r < M) ub[row0 + r] = un * LN2;
+            if (cp == 0 && lane == 0 && row0 + r < M) ub[row0 + r] = un * out_scale;
         }
 #pragma unroll
         for (int k = 0; k < CPL; ++k)
@@ -495,9 +499,11 @@ __global__ __launch_bounds__(256) void sinkhorn_combine_fast_kernel(int M, int N
                                                                     float inv_reg, float la_bin, float lb, float lb_bin,
                                                                     const float* __restrict__ v_in, float* __restrict__ v_out,
                                                                     int ldv, float* __restrict__ u, int ldu,
-                                                                    const float* __restrict__ ps, int ldp, int RB, RaggedDesc rd) {
+                                                                    const float* __restrict__ ps, int ldp, int RB, float in_scale,
+                                                                    float out_scale, RaggedDesc rd) {
     __shared__ float sm[4];
     const int b = blockIdx.y, tid = threadIdx.x;
+    const float u_scale = out_scale == 1.f ? 1.f : LOG2E;      // the sweep of this iteration stored u * out_scale
     int RBv = RB;
     if (rd.B > 0) {
         M = rd.off0[b + 1] - rd.off0[b];
@@ -514,17 +520,17 @@ __global__ __launch_bounds__(256) void sinkhorn_combine_fast_kernel(int M, int N
     // form relative to the old u_M would race with the block that publishes the new one).  1025 terms: max-subtracted.
     float m = OG_NEG_INF;
     for (int j = tid; j <= N; j += 256) m = fmaxf(m, vb[j]);
-    m = block_max(m, sm) * LOG2E;
+    m = block_max(m, sm) * in_scale;
     float s = 0.f;
-    for (int j = tid; j <= N; j += 256) s += __builtin_amdgcn_exp2f(vb[j] * LOG2E - m);
+    for (int j = tid; j <= N; j += 256) s += __builtin_amdgcn_exp2f(vb[j] * in_scale - m);
     s = block_sum(s, sm);
     const float uM = la_bin * LOG2E - (zr2 + m + __builtin_amdgcn_logf(s));      // base 2
-    if (blockIdx.x == 0 && tid == 0) ub[M] = uM * LN2;
+    if (blockIdx.x == 0 && tid == 0) ub[M] = uM * out_scale;
 
     const int j = blockIdx.x * 256 + tid;
     if (j < N) {
         const float* psb = ps + (int64_t)b * RB * ldp + j;
-        const float vo = vb[j] * LOG2E;
+        const float vo = vb[j] * in_scale;
         float cs = __builtin_amdgcn_exp2f(zr2 + vo + uM);          // dustbin row entry of column j with the new u_M
         for (int rb0 = 0; rb0 < RBv; rb0 += 8) {
             float t[8];
@@ -533,15 +539,15 @@ __global__ __launch_bounds__(256) void sinkhorn_combine_fast_kernel(int M, int N
 #pragma unroll
             for (int q = 0; q < 8; ++q) cs += t[q];
         }
-        v_out[(int64_t)b * ldv + j] = (vo + lb * LOG2E - __builtin_amdgcn_logf(cs)) * LN2;
+        v_out[(int64_t)b * ldv + j] = (vo + lb * LOG2E - __builtin_amdgcn_logf(cs)) * out_scale;
     }
     if ((int)blockIdx.x == N / 256) {          // the block that owns column N
         // dustbin column: v_N += log b_N - log sum_{i<=M} P_iN with the new u (u_M from above)
-        const float vNo = vb[N] * LOG2E;
+        const float vNo = vb[N] * in_scale;
         float us = 0.f;
-        for (int i = tid; i < M; i += 256) us += __builtin_amdgcn_exp2f(zr2 + vNo + ub[i] * LOG2E);
+        for (int i = tid; i < M; i += 256) us += __builtin_amdgcn_exp2f(zr2 + vNo + ub[i] * u_scale);
         us = block_sum(us, sm) + __builtin_amdgcn_exp2f(zr2 + vNo + uM);
-        if (tid == 0) v_out[(int64_t)b * ldv + N] = (vNo + lb_bin * LOG2E - __builtin_amdgcn_logf(us)) * LN2;
+        if (tid == 0) v_out[(int64_t)b * ldv + N] = (vNo + lb_bin * LOG2E - __builtin_amdgcn_logf(us)) * out_scale;
     }
 }
 
@@ -588,11 +594,11 @@ void launch_sweep(const float* S, int64_t lds, int B, int m, int n, const float*
 
 template <int CPL, int RG, int WPR>
 void launch_sweep_fast(const float* S, int64_t lds, int B, int m, int n, const float* zdev, float zhost, float inv_reg, float la,
-                       const float* v_in, const SinkhornWs& w, hipStream_t st, const RaggedDesc& rd) {
+                       const float* v_in, const SinkhornWs& w, hipStream_t st, const RaggedDesc& rd, float in_scale, float out_scale) {
     constexpr int NRS = 4 / WPR;
     const size_t shmem = sizeof(float) * ((size_t)NRS * 256 * CPL * WPR + 2 * NRS * RG * WPR);
     hipLaunchKernelGGL((sinkhorn_sweep_fast_kernel<CPL, RG, WPR>), dim3(w.RB, B), dim3(256), shmem, st, S, lds, m, n, zdev, zhost,
-                       inv_reg, la, v_in, w.ldv, w.u, w.ldu, w.ps, w.ldp, w.RB, (int64_t)m * lds, rd);
+                       inv_reg, la, v_in, w.ldv, w.u, w.ldu, w.ps, w.ldp, w.RB, (int64_t)m * lds, in_scale, out_scale, rd);
 }
 
 }  // namespace
@@ -628,14 +634,15 @@ int og_launch_sinkhorn(const float* S, int64_t lds, const float* zdev, float dus
     for (int it = 0; it < iters; ++it) {
         const float* vin = w.v[cur];
         if (it > 0 && !robust_only) {     // dual-stabilised form: valid once one max-subtracted iteration has been done
-            if (g.CPL == 1) launch_sweep_fast<1, 4, 1>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd);
-            else if (g.CPL == 2) launch_sweep_fast<2, 4, 1>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd);
-            else if (g.CPL == 8) launch_sweep_fast<8, 1, 4>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd);
-            else if (g.WPR == 1) launch_sweep_fast<4, 2, 1>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd);
-            else if (g.WPR == 2) launch_sweep_fast<4, 2, 2>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd);
-            else launch_sweep_fast<4, 2, 4>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd);
+            const float is = it == 1 ? LOG2E : 1.f, os = it == iters - 1 ? LN2 : 1.f;     // duals stay in base 2 in between
+            if (g.CPL == 1) launch_sweep_fast<1, 4, 1>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd, is, os);
+            else if (g.CPL == 2) launch_sweep_fast<2, 4, 1>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd, is, os);
+            else if (g.CPL == 8) launch_sweep_fast<8, 1, 4>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd, is, os);
+            else if (g.WPR == 1) launch_sweep_fast<4, 2, 1>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd, is, os);
+            else if (g.WPR == 2) launch_sweep_fast<4, 2, 2>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd, is, os);
+            else launch_sweep_fast<4, 2, 4>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd, is, os);
             hipLaunchKernelGGL(sinkhorn_combine_fast_kernel, dim3((n + 1 + 255) / 256, B), dim3(256), 0, st, m, n, zdev, dustbin,
-                               inv_reg, la_bin, lb, lb_bin, w.v[cur], w.v[cur ^ 1], w.ldv, w.u, w.ldu, w.ps, w.ldp, w.RB, rd);
+                               inv_reg, la_bin, lb, lb_bin, w.v[cur], w.v[cur ^ 1], w.ldv, w.u, w.ldu, w.ps, w.ldp, w.RB, is, os, rd);
             cur ^= 1;
             continue;
         }
