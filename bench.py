@@ -234,13 +234,13 @@ def main():
         launches = {k: profs[0][k][1] for k in profs[0]}
         per_step = {  # kernel class -> (algorithmic work per step, unit scale, bound, peak, kernel names, note)
             "gemm_f16x3": (counts["gemm_f16x3_flops"] * B, 1e12, "mfma", PEAK_F16_MFMA_TFLOPS, "TFLOP/s",
-                           "gemm_nt_f16x3_kernel (GNN 1x1 convs, split-f16 3-pass MFMA: executes 2.7x the algorithmic flops)"),
+                           "gemm_nt_f16x3_big_kernel / gemm_nt_f16x3_kernel (GNN 1x1 convs, split-f16 3-pass MFMA: executes 3x the algorithmic flops)"),
             "gemm_f32": (counts["gemm_f32_flops"] * B, 1e12, "mfma", PEAK_F32_MFMA_TFLOPS, "TFLOP/s",
                          "gemm_nt_f32_kernel (encoder MLP, final projection, score matrix; exact fp32 MFMA)"),
             "attention": (counts["attention_flops"] * B, 1e12, "mfma", PEAK_F16_MFMA_TFLOPS, "TFLOP/s",
                           "attention_kernel (split-f16 flash attention: executes 3x the algorithmic flops)"),
             "sinkhorn": (counts["sinkhorn_bytes"] * B, 1e9, "hbm", PEAK_HBM_GBS, "GB/s",
-                         "sinkhorn_sweep + sinkhorn_combine (stage time incl. launch gaps; one sweep of S per iteration)"),
+                         "sinkhorn_sweep_fast + sinkhorn_combine_fast (stage time incl. launch gaps; the kernels read S ONCE per iteration, the algorithmic figure of SURVEY 8d counts two sweeps: frac can exceed 1)"),
         }
         # HBM traffic per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
         # corrected as MI355X_MICROARCH.md prescribes); only valid for the configuration it was measured on (C2, B=32)
