@@ -421,6 +421,7 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_big_kernel(GemmHArgs g, int
             } else {
                 wait_frags(ks & 1, grp & 1, 0);                                // all my reads of stage kt are done
                 if (kt + 1 < nk) {
+                    // (the "memory" clobber also pins the LDS-DMA issue below behind the volatile fragment reads above)
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // my DMA pieces of stage kt+1 landed
                     __builtin_amdgcn_s_barrier();
                     if (kt + 2 < nk && !(OG_GEMM_ABL & 8)) issue_stage(kt + 2);   // overwrites the slot of stage kt
