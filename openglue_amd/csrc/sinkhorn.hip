@@ -501,7 +501,6 @@ __global__ __launch_bounds__(256) void sinkhorn_combine_fast_kernel(int M, int N
                                                                     int ldv, float* __restrict__ u, int ldu,
                                                                     const float* __restrict__ ps, int ldp, int RB, float in_scale,
                                                                     float out_scale, RaggedDesc rd) {
-    __shared__ float sm[4];
     const int b = blockIdx.y, tid = threadIdx.x;
     const float u_scale = out_scale == 1.f ? 1.f : LOG2E;      // the sweep of this iteration stored u * out_scale
     int RBv = RB;
@@ -516,38 +515,61 @@ __global__ __launch_bounds__(256) void sinkhorn_combine_fast_kernel(int M, int N
     const float zr2 = (zdev ? zdev[0] : zhost) * inv_reg * LOG2E;
     const float* vb = v_in + (int64_t)b * ldv;
     float* ub = u + (int64_t)b * ldu;
-    // dustbin row: u_M = log a_M - (z + LSE_{j<=N} v_j) from the old v alone (every block of the pair recomputes it; a
-    // form relative to the old u_M would race with the block that publishes the new one).  1025 terms: max-subtracted.
-    float m = OG_NEG_INF;
-    for (int j = tid; j <= N; j += 256) m = fmaxf(m, vb[j]);
-    m = block_max(m, sm) * in_scale;
-    float s = 0.f;
-    for (int j = tid; j <= N; j += 256) s += __builtin_amdgcn_exp2f(vb[j] * in_scale - m);
-    s = block_sum(s, sm);
-    const float uM = la_bin * LOG2E - (zr2 + m + __builtin_amdgcn_logf(s));      // base 2
-    if (blockIdx.x == 0 && tid == 0) ub[M] = uM * out_scale;
+    __shared__ float smx[3][4];
+    const int lane = tid & 63, wave = tid >> 6;
+    const bool owns_bin = (int)blockIdx.x == N / 256;          // the block that owns column N
 
+    // Everything that does not depend on the new u_M is issued first, so its latency overlaps the reduction below:
+    // (1) the column partials of this thread's column, (2) the dustbin-column terms of the new u (owning block only).
     const int j = blockIdx.x * 256 + tid;
+    float colsum = 0.f, vo = 0.f;
     if (j < N) {
         const float* psb = ps + (int64_t)b * RB * ldp + j;
-        const float vo = vb[j] * in_scale;
-        float cs = __builtin_amdgcn_exp2f(zr2 + vo + uM);          // dustbin row entry of column j with the new u_M
+        vo = vb[j] * in_scale;
         for (int rb0 = 0; rb0 < RBv; rb0 += 8) {
             float t[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) t[q] = rb0 + q < RBv ? psb[(int64_t)(rb0 + q) * ldp] : 0.f;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) cs += t[q];
+            for (int q = 0; q < 8; ++q) colsum += t[q];
         }
+    }
+    const float vNo = vb[N] * in_scale;
+    float us = 0.f;
+    if (owns_bin)
+        for (int i = tid; i < M; i += 256) us += __builtin_amdgcn_exp2f(zr2 + vNo + ub[i] * u_scale);
+
+    // dustbin row: u_M = log a_M - (z + LSE_{j<=N} v_j) from the old v alone (every block of the pair recomputes it; a
+    // form relative to the old u_M would race with the block that publishes the new one).  Max-subtracted, one exchange:
+    // per-wave (max, sum) pairs through LDS, together with the dustbin-column partial sums.
+    float m = OG_NEG_INF;
+    for (int jj = tid; jj <= N; jj += 256) m = fmaxf(m, vb[jj]);
+    m = wave_max(m) * in_scale;
+    float sv = 0.f;
+    if (m != OG_NEG_INF)
+        for (int jj = tid; jj <= N; jj += 256) sv += __builtin_amdgcn_exp2f(vb[jj] * in_scale - m);
+    sv = wave_sum(sv);
+    us = wave_sum(us);
+    if (lane == 0) { smx[0][wave] = m; smx[1][wave] = sv; smx[2][wave] = us; }
+    __syncthreads();
+    const float mm = fmaxf(fmaxf(smx[0][0], smx[0][1]), fmaxf(smx[0][2], smx[0][3]));
+    float st = 0.f, ust = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        st += smx[0][w] == OG_NEG_INF ? 0.f : smx[1][w] * __builtin_amdgcn_exp2f(smx[0][w] - mm);
+        ust += smx[2][w];
+    }
+    const float uM = la_bin * LOG2E - (zr2 + mm + __builtin_amdgcn_logf(st));      // base 2
+    if (blockIdx.x == 0 && tid == 0) ub[M] = uM * out_scale;
+
+    if (j < N) {
+        const float cs = colsum + __builtin_amdgcn_exp2f(zr2 + vo + uM);      // + the dustbin row entry with the new u_M
         v_out[(int64_t)b * ldv + j] = (vo + lb * LOG2E - __builtin_amdgcn_logf(cs)) * out_scale;
     }
-    if ((int)blockIdx.x == N / 256) {          // the block that owns column N
+    if (owns_bin && tid == 0) {
         // dustbin column: v_N += log b_N - log sum_{i<=M} P_iN with the new u (u_M from above)
-        const float vNo = vb[N] * in_scale;
-        float us = 0.f;
-        for (int i = tid; i < M; i += 256) us += __builtin_amdgcn_exp2f(zr2 + vNo + ub[i] * u_scale);
-        us = block_sum(us, sm) + __builtin_amdgcn_exp2f(zr2 + vNo + uM);
-        if (tid == 0) v_out[(int64_t)b * ldv + N] = (vNo + lb_bin * LOG2E - __builtin_amdgcn_logf(us)) * out_scale;
+        const float tot = ust + __builtin_amdgcn_exp2f(zr2 + vNo + uM);
+        v_out[(int64_t)b * ldv + N] = (vNo + lb_bin * LOG2E - __builtin_amdgcn_logf(tot)) * out_scale;
     }
 }
 
