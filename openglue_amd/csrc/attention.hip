@@ -216,43 +216,30 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a, RaggedDes
     auto pv = [&](auto BUF) {
         constexpr int b = decltype(BUF)::value;
 #pragma unroll
-        for (int d = 0; d < NDV; ++d)
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int t = 0; t < 2; ++t) {
+                // A operand element e of lane (dv, hi): key kb*32 + 16t + 8(e>>2) + 4hi + (e&3) -> two transposing reads
+                f16x8 vh[NDV], vl[NDV];
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    // A operand element e of lane (dv, hi): key kb*32 + 16t + 8(e>>2) + 4hi + (e&3) -> two transposing reads
+                for (int d = 0; d < NDV; ++d) {
                     const int off = vf_off + (kb * 32 + 16 * t) * VP + d * 32;
                     const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((og_lds_s16x4*)(Vh(b) + off));
                     const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((og_lds_s16x4*)(Vh(b) + off + 8 * VP));
                     const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((og_lds_s16x4*)(Vl(b) + off));
                     const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((og_lds_s16x4*)(Vl(b) + off + 8 * VP));
-                    const f16x8 vh = __builtin_bit_cast(f16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
-                    const f16x8 vl = __builtin_bit_cast(f16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
-                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, pf[kb][t], oacc[d], 0, 0, 0);
-                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[kb][t], oacc[d], 0, 0, 0);
-                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pf[kb][t], oacc[d], 0, 0, 0);
+                    vh[d] = __builtin_bit_cast(f16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+                    vl[d] = __builtin_bit_cast(f16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
                 }
+                // pass-major over the dv blocks: consecutive MFMAs write different accumulators (when NDV = 2)
+#pragma unroll
+                for (int d = 0; d < NDV; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[d], pf[kb][t], oacc[d], 0, 0, 0);
+#pragma unroll
+                for (int d = 0; d < NDV; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[d], pl[kb][t], oacc[d], 0, 0, 0);
+#pragma unroll
+                for (int d = 0; d < NDV; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[d], pf[kb][t], oacc[d], 0, 0, 0);
+            }
     };
-    // Four fp32 p -> two packed (hi, lo) f16 pairs, 3 instructions per pair: hi = RNE pack; lo = f16(p - hi) by the
-    // mixed-precision FMA (f32 p * 1.0 - f16 hi, one rounding) written straight into the low / high half of the result
-    // (bit-identical to og_split: scripts/probes/split_asm.hip).  ONE asm block with a fixed internal order, because
-    // the compiler's hazard recognizer does not look inside inline asm: gfx950 needs a wait state between a
-    // transcendental op (the v_exp_f32 that produced p) and a VALU reading its result, and between an op_sel partial
-    // register write (mixlo) and the next access of that register (mixhi) -- hence the leading s_nop and the A/B
-    // interleave.  (Without them the dh = 16 / 32 instantiations read stale p: 1.5e-3 errors on a few outputs.)
-    auto split_quad = [&](float p0, float p1, float p2, float p3, unsigned& ha, unsigned& la, unsigned& hb, unsigned& lb) {
-        asm("s_nop 0\n\t"
-            "v_cvt_pk_f16_f32 %0, %4, %5\n\t"
-            "v_cvt_pk_f16_f32 %2, %6, %7\n\t"
-            "v_fma_mixlo_f16 %1, %4, 1.0, -%0 op_sel_hi:[0,0,1]\n\t"
-            "v_fma_mixlo_f16 %3, %6, 1.0, -%2 op_sel_hi:[0,0,1]\n\t"
-            "v_fma_mixhi_f16 %1, %5, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-            "v_fma_mixhi_f16 %3, %7, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-            : "=&v"(ha), "=&v"(la), "=&v"(hb), "=&v"(lb)
-            : "v"(p0), "v"(p1), "v"(p2), "v"(p3));
-    };
-
     const int ntiles = (nk + KV_TILE - 1) / KV_TILE;
 #if OG_ATTN_TRACE
     const int tsel = blockIdx.x == 8 * 40 ? 0 : blockIdx.x == 8 * 41 + 3 ? 1 : -1;     // two workgroups somewhere in the middle
@@ -273,28 +260,41 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a, RaggedDes
         // ---- S' = K Qᵀ - m_run for the two 32-key blocks: the accumulator starts at -m_run, so the exponent
         //      arguments of the common (no-rescale) path come straight out of the matrix pipe ----
         float s[2][16];
+        {
+            // the two 32-key blocks are independent accumulator chains: interleaved, so consecutive MFMAs never depend
+            // on each other
+            f32x16 sacc[2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            f32x16 sacc;
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[r] = -m_run;
+                for (int r = 0; r < 16; ++r) sacc[kb][r] = -m_run;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                const f16x8 kh = *reinterpret_cast<const f16x8*>(Kh(b) + kf_off + kb * 32 * KW + 16 * c);
-                const f16x8 kl = *reinterpret_cast<const f16x8*>(Kl(b) + kf_off + kb * 32 * KW + 16 * c);
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[c], sacc, 0, 0, 0);
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[c], sacc, 0, 0, 0);
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[c], sacc, 0, 0, 0);
-            }
-            if (key0 + KV_TILE > nk) {                  // only the last tile can hold padded keys (block-uniform)
+                f16x8 kh[2], kl[2];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = key0 + kb * 32 + mfma32_row(r, lane);
-                    s[kb][r] = key < nk ? sacc[r] : OG_NEG_INF;
+                for (int kb = 0; kb < 2; ++kb) {
+                    kh[kb] = *reinterpret_cast<const f16x8*>(Kh(b) + kf_off + kb * 32 * KW + 16 * c);
+                    kl[kb] = *reinterpret_cast<const f16x8*>(Kl(b) + kf_off + kb * 32 * KW + 16 * c);
                 }
-            } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s[kb][r] = sacc[r];
+                for (int kb = 0; kb < 2; ++kb) sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[kb], qh[c], sacc[kb], 0, 0, 0);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[kb], ql[c], sacc[kb], 0, 0, 0);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[kb], qh[c], sacc[kb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                if (key0 + KV_TILE > nk) {                  // only the last tile can hold padded keys (block-uniform)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = key0 + kb * 32 + mfma32_row(r, lane);
+                        s[kb][r] = key < nk ? sacc[kb][r] : OG_NEG_INF;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[kb][r] = sacc[kb][r];
+                }
             }
         }
 
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a, RaggedDes
                 { _Float16 h0_, l0_, h1_, l1_; og_split(p0, h0_, l0_); og_split(p1, h1_, l1_); ha = pack(h0_, h1_); la = pack(l0_, l1_);
                   og_split(p2, h0_, l0_); og_split(p3, h1_, l1_); hb = pack(h0_, h1_); lb = pack(l0_, l1_); }
 #else
-                split_quad(p0, p1, p2, p3, ha, la, hb, lb);
+                og_split4(p0, p1, p2, p3, ha, la, hb, lb);      // og_common.h: 3 instructions per pair, hazard-safe
 #endif
                 unsigned* pfw = reinterpret_cast<unsigned*>(&pf[kb][r >> 3]);
                 unsigned* plw = reinterpret_cast<unsigned*>(&pl[kb][r >> 3]);

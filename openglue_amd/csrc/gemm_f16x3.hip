@@ -88,16 +88,11 @@ __device__ __forceinline__ void gemm_f16x3_epilogue(const GemmHArgs& g, f32x16 (
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    f16x4 th, tl;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        _Float16 h, l;
-                        og_split(acc0[i][j][4 * q + e], h, l);
-                        th[e] = h; tl[e] = l;
-                    }
+                    unsigned ha, la, hb, lb;
+                    og_split4(acc0[i][j][4 * q], acc0[i][j][4 * q + 1], acc0[i][j][4 * q + 2], acc0[i][j][4 * q + 3], ha, la, hb, lb);
                     char* d = slab + (j * 32 + l31) * ROWB + (8 * q + 4 * hi) * 2;
-                    *reinterpret_cast<f16x4*>(d) = th;
-                    *reinterpret_cast<f16x4*>(d + 64) = tl;
+                    *reinterpret_cast<uint2*>(d) = make_uint2(ha, hb);
+                    *reinterpret_cast<uint2*>(d + 64) = make_uint2(la, lb);
                 }
             const int oc = oc0 + i * 32;
 #pragma unroll
@@ -123,14 +118,10 @@ __device__ __forceinline__ void gemm_f16x3_epilogue(const GemmHArgs& g, f32x16 (
                 for (int i = 0; i < TI; ++i)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        f16x4 t;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            _Float16 h, l;
-                            og_split(acc0[i][j][4 * q + e], h, l);
-                            t[e] = pass == 0 ? h : l;
-                        }
-                        *reinterpret_cast<f16x4*>(slab + (j * 32 + l31) * ROWB + (i * 32 + 8 * q + 4 * hi) * 2) = t;
+                        unsigned ha, la, hb, lb;
+                        og_split4(acc0[i][j][4 * q], acc0[i][j][4 * q + 1], acc0[i][j][4 * q + 2], acc0[i][j][4 * q + 3], ha, la, hb, lb);
+                        *reinterpret_cast<uint2*>(slab + (j * 32 + l31) * ROWB + (i * 32 + 8 * q + 4 * hi) * 2) =
+                            pass == 0 ? make_uint2(ha, hb) : make_uint2(la, lb);
                     }
             _Float16* dst = pass == 0 ? g.Ch : g.Cl;
 #pragma unroll

@@ -57,6 +57,25 @@ __device__ __forceinline__ void og_split(float x, _Float16& hi, _Float16& lo) {
     lo = (_Float16)(x - (float)hi);
 }
 
+// Four fp32 values -> two packed (hi, lo) f16 pairs, 3 instructions per pair: hi = RNE pack; lo = f16(x - hi) by the
+// mixed-precision FMA (f32 x * 1.0 - f16 hi, one rounding) written straight into the low / high half of the result;
+// bit-identical to og_split (scripts/probes/split_asm.hip).  ONE asm block with a fixed internal order, because the
+// compiler's hazard recognizer does not look inside inline asm: gfx950 needs a wait state between a transcendental op
+// (e.g. the v_exp_f32 that produced x) and a VALU reading its result, and between an op_sel partial register write
+// (mixlo) and the next access of that register (mixhi) -- hence the leading s_nop and the A/B interleave.
+// ha = (hi(x0), hi(x1)), la = (lo(x0), lo(x1)), hb / lb likewise for x2, x3.
+__device__ __forceinline__ void og_split4(float x0, float x1, float x2, float x3, unsigned& ha, unsigned& la, unsigned& hb, unsigned& lb) {
+    asm("s_nop 0\n\t"
+        "v_cvt_pk_f16_f32 %0, %4, %5\n\t"
+        "v_cvt_pk_f16_f32 %2, %6, %7\n\t"
+        "v_fma_mixlo_f16 %1, %4, 1.0, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %3, %6, 1.0, -%2 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %5, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %3, %7, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(ha), "=&v"(la), "=&v"(hb), "=&v"(lb)
+        : "v"(x0), "v"(x1), "v"(x2), "v"(x3));
+}
+
 // "hl32" operand format of the split-f16 GEMM (gemm_f16x3.hip): the hi and lo halves of a row live in ONE
 // row of 2K halves, interleaved in groups of 32 channels -- [hi 0..31 | lo 0..31 | hi 32..63 | lo 32..63 | ...]
 // -- so that the 32-channel k-slab a GEMM stage consumes is one full 128-byte cache line (64 B hi + 64 B lo).
