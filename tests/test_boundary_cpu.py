@@ -113,6 +113,18 @@ def test_error_behaviour():
     # NULL arguments are rejected before any launch (no GPU needed)
     assert lib.og_forward(None, None, None, None, None, None) == -1
     assert lib.og_gemm_nt(None, 4, 0, None, 4, 0, None, 4, 0, 1, 1, 4, 1, None, 0, None, 0, None, 1.0, None) == -1
+    # split-f16 GEMM (hl32 operand rows): NULL operands, K not a multiple of the 32-channel slab, row stride < 2K, N % 32 with
+    # hl32 output -- all rejected before any launch (the pointers below are never dereferenced)
+    fake = 0x10000
+    g = lambda A, lda, B, ldb, M, N, K, chl=0, Ch=None, C32=fake: lib.og_gemm_nt_f16x3(A, lda, B, ldb, M, N, K, 1.0, None, 0, None, N,
+                                                                                     C32, N, Ch, None, 2 * N, chl, None)
+    assert g(None, 128, fake, 128, 64, 64, 64) == -1
+    assert g(fake, 128, fake, 128, 64, 64, 48) == -3            # K % 32
+    assert g(fake, 100, fake, 128, 64, 64, 64) == -3            # lda < 2K
+    assert g(fake, 128, fake, 128, 64, 48, 64, chl=1, Ch=fake) == -3      # hl32 output needs whole 32-channel groups
+    assert g(fake, 128, fake, 128, 64, 64, 64, C32=None) == -1  # no output at all
+    assert lib.og_split_f16_hl(fake, 8, 48, 48, fake, 96, None) == -3       # cols % 32
+    assert lib.og_split_f16_hl(None, 8, 64, 64, fake, 128, None) == -1
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
