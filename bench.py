@@ -41,7 +41,9 @@ def algorithmic_counts(cfg_kw, m, n):
     final = 2.0 * D * D * (m + n)
     score = 2.0 * m * n * D
     sink_bytes = 4.0 * ((m + 1) * (n + 1) * (2 * it + 1) + 2 * m * n)
-    return {"gemm_f32_flops": enc + final + score, "gemm_f16x3_flops": proj, "attention_flops": attn,
+    # kernel classes: the encoder MLP runs on the exact-fp32 MFMA kernel; the GNN 1x1 convs, the final projection and the
+    # score matrix on the split-f16 kernel
+    return {"gemm_f32_flops": enc, "gemm_f16x3_flops": proj + final + score, "attention_flops": attn,
             "total_flops": enc + proj + attn + final + score, "sinkhorn_bytes": sink_bytes}
 
 
@@ -234,9 +236,9 @@ def main():
         launches = {k: profs[0][k][1] for k in profs[0]}
         per_step = {  # kernel class -> (algorithmic work per step, unit scale, bound, peak, kernel names, note)
             "gemm_f16x3": (counts["gemm_f16x3_flops"] * B, 1e12, "mfma", PEAK_F16_MFMA_TFLOPS, "TFLOP/s",
-                           "gemm_nt_f16x3_big_kernel / gemm_nt_f16x3_kernel (GNN 1x1 convs, split-f16 3-pass MFMA: executes 3x the algorithmic flops)"),
+                           "gemm_nt_f16x3_big_kernel / gemm_nt_f16x3_kernel (GNN 1x1 convs, final projection, score matrix; split-f16 3-pass MFMA: executes 3x the algorithmic flops)"),
             "gemm_f32": (counts["gemm_f32_flops"] * B, 1e12, "mfma", PEAK_F32_MFMA_TFLOPS, "TFLOP/s",
-                         "gemm_nt_f32_kernel (encoder MLP, final projection, score matrix; exact fp32 MFMA)"),
+                         "gemm_nt_f32_kernel (keypoint-encoder MLP; exact fp32 MFMA)"),
             "attention": (counts["attention_flops"] * B, 1e12, "mfma", PEAK_F16_MFMA_TFLOPS, "TFLOP/s",
                           "attention_kernel (split-f16 flash attention: executes 3x the algorithmic flops)"),
             "sinkhorn": (counts["sinkhorn_bytes"] * B, 1e9, "hbm", PEAK_HBM_GBS, "GB/s",

@@ -142,7 +142,7 @@ int og_pack_weights(const og_shape* shape, const og_params* params, void* packed
  *                                                            BatchNorm i-1 folded in
  *   layer l at layer0 + l*layer_stride:  wqkv [3D][D] (q rows pre-scaled by (D/H)^-1/2 * log2 e), bqkv [3D],
  *                                        w0 [2D][2D] = [W0a | Wm*Wo], b0 [2D], w3 [D][2D] (BN folded), b3 [D]
- *   wp [D][D], bp [D], alpha [D] = sigmoid(mix_coefs), dustbin [1] */
+ *   wp [D][D] (hl32 rows of 256 * w like the GNN matrices), bp [D], alpha [D] = sigmoid(mix_coefs), dustbin [1] */
 typedef struct og_packed_layout_t {
     int32_t n_enc;
     int32_t enc_k[OG_MAX_HIDDEN + 1], enc_out[OG_MAX_HIDDEN + 1];

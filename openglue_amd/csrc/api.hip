@@ -263,7 +263,11 @@ extern "C" int og_pack_weights(const og_shape* shape, const og_params* P, void* 
 
     // ---- tail ----
     if (!P->linear_proj.weight || !P->linear_proj.bias) return OG_E_INVALID;
-    memcpy(out + L.wp, P->linear_proj.weight, sizeof(float) * (size_t)D * D);
+    {   // final projection: hl32 rows of 256*w like the GNN matrices (it runs on the split-f16 kernel, reading the x rows of XO)
+        _Float16* Wp = (_Float16*)(out + L.wp);
+        for (int o = 0; o < D; ++o)
+            for (int k = 0; k < D; ++k) put_split(Wp, o, k, D, P->linear_proj.weight[(int64_t)o * D + k]);
+    }
     memcpy(out + L.bp, P->linear_proj.bias, sizeof(float) * (size_t)D);
     if (s.flags & OG_FLAG_RESIDUAL) {
         if (!P->mix_coefs) return OG_E_INVALID;
@@ -427,31 +431,36 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
         }
     }
 
-    // ---- 3. final projection + residual mix (superglue.py:58-62), token-major G and channel-first outputs ----
+    // ---- 3. final projection + residual mix (superglue.py:58-62): G as hl32 rows (operands of the score GEMM) and the
+    //         channel-first context_descriptors.  Split-f16 kernel on the x rows of XO (fp32-class, 16/3 the fp32-MFMA rate).
+    _Float16* Gh = (_Float16*)G;                       // [T] hl32 rows of 2D halves (the slot holds T*D floats)
     for (int side = 0; side < 2; ++side) {
         const int64_t r0 = side ? T0 : 0, R = side ? T1 : T0;
         const bool resid = s.flags & OG_FLAG_RESIDUAL;
-        GemmArgs g{};
-        g.A = X32 + r0 * D; g.lda = D; g.B = pk + L.wp; g.ldb = D; g.C = G + r0 * D; g.ldc = D;
-        g.M = (int)R; g.N = D; g.K = D; g.batch = 1; g.bias = pk + L.bp; g.relu = 0;
+        GemmHArgs g{};
+        g.A = XO + r0 * D4; g.lda = D4; g.B = (const _Float16*)(pk + L.wp); g.ldb = D2;
+        g.M = (int)R; g.N = D; g.K = D; g.scale = (float)(1.0 / OG_W_SCALE); g.bias = pk + L.bp; g.relu = 0;
         g.res = resid ? (side ? in->descriptors1 : in->descriptors0) : nullptr; g.ldr = D;
-        g.alpha = resid ? pk + L.alpha : nullptr; g.scale = 1.f;
+        g.alpha = resid ? pk + L.alpha : nullptr;
+        g.Ch = Gh + r0 * D2; g.Cl = g.Ch + 32; g.ldch = D2; g.c_hl = 1;
         g.Ct = side ? outp->context_descriptors1 : outp->context_descriptors0;
         g.ct_rows = side ? n : m; g.ldct = g.ct_rows;
-        Scope sc(prof, OG_STAGE_GEMM);
-        if ((rc = og_launch_gemm(g, st))) return rc;
+        Scope sc(prof, OG_STAGE_GEMM_F16X3);
+        if ((rc = og_launch_gemm_f16x3(g, st))) return rc;
     }
 
-    // ---- 4. score matrix S = g0 g1^T * D^-1/2 (superglue.py:64, 81-86) ----
+    // ---- 4. score matrix S = g0 g1^T * D^-1/2 (superglue.py:64, 81-86): one batched split-f16 launch over the pairs ----
     {
-        GemmArgs g{};
-        g.A = G; g.lda = D; g.strideA = (int64_t)m * D; g.B = G + T0 * D; g.ldb = D; g.strideB = (int64_t)n * D;
-        g.C = Sb; g.ldc = W.lds; g.strideC = (int64_t)m * W.lds; g.M = m; g.N = n; g.K = D; g.batch = B;
-        g.scale = (float)pow((double)D, -0.5); g.ct_rows = 1;
+        GemmHArgs g{};
+        g.A = Gh; g.lda = D2; g.strideA = (int64_t)m * D2; g.B = Gh + T0 * D2; g.ldb = D2; g.strideB = (int64_t)n * D2;
+        g.C32 = Sb; g.ldc = W.lds; g.strideC32 = (int64_t)m * W.lds; g.M = m; g.N = n; g.K = D; g.batch = B;
+        g.scale = (float)pow((double)D, -0.5);
         g.rag = rag;                       // ragged: pair z multiplies rows off0[z].. of G by rows T0 + off1[z].. of G
-        if (rag) g.B = G;
-        Scope sc(prof, OG_STAGE_GEMM);
-        if ((rc = og_launch_gemm(g, st))) return rc;
+        if (rag) g.B = Gh;
+        Scope sc(prof, OG_STAGE_GEMM_F16X3);
+        if (B > 1 || rag) rc = og_launch_gemm_f16x3(g, st);
+        else { g.batch = 0; rc = og_launch_gemm_f16x3(g, st); }
+        if (rc) return rc;
     }
 
     // ---- 5. Sinkhorn with dustbins -> scores (superglue.py:88-111) ----

@@ -42,7 +42,9 @@ constexpr int EPI_SLAB = 64 * 144;   // per-wave epilogue scratch: 64 rows x (12
 // `slab` = this wave's private LDS scratch (EPI_SLAB bytes), free once all waves passed the last
 // k-tile barrier.  No block barrier is needed: a wave only re-reads what it wrote itself.
 // acc0: the wave's 64 token x TI*32 channel tile starting at (tok0, oc0).
-template <int TI>
+// FULL: also the residual MIX (alpha) and the channel-first copy (Ct) of the final projection; only instantiated for the
+// 128-tile kernel (in the 256-tile kernel the extra address registers push the epilogue into scratch).
+template <int TI, bool FULL>
 __device__ __forceinline__ void gemm_f16x3_epilogue(const GemmHArgs& g, f32x16 (&acc0)[TI][2], int tok0, int oc0, int lane,
                                                     char* slab) {
 #pragma clang fp contract(off)                  // og_split: hi and lo must see the same rounded value (og_common.h)
@@ -66,7 +68,16 @@ __device__ __forceinline__ void gemm_f16x3_epilogue(const GemmHArgs& g, f32x16 (
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
-                if (g.res && tok < g.M && oc < g.N) v += *reinterpret_cast<const f32x4*>(g.res + (int64_t)tok * g.ldr + oc);
+                if (g.res && tok < g.M && oc < g.N) {
+                    const f32x4 rr = *reinterpret_cast<const f32x4*>(g.res + (int64_t)tok * g.ldr + oc);
+                    if (FULL && g.alpha) {      // residual mix (superglue.py:60-62): alpha*v + (1-alpha)*res
+                        const f32x4 al = *reinterpret_cast<const f32x4*>(g.alpha + oc);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = al[e] * v[e] + (1.f - al[e]) * rr[e];
+                    } else {
+                        v += rr;
+                    }
+                }
                 if (g.res_hl && tok < g.M && oc < g.N) {         // residual carried as (hi, lo): 2^-22 relative
                     const _Float16* rp = g.res_hl + (int64_t)tok * g.ldrh + og_hl_col(oc);
                     const f16x4 rh = *reinterpret_cast<const f16x4*>(rp), rl = *reinterpret_cast<const f16x4*>(rp + 32);
@@ -78,6 +89,25 @@ __device__ __forceinline__ void gemm_f16x3_epilogue(const GemmHArgs& g, f32x16 (
             }
     }
 
+    // ---- channel-first fp32 copy: a lane owns one token, so 32 consecutive lanes write 32 consecutive tokens of a channel ----
+    if (FULL && g.Ct) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int tok = tok0 + j * 32 + l31;
+            if (tok >= g.M) continue;
+            const int bz = tok / g.ct_rows, ri = tok - bz * g.ct_rows;
+            float* cb = g.Ct + (int64_t)bz * g.ldct * g.N + ri;
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int oc = oc0 + i * 32 + 8 * q + 4 * hi + e;
+                        if (oc < g.N) cb[(int64_t)oc * g.ldct] = acc0[i][j][4 * q + e];
+                    }
+        }
+    }
     // ---- hl32 rows: per 32-channel group one pass through a [64 tok][hi 64 B | lo 64 B] slab, stored as whole
     //      128-byte lines (8 lanes x 16 B per token) ----
     if (g.Ch && g.c_hl) {
@@ -171,7 +201,7 @@ typedef __attribute__((address_space(3))) void og_lds_void;
 typedef __attribute__((address_space(1))) const void og_glb_void;
 
 template <int OC, int NS>
-__global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void gemm_nt_f16x3_kernel(GemmHArgs g, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void gemm_nt_f16x3_kernel(GemmHArgs g, int tiles_m, int tiles_n, RaggedDesc rd) {
     constexpr int TI = OC / 64;                // MFMA tiles per wave along channels
     constexpr int XB = TOK * 128;              // bytes of the token tile per stage (hi|lo rows)
     constexpr int WB = OC * 128;
@@ -185,7 +215,20 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void gemm_nt_f16x3_kernel(G
     const int tm = (local / tiles_n) * 8 + xcd;       // all channel tiles of a token tile on one XCD
     const int tn = local % tiles_n;
     if (tm >= tiles_m) return;
+    if (g.batch > 1 || rd.B > 0) {   // batched problems (the per-pair score matrices): z = blockIdx.y
+        const int z = blockIdx.y;
+        if (rd.B > 0) {           // ragged: problem z = pair z, operands are row ranges of the packed token matrix
+            g.M = rd.off0[z + 1] - rd.off0[z];
+            g.N = rd.off1[z + 1] - rd.off1[z];
+            g.A += (int64_t)rd.off0[z] * g.lda;
+            g.B += (int64_t)(rd.off0[rd.B] + rd.off1[z]) * g.ldb;
+        } else {
+            g.A += z * g.strideA; g.B += z * g.strideB;
+        }
+        if (g.C32) g.C32 += z * g.strideC32;
+    }
     const int t0 = tm * TOK, n0 = tn * OC;
+    if (t0 >= g.M || n0 >= g.N) return;          // ragged batches: this problem is smaller than the grid
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -285,7 +328,7 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void gemm_nt_f16x3_kernel(G
     }
 
     __builtin_amdgcn_s_barrier();      // every wave is past its last fragment reads: the ring is free
-    gemm_f16x3_epilogue<TI>(g, acc, t0 + wt * 64, n0 + wo * (OC / 2), lane, smem + wave * EPI_SLAB);
+    gemm_f16x3_epilogue<TI, true>(g, acc, t0 + wt * 64, n0 + wo * (OC / 2), lane, smem + wave * EPI_SLAB);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -298,7 +341,7 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void gemm_nt_f16x3_kernel(G
 // of the one-stage-ahead LDS-DMA prefetch.
 constexpr int BIG = 256;
 
-__global__ __launch_bounds__(512) void gemm_nt_f16x3_big_kernel(GemmHArgs g, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(512) void gemm_nt_f16x3_big_kernel(GemmHArgs g, int tiles_m, int tiles_n, RaggedDesc rd) {
     constexpr int NS = 2;
     constexpr int XB = BIG * 128;              // bytes of the token tile per stage
     constexpr int STAGE = 2 * XB;              // token tile + weight tile
@@ -310,7 +353,20 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_big_kernel(GemmHArgs g, int
     const int tm = (local / tiles_n) * 8 + xcd;       // all channel tiles of a token tile on one XCD
     const int tn = local % tiles_n;
     if (tm >= tiles_m) return;
+    if (g.batch > 1 || rd.B > 0) {   // batched problems (the per-pair score matrices): z = blockIdx.y
+        const int z = blockIdx.y;
+        if (rd.B > 0) {           // ragged: problem z = pair z, operands are row ranges of the packed token matrix
+            g.M = rd.off0[z + 1] - rd.off0[z];
+            g.N = rd.off1[z + 1] - rd.off1[z];
+            g.A += (int64_t)rd.off0[z] * g.lda;
+            g.B += (int64_t)(rd.off0[rd.B] + rd.off1[z]) * g.ldb;
+        } else {
+            g.A += z * g.strideA; g.B += z * g.strideB;
+        }
+        if (g.C32) g.C32 += z * g.strideC32;
+    }
     const int t0 = tm * BIG, n0 = tn * BIG;
+    if (t0 >= g.M || n0 >= g.N) return;          // ragged batches: this problem is smaller than the grid
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -444,7 +500,7 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_big_kernel(GemmHArgs g, int
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) part[i][j] = acc[i][2 * half + j];
-        gemm_f16x3_epilogue<2>(g, part, t0 + wt * 128 + half * 64, n0 + wo * 64, lane, smem + wave * EPI_SLAB);
+        gemm_f16x3_epilogue<2, false>(g, part, t0 + wt * 128 + half * 64, n0 + wo * 64, lane, smem + wave * EPI_SLAB);
     }
 }
 
@@ -489,9 +545,12 @@ __global__ __launch_bounds__(256) void split_f16_hl_kernel(const float* __restri
 
 int og_launch_gemm_f16x3(const GemmHArgs& a, hipStream_t stream) {
     if (!a.A || !a.B || a.M <= 0 || a.N <= 0 || a.K <= 0) return OG_E_INVALID;
-    if (!a.C32 && !a.Ch) return OG_E_INVALID;
+    if (!a.C32 && !a.Ch && !a.Ct) return OG_E_INVALID;
     if (a.Ch && !a.c_hl && !a.Cl) return OG_E_INVALID;
-    if ((a.K % BKH) || (a.N & 3) || (a.lda & 7) || (a.ldb & 7) || a.lda < 2 * (int64_t)a.K || a.ldb < 2 * (int64_t)a.K) return OG_E_ALIGN;
+    if ((a.K % BKH) || (a.lda & 7) || (a.ldb & 7) || a.lda < 2 * (int64_t)a.K || a.ldb < 2 * (int64_t)a.K) return OG_E_ALIGN;
+    // N % 4 != 0 is allowed for a bare fp32 output whose rows are padded to a multiple of 4 (the score matrix): the last
+    // float4 of a row then spills into the padding
+    if ((a.N & 3) && (a.bias || a.res || a.res_hl || a.Ch || a.Ct || !a.C32 || a.ldc < (a.N + 3) / 4 * 4)) return OG_E_ALIGN;
     if (((uintptr_t)a.A & 15) || ((uintptr_t)a.B & 15)) return OG_E_ALIGN;
     if (a.C32 && (((uintptr_t)a.C32 & 15) || (a.ldc & 3))) return OG_E_ALIGN;
     if (a.Ch && a.c_hl && (((uintptr_t)a.Ch & 15) || (a.ldch & 7) || (a.N & 31))) return OG_E_ALIGN;
@@ -499,13 +558,22 @@ int og_launch_gemm_f16x3(const GemmHArgs& a, hipStream_t stream) {
     if (a.res && (((uintptr_t)a.res & 15) || (a.ldr & 3))) return OG_E_ALIGN;
     if (a.res_hl && (a.res || ((uintptr_t)a.res_hl & 15) || (a.ldrh & 7) || (a.N & 31))) return OG_E_ALIGN;
     if (a.bias && ((uintptr_t)a.bias & 15)) return OG_E_ALIGN;
+    if (a.alpha && (!a.res || ((uintptr_t)a.alpha & 15))) return OG_E_INVALID;
+    if (a.Ct && (a.ct_rows <= 0 || a.batch > 1)) return OG_E_INVALID;
+    const int nz = a.batch > 1 ? a.batch : 1;
+    if (nz > 1 && (a.Ch || a.res || a.res_hl || (a.strideA & 7) || (a.strideB & 7) || (a.strideC32 & 3))) return OG_E_INVALID;
+    RaggedDesc rd;
+    rd.B = 0;
+    GemmHArgs g = a;
+    if (a.rag) { if (nz != a.rag->B) return OG_E_INVALID; rd = *a.rag; }
+    g.rag = nullptr;
     static const int force = [] { const char* e = getenv("OG_GEMM_TILE"); return e ? atoi(e) : 0; }();   // experiments: 128 / 256
     {   // large tiles when they still give (nearly) every CU a block
         const int tiles_m = (a.M + BIG - 1) / BIG, tiles_n = (a.N + BIG - 1) / BIG;
-        const bool fits = a.N % BIG == 0 && (int64_t)tiles_m * tiles_n >= 192;
-        if (force == 256 ? a.N >= BIG : (fits && force != 128)) {
+        const bool fits = (a.N % BIG == 0 || nz > 1) && (int64_t)tiles_m * tiles_n * nz >= 192 && !a.alpha && !a.Ct;
+        if (force == 256 ? (a.N >= BIG && !a.alpha && !a.Ct) : (fits && force != 128)) {
             const int tiles_m8 = (tiles_m + 7) / 8 * 8;
-            hipLaunchKernelGGL(gemm_nt_f16x3_big_kernel, dim3(tiles_m8 * tiles_n), dim3(512), 0, stream, a, tiles_m, tiles_n);
+            hipLaunchKernelGGL(gemm_nt_f16x3_big_kernel, dim3(tiles_m8 * tiles_n, nz), dim3(512), 0, stream, g, tiles_m, tiles_n, rd);
             return og_launch_status();
         }
     }
@@ -513,9 +581,9 @@ int og_launch_gemm_f16x3(const GemmHArgs& a, hipStream_t stream) {
     const int tiles_m8 = (tiles_m + 7) / 8 * 8;
     if (a.N > 64) {
         const int tiles_n = (a.N + 127) / 128;
-        hipLaunchKernelGGL((gemm_nt_f16x3_kernel<128, 2>), dim3(tiles_m8 * tiles_n), dim3(256), 0, stream, a, tiles_m, tiles_n);
+        hipLaunchKernelGGL((gemm_nt_f16x3_kernel<128, 2>), dim3(tiles_m8 * tiles_n, nz), dim3(256), 0, stream, g, tiles_m, tiles_n, rd);
     } else {
-        hipLaunchKernelGGL((gemm_nt_f16x3_kernel<64, 2>), dim3(tiles_m8), dim3(256), 0, stream, a, tiles_m, 1);
+        hipLaunchKernelGGL((gemm_nt_f16x3_kernel<64, 2>), dim3(tiles_m8, nz), dim3(256), 0, stream, g, tiles_m, 1, rd);
     }
     return og_launch_status();
 }

@@ -124,6 +124,12 @@ struct GemmHArgs {
     float* C32; int64_t ldc;                  // optional fp32 output
     _Float16* Ch; _Float16* Cl; int64_t ldch; // optional split-f16 output: two planes, or
     int c_hl;                                 //   1: hl32 rows (Cl == Ch + 32, ldch = row stride in halves)
+    const float* alpha;                       // [N] or null: with res, v = alpha*v + (1-alpha)*res instead of v + res
+    float* Ct; int64_t ldct; int ct_rows;     // optional channel-first fp32 copy: Ct[row / ct_rows][col][row % ct_rows] (ldct = ct_rows)
+    int batch;                                // 0/1: one problem; > 1: problems z = blockIdx.y with the strides below
+    int64_t strideA, strideB, strideC32;      // elements (halves / floats) between consecutive problems
+    const RaggedDesc* rag;                    // host pointer or null: batched problem z = pair z of a ragged batch
+                                              // (A rows off0[z].., B rows T0 + off1[z].., M = m_z, N = n_z; C32 at z*strideC32)
 };
 int og_launch_gemm_f16x3(const GemmHArgs& a, hipStream_t stream);
 int og_launch_split_f16(const float* x, int64_t n, void* hi, void* lo, hipStream_t stream);

@@ -76,7 +76,7 @@ def forward_from_packed(model, data, dtype=torch.float64):
         x0, x1 = prop(2 * l, x0, x0), prop(2 * l, x1, x1)
         x0 = prop(2 * l + 1, x0, x1)
         x1 = prop(2 * l + 1, x1, x0)
-    Wp, bp = mat(L.wp, D, D), vec(L.bp, D)
+    Wp, bp = planes(L.wp, D, D), vec(L.bp, D)
     g0, g1 = x0 @ Wp.T + bp, x1 @ Wp.T + bp
     if model.residual:
         a = vec(L.alpha, D)
