@@ -397,20 +397,18 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
     };
     // message MLP on token rows [r0, r0+R):  h = relu([x;O] W0'^T + b0') ; x += h W3'^T + b3'  (x kept in fp32 AND as planes)
     // message MLP on token rows [r0, r0+R):  h = relu([x;O] W0'^T + b0') ; x += h W3'^T + b3'.  x lives as hl32 (hi, lo)
-    // rows between the layers (the residual is read from them: 2^-22 relative per layer); only the last update of a row
-    // also writes the fp32 copy the final projection reads.
-    auto mlp = [&](const float* lw, int64_t r0, int64_t R, bool last) -> int {
+    // rows (the residual is read from them: 2^-22 relative per layer); no fp32 copy is kept.
+    auto mlp = [&](const float* lw, int64_t r0, int64_t R) -> int {
         int e = gemmh(XO + r0 * D4, lw, L.o_w0, 0, R, D2, D2, lw + L.o_b0, 1, nullptr, nullptr, Hb + r0 * D4, nullptr, D4, 1);
         if (e) return e;
-        return gemmh(Hb + r0 * D4, lw, L.o_w3, 0, R, D, D2, lw + L.o_b3, 0, XO + r0 * D4, last ? X32 + r0 * D : nullptr,
-                     XO + r0 * D4, nullptr, D4, 1);
+        return gemmh(Hb + r0 * D4, lw, L.o_w3, 0, R, D, D2, lw + L.o_b3, 0, XO + r0 * D4, nullptr, XO + r0 * D4, nullptr, D4, 1);
     };
     for (int l = 0; l < s.num_stages; ++l) {
         // self layer 2l: both images through the same weights (attention_gnn.py:63-66)
         const float* lw = pk + L.layer0 + (int64_t)(2 * l) * L.layer_stride;
         if ((rc = gemmh(XO, lw, L.o_wqkv, 0, T, D3, D, lw + L.o_bqkv, 0, nullptr, nullptr, QKVh, QKVl, D3, 0))) return rc;
         if ((rc = attention(2 * B, B, 0, m, m, 0, m, m, T0, n, n, T0, n, n, 1))) return rc;
-        if ((rc = mlp(lw, 0, T, false))) return rc;
+        if ((rc = mlp(lw, 0, T))) return rc;
         // cross layer 2l+1: image 0 first, then image 1 against the UPDATED image 0 (attention_gnn.py:74-77)
         lw = pk + L.layer0 + (int64_t)(2 * l + 1) * L.layer_stride;
         for (int side = 0; side < 2; ++side) {
@@ -427,7 +425,7 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
             if (side == 0) rc = attention(B, B, 0, m, m, T0, n, n, 0, 0, 0, 0, 0, 0, 2);
             else rc = attention(B, B, T0, n, n, 0, m, m, 0, 0, 0, 0, 0, 0, 3);
             if (rc) return rc;
-            if ((rc = mlp(lw, qr0, qR, l + 1 == s.num_stages))) return rc;
+            if ((rc = mlp(lw, qr0, qR))) return rc;
         }
     }
 
