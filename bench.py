@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """Benchmark of the SuperGlue hot path on MI355X: matched image-pairs / second.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2] [--no-cpu-baseline]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C1|C3|C4|C5] [--no-cpu-baseline]
+
+With --gpus N > 1 and no torch.distributed environment the script re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` (one process per GPU,
+like the reference's Lightning DDP, train.py:69-81); launched by the driver under torch.distributed.run it reads
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.
 
 A step = one pass of the whole hot path (keypoint encoder -> 9x(self, cross) attention -> scores ->
 100 Sinkhorn iterations -> mutual-NN matches) over one batch of synthetic pairs already resident in
@@ -14,6 +17,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
 import sys
 import time
 
@@ -29,6 +33,8 @@ MATCH_THRESHOLD = 0.2
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact fp32
 PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense f16/bf16 MFMA
 PEAK_HBM_GBS = 8000.0            # HBM3E spec
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")      # scripts/parse_pmc.py
+TRAFFIC_SUMMARY = os.path.join(ROOT, "profiles", "r02_traffic_c2.json")   # scripts/parse_traffic.py
 
 
 def algorithmic_counts(cfg_kw, m, n):
@@ -40,78 +46,218 @@ def algorithmic_counts(cfg_kw, m, n):
     attn = L * (4.0 * D * (m * m + n * n) + 8.0 * D * m * n)
     final = 2.0 * D * D * (m + n)
     score = 2.0 * m * n * D
-    sink_bytes = 4.0 * ((m + 1) * (n + 1) * (2 * it + 1) + 2 * m * n)
+    # SURVEY §8d counts TWO sweeps of the augmented matrix per iteration (the reference's structure: row LSE, column LSE)
+    sink_survey = 4.0 * ((m + 1) * (n + 1) * (2 * it + 1) + 2 * m * n)
+    # what the kernels here have to move: ONE read of S per iteration (row pass and column pass share the sweep), the
+    # per-row-block column partials (written by the sweep, read by the combine), the final read of S and the scores write
+    rb = (m + 31) // 32
+    sink_one = 4.0 * (m * n * (it + 1) + 2 * rb * n * it + (m + 1) * (n + 1))
     # kernel classes: the encoder MLP runs on the exact-fp32 MFMA kernel; the GNN 1x1 convs, the final projection and the
     # score matrix on the split-f16 kernel
     return {"gemm_f32_flops": enc, "gemm_f16x3_flops": proj + final + score, "attention_flops": attn,
-            "total_flops": enc + proj + attn + final + score, "sinkhorn_bytes": sink_bytes}
+            "total_flops": enc + proj + attn + final + score, "sinkhorn_bytes": sink_one, "sinkhorn_bytes_survey": sink_survey}
 
 
-def profiled_forward(model, data, thr):
-    """One og_forward_profiled call through the model's own buffers -> {stage: (ms, launches)}."""
-    lib = _lib.load()
-    out = model.match(data, thr)            # makes sure weights are packed / workspace exists
-    dev = data["keypoints0"].device
-    B, m, _ = data["keypoints0"].shape
-    n = data["keypoints1"].shape[1]
-    shape = model._shape(B, m, n, thr)
-    t = {k: data[k].contiguous() for k in ("keypoints0", "keypoints1", "local_descriptors0", "local_descriptors1", "side_info0", "side_info1")}
-    inp = _lib.og_inputs(t["keypoints0"].data_ptr(), t["keypoints1"].data_ptr(), t["local_descriptors0"].data_ptr(),
-                         t["local_descriptors1"].data_ptr(), t["side_info0"].data_ptr(), t["side_info1"].data_ptr())
-    inp.image0_wh[0], inp.image0_wh[1] = data["image0_size"][:2]
-    inp.image1_wh[0], inp.image1_wh[1] = data["image1_size"][:2]
-    o = _lib.og_outputs(out["scores"].data_ptr(), out["context_descriptors0"].data_ptr(), out["context_descriptors1"].data_ptr(),
-                        out["matches0"].data_ptr(), out["matching_scores0"].data_ptr(), out["matches1"].data_ptr(),
-                        out["matching_scores1"].data_ptr())
-    ms = (C.c_float * len(_lib.OG_STAGES))()
-    cnt = (C.c_int32 * len(_lib.OG_STAGES))()
-    ws = next(iter(model._workspace.values()))
-    rc = lib.og_forward_profiled(C.byref(shape), C.byref(inp), model._packed.data_ptr(), ws.data_ptr(), C.byref(o),
-                                 torch.cuda.current_stream(dev).cuda_stream, ms, cnt)
-    _lib.check(rc, "og_forward_profiled")
-    return {name: (float(ms[i]), int(cnt[i])) for i, name in enumerate(_lib.OG_STAGES)}
+def _sum_counts(cfg_kw, lens):
+    tot = None
+    for m, n in lens:
+        c = algorithmic_counts(cfg_kw, m, n)
+        tot = c if tot is None else {k: tot[k] + c[k] for k in c}
+    return tot
 
 
-def cpu_baseline(cfg, sd, cfg_kw, m, n, budget_s=20.0):
-    """The CPU oracle (a torch-CPU port of the reference algorithm, oracle/superglue_oracle.py) on this
-    box's host cores, B=1 pairs of the same workload, bounded to ~budget_s seconds.  The thread count is
-    picked by a short probe (torch's intra-op pool oversubscribes badly on 256-thread hosts: all 256
-    threads ran 250 s/pair); `cores` reports the threads actually used."""
+def _load_json(path):
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
+def roofline_block(counts_per_step, stages, launches, num_iters, measured_on_this_workload):
+    """Per-kernel-class roofline objects.  achieved = algorithmic work per step / class time (HIP events on the launch
+    stream, median of 3 profiled steps) = algorithmic work per launch / average launch duration."""
+    pmc = _load_json(PMC_SUMMARY) if measured_on_this_workload else {}
+    tj = _load_json(TRAFFIC_SUMMARY) if measured_on_this_workload else {}
+    traffic = {"gemm_f16x3": tj.get("gemm_f16x3"), "gemm_f32": tj.get("gemm_f32"), "attention": tj.get("attention")}
+    if "sinkhorn_sweep" in tj and "sinkhorn_combine" in tj:
+        traffic["sinkhorn"] = {"hbm_bytes_per_launch": (tj["sinkhorn_sweep"]["hbm_bytes_per_launch"]
+                                                        + tj["sinkhorn_combine"]["hbm_bytes_per_launch"]) * num_iters}
+    per_step = {  # kernel class -> (algorithmic work per step, unit scale, bound, peak, unit, kernels)
+        "gemm_f16x3": (counts_per_step["gemm_f16x3_flops"], 1e12, "mfma", PEAK_F16_MFMA_TFLOPS, "TFLOP/s",
+                       "gemm_nt_f16x3_big_kernel / gemm_nt_f16x3_kernel (GNN 1x1 convs, final projection, score matrix; split-f16 3-pass MFMA: executes 3x the algorithmic flops)"),
+        "gemm_f32": (counts_per_step["gemm_f32_flops"], 1e12, "mfma", PEAK_F32_MFMA_TFLOPS, "TFLOP/s",
+                     "gemm_nt_f32_kernel (keypoint-encoder MLP; exact fp32 MFMA)"),
+        "attention": (counts_per_step["attention_flops"], 1e12, "mfma", PEAK_F16_MFMA_TFLOPS, "TFLOP/s",
+                      "attention_kernel (split-f16 flash attention: executes 3x the algorithmic flops)"),
+        "sinkhorn": (counts_per_step["sinkhorn_bytes"], 1e9, "hbm", PEAK_HBM_GBS, "GB/s",
+                     "sinkhorn_sweep(_fast) + sinkhorn_combine(_fast) + sinkhorn_scores, one stage bracket incl. launch gaps; algorithmic "
+                     "bytes = ONE read of S per iteration + column partials + scores write (what these kernels must move)"),
+    }
+    roofs = {}
+    for k, (work, scale, bound, peak, unit, kern) in per_step.items():
+        ms = stages[k]
+        ach = work / (ms * 1e-3) / scale if ms > 0 else 0.0
+        nl = max(1, launches[k])
+        roofs[k] = {"kernel": kern, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
+                    "frac": round(ach / peak, 4),
+                    "traffic": (traffic.get(k) or {}).get("hbm_bytes_per_launch"), "class_ms_per_step": round(ms, 3),
+                    "launches_per_step": launches[k], "avg_launch_ms": round(ms / nl, 4),
+                    "algorithmic_work_per_launch": round(work / nl / scale, 6)}
+        if k in pmc:       # SQ counter summary of the same kernels (rocprofv3 --pmc passes, profiles/r02_pmc_*.json)
+            roofs[k]["mfma_busy_frac"] = pmc[k].get("mfma_busy_frac")
+            roofs[k]["pmc"] = {kk: vv for kk, vv in pmc[k].items() if kk != "mfma_busy_frac"}
+    ms = stages["sinkhorn"]
+    if ms > 0:   # the SURVEY §8d accounting (two sweeps per iteration), for comparison only: NOT a roofline fraction
+        roofs["sinkhorn"]["survey_two_sweep_equivalent_gbs"] = round(counts_per_step["sinkhorn_bytes_survey"] / (ms * 1e-3) / 1e9, 1)
+    dominant = max(per_step, key=lambda k: stages[k])
+    roof = roofs.pop(dominant)
+    return roof, roofs
+
+
+# ----------------------------------------------------------------------------------------------- CPU baseline
+def _physical_cores():
+    try:
+        seen = set()
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        return len(seen) or (os.cpu_count() or 1)
+    except OSError:
+        return os.cpu_count() or 1
+
+
+def _cpu_worker(cfg_kw, m, n, threads, seconds, start_at, q):
+    """One process of the throughput baseline: B=1 pairs of the workload back to back for `seconds` seconds."""
+    import torch as th
+    th.set_num_threads(threads)
     from oracle import superglue_oracle as orc
-    ncpu = os.cpu_count() or 1
+    cfg = syn.make_config(**cfg_kw)
+    sd = syn.make_state_dict(cfg, seed=0)
+    data = syn.make_batch(1, m, n, cfg_kw["descriptor_dim"], cfg_kw["side_info_size"], seed=0)
+    with th.no_grad():
+        orc.match_pairs(sd, cfg, data, MATCH_THRESHOLD)            # warm-up
+        while time.time() < start_at:
+            time.sleep(0.01)
+        t0 = time.time(); done = 0
+        while time.time() - t0 < seconds:
+            orc.match_pairs(sd, cfg, data, MATCH_THRESHOLD)
+            done += 1
+        q.put((done, time.time() - t0))
+
+
+def cpu_baseline(cfg, sd, cfg_kw, m, n, budget_s=24.0):
+    """The CPU oracle (a torch-CPU port of the reference algorithm, oracle/superglue_oracle.py: `kind: port`; the GPU box
+    has no /root/reference) on this box's host cores, B=1 pairs of the same workload, bounded to ~budget_s seconds:
+    (a) latency: one process, thread count picked by a short probe (torch's intra-op pool oversubscribes badly on
+    256-thread hosts); (b) throughput: k processes x t threads covering the physical cores.  `value` is the better of
+    the two pairs/s figures, `cores` the threads it used."""
+    import multiprocessing as mp
+    from oracle import superglue_oracle as orc
+    ncpu, nphys = os.cpu_count() or 1, _physical_cores()
     data = syn.make_batch(1, m, n, cfg_kw["descriptor_dim"], cfg_kw["side_info_size"], seed=0)
     probe_kw = dict(cfg_kw, num_stages=1, num_iters=4)
     pcfg = syn.make_config(**probe_kw)
-    psd = {k: v for k, v in sd.items()}
     best_t, best_dt = 1, float("inf")
     with torch.no_grad():
         for t in [c for c in (4, 8, 16, 32, 64) if c <= ncpu] or [1]:
             torch.set_num_threads(t)
-            orc.superglue_forward(psd, pcfg, data)
-            t0 = time.perf_counter(); orc.superglue_forward(psd, pcfg, data); dt = time.perf_counter() - t0
+            orc.superglue_forward(sd, pcfg, data)
+            t0 = time.perf_counter(); orc.superglue_forward(sd, pcfg, data); dt = time.perf_counter() - t0
             if dt < best_dt:
                 best_t, best_dt = t, dt
             if dt > 5.0:
                 break
         torch.set_num_threads(best_t)
         t0 = time.perf_counter(); orc.match_pairs(sd, cfg, data, MATCH_THRESHOLD); warm = time.perf_counter() - t0
-        reps = max(1, min(5, int(budget_s / max(warm, 1e-3)) - 1))
+        reps = max(1, min(3, int(0.3 * budget_s / max(warm, 1e-3))))
         t0 = time.perf_counter()
         for _ in range(reps):
             orc.match_pairs(sd, cfg, data, MATCH_THRESHOLD)
         dt = (time.perf_counter() - t0) / reps
-    return {"value": round(1.0 / dt, 4), "unit": "image-pairs/s", "cores": best_t, "kind": "port",
-            "sample": f"{reps} x 1 pair of the same workload (B=1, torch-CPU oracle, {best_t} of {ncpu} host threads), {dt * 1e3:.0f} ms/pair"}
+    single = 1.0 / dt
+    out = {"value": round(single, 4), "unit": "image-pairs/s", "cores": best_t, "kind": "port",
+           "host_threads": ncpu, "physical_cores": nphys,
+           "single_process": {"pairs_per_s": round(single, 4), "threads": best_t, "ms_per_pair": round(dt * 1e3, 1)},
+           "sample": f"{reps} x 1 pair of the same workload (B=1, torch-CPU oracle, {best_t} of {ncpu} host threads), {dt * 1e3:.0f} ms/pair"}
+    # (b) throughput: k processes x t threads, pinned by nothing but the OS scheduler
+    t_per = max(1, min(best_t, 16))
+    k = max(1, min(16, nphys // t_per))
+    window = max(4.0, min(12.0, 0.5 * budget_s))
+    if k > 1 and dt * 2 < window:
+        try:
+            ctx = mp.get_context("spawn")
+            q = ctx.Queue()
+            start_at = time.time() + 10.0 + 2.0 * dt       # import torch + weights + one warm-up pair in every worker
+            procs = [ctx.Process(target=_cpu_worker, args=(cfg_kw, m, n, t_per, window, start_at, q)) for _ in range(k)]
+            for p_ in procs:
+                p_.start()
+            res = [q.get(timeout=start_at - time.time() + window + 60.0) for _ in procs]
+            for p_ in procs:
+                p_.join(timeout=30)
+            thr = sum(d / el for d, el in res)
+            out["multi_process"] = {"pairs_per_s": round(thr, 4), "processes": k, "threads_each": t_per, "window_s": window,
+                                    "pairs_done": sum(d for d, _ in res)}
+            if thr > single:
+                out.update(value=round(thr, 4), cores=k * t_per,
+                           sample=f"{k} processes x {t_per} threads ({k * t_per} of {nphys} physical cores), B=1 pairs of the same "
+                                  f"workload back to back for {window:.0f} s: {sum(d for d, _ in res)} pairs; single process "
+                                  f"{best_t} threads: {dt * 1e3:.0f} ms/pair")
+        except Exception as e:       # the baseline is informational: never fail the bench line over it
+            out["multi_process"] = {"error": repr(e)[:200]}
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- helpers
+def _stage_dict(ms, cnt):
+    return {name: (float(ms[i]), int(cnt[i])) for i, name in enumerate(_lib.OG_STAGES)}
+
+
+def _median_stages(run_profiled, n=3):
+    profs = [run_profiled() for _ in range(n)]
+    stages = {k: sorted(p[k][0] for p in profs)[n // 2] for k in profs[0]}
+    launches = {k: profs[0][k][1] for k in profs[0]}
+    return stages, launches
+
+
+def _timed_steps(step, args, dist_on, dev):
+    for _ in range(args.warmup):
+        step()
+    if dist_on:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist_on:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    return dt, out
 
 
 def bench_ragged(args, world, rank, dev, dist_on=False):
-    """BASELINE configs[4]: 128 pairs with 512-2048 keypoints per image, cost-balanced over the ranks, through the
-    token-packed ragged path (SuperGlue.match_ragged -> og_forward_ragged)."""
+    """BASELINE configs[4]: ragged pairs with 512-2048 keypoints per image, 16 per GPU, cost-balanced over the ranks, through
+    the token-packed ragged path (SuperGlue.match_ragged_packed -> og_forward_ragged)."""
     kw = dict(syn.CONFIGS["C2"]); kw.pop("kpts"); kw.pop("batch")
-    total = (args.batch or 16) * world
+    per_gpu = args.batch or 16
+    total = per_gpu * world
     lens = syn.ragged_lengths(total, 512, 2048, seed=0)
     costs = [sharding.pair_cost(m, n) for m, n in lens]
-    mine = sharding.shard_pairs(total, world, costs)[rank]
+    shards = sharding.shard_pairs(total, world, costs)
+    mine = shards[rank]
     cfg = syn.make_config(**kw)
     sd = syn.make_state_dict(cfg, seed=0)
     model = SuperGlue(cfg).eval(); model.load_state_dict(sd, strict=True); model.to(dev)
@@ -121,46 +267,88 @@ def bench_ragged(args, world, rank, dev, dist_on=False):
         p = {k: v.to(dev) for k, v in p.items()}
         p["image0_size"] = list(syn.IMAGE_WH); p["image1_size"] = list(syn.IMAGE_WH)
         pairs.append(p)
+    packed = model.pack_ragged(pairs)          # inputs resident in HBM in the token-packed layout the boundary takes
+
+    def match_mine(_ids):
+        return model.match_ragged_packed(packed, MATCH_THRESHOLD, both_sides=False)
 
     def step():
-        res = model.match_ragged(pairs, MATCH_THRESHOLD, both_sides=False)
-        if dist_on:   # the one collective: match lists to rank 0, padded to the longest keypoint set (2048)
-            width = 2048
-            m0 = torch.full((len(res), width), -1, dtype=torch.int64, device=dev)
-            s0 = torch.zeros((len(res), width), dtype=torch.float32, device=dev)
-            for i, r in enumerate(res):
-                m0[i, :r["matches0"].numel()] = r["matches0"]; s0[i, :r["matches0"].numel()] = r["matching_scores0"]
-            sharding.gather_matches({"matches0": m0, "matching_scores0": s0}, mine, total, dst=0, always_collective=True)
-        return res
-    for _ in range(args.warmup):
-        step()
-    if dist_on:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    torch.cuda.synchronize()
-    if dist_on:
-        torch.distributed.barrier()
-    dt = time.perf_counter() - t0
-    if dist_on:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt.item())
+        if dist_on:      # the one collective: match lists to rank 0, padded to the longest keypoint set of the job
+            return sharding.match_sharded_ragged(match_mine, lens, costs, dst=0, always_collective=True, device=dev)
+        return match_mine(mine)
+
+    dt, _ = _timed_steps(step, args, dist_on, dev)
     if rank == 0:
+        res = match_mine(mine)
+        my_lens = [lens[i] for i in mine]
+        counts = _sum_counts(kw, my_lens)
+
+        def run_profiled():
+            ms = (C.c_float * len(_lib.OG_STAGES))(); cnt = (C.c_int32 * len(_lib.OG_STAGES))()
+            model.match_ragged_packed(packed, MATCH_THRESHOLD, both_sides=False, _profile=(ms, cnt))
+            return _stage_dict(ms, cnt)
+        stages, launches = _median_stages(run_profiled)
+        roof, roof2 = roofline_block(counts, stages, launches, kw["num_iters"], False)
         line = {"metric": "image-pairs/sec (C5 ragged 512-2048 kpts)", "value": round(total * args.steps / dt, 2), "unit": "image-pairs/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": f"BASELINE configs[4]: {total} ragged pairs, 512-2048 kpts/image, 256-dim, 9 stages, 100 Sinkhorn iters, "
-                                       "token-packed ragged kernels (og_forward_ragged), LPT cost-balanced over ranks",
-                           "mean_kpts": round(sum(a + b for a, b in lens) / (2 * total), 1)},
-                "roofline": None, "cpu_baseline": None,
+                "config": {"workload": f"BASELINE configs[4]: {total} ragged pairs ({per_gpu}/GPU), 512-2048 kpts/image, 256-dim, 9 stages, "
+                                       "100 Sinkhorn iters, token-packed ragged kernels (og_forward_ragged), LPT cost-balanced over ranks",
+                           "mean_kpts": round(sum(a + b for a, b in lens) / (2 * total), 1), "pairs_per_gpu": per_gpu},
+                "roofline": roof, "roofline_other": roof2, "stages_ms": {k: round(v, 3) for k, v in stages.items()},
+                "algorithmic": {"gflop_per_step_rank0": round(counts["total_flops"] / 1e9, 2),
+                                "sinkhorn_gb_per_step_rank0": round(counts["sinkhorn_bytes"] / 1e9, 3)},
                 "valid_matches_per_pair": round(sum(int((r["matches0"] >= 0).sum()) for r in res) / max(1, len(res)), 1)}
+        if world == 1 and not args.no_cpu_baseline:   # the mean-size pair of the job as the CPU sample
+            mm = int(round(sum(a for a, _ in lens) / total)); nn_ = int(round(sum(b for _, b in lens) / total))
+            line["cpu_baseline"] = cpu_baseline(cfg, sd, kw, mm, nn_)
+            line["cpu_baseline"]["sample"] += f" [one {mm}x{nn_}-keypoint pair = the mean size of the ragged job]"
+        else:
+            line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
     if dist_on:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _respawn(args):
+    """`python bench.py --gpus N` without a torch.distributed environment: one process per GPU under torch.distributed.run."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
+def _dry_run(args, world, rank):
+    """OG_BENCH_DRYRUN=1 (tests, no GPU): the launch / rendezvous / gather plumbing of the N-rank bench under gloo with
+    the matcher replaced by a stub.  Prints a line marked "dry_run": true -- never a measurement."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    lens = syn.ragged_lengths(3 * world, 8, 32, seed=0)
+
+    def stub(ids):
+        return [{"matches0": torch.full((lens[i][0],), i, dtype=torch.int64), "matching_scores0": torch.full((lens[i][0],), 0.5)}
+                for i in ids]
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        got = sharding.match_sharded_ragged(stub, lens, always_collective=world > 1)
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        ok = all(bool((got["matches0"][i, :lens[i][0]] == i).all()) for i in range(len(lens)))
+        print(json.dumps({"metric": "dry run (no GPU, gloo, stub matcher)", "dry_run": True, "n_gpus": world, "steps": args.steps,
+                          "gather_ok": ok, "value": round(len(lens) * args.steps / dt, 1), "unit": "stub-pairs/s"}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -173,11 +361,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _respawn(args)                                   # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
+    if os.environ.get("OG_BENCH_DRYRUN") == "1":
+        return _dry_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path")
     torch.cuda.set_device(local_rank)
@@ -206,65 +398,23 @@ def main():
     def step():
         out = model.match(data, MATCH_THRESHOLD, both_sides=True)
         if dist_on:
-            sharding.gather_matches(out, pair_ids, world * B, dst=0, always_collective=True)
+            sharding.gather_matches(out, pair_ids, world * B, dst=0, always_collective=True, cap=B)
         return out
 
-    for _ in range(args.warmup):
-        step()
-    if dist_on:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if dist_on:
-        torch.distributed.barrier()
-    dt = time.perf_counter() - t0
-    if dist_on:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt, out = _timed_steps(step, args, dist_on, dev)
 
     if rank == 0:
-        counts = algorithmic_counts(kw, m, n)
+        c1 = algorithmic_counts(kw, m, n)
+        counts = {k: v * B for k, v in c1.items()}
         ms_per_step = dt / args.steps * 1e3
         value = world * B * args.steps / dt
-        # per-kernel-class time of one step, HIP events on the launch stream (median of 3 profiled steps)
-        profs = [profiled_forward(model, data, MATCH_THRESHOLD) for _ in range(3)]
-        stages = {k: sorted(p[k][0] for p in profs)[1] for k in profs[0]}
-        launches = {k: profs[0][k][1] for k in profs[0]}
-        per_step = {  # kernel class -> (algorithmic work per step, unit scale, bound, peak, kernel names, note)
-            "gemm_f16x3": (counts["gemm_f16x3_flops"] * B, 1e12, "mfma", PEAK_F16_MFMA_TFLOPS, "TFLOP/s",
-                           "gemm_nt_f16x3_big_kernel / gemm_nt_f16x3_kernel (GNN 1x1 convs, final projection, score matrix; split-f16 3-pass MFMA: executes 3x the algorithmic flops)"),
-            "gemm_f32": (counts["gemm_f32_flops"] * B, 1e12, "mfma", PEAK_F32_MFMA_TFLOPS, "TFLOP/s",
-                         "gemm_nt_f32_kernel (keypoint-encoder MLP; exact fp32 MFMA)"),
-            "attention": (counts["attention_flops"] * B, 1e12, "mfma", PEAK_F16_MFMA_TFLOPS, "TFLOP/s",
-                          "attention_kernel (split-f16 flash attention: executes 3x the algorithmic flops)"),
-            "sinkhorn": (counts["sinkhorn_bytes"] * B, 1e9, "hbm", PEAK_HBM_GBS, "GB/s",
-                         "sinkhorn_sweep_fast + sinkhorn_combine_fast (stage time incl. launch gaps; the kernels read S ONCE per iteration, the algorithmic figure of SURVEY 8d counts two sweeps: frac can exceed 1)"),
-        }
-        # HBM traffic per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
-        # corrected as MI355X_MICROARCH.md prescribes); only valid for the configuration it was measured on (C2, B=32)
-        traffic = {}
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic_c2.json")
-        if args.config == "C2" and B == 32 and os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            traffic = {"gemm_f16x3": tj.get("gemm_f16x3"), "gemm_f32": tj.get("gemm_f32"), "attention": tj.get("attention"),
-                       "sinkhorn": {"hbm_bytes_per_launch": (tj["sinkhorn_sweep"]["hbm_bytes_per_launch"] + tj["sinkhorn_combine"]["hbm_bytes_per_launch"]) * kw["num_iters"]}}
-        roofs = {}
-        for k, (work, scale, bound, peak, unit, kern) in per_step.items():
-            ms = stages[k]
-            ach = work / (ms * 1e-3) / scale if ms > 0 else 0.0
-            nl = max(1, launches[k])
-            roofs[k] = {"kernel": kern, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
-                        "frac": round(ach / peak, 4),
-                        "traffic": (traffic.get(k) or {}).get("hbm_bytes_per_launch"), "class_ms_per_step": round(ms, 3),
-                        "launches_per_step": launches[k], "avg_launch_ms": round(ms / nl, 4),
-                        "algorithmic_work_per_launch": round(work / nl / scale, 6)}
-        dominant = max(per_step, key=lambda k: stages[k])
-        roof = roofs.pop(dominant)
-        roof2 = roofs
+
+        def run_profiled():     # per-kernel-class time of one step, HIP events on the launch stream
+            ms = (C.c_float * len(_lib.OG_STAGES))(); cnt = (C.c_int32 * len(_lib.OG_STAGES))()
+            model.match(data, MATCH_THRESHOLD, both_sides=True, _profile=(ms, cnt))
+            return _stage_dict(ms, cnt)
+        stages, launches = _median_stages(run_profiled)
+        roof, roof2 = roofline_block(counts, stages, launches, kw["num_iters"], args.config == "C2" and B == 32)
         line = {
             "metric": "image-pairs/sec (1024 kpts, 256-dim, 9 GNN layers)" if args.config == "C2" else f"image-pairs/sec ({args.config})",
             "value": round(value, 2), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -276,20 +426,38 @@ def main():
                        "pairs_per_gpu": B, "kpts": [m, n], "parallelism": f"pairs sharded over {world} GPU(s), 1 RCCL gather"},
             "roofline": roof, "roofline_other": roof2,
             "stages_ms": {k: round(v, 3) for k, v in stages.items()},
-            "algorithmic": {"gflop_per_pair": round(counts["total_flops"] / 1e9, 2), "sinkhorn_gb_per_pair": round(counts["sinkhorn_bytes"] / 1e9, 3)},
+            "algorithmic": {"gflop_per_pair": round(c1["total_flops"] / 1e9, 2), "sinkhorn_gb_per_pair": round(c1["sinkhorn_bytes"] / 1e9, 3),
+                            "sinkhorn_gb_per_pair_survey_two_sweeps": round(c1["sinkhorn_bytes_survey"] / 1e9, 3)},
             "valid_matches_per_pair": round(float((out["matches0"] >= 0).sum().item()) / B, 1),
         }
-        # the same step fed from pinned HOST buffers (H2D of keypoints/descriptors/side-info included, synchronous with
-        # the step: the boundary hands over device tensors, so this is informational and never `value`)
+        # The same step fed from pinned HOST buffers, H2D of keypoints/descriptors/side-info included and double-buffered
+        # on a copy stream (batch k+1 uploads while batch k computes).  The boundary hands over device tensors, so this is
+        # informational and never `value`.
         host = {k: v.cpu().pin_memory() for k, v in data.items() if torch.is_tensor(v)}
-        def step_h2d():
-            d = {k: v.to(dev, non_blocking=True) for k, v in host.items()}
-            d["image0_size"], d["image1_size"] = data["image0_size"], data["image1_size"]
-            return model.match(d, MATCH_THRESHOLD, both_sides=True)
-        step_h2d(); torch.cuda.synchronize()
+        copy_stream = torch.cuda.Stream(device=dev)
+        bufs = [{k: torch.empty_like(v, device=dev) for k, v in host.items()} for _ in range(2)]
+        ready = [torch.cuda.Event() for _ in range(2)]
+        freed = [torch.cuda.Event() for _ in range(2)]
+
+        def upload(i):
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(freed[i])            # the step that read this buffer has finished
+                for k, v in host.items():
+                    bufs[i][k].copy_(v, non_blocking=True)
+                ready[i].record(copy_stream)
+        for i in range(2):
+            freed[i].record(torch.cuda.current_stream(dev))
+        upload(0)
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step_h2d()
+        for s_ in range(args.steps):
+            i = s_ & 1
+            if s_ + 1 < args.steps:
+                upload(i ^ 1)
+            torch.cuda.current_stream(dev).wait_event(ready[i])
+            d = dict(bufs[i]); d["image0_size"], d["image1_size"] = data["image0_size"], data["image1_size"]
+            model.match(d, MATCH_THRESHOLD, both_sides=True)
+            freed[i].record(torch.cuda.current_stream(dev))
         torch.cuda.synchronize()
         line["value_incl_h2d"] = round(B * args.steps / (time.perf_counter() - t0), 2)
         if world == 1 and not args.no_cpu_baseline:

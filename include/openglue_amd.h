@@ -31,12 +31,14 @@
 extern "C" {
 #endif
 
-#define OG_ABI_VERSION 2
+#define OG_ABI_VERSION 3
 
 #define OG_E_INVALID   (-1)  /* NULL pointer / non-positive size                         */
 #define OG_E_SHAPE     (-2)  /* unsupported shape (see og_check_shape)                   */
 #define OG_E_ALIGN     (-3)  /* a device pointer is not 16-byte aligned                  */
 #define OG_E_FLAG      (-4)  /* unknown flag bits                                        */
+#define OG_E_RANGE     (-5)  /* og_pack_weights: a folded weight is not finite or |256 w| > 65504 (binary16 range of
+                                the split-f16 GEMM operands), e.g. BatchNorm over a dead channel with running_var ~ 0 */
 
 /* config flags (reference keys: superglue.py:18-19 `residual`, `no_descriptors`;
  * attention_gnn.py:51-52 `use_offset`) */
@@ -162,12 +164,15 @@ int og_forward(const og_shape* shape, const og_inputs* in, const void* packed_de
 /* Ragged batch (BASELINE config 5): pair b has lens0[b] keypoints in image 0 and lens1[b] in image 1
  * (host arrays, batch <= OG_MAX_RAGGED; shape->m / shape->n are the maxima).  Every tensor is PACKED without
  * padding in pair order: keypoints0 [sum m_b][2], descriptors0 [sum m_b][D], ..., scores = the
- * [m_b+1][n_b+1] blocks one after the other, matches0 / matching_scores0 [sum m_b], matches1 [sum n_b].
- * The result of pair b equals og_forward on that pair alone (the reference has no masks: SURVEY.md 3.5).
- * context_descriptors{0,1} are not produced (must be NULL). */
+ * [m_b+1][n_b+1] blocks one after the other, matches0 / matching_scores0 [sum m_b], matches1 [sum n_b],
+ * context_descriptors0 = the channel-first [D][m_b] blocks one after the other (may be NULL), likewise 1.
+ * image0_wh / image1_wh: host arrays [batch][2] = (W, H) of every pair's images (keypoint normalisation,
+ * superglue.py:35-41, 74-78); NULL = in->image{0,1}_wh for all pairs.
+ * The result of pair b equals og_forward on that pair alone (the reference has no masks: SURVEY.md 3.5). */
 #define OG_MAX_RAGGED 64
-int og_forward_ragged(const og_shape* shape, const int32_t* lens0, const int32_t* lens1, const og_inputs* in,
-                      const void* packed_dev, void* workspace_dev, const og_outputs* out, void* stream);
+int og_forward_ragged(const og_shape* shape, const int32_t* lens0, const int32_t* lens1, const float* image0_wh,
+                      const float* image1_wh, const og_inputs* in, const void* packed_dev, void* workspace_dev,
+                      const og_outputs* out, void* stream);
 
 /* Profiling variant of og_forward (bench.py): same work, but every launch group is bracketed by HIP
  * events recorded on `stream`; the call SYNCHRONISES the stream and returns the summed elapsed
@@ -183,6 +188,9 @@ int og_forward_ragged(const og_shape* shape, const int32_t* lens0, const int32_t
 int og_forward_profiled(const og_shape* shape, const og_inputs* in, const void* packed_dev,
                         void* workspace_dev, const og_outputs* out, void* stream,
                         float* stage_ms /*[OG_NUM_STAGES]*/, int32_t* stage_launches /*[OG_NUM_STAGES]*/);
+int og_forward_ragged_profiled(const og_shape* shape, const int32_t* lens0, const int32_t* lens1, const float* image0_wh,
+                               const float* image1_wh, const og_inputs* in, const void* packed_dev, void* workspace_dev,
+                               const og_outputs* out, void* stream, float* stage_ms, int32_t* stage_launches);
 
 /* ---- per-stage entry points (unit parity tests; also usable on their own) ---- */
 

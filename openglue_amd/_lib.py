@@ -11,14 +11,15 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OPENGLUE_AMD_LIB") or os.path.join(HERE, "lib", "libopenglue_amd.so")   # override: A/B builds
 
-OG_ABI_VERSION = 2
+OG_ABI_VERSION = 3
 OG_FLAG_RESIDUAL, OG_FLAG_USE_OFFSET, OG_FLAG_NO_DESCRIPTORS, OG_FLAG_SIREN_ENCODER, OG_FLAG_LINEAR_ATTENTION = 1, 2, 4, 8, 16
 OG_MAX_HIDDEN = 8
 OG_MAX_RAGGED = 64
 OG_STAGES = ("encoder_input", "gemm_f32", "attention", "sinkhorn", "matches", "gemm_f16x3")
 
 _ERRORS = {-1: "OG_E_INVALID (null pointer / bad size)", -2: "OG_E_SHAPE (unsupported shape)",
-           -3: "OG_E_ALIGN (pointer or leading dimension not 16-byte aligned)", -4: "OG_E_FLAG (unknown flag)"}
+           -3: "OG_E_ALIGN (pointer or leading dimension not 16-byte aligned)", -4: "OG_E_FLAG (unknown flag)",
+           -5: "OG_E_RANGE (a folded weight is not finite or exceeds the binary16 range of the split-f16 operands: |256 w| > 65504)"}
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -79,10 +80,13 @@ SYMBOLS = {
     "og_packed_layout": (C.c_int, [C.POINTER(og_shape), C.POINTER(og_packed_layout_t)]),
     "og_pack_weights": (C.c_int, [C.POINTER(og_shape), C.POINTER(og_params), _vp]),
     "og_forward": (C.c_int, [C.POINTER(og_shape), C.POINTER(og_inputs), _vp, _vp, C.POINTER(og_outputs), _vp]),
-    "og_forward_ragged": (C.c_int, [C.POINTER(og_shape), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(og_inputs), _vp, _vp,
-                                    C.POINTER(og_outputs), _vp]),
+    "og_forward_ragged": (C.c_int, [C.POINTER(og_shape), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_float),
+                                    C.POINTER(C.c_float), C.POINTER(og_inputs), _vp, _vp, C.POINTER(og_outputs), _vp]),
     "og_forward_profiled": (C.c_int, [C.POINTER(og_shape), C.POINTER(og_inputs), _vp, _vp, C.POINTER(og_outputs), _vp,
                                       C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
+    "og_forward_ragged_profiled": (C.c_int, [C.POINTER(og_shape), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_float),
+                                             C.POINTER(C.c_float), C.POINTER(og_inputs), _vp, _vp, C.POINTER(og_outputs), _vp,
+                                             C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "og_gemm_nt": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _i32,
                              _vp, _i64, _vp, _f, _vp]),
     "og_split_f16": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),

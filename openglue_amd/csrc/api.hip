@@ -1,6 +1,7 @@
 // C-ABI entry points: shape checks, host-side weight packing, workspace layout and the launch
 // sequence of the whole hot path (og_forward).  See include/openglue_amd.h for the contract.
 #include <math.h>
+#include <cmath>
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
@@ -105,13 +106,17 @@ int check_shape(const og_shape* s) {
     return 0;
 }
 
-// w -> (hi, lo) of w * OG_W_SCALE, element (row, col) of an hl32 weight matrix with K columns (og_common.h)
-inline void put_split(_Float16* W, int64_t row, int col, int K, double w) {
+// w -> (hi, lo) of w * OG_W_SCALE, element (row, col) of an hl32 weight matrix with K columns (og_common.h).
+// Returns false when the scaled weight does not fit binary16 (|w * 256| > 65504, e.g. a BatchNorm fold over a dead
+// channel with running_var ~ 0) or is not finite: og_pack_weights then fails with OG_E_RANGE instead of packing an inf.
+inline bool put_split(_Float16* W, int64_t row, int col, int K, double w) {
     w *= OG_W_SCALE;
+    if (!(fabs(w) <= 65504.0)) return false;
     const _Float16 hi = (_Float16)w;
     _Float16* d = W + row * 2 * K + og_hl_col(col);
     d[0] = hi;
     d[32] = (_Float16)(w - (double)hi);
+    return true;
 }
 
 // BatchNorm (eval) as y*g + c
@@ -206,6 +211,7 @@ extern "C" int og_pack_weights(const og_shape* shape, const og_params* P, void* 
     const double qscale = (s.flags & OG_FLAG_LINEAR_ATTENTION) ? 1.0 : 1.4426950408889634 / sqrt((double)dh);
     const bool offset = s.flags & OG_FLAG_USE_OFFSET;
     std::vector<double> Wm((size_t)D2 * D), prod((size_t)D2 * D), g, c;
+    bool ok = true;                     // every split-f16 weight fits binary16 after the 256x pre-scale
     for (int l = 0; l < 2 * s.num_stages; ++l) {
         if (!P->layers) return OG_E_INVALID;
         const og_layer_params& lp = P->layers[l];
@@ -217,7 +223,7 @@ extern "C" int og_pack_weights(const og_shape* shape, const og_params* P, void* 
             if (!proj[p]->weight || !proj[p]->bias) return OG_E_INVALID;
             const double sc = p == 0 ? qscale : 1.0;
             for (int o = 0; o < D; ++o)
-                for (int k = 0; k < D; ++k) put_split(Wqkv, (int64_t)p * D + o, k, D, proj[p]->weight[(int64_t)o * D + k] * sc);
+                for (int k = 0; k < D; ++k) ok &= put_split(Wqkv, (int64_t)p * D + o, k, D, proj[p]->weight[(int64_t)o * D + k] * sc);
             for (int i = 0; i < D; ++i) bqkv[p * D + i] = (float)(proj[p]->bias[i] * sc);
         }
         // fc.0 on y = [x ; msg] (or [x - msg ; msg] with use_offset, attention_gnn.py:51-54), msg = Wo O + bo:
@@ -229,7 +235,7 @@ extern "C" int og_pack_weights(const og_shape* shape, const og_params* P, void* 
         for (int o = 0; o < D2; ++o)
             for (int k = 0; k < D; ++k) {
                 const double wa = lp.fc0.weight[(int64_t)o * D2 + k], wb = lp.fc0.weight[(int64_t)o * D2 + D + k];
-                put_split(W0, o, k, D2, wa);
+                ok &= put_split(W0, o, k, D2, wa);
                 Wm[(size_t)o * D + k] = offset ? wb - wa : wb;
             }
         std::fill(prod.begin(), prod.end(), 0.0);
@@ -242,7 +248,7 @@ extern "C" int og_pack_weights(const og_shape* shape, const og_params* P, void* 
                 for (int j = 0; j < D; ++j) pr[j] += w * (double)wo[j];
                 bb += w * (double)lp.out_proj.bias[k];
             }
-            for (int j = 0; j < D; ++j) put_split(W0, o, D + j, D2, pr[j]);
+            for (int j = 0; j < D; ++j) ok &= put_split(W0, o, D + j, D2, pr[j]);
             b0[o] = (float)bb;
         }
         // fc.3 with BN(2D) folded in
@@ -254,7 +260,7 @@ extern "C" int og_pack_weights(const og_shape* shape, const og_params* P, void* 
             double bb = lp.fc3.bias[o];
             for (int k = 0; k < D2; ++k) {
                 const double w = lp.fc3.weight[(int64_t)o * D2 + k];
-                put_split(W3, o, k, D2, w * g[k]);
+                ok &= put_split(W3, o, k, D2, w * g[k]);
                 bb += w * c[k];
             }
             b3[o] = (float)bb;
@@ -266,7 +272,7 @@ extern "C" int og_pack_weights(const og_shape* shape, const og_params* P, void* 
     {   // final projection: hl32 rows of 256*w like the GNN matrices (it runs on the split-f16 kernel, reading the x rows of XO)
         _Float16* Wp = (_Float16*)(out + L.wp);
         for (int o = 0; o < D; ++o)
-            for (int k = 0; k < D; ++k) put_split(Wp, o, k, D, P->linear_proj.weight[(int64_t)o * D + k]);
+            for (int k = 0; k < D; ++k) ok &= put_split(Wp, o, k, D, P->linear_proj.weight[(int64_t)o * D + k]);
     }
     memcpy(out + L.bp, P->linear_proj.bias, sizeof(float) * (size_t)D);
     if (s.flags & OG_FLAG_RESIDUAL) {
@@ -274,6 +280,13 @@ extern "C" int og_pack_weights(const og_shape* shape, const og_params* P, void* 
         for (int i = 0; i < D; ++i) out[L.alpha + i] = (float)(1.0 / (1.0 + exp(-(double)P->mix_coefs[i])));   // superglue.py:60
     }
     out[L.dustbin] = P->dustbin_score;
+    if (!ok) return OG_E_RANGE;
+    for (int64_t i = 0; i < L.total; ++i)      // fp32 sections (encoder, biases): a non-finite fold (var + eps <= 0, inf weights)
+        if (!std::isfinite(out[i])) {
+            // the split-f16 sections hold pairs of halves, not floats: a NaN bit pattern there cannot occur for finite
+            // halves with |hi| <= 65504 unless both halves have all-ones exponents, which put_split already excluded
+            return OG_E_RANGE;
+        }
     return 0;
 }
 
@@ -300,7 +313,8 @@ struct Scope {
 };
 
 int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_dev, void* workspace_dev,
-                 const og_outputs* outp, void* stream, Profiler* prof, const RaggedDesc* rag = nullptr) {
+                 const og_outputs* outp, void* stream, Profiler* prof, const RaggedDesc* rag = nullptr,
+                 const EncoderRagged* er0 = nullptr, const EncoderRagged* er1 = nullptr) {
     if (!shape || !in || !packed_dev || !workspace_dev || !outp) return OG_E_INVALID;
     if (int e = check_shape(shape)) return e;
     og_clear_status();
@@ -321,7 +335,6 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
     const int D = s.desc_dim, D2 = 2 * D, D3 = 3 * D, B = s.batch, m = s.m, n = s.n;
     // uniform batch: B sets of m (n) tokens; ragged batch: packed sets, m and n are the maxima
     const int64_t T0 = rag ? rag->off0[B] : (int64_t)B * m, T1 = rag ? rag->off1[B] : (int64_t)B * n, T = T0 + T1;
-    if (rag && (outp->context_descriptors0 || outp->context_descriptors1)) return OG_E_INVALID;
     float* X32 = ws + W.x32; float* G = ws + W.g; float* Sb = ws + W.sbuf;
     const int D4 = 4 * D;
     _Float16* XO = (_Float16*)(ws + W.xo);             // [T] hl32 rows of [x | O]: 4D halves, x in the first 2D, O in the last 2D
@@ -360,8 +373,8 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
         float* Eb = ws + W.eb;
         {
             Scope sc(prof, OG_STAGE_ENCODER_INPUT);
-            if ((rc = og_launch_encoder_input(in->keypoints0, in->side_info0, T0, s.side_info, in->image0_wh[0], in->image0_wh[1], EI, st))) return rc;
-            if ((rc = og_launch_encoder_input(in->keypoints1, in->side_info1, T1, s.side_info, in->image1_wh[0], in->image1_wh[1], EI + T0 * 32, st))) return rc;
+            if ((rc = og_launch_encoder_input(in->keypoints0, in->side_info0, T0, s.side_info, in->image0_wh[0], in->image0_wh[1], EI, st, er0))) return rc;
+            if ((rc = og_launch_encoder_input(in->keypoints1, in->side_info1, T1, s.side_info, in->image1_wh[0], in->image1_wh[1], EI + T0 * 32, st, er1))) return rc;
         }
         const float* cur = EI; int64_t ldcur = 32;
         for (int i = 0; i < L.n_enc; ++i) {
@@ -443,6 +456,7 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
         g.Ch = Gh + r0 * D2; g.Cl = g.Ch + 32; g.ldch = D2; g.c_hl = 1;
         g.Ct = side ? outp->context_descriptors1 : outp->context_descriptors0;
         g.ct_rows = side ? n : m; g.ldct = g.ct_rows;
+        if (rag && g.Ct) { g.rag = rag; g.ct_rag = side ? 2 : 1; }     // ragged: per-pair [D][m_b] blocks, packed
         Scope sc(prof, OG_STAGE_GEMM_F16X3);
         if ((rc = og_launch_gemm_f16x3(g, st))) return rc;
     }
@@ -484,12 +498,16 @@ extern "C" int og_forward(const og_shape* shape, const og_inputs* in, const void
     return forward_impl(shape, in, packed_dev, workspace_dev, outp, stream, nullptr);
 }
 
-extern "C" int og_forward_ragged(const og_shape* shape, const int32_t* lens0, const int32_t* lens1, const og_inputs* in,
-                                 const void* packed_dev, void* workspace_dev, const og_outputs* outp, void* stream) {
-    if (!shape || !lens0 || !lens1) return OG_E_INVALID;
+extern "C" int og_forward_ragged(const og_shape* shape, const int32_t* lens0, const int32_t* lens1, const float* image0_wh,
+                                 const float* image1_wh, const og_inputs* in, const void* packed_dev, void* workspace_dev,
+                                 const og_outputs* outp, void* stream);
+
+namespace {
+int build_ragged(const og_shape* shape, const int32_t* lens0, const int32_t* lens1, const float* image0_wh, const float* image1_wh,
+                 const og_inputs* in, RaggedDesc& rd, EncoderRagged& er0, EncoderRagged& er1) {
+    if (!shape || !lens0 || !lens1 || !in) return OG_E_INVALID;
     if (shape->batch <= 0 || shape->batch > OG_MAX_RAGGED) return OG_E_SHAPE;
-    RaggedDesc rd;
-    rd.B = shape->batch;
+    rd.B = er0.B = er1.B = shape->batch;
     rd.off0[0] = rd.off1[0] = 0;
     rd.soff[0] = 0;
     for (int b = 0; b < rd.B; ++b) {
@@ -497,15 +515,42 @@ extern "C" int og_forward_ragged(const og_shape* shape, const int32_t* lens0, co
         rd.off0[b + 1] = rd.off0[b] + lens0[b];
         rd.off1[b + 1] = rd.off1[b] + lens1[b];
         rd.soff[b + 1] = rd.soff[b] + (int64_t)(lens0[b] + 1) * (lens1[b] + 1);
+        // every pair is normalised with ITS OWN image size (superglue.py:35-41 runs per call = per pair at B = 1)
+        er0.wm1[b] = (image0_wh ? image0_wh[2 * b] : in->image0_wh[0]) - 1.f;
+        er0.hm1[b] = (image0_wh ? image0_wh[2 * b + 1] : in->image0_wh[1]) - 1.f;
+        er1.wm1[b] = (image1_wh ? image1_wh[2 * b] : in->image1_wh[0]) - 1.f;
+        er1.hm1[b] = (image1_wh ? image1_wh[2 * b + 1] : in->image1_wh[1]) - 1.f;
     }
-    return forward_impl(shape, in, packed_dev, workspace_dev, outp, stream, nullptr, &rd);
+    for (int b = 0; b <= rd.B; ++b) { er0.off[b] = rd.off0[b]; er1.off[b] = rd.off1[b]; }
+    return 0;
 }
+
+int profiled(const og_shape* shape, const og_inputs* in, const void* packed_dev, void* workspace_dev, const og_outputs* outp,
+             void* stream, float* stage_ms, int32_t* stage_launches, const RaggedDesc* rd, const EncoderRagged* er0,
+             const EncoderRagged* er1);
+}  // namespace
 
 extern "C" int og_forward_profiled(const og_shape* shape, const og_inputs* in, const void* packed_dev, void* workspace_dev,
                                    const og_outputs* outp, void* stream, float* stage_ms, int32_t* stage_launches) {
+    return profiled(shape, in, packed_dev, workspace_dev, outp, stream, stage_ms, stage_launches, nullptr, nullptr, nullptr);
+}
+
+extern "C" int og_forward_ragged_profiled(const og_shape* shape, const int32_t* lens0, const int32_t* lens1, const float* image0_wh,
+                                          const float* image1_wh, const og_inputs* in, const void* packed_dev, void* workspace_dev,
+                                          const og_outputs* outp, void* stream, float* stage_ms, int32_t* stage_launches) {
+    RaggedDesc rd;
+    EncoderRagged er0, er1;
+    if (int e = build_ragged(shape, lens0, lens1, image0_wh, image1_wh, in, rd, er0, er1)) return e;
+    return profiled(shape, in, packed_dev, workspace_dev, outp, stream, stage_ms, stage_launches, &rd, &er0, &er1);
+}
+
+namespace {
+int profiled(const og_shape* shape, const og_inputs* in, const void* packed_dev, void* workspace_dev, const og_outputs* outp,
+             void* stream, float* stage_ms, int32_t* stage_launches, const RaggedDesc* rd, const EncoderRagged* er0,
+             const EncoderRagged* er1) {
     if (!stage_ms || !stage_launches) return OG_E_INVALID;
     Profiler prof{(hipStream_t)stream, {}, {}};
-    int rc = forward_impl(shape, in, packed_dev, workspace_dev, outp, stream, &prof);
+    int rc = forward_impl(shape, in, packed_dev, workspace_dev, outp, stream, &prof, rd, er0, er1);
     hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     for (int c = 0; c < OG_NUM_STAGES; ++c) { stage_ms[c] = 0.f; stage_launches[c] = 0; }
     for (size_t i = 0; i < prof.cls.size(); ++i) {
@@ -519,4 +564,14 @@ extern "C" int og_forward_profiled(const og_shape* shape, const og_inputs* in, c
     }
     if (rc) return rc;
     return e == hipSuccess ? 0 : (int)e;
+}
+}  // namespace
+
+extern "C" int og_forward_ragged(const og_shape* shape, const int32_t* lens0, const int32_t* lens1, const float* image0_wh,
+                                 const float* image1_wh, const og_inputs* in, const void* packed_dev, void* workspace_dev,
+                                 const og_outputs* outp, void* stream) {
+    RaggedDesc rd;
+    EncoderRagged er0, er1;
+    if (int e = build_ragged(shape, lens0, lens1, image0_wh, image1_wh, in, rd, er0, er1)) return e;
+    return forward_impl(shape, in, packed_dev, workspace_dev, outp, stream, nullptr, &rd, &er0, &er1);
 }

@@ -19,6 +19,7 @@
 // and all stores are vectorised along the channel axis.
 // v_mfma_f32_32x32x16_f16; block tile 128 tokens x OC channels x 32 k, 4 waves as 2x2.
 #include <stdlib.h>
+#include <cmath>
 
 #include "og_common.h"
 
@@ -26,7 +27,7 @@ namespace {
 
 constexpr int TOK = 128;
 constexpr int BKH = 32;          // k per tile (halves)
-constexpr int EPI_SLAB = 64 * 144;   // per-wave epilogue scratch: 64 rows x (128 B + 16 B pad)
+constexpr int EPI_SLAB = 32 * 144;   // per-wave epilogue scratch: one 32-token slice, rows of (128 B + 16 B pad)
 
 // Compile-time ablations of the LDS-DMA kernel (scripts/build_ablation.sh; results are wrong by construction):
 // 1 = no global stores, 2 = every block reads token tile 0 (operands L2-resident), 4 = no MFMA,
@@ -37,152 +38,241 @@ constexpr int EPI_SLAB = 64 * 144;   // per-wave epilogue scratch: 64 rows x (12
 
 // Epilogue.  After the MFMAs a lane owns ONE token and 4 consecutive channels per register group; storing
 // that directly means 8-byte pieces scattered over 32 rows per instruction (measured: 113 of 210 us of the
-// qkv GEMM).  Instead every wave transposes its 64 token x OC/2 channel tile through its own LDS slab and
+// qkv GEMM).  Instead every wave transposes 32-token slices of its tile through its own LDS slab and
 // writes whole rows: 16 B per lane, 128-byte (or 64-byte) contiguous row segments.
 // `slab` = this wave's private LDS scratch (EPI_SLAB bytes), free once all waves passed the last
 // k-tile barrier.  No block barrier is needed: a wave only re-reads what it wrote itself.
-// acc0: the wave's 64 token x TI*32 channel tile starting at (tok0, oc0).
-// FULL: also the residual MIX (alpha) and the channel-first copy (Ct) of the final projection; only instantiated for the
-// 128-tile kernel (in the 256-tile kernel the extra address registers push the epilogue into scratch).
-template <int TI, bool FULL>
-__device__ __forceinline__ void gemm_f16x3_epilogue(const GemmHArgs& g, f32x16 (&acc0)[TI][2], int tok0, int oc0, int lane,
-                                                    char* slab) {
-#pragma clang fp contract(off)                  // og_split: hi and lo must see the same rounded value (og_common.h)
-    constexpr int OCW = TI * 32;                // channels of a wave tile
-    const int l31 = lane & 31, hi = lane >> 5;
+//
+// Global operands of the epilogue never sit on its critical path one by one.  [Round 1 loaded every float4 of
+// bias / residual inside its own `if (oc < N && tok < M)`; hipcc emitted `global_load ; s_waitcnt vmcnt(0)` per
+// 4-value group: 64 exposed L2 round trips per wave per 256x256 tile, ~20 us of a 55 us tile -- the whole
+// "MFMAs + barriers + epilogue arithmetic" gap of the round-1 ablation study.]
+//   * the bias is folded into the accumulator initialisation (gemm_f16x3_acc_init, in the shadow of the first
+//     LDS-DMA wait): acc0 = bias / scale, so that acc * scale = W x + bias;
+//   * the residual of a 32-token slice (8 * TI/2 sixteen-byte pieces per lane) is fetched with clamped, always
+//     valid addresses under wave-uniform conditions only, one slice AHEAD of the slice being finished.
+typedef unsigned og_u32x4 __attribute__((ext_vector_type(4)));
 
-    // finish the arithmetic in registers: v = acc * scale + bias (+relu) (+res)
+// acc[i][j][4q + e] = bias[oc0 + 32 i + 8 q + 4 hi + e] / scale for every token block j; clears g.bias
+template <int NI, int NJ>
+__device__ __forceinline__ void gemm_f16x3_acc_init(GemmHArgs& g, f32x16 (&acc)[NI][NJ], int oc0, int lane) {
+    const int hi = lane >> 5;
+    f32x4 b[NI][4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int tok = tok0 + j * 32 + l31;
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[i][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (g.bias) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int oc = oc0 + i * 32 + 8 * q + 4 * hi;
+                b[i][q] = *reinterpret_cast<const f32x4*>(g.bias + (oc < g.N ? oc : 0)) * g.inv_scale;   // bias => N % 4 == 0
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] = b[i][q][e];
+    g.bias = nullptr;
+}
+
+// residual of the 32-token slice starting at tok0 (one 4-dword slot per group for either residual form: they are
+// mutually exclusive, og_launch_gemm_f16x3)
+template <int TI>
+__device__ __forceinline__ void gemm_f16x3_load_residual(const GemmHArgs& g, og_u32x4 (&raw)[TI][4], int tok0, int oc0, int lane) {
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int tok = tok0 + l31;
+    const int tokc = tok < g.M ? tok : g.M - 1;              // clamped: rows past M are computed, never stored
+    // N % 32 == 0 with either residual form (og_launch_gemm_f16x3): a 32-channel block is valid or not as a whole, so the
+    // column clamp is wave-uniform and every load is one per-lane row pointer + a scalar block offset + an immediate
+    if (g.res) {
+        const float* rp = g.res + (int64_t)tokc * g.ldr + 4 * hi;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const int ocb = oc0 + i * 32;
+            const float* p2 = rp + (ocb < g.N ? ocb : 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) raw[i][q] = *reinterpret_cast<const og_u32x4*>(p2 + 8 * q);
+        }
+    } else if (g.res_hl) {                                   // residual carried as (hi, lo): 2^-22 relative
+        const _Float16* rp = g.res_hl + (int64_t)tokc * g.ldrh + 4 * hi;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const int ocb = oc0 + i * 32;
+            const _Float16* p2 = rp + og_hl_col(ocb < g.N ? ocb : 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint2 h2 = *reinterpret_cast<const uint2*>(p2 + 8 * q), l2 = *reinterpret_cast<const uint2*>(p2 + 8 * q + 32);
+                raw[i][q] = og_u32x4{h2.x, h2.y, l2.x, l2.y};
+            }
+        }
+    }
+}
+
+// One 32-token x TI*32-channel slice: a[i] = the accumulators of channel block i, raw = its residual (if any).
+// FULL: also the residual MIX (alpha) and the channel-first copy (Ct) of the final projection; only instantiated for the
+// 128-tile kernel.
+template <int TI, bool FULL>
+__device__ __forceinline__ void gemm_f16x3_epilogue_finish(const GemmHArgs& g, f32x16 (&a)[TI], const og_u32x4 (&raw)[TI][4], int oc0,
+                                                           int lane) {
+#pragma clang fp contract(off)                  // og_split: hi and lo must see the same rounded value (og_common.h)
+    const int hi = lane >> 5;
+    const float relu_floor = g.relu ? 0.f : OG_NEG_INF;      // max(v, -inf) = v: no branch per group
+
+    // finish the arithmetic in registers: v = acc * scale (bias already inside) (+relu) (+res)
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[i][r] = fmaxf(a[i][r] * g.scale, relu_floor);
+    if (g.res) {
+        if (FULL && g.alpha) {      // residual mix (superglue.py:60-62): alpha*v + (1-alpha)*res
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int oc = oc0 + i * 32 + 8 * q + 4 * hi;
+                    const f32x4 al = *reinterpret_cast<const f32x4*>(g.alpha + (oc < g.N ? oc : 0));
+                    const f32x4 rr = __builtin_bit_cast(f32x4, raw[i][q]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[i][4 * q + e] = al[e] * a[i][4 * q + e] + (1.f - al[e]) * rr[e];
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 rr = __builtin_bit_cast(f32x4, raw[i][q]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[i][4 * q + e] += rr[e];
+                }
+        }
+    } else if (g.res_hl) {
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int oc = oc0 + i * 32 + 8 * q + 4 * hi;
-                f32x4 v;
+                const f16x4 rh = __builtin_bit_cast(f16x4, uint2{raw[i][q][0], raw[i][q][1]});
+                const f16x4 rl = __builtin_bit_cast(f16x4, uint2{raw[i][q][2], raw[i][q][3]});
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc0[i][j][4 * q + e] * g.scale;
-                if (g.bias && oc < g.N) v += *reinterpret_cast<const f32x4*>(g.bias + oc);
-                if (g.relu) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                }
-                if (g.res && tok < g.M && oc < g.N) {
-                    const f32x4 rr = *reinterpret_cast<const f32x4*>(g.res + (int64_t)tok * g.ldr + oc);
-                    if (FULL && g.alpha) {      // residual mix (superglue.py:60-62): alpha*v + (1-alpha)*res
-                        const f32x4 al = *reinterpret_cast<const f32x4*>(g.alpha + oc);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = al[e] * v[e] + (1.f - al[e]) * rr[e];
-                    } else {
-                        v += rr;
-                    }
-                }
-                if (g.res_hl && tok < g.M && oc < g.N) {         // residual carried as (hi, lo): 2^-22 relative
-                    const _Float16* rp = g.res_hl + (int64_t)tok * g.ldrh + og_hl_col(oc);
-                    const f16x4 rh = *reinterpret_cast<const f16x4*>(rp), rl = *reinterpret_cast<const f16x4*>(rp + 32);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += (float)rh[e] + (float)rl[e];
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc0[i][j][4 * q + e] = v[e];
+                for (int e = 0; e < 4; ++e) a[i][4 * q + e] += (float)rh[e] + (float)rl[e];
             }
     }
 
+}
+
+// ... and its stores (a = the finished values of the slice)
+template <int TI, bool FULL>
+__device__ __forceinline__ void gemm_f16x3_epilogue_store(const GemmHArgs& g, f32x16 (&a)[TI], int tok0, int oc0, int lane, char* slab,
+                                                          const RaggedDesc& rd) {
+#pragma clang fp contract(off)                  // og_split: hi and lo must see the same rounded value (og_common.h)
+    constexpr int OCW = TI * 32;                // channels of a wave tile
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int tok = tok0 + l31;
     // ---- channel-first fp32 copy: a lane owns one token, so 32 consecutive lanes write 32 consecutive tokens of a channel ----
-    if (FULL && g.Ct) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int tok = tok0 + j * 32 + l31;
-            if (tok >= g.M) continue;
+    if (FULL && g.Ct && tok < g.M) {
+        float* cb;
+        int64_t ldct = g.ldct;
+        if (g.ct_rag) {      // ragged batch: pair b's [N][rows_b] block starts at N * off[b] (superglue.py:68-72 per pair)
+            const int* off = g.ct_rag == 1 ? rd.off0 : rd.off1;
+            int lo = 0, hb = rd.B - 1;           // last b with off[b] <= tok
+            while (lo < hb) {
+                const int mid = (lo + hb + 1) >> 1;
+                if (off[mid] <= tok) lo = mid; else hb = mid - 1;
+            }
+            ldct = off[lo + 1] - off[lo];
+            cb = g.Ct + (int64_t)off[lo] * g.N + (tok - off[lo]);
+        } else {
             const int bz = tok / g.ct_rows, ri = tok - bz * g.ct_rows;
-            float* cb = g.Ct + (int64_t)bz * g.ldct * g.N + ri;
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int oc = oc0 + i * 32 + 8 * q + 4 * hi + e;
-                        if (oc < g.N) cb[(int64_t)oc * g.ldct] = acc0[i][j][4 * q + e];
-                    }
+            cb = g.Ct + (int64_t)bz * g.ldct * g.N + ri;
         }
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int oc = oc0 + i * 32 + 8 * q + 4 * hi + e;
+                    if (oc < g.N) cb[(int64_t)oc * ldct] = a[i][4 * q + e];
+                }
     }
-    // ---- hl32 rows: per 32-channel group one pass through a [64 tok][hi 64 B | lo 64 B] slab, stored as whole
+    // ---- hl32 rows: per 32-channel group one pass through a [32 tok][hi 64 B | lo 64 B] slab, stored as whole
     //      128-byte lines (8 lanes x 16 B per token) ----
     if (g.Ch && g.c_hl) {
         constexpr int ROWB = 128 + 16;
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    unsigned ha, la, hb, lb;
-                    og_split4(acc0[i][j][4 * q], acc0[i][j][4 * q + 1], acc0[i][j][4 * q + 2], acc0[i][j][4 * q + 3], ha, la, hb, lb);
-                    char* d = slab + (j * 32 + l31) * ROWB + (8 * q + 4 * hi) * 2;
-                    *reinterpret_cast<uint2*>(d) = make_uint2(ha, hb);
-                    *reinterpret_cast<uint2*>(d + 64) = make_uint2(la, lb);
-                }
+            for (int q = 0; q < 4; ++q) {
+                unsigned ha, la, hb, lb;
+                og_split4(a[i][4 * q], a[i][4 * q + 1], a[i][4 * q + 2], a[i][4 * q + 3], ha, la, hb, lb);
+                char* d = slab + l31 * ROWB + (8 * q + 4 * hi) * 2;
+                *reinterpret_cast<uint2*>(d) = make_uint2(ha, hb);
+                *reinterpret_cast<uint2*>(d + 64) = make_uint2(la, lb);
+            }
             const int oc = oc0 + i * 32;
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
+            for (int it = 0; it < 4; ++it) {
                 const int r = it * 8 + (lane >> 3), c = lane & 7;
                 const f16x8 t = *reinterpret_cast<const f16x8*>(slab + r * ROWB + c * 16);
-                const int tok = tok0 + r;
-                if (tok < g.M && oc < g.N && !((OG_GEMM_ABL & 1) && tok >= 0))
-                    *reinterpret_cast<f16x8*>(g.Ch + (int64_t)tok * g.ldch + og_hl_col(oc) + c * 8) = t;
+                const int tk = tok0 + r;
+                if (tk < g.M && oc < g.N && !((OG_GEMM_ABL & 1) && tk >= 0))
+                    *reinterpret_cast<f16x8*>(g.Ch + (int64_t)tk * g.ldch + og_hl_col(oc) + c * 8) = t;
             }
         }
     }
-    // ---- split-f16 planes: two passes (hi, lo) through a [64 tok][OCW halves] slab ----
+    // ---- split-f16 planes: two passes (hi, lo) through a [32 tok][OCW halves] slab ----
     if (g.Ch && !g.c_hl) {
         constexpr int ROWB = OCW * 2 + 16;              // padded LDS row (bytes), 16-byte aligned
         constexpr int CPR = OCW * 2 / 16;               // 16-byte chunks per row
         constexpr int RPI = 64 / CPR;                   // rows per store instruction
+        unsigned sh[TI][4][2], sl[TI][4][2];
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                og_split4(a[i][4 * q], a[i][4 * q + 1], a[i][4 * q + 2], a[i][4 * q + 3], sh[i][q][0], sl[i][q][0], sh[i][q][1], sl[i][q][1]);
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int i = 0; i < TI; ++i)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        unsigned ha, la, hb, lb;
-                        og_split4(acc0[i][j][4 * q], acc0[i][j][4 * q + 1], acc0[i][j][4 * q + 2], acc0[i][j][4 * q + 3], ha, la, hb, lb);
-                        *reinterpret_cast<uint2*>(slab + (j * 32 + l31) * ROWB + (i * 32 + 8 * q + 4 * hi) * 2) =
-                            pass == 0 ? make_uint2(ha, hb) : make_uint2(la, lb);
-                    }
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<uint2*>(slab + l31 * ROWB + (i * 32 + 8 * q + 4 * hi) * 2) =
+                        pass == 0 ? make_uint2(sh[i][q][0], sh[i][q][1]) : make_uint2(sl[i][q][0], sl[i][q][1]);
             _Float16* dst = pass == 0 ? g.Ch : g.Cl;
 #pragma unroll
-            for (int it = 0; it < 64 / RPI; ++it) {
+            for (int it = 0; it < 32 / RPI; ++it) {
                 const int r = it * RPI + lane / CPR, c = lane % CPR;
                 const f16x8 t = *reinterpret_cast<const f16x8*>(slab + r * ROWB + c * 16);
-                const int tok = tok0 + r, oc = oc0 + c * 8;
-                if (tok < g.M && oc < g.N && !((OG_GEMM_ABL & 1) && tok >= 0)) *reinterpret_cast<f16x8*>(dst + (int64_t)tok * g.ldch + oc) = t;
+                const int tk = tok0 + r, oc = oc0 + c * 8;
+                if (tk < g.M && oc < g.N && !((OG_GEMM_ABL & 1) && tk >= 0)) *reinterpret_cast<f16x8*>(dst + (int64_t)tk * g.ldch + oc) = t;
             }
         }
     }
-    // ---- fp32 output: one pass per 32-channel half through a [64 tok][32 floats] slab ----
+    // ---- fp32 output: one pass per 32-channel block through a [32 tok][32 floats] slab ----
     if (g.C32) {
         constexpr int ROWB = 32 * 4 + 16;
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int q = 0; q < 4; ++q) {
+                f32x4 t;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4 t;
+                for (int e = 0; e < 4; ++e) t[e] = a[i][4 * q + e];
+                *reinterpret_cast<f32x4*>(slab + l31 * ROWB + (8 * q + 4 * hi) * 4) = t;
+            }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) t[e] = acc0[i][j][4 * q + e];
-                    *reinterpret_cast<f32x4*>(slab + (j * 32 + l31) * ROWB + (8 * q + 4 * hi) * 4) = t;
-                }
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
+            for (int it = 0; it < 4; ++it) {
                 const int r = it * 8 + (lane >> 3), c = lane & 7;
                 const f32x4 t = *reinterpret_cast<const f32x4*>(slab + r * ROWB + c * 16);
-                const int tok = tok0 + r, oc = oc0 + i * 32 + c * 4;
-                if (tok < g.M && oc < g.N && !((OG_GEMM_ABL & 1) && tok >= 0)) *reinterpret_cast<f32x4*>(g.C32 + (int64_t)tok * g.ldc + oc) = t;
+                const int tk = tok0 + r, oc = oc0 + i * 32 + c * 4;
+                if (tk < g.M && oc < g.N && !((OG_GEMM_ABL & 1) && tk >= 0)) *reinterpret_cast<f32x4*>(g.C32 + (int64_t)tk * g.ldc + oc) = t;
             }
         }
     }
@@ -215,9 +305,9 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void gemm_nt_f16x3_kernel(G
     const int tm = (local / tiles_n) * 8 + xcd;       // all channel tiles of a token tile on one XCD
     const int tn = local % tiles_n;
     if (tm >= tiles_m) return;
-    if (g.batch > 1 || rd.B > 0) {   // batched problems (the per-pair score matrices): z = blockIdx.y
+    if (g.batch > 1 || (rd.B > 0 && !g.ct_rag)) {   // batched problems (the per-pair score matrices): z = blockIdx.y
         const int z = blockIdx.y;
-        if (rd.B > 0) {           // ragged: problem z = pair z, operands are row ranges of the packed token matrix
+        if (rd.B > 0 && !g.ct_rag) {           // ragged: problem z = pair z, operands are row ranges of the packed token matrix
             g.M = rd.off0[z + 1] - rd.off0[z];
             g.N = rd.off1[z + 1] - rd.off1[z];
             g.A += (int64_t)rd.off0[z] * g.lda;
@@ -267,12 +357,6 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void gemm_nt_f16x3_kernel(G
     };
 
     f32x16 acc[TI][2];
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int swz = (l31 >> 1) & 7;                    // tile rows differ from l31 by multiples of 16 only
     const int x_row = (wt * 64 + l31) * 128;           // byte offset of this lane's token row (j = 0)
@@ -281,6 +365,9 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void gemm_nt_f16x3_kernel(G
     const int nk = g.K / BKH;
     const int pre = nk < NS - 1 ? nk : NS - 1;
     for (int kt = 0; kt < pre; ++kt) issue_stage(kt);
+    gemm_f16x3_acc_init<TI, 2>(g, acc, n0 + wo * (OC / 2), lane);     // bias / scale, in the shadow of the first DMA (the vmcnt
+                                                                       // waits below are counted from the newest DMA: they also
+                                                                       // cover these older loads)
     for (int kt = 0; kt < nk; ++kt) {
         const int issued = (kt + NS - 1 < nk) ? kt + NS - 1 : nk;
         const int ahead = issued - kt - 1;              // later stages that may stay in flight
@@ -328,7 +415,23 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void gemm_nt_f16x3_kernel(G
     }
 
     __builtin_amdgcn_s_barrier();      // every wave is past its last fragment reads: the ring is free
-    gemm_f16x3_epilogue<TI, true>(g, acc, t0 + wt * 64, n0 + wo * (OC / 2), lane, smem + wave * EPI_SLAB);
+    {
+        // two 32-token slices; the residual of slice 1 is fetched (into the same registers) as soon as slice 0 has consumed
+        // its own, and is in flight while slice 0 is split, transposed and stored
+        og_u32x4 raw[TI][4];
+        const int tok0 = t0 + wt * 64, oc0 = n0 + wo * (OC / 2);
+        char* slab = smem + wave * EPI_SLAB;
+        gemm_f16x3_load_residual<TI>(g, raw, tok0, oc0, lane);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x16 a[TI];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) a[i] = acc[i][j];
+            gemm_f16x3_epilogue_finish<TI, true>(g, a, raw, oc0, lane);
+            if (j + 1 < 2) gemm_f16x3_load_residual<TI>(g, raw, tok0 + (j + 1) * 32, oc0, lane);
+            gemm_f16x3_epilogue_store<TI, true>(g, a, tok0 + j * 32, oc0, lane, slab, rd);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -353,9 +456,9 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_big_kernel(GemmHArgs g, int
     const int tm = (local / tiles_n) * 8 + xcd;       // all channel tiles of a token tile on one XCD
     const int tn = local % tiles_n;
     if (tm >= tiles_m) return;
-    if (g.batch > 1 || rd.B > 0) {   // batched problems (the per-pair score matrices): z = blockIdx.y
+    if (g.batch > 1 || (rd.B > 0 && !g.ct_rag)) {   // batched problems (the per-pair score matrices): z = blockIdx.y
         const int z = blockIdx.y;
-        if (rd.B > 0) {           // ragged: problem z = pair z, operands are row ranges of the packed token matrix
+        if (rd.B > 0 && !g.ct_rag) {           // ragged: problem z = pair z, operands are row ranges of the packed token matrix
             g.M = rd.off0[z + 1] - rd.off0[z];
             g.N = rd.off1[z + 1] - rd.off1[z];
             g.A += (int64_t)rd.off0[z] * g.lda;
@@ -399,12 +502,6 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_big_kernel(GemmHArgs g, int
     };
 
     f32x16 acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int swz = (l31 >> 1) & 7;
     const int x_row = (wt * 128 + l31) * 128;
@@ -446,6 +543,7 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_big_kernel(GemmHArgs g, int
 
     const int nk = g.K / BKH;
     issue_stage(0);
+    gemm_f16x3_acc_init<2, 4>(g, acc, n0 + wo * 64, lane);     // bias / scale, in the shadow of the first DMA
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (nk > 1) issue_stage(1);
@@ -493,14 +591,21 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_big_kernel(GemmHArgs g, int
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
     __builtin_amdgcn_s_barrier();      // the ring is free: per-wave epilogue slabs
+    {
+        // four 32-token slices; the residual of slice s + 1 is fetched (into the same registers) as soon as slice s has
+        // consumed its own, and is in flight while slice s is split, transposed and stored
+        og_u32x4 raw[2][4];
+        const int tok0 = t0 + wt * 128, oc0 = n0 + wo * 64;
+        char* slab = smem + wave * EPI_SLAB;
+        gemm_f16x3_load_residual<2>(g, raw, tok0, oc0, lane);
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        f32x16 part[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) part[i][j] = acc[i][2 * half + j];
-        gemm_f16x3_epilogue<2, false>(g, part, t0 + wt * 128 + half * 64, n0 + wo * 64, lane, smem + wave * EPI_SLAB);
+        for (int j = 0; j < 4; ++j) {
+            f32x16 a[2];
+            a[0] = acc[0][j]; a[1] = acc[1][j];
+            gemm_f16x3_epilogue_finish<2, false>(g, a, raw, oc0, lane);
+            if (j + 1 < 4) gemm_f16x3_load_residual<2>(g, raw, tok0 + (j + 1) * 32, oc0, lane);
+            gemm_f16x3_epilogue_store<2, false>(g, a, tok0 + j * 32, oc0, lane, slab, rd);
+        }
     }
 }
 
@@ -555,17 +660,20 @@ int og_launch_gemm_f16x3(const GemmHArgs& a, hipStream_t stream) {
     if (a.C32 && (((uintptr_t)a.C32 & 15) || (a.ldc & 3))) return OG_E_ALIGN;
     if (a.Ch && a.c_hl && (((uintptr_t)a.Ch & 15) || (a.ldch & 7) || (a.N & 31))) return OG_E_ALIGN;
     if (a.Ch && !a.c_hl && (((uintptr_t)a.Ch & 7) || ((uintptr_t)a.Cl & 7) || (a.ldch & 3))) return OG_E_ALIGN;
-    if (a.res && (((uintptr_t)a.res & 15) || (a.ldr & 3))) return OG_E_ALIGN;
+    if (a.res && (((uintptr_t)a.res & 15) || (a.ldr & 3) || (a.N & 31))) return OG_E_ALIGN;
     if (a.res_hl && (a.res || ((uintptr_t)a.res_hl & 15) || (a.ldrh & 7) || (a.N & 31))) return OG_E_ALIGN;
     if (a.bias && ((uintptr_t)a.bias & 15)) return OG_E_ALIGN;
     if (a.alpha && (!a.res || ((uintptr_t)a.alpha & 15))) return OG_E_INVALID;
-    if (a.Ct && (a.ct_rows <= 0 || a.batch > 1)) return OG_E_INVALID;
+    if (!(a.scale != 0.f) || !std::isfinite(a.scale)) return OG_E_INVALID;     // the bias enters the accumulators as bias / scale
+    if (a.Ct && ((!a.ct_rag && a.ct_rows <= 0) || a.batch > 1)) return OG_E_INVALID;
+    if (a.ct_rag && (!a.Ct || !a.rag || a.batch > 1 || a.ct_rag < 0 || a.ct_rag > 2)) return OG_E_INVALID;
     const int nz = a.batch > 1 ? a.batch : 1;
     if (nz > 1 && (a.Ch || a.res || a.res_hl || (a.strideA & 7) || (a.strideB & 7) || (a.strideC32 & 3))) return OG_E_INVALID;
     RaggedDesc rd;
     rd.B = 0;
     GemmHArgs g = a;
-    if (a.rag) { if (nz != a.rag->B) return OG_E_INVALID; rd = *a.rag; }
+    g.inv_scale = (float)(1.0 / (double)a.scale);
+    if (a.rag) { if (!a.ct_rag && nz != a.rag->B) return OG_E_INVALID; rd = *a.rag; }
     g.rag = nullptr;
     static const int force = [] { const char* e = getenv("OG_GEMM_TILE"); return e ? atoi(e) : 0; }();   // experiments: 128 / 256
     {   // large tiles when they still give (nearly) every CU a block

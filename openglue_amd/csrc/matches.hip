@@ -114,13 +114,22 @@ __global__ __launch_bounds__(256) void mutual_kernel(int M, int N, float thr, co
 
 // rows of the keypoint-encoder input: [2*x/(W-1)-1, 2*y/(H-1)-1, side_info..., 0 ... 0]  (32 floats/token)
 // reference: superglue.py:74-78 (normalize_keypoints), positional_encoding.py:18 (cat + transpose).
+// Ragged batches: every pair has its own image size (er.B > 0: pair b owns tokens er.off[b] .. er.off[b+1]).
 __global__ __launch_bounds__(256) void encoder_input_kernel(const float* __restrict__ kpts, const float* __restrict__ side,
                                                             int64_t tokens, int s, float wm1, float hm1,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out, EncoderRagged er) {
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t t = g >> 3;
     const int c4 = (int)(g & 7) * 4;
     if (t >= tokens) return;
+    if (er.B > 0) {
+        int lo = 0, hi = er.B - 1;               // last b with off[b] <= t
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (er.off[mid] <= (int)t) lo = mid; else hi = mid - 1;
+        }
+        wm1 = er.wm1[lo]; hm1 = er.hm1[lo];
+    }
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -169,10 +178,13 @@ extern "C" int og_extract_matches(const float* scores, int32_t batch, int32_t m,
 }
 
 int og_launch_encoder_input(const float* kpts, const float* side, int64_t tokens, int s, float wx, float wy,
-                            float* out, hipStream_t st) {
+                            float* out, hipStream_t st, const EncoderRagged* er) {
     if (!kpts || !out || tokens <= 0 || s < 0 || 2 + s > 32 || (s > 0 && !side)) return OG_E_INVALID;
     const int64_t threads = tokens * 8;
+    EncoderRagged e;
+    e.B = 0;
+    if (er) e = *er;
     hipLaunchKernelGGL(encoder_input_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, kpts, side, tokens,
-                       s, wx - 1.f, wy - 1.f, out);
+                       s, wx - 1.f, wy - 1.f, out, e);
     return og_launch_status();
 }

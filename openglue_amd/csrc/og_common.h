@@ -118,6 +118,7 @@ struct GemmHArgs {
     const _Float16* B; int64_t ldb;
     int M, N, K;
     float scale;                              // v = acc * scale + bias (undoes a power-of-two pre-scale of B)
+    float inv_scale;                          // set by the launcher: 1 / scale (the bias enters the accumulators as bias / scale)
     const float* bias; int relu;
     const float* res; int64_t ldr;            // fp32 residual [M][N] (may alias C32), or
     const _Float16* res_hl; int64_t ldrh;     //   split-f16 residual in hl32 rows (may alias Ch when c_hl): v += hi + lo
@@ -126,6 +127,8 @@ struct GemmHArgs {
     int c_hl;                                 //   1: hl32 rows (Cl == Ch + 32, ldch = row stride in halves)
     const float* alpha;                       // [N] or null: with res, v = alpha*v + (1-alpha)*res instead of v + res
     float* Ct; int64_t ldct; int ct_rows;     // optional channel-first fp32 copy: Ct[row / ct_rows][col][row % ct_rows] (ldct = ct_rows)
+    int ct_rag;                               //   ragged batch (with `rag`, batch <= 1): 1 = rows are image-0 tokens, 2 = image-1 tokens;
+                                              //   pair b's [N][rows_b] block starts at Ct + N * off[b] (packed, no padding)
     int batch;                                // 0/1: one problem; > 1: problems z = blockIdx.y with the strides below
     int64_t strideA, strideB, strideC32;      // elements (halves / floats) between consecutive problems
     const RaggedDesc* rag;                    // host pointer or null: batched problem z = pair z of a ragged batch
@@ -159,5 +162,11 @@ int og_launch_sinkhorn(const float* S, int64_t lds, const float* dustbin_dev /*o
 int og_launch_matches(const float* scores, int batch, int m, int n, float thr, int64_t* matches0,
                       float* ms0, int64_t* matches1, float* ms1, void* workspace, hipStream_t stream,
                       const RaggedDesc* rag = nullptr);
+// per-pair image sizes of a ragged batch (keypoint normalisation, superglue.py:74-78): pair b owns tokens off[b] .. off[b+1]
+struct EncoderRagged {
+    int B;                              // 0: uniform batch, one image size for every token
+    int off[OG_MAX_RAGGED + 1];
+    float wm1[OG_MAX_RAGGED], hm1[OG_MAX_RAGGED];   // W - 1, H - 1
+};
 int og_launch_encoder_input(const float* kpts, const float* side, int64_t tokens, int s, float wx, float wy,
-                            float* out /*[tokens][32]*/, hipStream_t stream);
+                            float* out /*[tokens][32]*/, hipStream_t stream, const EncoderRagged* er = nullptr);

@@ -29,23 +29,36 @@ class GraphedMatcher:
         for k in ("image0_size", "image1_size", "image0", "image1"):
             if k in example:
                 self.static_in[k] = example[k]
-        dev = self.static_in["keypoints0"].device
-        self.match_threshold, self.both_sides = match_threshold, both_sides
+        self.match_threshold, self.both_sides, self.warmup = match_threshold, both_sides, warmup
+        self._capture()
+
+    def _capture(self) -> None:
+        model, dev = self.model, self.static_in["keypoints0"].device
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):                 # warm-up outside the capture: packs weights, sizes the workspace
-            for _ in range(warmup):
-                model.match(self.static_in, match_threshold, both_sides=both_sides)
+            for _ in range(self.warmup):
+                model.match(self.static_in, self.match_threshold, both_sides=self.both_sides)
         torch.cuda.current_stream(dev).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.static_out = model.match(self.static_in, match_threshold, both_sides=both_sides)
+            self.static_out = model.match(self.static_in, self.match_threshold, both_sides=self.both_sides)
+        # The graph bakes in raw pointers to the packed weights and the workspace, which live in the MODEL's caches:
+        # keep our own references (a later model.match with another shape drops the model's workspace, a parameter
+        # update re-packs), and remember which parameter state the captured blob belongs to.
+        self._packed = model._packed
+        self._packed_key = model._packed_key
+        self._workspaces = list(model._workspace.values())
 
     @torch.no_grad()
     def __call__(self, data: Mapping) -> Dict[str, torch.Tensor]:
         for k in _KEYS:
             if data[k].shape != self.static_in[k].shape:
                 raise ValueError(f"GraphedMatcher was captured for {k} of shape {tuple(self.static_in[k].shape)}")
+        dev = self.static_in["keypoints0"].device
+        if self.model._param_key(dev) != self._packed_key:      # parameters changed since the capture: stale weights
+            self._capture()
+        for k in _KEYS:
             self.static_in[k].copy_(data[k], non_blocking=True)
         self.graph.replay()
         return self.static_out

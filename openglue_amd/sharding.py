@@ -71,16 +71,27 @@ def _ids_on(device: torch.device, pair_ids: Sequence[int]) -> torch.Tensor:
     return t
 
 
+def max_shard(shards: Sequence[Sequence[int]]) -> int:
+    """Rows every rank's gather payload is padded to: the LARGEST shard (cost-balanced shards are not bounded by
+    ceil(num_pairs / world): shard_pairs(4, 2, [10, 1, 1, 1]) = [[0], [1, 2, 3]])."""
+    return max((len(x) for x in shards), default=0)
+
+
 def gather_matches(local: Mapping[str, torch.Tensor], pair_ids: Sequence[int], num_pairs: int, dst: int = 0,
-                   group=None, always_collective: bool = False) -> Optional[Dict[str, torch.Tensor]]:
+                   group=None, always_collective: bool = False, cap: Optional[int] = None) -> Optional[Dict[str, torch.Tensor]]:
     """The one collective: every rank contributes matches0 [b, m] (int64) and matching_scores0 [b, m]
     (fp32) of its shard; rank `dst` returns them re-assembled in job order [num_pairs, m]; others None.
-    Shards are padded to the largest shard so a single fixed-size gather suffices.  Nothing here synchronises
-    the host with the device (no boolean-mask indexing, no per-call host-to-device copy): the collective and the
-    re-assembly are only enqueued behind the kernels that produced the matches."""
+    Shards are padded to `cap` rows = the largest shard of the job (max_shard(shard_pairs(...)), identical on every
+    rank), so a single fixed-size gather suffices; without `cap` the ranks agree on it with one all_reduce(MAX), which
+    synchronises the host -- steady-state callers pass it.  Otherwise nothing here synchronises the host with the device
+    (no boolean-mask indexing, no per-call host-to-device copy): the collective and the re-assembly are only enqueued
+    behind the kernels that produced the matches."""
     m0, s0 = local["matches0"], local["matching_scores0"]
     dev = m0.device
     width = m0.shape[1]
+    b = m0.shape[0]
+    if len(pair_ids) != b:
+        raise ValueError(f"{b} rows of matches for {len(pair_ids)} pair ids")
     if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not always_collective):
         order = _ids_on(dev, pair_ids)
         out_m = torch.full((num_pairs, width), -1, dtype=torch.int64, device=dev)
@@ -88,10 +99,14 @@ def gather_matches(local: Mapping[str, torch.Tensor], pair_ids: Sequence[int], n
         out_m[order], out_s[order] = m0, s0
         return {"matches0": out_m, "matching_scores0": out_s}
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    cap = (num_pairs + world - 1) // world
     if width >= (1 << 24) or num_pairs >= (1 << 24):
         raise ValueError("index does not fit the packed fp32 payload")
-    b = m0.shape[0]
+    if cap is None:
+        t = torch.tensor([b], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        cap = int(t.item())
+    if b > cap:          # would otherwise surface as a shape error on ONE rank while the others block in the collective
+        raise ValueError(f"rank {rank}: shard of {b} pairs exceeds the gather capacity {cap}; pass cap=max_shard(shards)")
     ids = _ids_on(dev, pair_ids)
     # one packed fp32 payload per rank: [cap, 1 + 2*width] = pair id | matches (exact in fp32 below 2^24) | scores;
     # padding rows carry pair id -1
@@ -124,11 +139,48 @@ def match_sharded(match_fn: Callable[[Mapping], Mapping[str, torch.Tensor]], dat
     full input `data` every rank can index, then gather the match lists on `dst`."""
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank(group) if world > 1 else 0
-    mine = shard_pairs(num_pairs, world, costs)[rank]
+    shards = shard_pairs(num_pairs, world, costs)
+    mine = shards[rank]
     local = match_fn(take_pairs(data, mine)) if mine else None
     if local is None:
         width = data["keypoints0"].shape[1]
         dev = data["keypoints0"].device
         local = {"matches0": torch.empty(0, width, dtype=torch.int64, device=dev),
                  "matching_scores0": torch.empty(0, width, dtype=torch.float32, device=dev)}
-    return gather_matches(local, mine, num_pairs, dst, group)
+    return gather_matches(local, mine, num_pairs, dst, group, cap=max_shard(shards))
+
+
+def pad_ragged_matches(results: Sequence[Mapping[str, torch.Tensor]], width: int) -> Dict[str, torch.Tensor]:
+    """Per-pair match lists of different lengths (SuperGlue.match_ragged) -> one [b, width] block, padded with -1 / 0:
+    the fixed-size payload the single gather needs."""
+    dev = results[0]["matches0"].device if results else torch.device("cpu")
+    m0 = torch.full((len(results), width), -1, dtype=torch.int64, device=dev)
+    s0 = torch.zeros((len(results), width), dtype=torch.float32, device=dev)
+    for i, r in enumerate(results):
+        k = r["matches0"].numel()
+        if k > width:
+            raise ValueError(f"pair with {k} keypoints does not fit the gather width {width}")
+        m0[i, :k] = r["matches0"]
+        s0[i, :k] = r["matching_scores0"]
+    return {"matches0": m0, "matching_scores0": s0}
+
+
+def match_sharded_ragged(match_list_fn: Callable[[Sequence[int]], Sequence[Mapping[str, torch.Tensor]]],
+                         lens: Sequence[Sequence[int]], costs: Optional[Sequence[float]] = None, dst: int = 0, group=None,
+                         always_collective: bool = False, device: Optional[torch.device] = None) -> Optional[Dict[str, torch.Tensor]]:
+    """Ragged job (BASELINE config 5): pair i has lens[i] = (m_i, n_i) keypoints.  Pairs are cost-balanced over the ranks
+    (LPT on `costs`, default pair_cost(m_i, n_i)), every rank runs `match_list_fn(its pair ids)` -> one result dict per
+    pair, and the match lists travel to `dst` in ONE gather, padded to the longest image-0 keypoint set of the JOB."""
+    num_pairs = len(lens)
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    if costs is None:
+        costs = [pair_cost(m, n) for m, n in lens]
+    shards = shard_pairs(num_pairs, world, costs)
+    mine = shards[rank]
+    width = max(m for m, _ in lens)
+    res = list(match_list_fn(mine)) if mine else []
+    local = pad_ragged_matches(res, width)
+    if not res and device is not None:
+        local = {k: v.to(device) for k, v in local.items()}
+    return gather_matches(local, mine, num_pairs, dst, group, always_collective=always_collective, cap=max_shard(shards))

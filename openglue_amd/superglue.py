@@ -112,6 +112,7 @@ class SuperGlue(nn.Module):
 
         self._packed: Optional[torch.Tensor] = None
         self._packed_key = None
+        self._tensor_cache = None
         self._workspace: Dict[tuple, torch.Tensor] = {}
 
     # ------------------------------------------------------------------ shape / packing
@@ -131,9 +132,41 @@ class SuperGlue(nn.Module):
         s.match_threshold = float(match_threshold)
         return s
 
+    def _tensors(self):
+        """Parameters and buffers, cached: walking the module tree (~250 tensors) on every call costs more than the
+        launch sequence of a single small pair.  Invalidated by _apply (.to/.cuda/.float) and load_state_dict; a caller
+        that REPLACES Parameter objects by hand calls invalidate_packed()."""
+        if self._tensor_cache is None:
+            self._tensor_cache = list(self.parameters()) + list(self.buffers())
+        return self._tensor_cache
+
+    def invalidate_packed(self) -> None:
+        self._tensor_cache = None
+        self._packed = None
+        self._packed_key = None
+
+    def _apply(self, fn, *a, **kw):
+        self.invalidate_packed()
+        return super()._apply(fn, *a, **kw)
+
+    def load_state_dict(self, *a, **kw):
+        self.invalidate_packed()
+        return super().load_state_dict(*a, **kw)
+
     def _param_key(self, device):
-        return (str(device),) + tuple((id(t), t._version, t.data_ptr())
-                                      for t in list(self.parameters()) + list(self.buffers()))
+        ts = self._tensors()
+        # in-place updates (optimizer steps, copy_) bump _version; moves re-create the tensors (_apply above)
+        return (str(device), ts[0].data_ptr()) + tuple(t._version for t in ts)
+
+    def _get_workspace(self, dev, key, nbytes: int) -> torch.Tensor:
+        """One live workspace (shapes rarely change between calls); re-used while it is large enough."""
+        wkey = (str(dev),) + tuple(key)
+        ws = self._workspace.get(wkey)
+        if ws is None or ws.numel() < nbytes:
+            self._workspace.clear()
+            ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+            self._workspace[wkey] = ws
+        return ws
 
     def _pack(self, device: torch.device) -> torch.Tensor:
         """Packed weights on `device`, cached until a parameter changes."""
@@ -190,7 +223,7 @@ class SuperGlue(nn.Module):
         return blob
 
     # ------------------------------------------------------------------ the hot path
-    def _run(self, data: Mapping, want_matches: bool, match_threshold: float, both_sides: bool) -> Dict[str, torch.Tensor]:
+    def _run(self, data: Mapping, want_matches: bool, match_threshold: float, both_sides: bool, _profile=None) -> Dict[str, torch.Tensor]:
         if self.training:
             raise RuntimeError("openglue_amd.SuperGlue implements the eval()/inference path only "
                                "(train-mode BatchNorm + backward is the next scope row, SURVEY.md §8 f2); call .eval()")
@@ -203,9 +236,15 @@ class SuperGlue(nn.Module):
                 raise RuntimeError(f"data['{k}'] must be a tensor on the MI355X; openglue_amd has no CPU fallback")
             t[k] = v.detach().to(torch.float32).contiguous()
         dev = t["keypoints0"].device
+        if t["keypoints0"].dim() != 3 or t["keypoints1"].dim() != 3:
+            raise ValueError("keypoints must be [B, n, 2]")
         B, m, _ = t["keypoints0"].shape
         n = t["keypoints1"].shape[1]
         D, s = self.descriptor_dim, self.side_info_size
+        if t["keypoints0"].shape != (B, m, 2) or t["keypoints1"].shape != (B, n, 2):
+            raise ValueError("keypoints0 / keypoints1 must be [B, m, 2] / [B, n, 2] with the same batch size")
+        if any(v.device != dev for v in t.values()):
+            raise ValueError("all input tensors must be on the same device")
         if t["local_descriptors0"].shape != (B, m, D) or t["local_descriptors1"].shape != (B, n, D):
             raise ValueError("local_descriptors must be [B, n, descriptor_dim]")
         if t["side_info0"].shape != (B, m, s) or t["side_info1"].shape != (B, n, s):
@@ -214,12 +253,7 @@ class SuperGlue(nn.Module):
         _lib.check(lib.og_check_shape(C.byref(shape)), "og_check_shape")
         with torch.cuda.device(dev):
             packed = self._pack(dev)
-            wkey = (str(dev), B, m, n)
-            ws = self._workspace.get(wkey)
-            if ws is None:
-                self._workspace.clear()          # one live workspace; shapes rarely change between calls
-                ws = torch.empty(lib.og_workspace_bytes(C.byref(shape)), device=dev, dtype=torch.uint8)
-                self._workspace[wkey] = ws
+            ws = self._get_workspace(dev, (B, m, n), lib.og_workspace_bytes(C.byref(shape)))
             out = {
                 "context_descriptors0": torch.empty(B, D, m, device=dev, dtype=torch.float32),
                 "context_descriptors1": torch.empty(B, D, n, device=dev, dtype=torch.float32),
@@ -239,57 +273,115 @@ class SuperGlue(nn.Module):
             ptr = lambda k: out[k].data_ptr() if k in out else None
             o = _lib.og_outputs(ptr("scores"), ptr("context_descriptors0"), ptr("context_descriptors1"),
                                 ptr("matches0"), ptr("matching_scores0"), ptr("matches1"), ptr("matching_scores1"))
-            rc = lib.og_forward(C.byref(shape), C.byref(inp), packed.data_ptr(), ws.data_ptr(), C.byref(o),
-                                torch.cuda.current_stream(dev).cuda_stream)
+            st = torch.cuda.current_stream(dev).cuda_stream
+            if _profile is None:
+                rc = lib.og_forward(C.byref(shape), C.byref(inp), packed.data_ptr(), ws.data_ptr(), C.byref(o), st)
+            else:      # bench.py: per-kernel-class HIP-event times (synchronises the stream)
+                rc = lib.og_forward_profiled(C.byref(shape), C.byref(inp), packed.data_ptr(), ws.data_ptr(), C.byref(o), st,
+                                             _profile[0], _profile[1])
             _lib.check(rc, "og_forward")
         return out
 
+    # ------------------------------------------------------------------ ragged batches (BASELINE config 5)
+    _RAGGED_KEYS = ("keypoints0", "keypoints1", "local_descriptors0", "local_descriptors1", "side_info0", "side_info1")
+
+    def pack_ragged(self, pairs) -> Dict[str, object]:
+        """Token-pack a list of UN-batched data dicts (keypoints0 [m_i, 2], local_descriptors0 [m_i, D], side_info0
+        [m_i, s], ... on the GPU, each with its own image0/image1 tensors or image{0,1}_size = [W, H]) into the layout
+        og_forward_ragged consumes: every tensor concatenated over the pairs without padding, plus the host-side
+        per-pair lengths and image sizes.  A caller that keeps its features packed can build this dict itself."""
+        if not pairs:
+            raise ValueError("pack_ragged: empty list of pairs")
+        D, s = self.descriptor_dim, self.side_info_size
+        dev = None
+        for i, p in enumerate(pairs):
+            for k in self._RAGGED_KEYS:
+                v = p[k]
+                if not isinstance(v, torch.Tensor) or not v.is_cuda:
+                    raise RuntimeError(f"pairs[{i}]['{k}'] must be a tensor on the MI355X; openglue_amd has no CPU fallback")
+                if dev is None:
+                    dev = v.device
+                if v.device != dev:
+                    raise ValueError(f"pairs[{i}]['{k}'] is on {v.device}, expected {dev}")
+            for side in (0, 1):
+                cnt = p[f"keypoints{side}"].shape[0]
+                if tuple(p[f"keypoints{side}"].shape) != (cnt, 2):
+                    raise ValueError(f"pairs[{i}]['keypoints{side}'] must be [n, 2]")
+                if tuple(p[f"local_descriptors{side}"].shape) != (cnt, D):
+                    raise ValueError(f"pairs[{i}]['local_descriptors{side}'] must be [{cnt}, {D}]")
+                if tuple(p[f"side_info{side}"].shape) != (cnt, s):
+                    raise ValueError(f"pairs[{i}]['side_info{side}'] must be [{cnt}, {s}]")
+        out: Dict[str, object] = {k: torch.cat([p[k].detach().to(torch.float32) for p in pairs], 0).contiguous()
+                                  for k in self._RAGGED_KEYS}
+        out["lens0"] = [int(p["keypoints0"].shape[0]) for p in pairs]
+        out["lens1"] = [int(p["keypoints1"].shape[0]) for p in pairs]
+        out["image0_wh"] = [_get_wh(p, 0) for p in pairs]         # every pair is normalised with ITS OWN image size
+        out["image1_wh"] = [_get_wh(p, 1) for p in pairs]
+        return out
+
     @torch.no_grad()
-    def match_ragged(self, pairs, match_threshold: float = 0.2, both_sides: bool = True) -> List[Dict[str, torch.Tensor]]:
-        """Ragged batch (BASELINE config 5): `pairs[i]` is an UN-batched data dict (keypoints0 [m_i, 2],
-        local_descriptors0 [m_i, D], side_info0 [m_i, s], ... on the GPU; image sizes taken from pairs[0]).  All pairs
-        go through ONE og_forward_ragged call on token-packed tensors (chunks of 64 pairs); the result of every pair
-        equals running it alone, which is the only semantics the mask-free reference defines.
-        Returns one dict per pair: 'scores' [m_i+1, n_i+1], 'matches0' [m_i], 'matching_scores0' [m_i] (+ side 1)."""
+    def match_ragged_packed(self, packed: Mapping, match_threshold: float = 0.2, both_sides: bool = True,
+                            context_descriptors: bool = False, _profile=None) -> List[Dict[str, torch.Tensor]]:
+        """One og_forward_ragged call per chunk of 64 pairs on token-packed tensors (see pack_ragged).
+        `_profile` (bench.py): a (c_float[OG_NUM_STAGES], c_int32[OG_NUM_STAGES]) pair -> og_forward_ragged_profiled
+        (synchronises; per-kernel-class HIP-event times of the LAST chunk)."""
         if self.training:
-            raise RuntimeError("openglue_amd.SuperGlue implements the eval()/inference path only; call .eval()")
+            raise RuntimeError("openglue_amd.SuperGlue: ragged batches are an inference path; call .eval()")
         lib = _lib.load()
+        l0_all, l1_all = list(packed["lens0"]), list(packed["lens1"])
+        P = len(l0_all)
+        if len(l1_all) != P or len(packed["image0_wh"]) != P or len(packed["image1_wh"]) != P:
+            raise ValueError("lens0, lens1, image0_wh, image1_wh must have one entry per pair")
+        D, s_ = self.descriptor_dim, self.side_info_size
+        t = {k: packed[k] for k in self._RAGGED_KEYS}
+        dev = t["keypoints0"].device
+        for side, lens in ((0, l0_all), (1, l1_all)):
+            tot = sum(lens)
+            for k, w in ((f"keypoints{side}", 2), (f"local_descriptors{side}", D), (f"side_info{side}", s_)):
+                v = t[k]
+                if not isinstance(v, torch.Tensor) or not v.is_cuda or v.device != dev or v.dtype != torch.float32 or not v.is_contiguous():
+                    raise RuntimeError(f"packed['{k}'] must be a contiguous fp32 tensor on {dev}")
+                if tuple(v.shape) != (tot, w):
+                    raise ValueError(f"packed['{k}'] must be [{tot}, {w}], got {tuple(v.shape)}")
         results: List[Dict[str, torch.Tensor]] = []
-        for c0 in range(0, len(pairs), _lib.OG_MAX_RAGGED):
-            chunk = pairs[c0:c0 + _lib.OG_MAX_RAGGED]
-            B = len(chunk)
-            names = ("keypoints0", "keypoints1", "local_descriptors0", "local_descriptors1", "side_info0", "side_info1")
-            for p in chunk:
-                for k in names:
-                    if not isinstance(p[k], torch.Tensor) or not p[k].is_cuda:
-                        raise RuntimeError(f"pairs[*]['{k}'] must be a tensor on the MI355X; openglue_amd has no CPU fallback")
-            t = {k: torch.cat([p[k].detach().to(torch.float32) for p in chunk], 0).contiguous() for k in names}
-            dev = t["keypoints0"].device
-            l0 = [int(p["keypoints0"].shape[0]) for p in chunk]
-            l1 = [int(p["keypoints1"].shape[0]) for p in chunk]
+        r0 = r1 = 0
+        for c0 in range(0, P, _lib.OG_MAX_RAGGED):
+            l0, l1 = l0_all[c0:c0 + _lib.OG_MAX_RAGGED], l1_all[c0:c0 + _lib.OG_MAX_RAGGED]
+            B = len(l0)
+            T0, T1 = sum(l0), sum(l1)
             shape = self._shape(B, max(l0), max(l1), match_threshold)
             _lib.check(lib.og_check_shape(C.byref(shape)), "og_check_shape")
             n_scores = sum((a + 1) * (b + 1) for a, b in zip(l0, l1))
             with torch.cuda.device(dev):
-                packed = self._pack(dev)
-                ws = torch.empty(lib.og_workspace_bytes(C.byref(shape)), device=dev, dtype=torch.uint8)
+                pk = self._pack(dev)
+                ws = self._get_workspace(dev, ("ragged", B, max(l0), max(l1)), lib.og_workspace_bytes(C.byref(shape)))
                 scores = torch.empty(n_scores, device=dev, dtype=torch.float32)
-                m0 = torch.empty(sum(l0), device=dev, dtype=torch.int64)
-                s0 = torch.empty(sum(l0), device=dev, dtype=torch.float32)
-                m1 = torch.empty(sum(l1), device=dev, dtype=torch.int64) if both_sides else None
-                s1 = torch.empty(sum(l1), device=dev, dtype=torch.float32) if both_sides else None
-                s_ = self.side_info_size
-                inp = _lib.og_inputs(t["keypoints0"].data_ptr(), t["keypoints1"].data_ptr(), t["local_descriptors0"].data_ptr(),
-                                     t["local_descriptors1"].data_ptr(), t["side_info0"].data_ptr() if s_ else None,
-                                     t["side_info1"].data_ptr() if s_ else None)
-                inp.image0_wh[0], inp.image0_wh[1] = _get_wh(chunk[0], 0)
-                inp.image1_wh[0], inp.image1_wh[1] = _get_wh(chunk[0], 1)
-                o = _lib.og_outputs(scores.data_ptr(), None, None, m0.data_ptr(), s0.data_ptr(),
+                m0 = torch.empty(T0, device=dev, dtype=torch.int64)
+                s0 = torch.empty(T0, device=dev, dtype=torch.float32)
+                m1 = torch.empty(T1, device=dev, dtype=torch.int64) if both_sides else None
+                s1 = torch.empty(T1, device=dev, dtype=torch.float32) if both_sides else None
+                c0d = torch.empty(T0 * D, device=dev, dtype=torch.float32) if context_descriptors else None
+                c1d = torch.empty(T1 * D, device=dev, dtype=torch.float32) if context_descriptors else None
+                sl = lambda k, a, b: t[k][a:b]                       # row slices of contiguous 2-D tensors stay contiguous
+                inp = _lib.og_inputs(sl("keypoints0", r0, r0 + T0).data_ptr(), sl("keypoints1", r1, r1 + T1).data_ptr(),
+                                     sl("local_descriptors0", r0, r0 + T0).data_ptr(), sl("local_descriptors1", r1, r1 + T1).data_ptr(),
+                                     sl("side_info0", r0, r0 + T0).data_ptr() if s_ else None,
+                                     sl("side_info1", r1, r1 + T1).data_ptr() if s_ else None)
+                wh0 = (C.c_float * (2 * B))(*[v for wh in packed["image0_wh"][c0:c0 + B] for v in wh])
+                wh1 = (C.c_float * (2 * B))(*[v for wh in packed["image1_wh"][c0:c0 + B] for v in wh])
+                inp.image0_wh[0], inp.image0_wh[1] = wh0[0], wh0[1]
+                inp.image1_wh[0], inp.image1_wh[1] = wh1[0], wh1[1]
+                o = _lib.og_outputs(scores.data_ptr(), c0d.data_ptr() if context_descriptors else None,
+                                    c1d.data_ptr() if context_descriptors else None, m0.data_ptr(), s0.data_ptr(),
                                     m1.data_ptr() if both_sides else None, s1.data_ptr() if both_sides else None)
                 a0 = (C.c_int32 * B)(*l0)
                 a1 = (C.c_int32 * B)(*l1)
-                rc = lib.og_forward_ragged(C.byref(shape), a0, a1, C.byref(inp), packed.data_ptr(), ws.data_ptr(), C.byref(o),
-                                           torch.cuda.current_stream(dev).cuda_stream)
+                st = torch.cuda.current_stream(dev).cuda_stream
+                if _profile is None:
+                    rc = lib.og_forward_ragged(C.byref(shape), a0, a1, wh0, wh1, C.byref(inp), pk.data_ptr(), ws.data_ptr(), C.byref(o), st)
+                else:
+                    rc = lib.og_forward_ragged_profiled(C.byref(shape), a0, a1, wh0, wh1, C.byref(inp), pk.data_ptr(), ws.data_ptr(),
+                                                        C.byref(o), st, _profile[0], _profile[1])
                 _lib.check(rc, "og_forward_ragged")
             so = o0 = o1 = 0
             for a, b in zip(l0, l1):
@@ -297,9 +389,24 @@ class SuperGlue(nn.Module):
                      "matching_scores0": s0[o0:o0 + a]}
                 if both_sides:
                     r["matches1"], r["matching_scores1"] = m1[o1:o1 + b], s1[o1:o1 + b]
+                if context_descriptors:       # channel-first [D, m_i] like the reference (superglue.py:68-72)
+                    r["context_descriptors0"] = c0d[o0 * D:(o0 + a) * D].view(D, a)
+                    r["context_descriptors1"] = c1d[o1 * D:(o1 + b) * D].view(D, b)
                 results.append(r)
                 so += (a + 1) * (b + 1); o0 += a; o1 += b
+            r0 += T0; r1 += T1
         return results
+
+    @torch.no_grad()
+    def match_ragged(self, pairs, match_threshold: float = 0.2, both_sides: bool = True,
+                     context_descriptors: bool = False) -> List[Dict[str, torch.Tensor]]:
+        """Ragged batch (BASELINE config 5): `pairs[i]` is an UN-batched data dict (keypoints0 [m_i, 2],
+        local_descriptors0 [m_i, D], side_info0 [m_i, s], ... on the GPU) with its own image sizes.  All pairs go through
+        og_forward_ragged on token-packed tensors (chunks of 64 pairs); the result of every pair equals running it
+        alone, which is the only semantics the mask-free reference defines.
+        Returns one dict per pair: 'scores' [m_i+1, n_i+1], 'matches0' [m_i], 'matching_scores0' [m_i] (+ side 1,
+        + 'context_descriptors{0,1}' [D, m_i] on request)."""
+        return self.match_ragged_packed(self.pack_ragged(pairs), match_threshold, both_sides, context_descriptors)
 
     @torch.no_grad()
     def forward(self, data: Mapping) -> Dict[str, torch.Tensor]:
@@ -307,7 +414,7 @@ class SuperGlue(nn.Module):
         return self._run(data, want_matches=False, match_threshold=0.0, both_sides=False)
 
     @torch.no_grad()
-    def match(self, data: Mapping, match_threshold: float = 0.2, both_sides: bool = True) -> Dict[str, torch.Tensor]:
+    def match(self, data: Mapping, match_threshold: float = 0.2, both_sides: bool = True, _profile=None) -> Dict[str, torch.Tensor]:
         """forward + mutual-NN extraction in one enqueue: adds 'matches0', 'matching_scores0'
         (matching_module.py:183-187) and, with both_sides, 'matches1', 'matching_scores1' (inference.py:183-188)."""
-        return self._run(data, want_matches=True, match_threshold=match_threshold, both_sides=both_sides)
+        return self._run(data, want_matches=True, match_threshold=match_threshold, both_sides=both_sides, _profile=_profile)

@@ -17,4 +17,6 @@ def gpu_device():
     import torch
     if not torch.cuda.is_available():
         pytest.fail("test marked gpu but no GPU is visible")
+    # the CPU oracle runs beside the GPU: torch's intra-op pool oversubscribes badly on the 256-thread GPU hosts
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
     return torch.device("cuda:0")

@@ -57,7 +57,7 @@ def test_state_dict_equals_live_reference():
     from models.superglue.superglue import SuperGlue as Ref
     cfg = syn.make_config(descriptor_dim=64, num_stages=2, num_heads=4, num_iters=3, side_info_size=6)
     a, b = Ref(cfg).state_dict(), SuperGlue(cfg).state_dict()
-    assert list(a.keys()).sort() == list(b.keys()).sort()
+    assert list(a.keys()) == list(b.keys())          # same names in the same registration order
     assert {k: tuple(v.shape) for k, v in a.items()} == {k: tuple(v.shape) for k, v in b.items()}
 
 
@@ -132,3 +132,53 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU / eager fallback"):
         _lib.load()
+
+
+def test_pack_rejects_weights_outside_the_f16_operand_range():
+    """a BatchNorm fold over a dead channel (running_var ~ 0) multiplies a weight by ~316*gamma; 256*w then
+    leaves binary16 and used to be packed as inf (NaN scores).  og_pack_weights must refuse with OG_E_RANGE."""
+    cfg = syn.make_config(descriptor_dim=64, num_stages=1, num_heads=4, num_iters=3)
+    model = SuperGlue(cfg).eval()
+    model.load_state_dict(syn.make_state_dict(cfg, seed=0), strict=True)
+    model.pack_host()                                           # fine as generated
+    bn = model.attention_gnn.layers[0].module.fc[2]
+    with torch.no_grad():
+        bn.running_var[5] = 0.0                                 # dead post-ReLU channel
+        bn.weight[5] = 4.0
+        model.attention_gnn.layers[0].module.fc[3].weight[:, 5, 0] = 0.9     # 0.9 * 4 / sqrt(1e-5) * 256 = 2.9e5 > 65504
+    with pytest.raises(RuntimeError, match="OG_E_RANGE"):
+        model.pack_host()
+    with torch.no_grad():
+        bn.running_var[5] = 1.0
+        model.linear_proj.weight[3, 3, 0] = float("nan")
+    with pytest.raises(RuntimeError, match="OG_E_RANGE"):
+        model.pack_host()
+
+
+def test_bench_self_spawns_one_process_per_gpu():
+    """`python bench.py --gpus 2` invoked directly (no torch.distributed environment) must run: it
+    re-executes itself under torch.distributed.run.  Dry run = gloo + stub matcher (no GPU here): checks the launch, the
+    rendezvous on 127.0.0.1, the cost-balanced ragged gather and that rank 0 prints ONE JSON line with n_gpus = 2."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OG_BENCH_DRYRUN"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["dry_run"] is True and out["gather_ok"] is True
+
+
+def test_input_validation_before_any_launch():
+    """mismatched batch / channel dims must raise in Python, not read out of bounds on the device."""
+    cfg = syn.make_config(descriptor_dim=64, num_stages=1, num_heads=4, num_iters=3)
+    model = SuperGlue(cfg).eval()
+    p = syn.make_pair(10, 12, 64, 1, seed=0)
+    p["image0_size"] = p["image1_size"] = list(syn.IMAGE_WH)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model.pack_ragged([p])
+    with pytest.raises(ValueError):
+        model.pack_ragged([])

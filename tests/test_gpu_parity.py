@@ -343,36 +343,6 @@ def test_full_size_c2_batch_properties(gpu_device):
         assert (s[p].cpu() - ref["scores"][0]).abs().max() < TOL_SCORES
 
 
-@pytest.mark.parametrize("cfg_name,B", [("C3", 2), ("C4", 1)])
-def test_larger_baseline_configs(gpu_device, cfg_name, B):
-    """BASELINE configs[2] (2048 kpts, 256-d) and configs[3] (4096 kpts, 128-d, 6 side-info channels) at
-    reduced batch: oracle spot check on one pair + size-independent properties."""
-    kw = dict(syn.CONFIGS[cfg_name])
-    (m, n), _ = kw.pop("kpts"), kw.pop("batch")
-    cfg = syn.make_config(**kw)
-    sd = syn.make_state_dict(cfg, seed=0)
-    model = _build(cfg, sd, gpu_device)
-    data = syn.make_batch(B, m, n, kw["descriptor_dim"], kw["side_info_size"], seed=21)
-    out = model.match(to_device(data, gpu_device), MATCH_THRESHOLD)
-    s = out["scores"]
-    assert s.shape == (B, m + 1, n + 1) and torch.isfinite(s).all()
-    norm = -math.log(m + n)
-    lb = torch.full((n + 1,), norm, dtype=torch.float64, device=s.device); lb[-1] += math.log(m)
-    assert (torch.logsumexp(s.double() + norm, dim=1) - lb).abs().max() < 1e-4       # column marginals exact
-    one = {k: (v[:1] if torch.is_tensor(v) else v) for k, v in data.items()}
-    with torch.no_grad():
-        ref = orc.match_pairs(sd, cfg, one, MATCH_THRESHOLD)
-    err = (s[0].cpu() - ref["scores"][0]).abs().max().item()
-    same = (out["matches0"][0].cpu() == ref["matches0"][0]).float().mean().item()
-    print(f"[{cfg_name}] scores err vs oracle {err:.2e}; matches0 identical on {same * 100:.2f}% rows; valid {int((ref['matches0'] >= 0).sum())}")
-    assert err < TOL_SCORES
-    if m <= 2048:       # the float64 oracle at 4096 keypoints takes minutes on the host: fp32 oracle only there
-        ndiff, unexplained, _ = _index_agreement(out["matches0"][:1].cpu(), s[:1].cpu(), sd, cfg, one)
-        assert unexplained == 0, (ndiff, unexplained)
-    else:
-        assert same > 0.999
-
-
 def test_ragged_packed_wide_range(gpu_device):
     """Packed ragged kernels on a spread of sizes that crosses the Sinkhorn / attention tile geometries
     (1..2 column parts, partial last key tile, m < 32), against the uniform path run per pair."""

@@ -27,6 +27,19 @@ def test_shard_pairs_uniform_and_balanced():
     assert max(load) <= max(naive)
 
 
+def test_cost_balanced_shards_can_exceed_the_even_split():
+    """LPT shards are not bounded by ceil(P / world); the gather capacity must be the real maximum."""
+    shards = sharding.shard_pairs(4, 2, [10, 1, 1, 1])
+    assert shards == [[0], [1, 2, 3]]
+    assert sharding.max_shard(shards) == 3 > (4 + 1) // 2
+    bad = 0
+    for seed in range(50):
+        lens = syn.ragged_lengths(24, 512, 2048, seed=seed)
+        sh = sharding.shard_pairs(24, 8, [sharding.pair_cost(m, n) for m, n in lens])
+        bad += sharding.max_shard(sh) > 3
+    assert bad > 0           # the situation the old fixed capacity crashed on really occurs with BASELINE config 5 lengths
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -75,3 +88,67 @@ def test_single_process_gather_is_a_reorder():
     s0 = torch.tensor([[0.5, 0.0], [0.9, 0.3]])
     out = sharding.gather_matches({"matches0": m0, "matching_scores0": s0}, [2, 0], 3)
     assert out["matches0"].tolist() == [[0, 1], [-1, -1], [1, -1]]
+
+
+def _ragged_job():
+    lens = [(61, 40), (9, 12), (11, 10), (8, 9), (10, 7)]
+    costs = [10.0, 1.0, 1.0, 1.0, 1.0]          # skewed: rank 0 gets one pair, rank 1 four (> ceil(5 / 2))
+    cfg = syn.make_config(descriptor_dim=64, num_stages=1, num_heads=4, num_iters=5)
+    sd = syn.make_state_dict(cfg, 0)
+    pairs = []
+    for i, (m, n) in enumerate(lens):
+        p = syn.make_pair(m, n, 64, 1, seed=50 + i)
+        p["image0_size"] = list(syn.IMAGE_WH); p["image1_size"] = list(syn.IMAGE_WH)
+        pairs.append(p)
+    def run(ids):
+        out = []
+        for i in ids:
+            one = {k: (v[None] if torch.is_tensor(v) else v) for k, v in pairs[i].items()}
+            r = orc.match_pairs(sd, cfg, one, MATCH_THRESHOLD)
+            out.append({"matches0": r["matches0"][0], "matching_scores0": r["matching_scores0"][0]})
+        return out
+    return lens, costs, run
+
+
+def _ragged_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    lens, costs, run = _ragged_job()
+    assert [len(x) for x in sharding.shard_pairs(len(lens), world, costs)] == [1, 4]
+    got = sharding.match_sharded_ragged(run, lens, costs)
+    if rank == 0:
+        q.put({k: v.clone() for k, v in got.items()})
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ragged_cost_balanced_gather_gloo_world2():
+    """The ragged, cost-balanced gather of bench.py --config C5 with UNEVEN shards (1 and 4 pairs)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    lens, costs, run = _ragged_job()
+    want = run(range(len(lens)))
+    assert got["matches0"].shape == (len(lens), 61)
+    for i, (m, _n) in enumerate(lens):
+        assert torch.equal(got["matches0"][i, :m], want[i]["matches0"])
+        assert (got["matches0"][i, m:] == -1).all()
+        assert torch.allclose(got["matching_scores0"][i, :m], want[i]["matching_scores0"], atol=1e-6)
+
+
+def test_gather_validates_its_arguments():
+    m0 = torch.zeros(3, 4, dtype=torch.int64); s0 = torch.zeros(3, 4)
+    with pytest.raises(ValueError, match="pair ids"):
+        sharding.gather_matches({"matches0": m0, "matching_scores0": s0}, [0, 1], 3)
+    with pytest.raises(ValueError, match="does not fit"):
+        sharding.pad_ragged_matches([{"matches0": torch.zeros(9, dtype=torch.int64), "matching_scores0": torch.zeros(9)}], 8)
