@@ -235,6 +235,14 @@ size_t og_sinkhorn_workspace_bytes(int32_t batch, int32_t m, int32_t n);
 int og_sinkhorn(const float* S, int64_t lds, float dustbin, int32_t batch, int32_t m, int32_t n,
                 int32_t iters, float reg, float* scores, void* workspace_dev, void* stream);
 
+/* Diagnostics (synchronises the device, copies 4 bytes): state of the last og_sinkhorn / og_forward Sinkhorn stage that ran on
+ * this Sinkhorn workspace.  0 = completed (or the streaming kernels were used); 1 = a cross-workgroup wait of the
+ * on-chip-resident iteration kernel timed out and the scores are invalid (cannot happen while batch * ceil(m/128)
+ * workgroups are co-resident, which the launcher checks against the CU count); -1 = bad arguments.
+ * When the batch fits (batch * ceil(m/128) <= #CUs, n <= 1024, >= 16 MB of scores; OG_SINKHORN_RESIDENT=0 disables, =2 drops
+ * the size threshold) iterations 2..iters run in ONE launch with the score matrices held in registers + LDS. */
+int og_sinkhorn_status(const void* sinkhorn_workspace_dev, int32_t batch, int32_t m, int32_t n);
+
 /* mutual-NN match extraction from a scores tensor [B][m+1][n+1] (matching_module.py:174-187;
  * matches1/matching_scores1 as inference.py:183-188, may be NULL).  First maximal index wins.
  * workspace: og_matches_workspace_bytes. */

@@ -62,8 +62,8 @@ __device__ unsigned og_attn_trace_buf[2][4][16][8];
 #define OG_TP(i) do {} while (0)
 #endif
 
-template <int DH>
-__global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a, RaggedDesc rd) {
+template <int DH, class RD>
+__global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a, RD rd) {
     constexpr int DHP = DH < 32 ? 32 : DH;        // Vᵀ rows padded to a full 32-row MFMA tile
     constexpr int NDV = DHP / 32;                 // output row blocks
     constexpr int NCH = DH / 16;                  // 16-wide k chunks of the QKᵀ contraction
@@ -425,11 +425,20 @@ int og_launch_attention(const AttnArgs& a, hipStream_t stream) {
     a2.rag = nullptr;
     const int groups8 = (a.nz * a.num_heads + 7) / 8 * 8;
     dim3 grid(groups8 * a2.qtiles), block(256);
-    switch (a.dh) {
-        case 16: hipLaunchKernelGGL(attention_kernel<16>, grid, block, 0, stream, a2, rd); break;
-        case 32: hipLaunchKernelGGL(attention_kernel<32>, grid, block, 0, stream, a2, rd); break;
-        case 64: hipLaunchKernelGGL(attention_kernel<64>, grid, block, 0, stream, a2, rd); break;
-        default: return OG_E_SHAPE;
+    if (a.rag) {
+        switch (a.dh) {
+            case 16: hipLaunchKernelGGL((attention_kernel<16, RaggedDesc>), grid, block, 0, stream, a2, rd); break;
+            case 32: hipLaunchKernelGGL((attention_kernel<32, RaggedDesc>), grid, block, 0, stream, a2, rd); break;
+            case 64: hipLaunchKernelGGL((attention_kernel<64, RaggedDesc>), grid, block, 0, stream, a2, rd); break;
+            default: return OG_E_SHAPE;
+        }
+    } else {          // uniform batch: no descriptor in the kernarg segment (og_common.h: RaggedNone)
+        switch (a.dh) {
+            case 16: hipLaunchKernelGGL((attention_kernel<16, RaggedNone>), grid, block, 0, stream, a2, RaggedNone{}); break;
+            case 32: hipLaunchKernelGGL((attention_kernel<32, RaggedNone>), grid, block, 0, stream, a2, RaggedNone{}); break;
+            case 64: hipLaunchKernelGGL((attention_kernel<64, RaggedNone>), grid, block, 0, stream, a2, RaggedNone{}); break;
+            default: return OG_E_SHAPE;
+        }
     }
     return og_launch_status();
 }

@@ -167,9 +167,9 @@ __device__ __forceinline__ void gemm_f16x3_epilogue_finish(const GemmHArgs& g, f
 }
 
 // ... and its stores (a = the finished values of the slice)
-template <int TI, bool FULL>
+template <int TI, bool FULL, class RD>
 __device__ __forceinline__ void gemm_f16x3_epilogue_store(const GemmHArgs& g, f32x16 (&a)[TI], int tok0, int oc0, int lane, char* slab,
-                                                          const RaggedDesc& rd) {
+                                                          const RD& rd) {
 #pragma clang fp contract(off)                  // og_split: hi and lo must see the same rounded value (og_common.h)
     constexpr int OCW = TI * 32;                // channels of a wave tile
     const int l31 = lane & 31, hi = lane >> 5;
@@ -278,6 +278,39 @@ __device__ __forceinline__ void gemm_f16x3_epilogue_store(const GemmHArgs& g, f3
     }
 }
 
+// Experiment builds only (scripts/build_ablation.sh gemm_trace -DOG_GEMM_TRACE=1): shader-cycle stamps of every wave of every
+// block of the 256-tile kernel at the stage hand-overs (read back by og_debug_gemm_trace, scripts/trace_gemm.py).  The stamps
+// sit where the LDS queue is already drained; they cost an SMEM round trip each (compare the traced build's time first).
+#ifndef OG_GEMM_TRACE
+#define OG_GEMM_TRACE 0
+#endif
+#if OG_GEMM_TRACE
+constexpr int OG_GT_BLOCKS = 1024, OG_GT_WORDS = 64;
+__device__ unsigned og_gemm_trace_buf[OG_GT_BLOCKS][8][OG_GT_WORDS];
+// stamp i of this wave lives in lane i of ONE VGPR (v_writelane): no LDS, no VMEM while the kernel runs
+#define OG_GT_PUT(idx_, val_) do { gt_v = lane == (int)(idx_) ? (int)(val_) : gt_v; } while (0)
+#define OG_GT(i)                                                                                             \
+    do {                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        const unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime();                                          \
+        if ((i) < OG_GT_WORDS) OG_GT_PUT((i), t_);                                                           \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+    } while (0)
+#define OG_GT_FLUSH(nk_)                                                                                     \
+    do {                                                                                                     \
+        OG_GT_PUT(0, blockIdx.x);                                                                            \
+        OG_GT_PUT(1, __builtin_amdgcn_s_getreg(0xF804));                                                     \
+        OG_GT_PUT(2, __builtin_amdgcn_s_getreg(0xF814));                                                     \
+        OG_GT_PUT(3, gt_rt0);                                                                                \
+        OG_GT_PUT(4, (unsigned)__builtin_amdgcn_s_memrealtime());                                            \
+        OG_GT_PUT(5, (nk_));                                                                                 \
+        if (blockIdx.y == 0 && blockIdx.x < OG_GT_BLOCKS) og_gemm_trace_buf[blockIdx.x][wave][lane] = (unsigned)gt_v;   \
+    } while (0)
+#else
+#define OG_GT(i) do {} while (0)
+#endif
+
 // Operands reach LDS by LDS-DMA (global_load_lds, 16 B per lane, no staging registers) into a 2-deep ring; two
 // blocks per CU.  A stage is one 32-channel k-slab: in the hl32 row format (og_common.h) that is ONE full
 // 128-byte line per row (64 B hi + 64 B lo).  [Measured on MI355X, scripts/probes/l2_bandwidth.hip: fetching
@@ -290,8 +323,8 @@ __device__ __forceinline__ void gemm_f16x3_epilogue_store(const GemmHArgs& g, f3
 typedef __attribute__((address_space(3))) void og_lds_void;
 typedef __attribute__((address_space(1))) const void og_glb_void;
 
-template <int OC, int NS>
-__global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void gemm_nt_f16x3_kernel(GemmHArgs g, int tiles_m, int tiles_n, RaggedDesc rd) {
+template <int OC, int NS, class RD>
+__global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void gemm_nt_f16x3_kernel(GemmHArgs g, int tiles_m, int tiles_n, RD rd) {
     constexpr int TI = OC / 64;                // MFMA tiles per wave along channels
     constexpr int XB = TOK * 128;              // bytes of the token tile per stage (hi|lo rows)
     constexpr int WB = OC * 128;
@@ -444,7 +477,8 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void gemm_nt_f16x3_kernel(G
 // of the one-stage-ahead LDS-DMA prefetch.
 constexpr int BIG = 256;
 
-__global__ __launch_bounds__(512) void gemm_nt_f16x3_big_kernel(GemmHArgs g, int tiles_m, int tiles_n, RaggedDesc rd) {
+template <class RD>
+__global__ __launch_bounds__(512) void gemm_nt_f16x3_big_kernel(GemmHArgs g, int tiles_m, int tiles_n, RD rd) {
     constexpr int NS = 2;
     constexpr int XB = BIG * 128;              // bytes of the token tile per stage
     constexpr int STAGE = 2 * XB;              // token tile + weight tile
@@ -474,6 +508,11 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_big_kernel(GemmHArgs g, int
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wt = wave >> 2, wo = wave & 3;
+#if OG_GEMM_TRACE
+    int gt_v = 0;
+    const unsigned gt_rt0 = (unsigned)__builtin_amdgcn_s_memrealtime();
+    OG_GT(6);
+#endif
     const int l31 = lane & 31, hi = lane >> 5;
 
     // ---- DMA pieces (1 KiB = 8 rows x 128 B): wave w fills rows [32w, 32w+32) of the token tile and of the W tile ----
@@ -546,6 +585,7 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_big_kernel(GemmHArgs g, int
     gemm_f16x3_acc_init<2, 4>(g, acc, n0 + wo * 64, lane);     // bias / scale, in the shadow of the first DMA
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    OG_GT(7);
     if (nk > 1) issue_stage(1);
     read_x(lds0, 0, 0, 0);
     read_w(lds0, 0, 0);
@@ -566,9 +606,12 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_big_kernel(GemmHArgs g, int
             } else {
                 wait_frags(ks & 1, grp & 1, 0);                                // all my reads of stage kt are done
                 if (kt + 1 < nk) {
+                    OG_GT(8 + 3 * kt);
                     // (the "memory" clobber also pins the LDS-DMA issue below behind the volatile fragment reads above)
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // my DMA pieces of stage kt+1 landed
+                    OG_GT(9 + 3 * kt);
                     __builtin_amdgcn_s_barrier();
+                    OG_GT(10 + 3 * kt);
                     if (kt + 2 < nk && !(OG_GEMM_ABL & 8)) issue_stage(kt + 2);   // overwrites the slot of stage kt
                     if (!(OG_GEMM_ABL & 16)) { read_x(sbn, 0, 0, 0); read_w(sbn, 0, 0); }
                 }
@@ -589,6 +632,10 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_big_kernel(GemmHArgs g, int
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if OG_GEMM_TRACE
+    const int gt_e = 8 + 3 * (nk - 1);
+    OG_GT(gt_e);
+#endif
 
     __builtin_amdgcn_s_barrier();      // the ring is free: per-wave epilogue slabs
     {
@@ -607,6 +654,202 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_big_kernel(GemmHArgs g, int
             gemm_f16x3_epilogue_store<2, false>(g, a, tok0 + j * 32, oc0, lane, slab, rd);
         }
     }
+#if OG_GEMM_TRACE
+    OG_GT(gt_e + 1);                                   // all stores issued (not necessarily complete)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    OG_GT(gt_e + 2);                                   // all stores acknowledged
+    OG_GT_FLUSH(nk);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 256 x 256 tile, second generation.  What the per-wave cycle trace of the kernel above showed at C2
+// (scripts/trace_gemm.py, profiles/r02_gemm_trace_*.log): a k-stage takes ~4650 cycles against 3072 of matrix-pipe
+// time, and the gap is the stage hand-over -- every wave meets at the barrier and then issues its 8 LDS-DMA pieces
+// (60-185 cycles of issue each, MI355X_MICROARCH.md) back to back while the matrix pipe of all four SIMDs runs dry; the
+// DMA itself is never waited for (156 cycles = the stamp).  Here
+//   * the DMA pieces of the NEXT stages are issued two at a time behind the first MFMAs of groups 0-3 of a stage, in
+//     the shadow of the matrix pipe; the hand-over is wait + barrier + first fragment reads only;
+//   * the token operand (HBM / Infinity Cache, long latency) has a 3-slot ring and is fetched TWO stages ahead, the
+//     weight operand (L2-resident) a 2-slot ring, one stage ahead: 3 x 32 KB + 2 x 32 KB = the whole 160 KB LDS.
+//     Counted waits: LDS-DMA completes in issue order, every stage issues W(kt+1) first and X(kt+2) second, so at the
+//     end of stage kt `s_waitcnt vmcnt(4)` = "everything but the four X(kt+2) pieces has landed" = X(kt+1), W(kt+1).
+// One problem per launch (no batch, no ragged descriptor): the per-pair score GEMM stays on the kernel above.
+__global__ __launch_bounds__(512) void gemm_nt_f16x3_big2_kernel(GemmHArgs g, int tiles_m, int tiles_n) {
+    constexpr int XS = BIG * 128;              // one stage of one operand: 256 rows x 128 B (hi 64 B | lo 64 B)
+    constexpr int WOFF = 3 * XS;
+    __shared__ __attribute__((aligned(16))) char smem[5 * XS];
+    static_assert(5 * XS == 163840 && 5 * XS >= 8 * EPI_SLAB, "the rings take the whole LDS; the epilogue slabs alias them");
+
+    const int id = blockIdx.x;
+    const int xcd = id & 7, local = id >> 3;
+    const int tm = (local / tiles_n) * 8 + xcd;       // all channel tiles of a token tile on one XCD
+    const int tn = local % tiles_n;
+    if (tm >= tiles_m) return;
+    const int t0 = tm * BIG, n0 = tn * BIG;
+    if (t0 >= g.M || n0 >= g.N) return;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wt = wave >> 2, wo = wave & 3;
+#if OG_GEMM_TRACE
+    int gt_v = 0;
+    const unsigned gt_rt0 = (unsigned)__builtin_amdgcn_s_memrealtime();
+    OG_GT(6);
+#endif
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    // ---- DMA pieces (1 KiB = 8 rows x 128 B): wave w fills rows [32w, 32w+32) of the token tile and of the W tile ----
+    const char* src[8];
+    {
+        const int rl = lane >> 3, pc = lane & 7;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int rt = wave * 32 + h * 8 + rl;
+            const int sw = (pc ^ ((rt >> 1) & 7)) * 16;
+            int row = t0 + rt; if (row >= g.M) row = g.M - 1;
+            src[h] = reinterpret_cast<const char*>(g.A + (int64_t)row * g.lda) + sw;
+            row = n0 + rt; if (row >= g.N) row = g.N - 1;
+            src[4 + h] = reinterpret_cast<const char*>(g.B + (int64_t)row * g.ldb) + sw;
+        }
+    }
+    // piece h of the token / weight operand of stage kt
+    auto issue_x = [&](int kt, int h) {
+        __builtin_amdgcn_global_load_lds((og_glb_void*)(src[h] + (int64_t)kt * 128),
+                                         (og_lds_void*)(smem + (kt % 3) * XS + (wave * 32 + h * 8) * 128), 16, 0, 0);
+    };
+    auto issue_w = [&](int kt, int h) {
+        __builtin_amdgcn_global_load_lds((og_glb_void*)(src[4 + h] + (int64_t)kt * 128),
+                                         (og_lds_void*)(smem + WOFF + (kt & 1) * XS + (wave * 32 + h * 8) * 128), 16, 0, 0);
+    };
+
+    f32x16 acc[2][4];
+    const int swz = (l31 >> 1) & 7;
+    const int x_row = (wt * 128 + l31) * 128;
+    const int w_row = (wo * 64 + l31) * 128;
+
+    // fragment pipeline as in the kernel above (hand-counted lgkmcnt: LDS-DMA does not touch that counter)
+    f16x8 wh[2][2], wl[2][2], xh[2], xl[2];
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    auto lds_read = [&](f16x8& dst, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr)); };
+    auto read_w = [&](unsigned wb, int ks, int buf) {
+        const unsigned a = wb + w_row + (((2 * ks + hi) ^ swz) * 16);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            lds_read(wh[buf][i], a + i * 32 * 128);
+            lds_read(wl[buf][i], (a + i * 32 * 128) ^ 64);
+        }
+    };
+    auto read_x = [&](unsigned xb, int ks, int j, int buf) {
+        const unsigned a = xb + x_row + j * 32 * 128 + (((2 * ks + hi) ^ swz) * 16);
+        lds_read(xh[buf], a);
+        lds_read(xl[buf], a ^ 64);
+    };
+    auto wait_frags = [&](int wb, int xb, int newer) {
+        if (newer == 0)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wh[wb][0]), "+v"(wl[wb][0]), "+v"(wh[wb][1]), "+v"(wl[wb][1]), "+v"(xh[xb]), "+v"(xl[xb]));
+        else if (newer == 2)
+            asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(wh[wb][0]), "+v"(wl[wb][0]), "+v"(wh[wb][1]), "+v"(wl[wb][1]), "+v"(xh[xb]), "+v"(xl[xb]));
+        else
+            asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(wh[wb][0]), "+v"(wl[wb][0]), "+v"(wh[wb][1]), "+v"(wl[wb][1]), "+v"(xh[xb]), "+v"(xl[xb]));
+    };
+
+    const int nk = g.K / BKH;
+    // prologue: X(0), W(0), X(1); the bias (acc init) in their shadow
+#pragma unroll
+    for (int h = 0; h < 4; ++h) issue_x(0, h);
+#pragma unroll
+    for (int h = 0; h < 4; ++h) issue_w(0, h);
+    if (nk > 1) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) issue_x(1, h);
+    }
+    gemm_f16x3_acc_init<2, 4>(g, acc, n0 + wo * 64, lane);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // X(0), W(0) landed; X(1) may still fly
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    OG_GT(7);
+    read_x(lds0, 0, 0, 0);
+    read_w(lds0 + WOFF, 0, 0);
+    int xs = 0;                                     // kt % 3
+    for (int kt = 0; kt < nk; ++kt) {
+        const unsigned xb = lds0 + xs * XS, wb = lds0 + WOFF + (kt & 1) * XS;
+        const int xs1 = xs == 2 ? 0 : xs + 1;
+        const unsigned xbn = lds0 + xs1 * XS, wbn = lds0 + WOFF + ((kt + 1) & 1) * XS;
+        const bool iw = kt + 1 < nk, ix = kt + 2 < nk;      // W(kt+1) / X(kt+2) exist
+#pragma unroll
+        for (int grp = 0; grp < 8; ++grp) {
+            const int ks = grp >> 2, j = grp & 3;
+            if (grp < 7) {
+                const int ks1 = (grp + 1) >> 2, j1 = (grp + 1) & 3;
+                read_x(xb, ks1, j1, (grp + 1) & 1);
+                if (j1 == 0) read_w(wb, ks1, ks1 & 1);
+                wait_frags(ks & 1, grp & 1, j1 == 0 ? 6 : 2);
+            } else {
+                wait_frags(ks & 1, grp & 1, 0);                                // all my reads of stage kt are done
+                if (iw) {
+                    OG_GT(8 + 3 * kt);
+                    // my pieces of X(kt+1), W(kt+1) landed (everything but the four newest = X(kt+2))
+                    if (ix) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    OG_GT(9 + 3 * kt);
+                    __builtin_amdgcn_s_barrier();
+                    OG_GT(10 + 3 * kt);
+                    read_x(xbn, 0, 0, 0);
+                    read_w(wbn, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // pass-major: consecutive MFMAs write different accumulators
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks & 1][0], xh[grp & 1], acc[0][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks & 1][1], xh[grp & 1], acc[1][j], 0, 0, 0);
+            if (grp < 4) {
+                // two DMA pieces in the shadow of the matrix pipe: W(kt+1) in groups 0-1 (its slot held W(kt-1): free since
+                // the barrier that ended stage kt-1), then X(kt+2) in groups 2-3 (its slot held X(kt-1))
+                __builtin_amdgcn_sched_barrier(0);
+                if (grp < 2) {
+                    if (iw) { issue_w(kt + 1, 2 * grp); issue_w(kt + 1, 2 * grp + 1); }
+                } else {
+                    if (ix) { issue_x(kt + 2, 2 * (grp - 2)); issue_x(kt + 2, 2 * (grp - 2) + 1); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks & 1][0], xl[grp & 1], acc[0][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks & 1][1], xl[grp & 1], acc[1][j], 0, 0, 0);
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks & 1][0], xh[grp & 1], acc[0][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks & 1][1], xh[grp & 1], acc[1][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        xs = xs1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if OG_GEMM_TRACE
+    const int gt_e = 8 + 3 * (nk - 1);
+    OG_GT(gt_e);
+#endif
+
+    __builtin_amdgcn_s_barrier();      // every wave is past its last fragment reads, no DMA is in flight: the rings are free
+    {
+        og_u32x4 raw[2][4];
+        const int tok0 = t0 + wt * 128, oc0 = n0 + wo * 64;
+        char* slab = smem + wave * EPI_SLAB;
+        const RaggedNone no_rd{};                   // FULL = false: the channel-first copy (the only user of the descriptor) is compiled out
+        gemm_f16x3_load_residual<2>(g, raw, tok0, oc0, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x16 a[2];
+            a[0] = acc[0][j]; a[1] = acc[1][j];
+            gemm_f16x3_epilogue_finish<2, false>(g, a, raw, oc0, lane);
+            if (j + 1 < 4) gemm_f16x3_load_residual<2>(g, raw, tok0 + (j + 1) * 32, oc0, lane);
+            gemm_f16x3_epilogue_store<2, false>(g, a, tok0 + j * 32, oc0, lane, slab, no_rd);
+        }
+    }
+#if OG_GEMM_TRACE
+    OG_GT(gt_e + 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    OG_GT(gt_e + 2);
+    OG_GT_FLUSH(nk);
+#endif
 }
 
 // x -> (hi, lo) planes, elementwise (test helper and weight/activation conversion outside the GEMMs)
@@ -669,31 +912,39 @@ int og_launch_gemm_f16x3(const GemmHArgs& a, hipStream_t stream) {
     if (a.ct_rag && (!a.Ct || !a.rag || a.batch > 1 || a.ct_rag < 0 || a.ct_rag > 2)) return OG_E_INVALID;
     const int nz = a.batch > 1 ? a.batch : 1;
     if (nz > 1 && (a.Ch || a.res || a.res_hl || (a.strideA & 7) || (a.strideB & 7) || (a.strideC32 & 3))) return OG_E_INVALID;
-    RaggedDesc rd;
-    rd.B = 0;
     GemmHArgs g = a;
     g.inv_scale = (float)(1.0 / (double)a.scale);
-    if (a.rag) { if (!a.ct_rag && nz != a.rag->B) return OG_E_INVALID; rd = *a.rag; }
+    if (a.rag && !a.ct_rag && nz != a.rag->B) return OG_E_INVALID;
     g.rag = nullptr;
     static const int force = [] { const char* e = getenv("OG_GEMM_TILE"); return e ? atoi(e) : 0; }();   // experiments: 128 / 256
-    {   // large tiles when they still give (nearly) every CU a block
-        const int tiles_m = (a.M + BIG - 1) / BIG, tiles_n = (a.N + BIG - 1) / BIG;
-        const bool fits = (a.N % BIG == 0 || nz > 1) && (int64_t)tiles_m * tiles_n * nz >= 192 && !a.alpha && !a.Ct;
-        if (force == 256 ? (a.N >= BIG && !a.alpha && !a.Ct) : (fits && force != 128)) {
-            const int tiles_m8 = (tiles_m + 7) / 8 * 8;
-            hipLaunchKernelGGL(gemm_nt_f16x3_big_kernel, dim3(tiles_m8 * tiles_n, nz), dim3(512), 0, stream, g, tiles_m, tiles_n, rd);
-            return og_launch_status();
+    // The per-pair descriptor travels by value in the kernarg segment ONLY for ragged launches (og_common.h: RaggedNone).
+    auto launch = [&](auto rd) -> int {
+        using RD = decltype(rd);
+        {   // large tiles when they still give (nearly) every CU a block
+            const int tiles_m = (a.M + BIG - 1) / BIG, tiles_n = (a.N + BIG - 1) / BIG;
+            const bool fits = (a.N % BIG == 0 || nz > 1) && (int64_t)tiles_m * tiles_n * nz >= 192 && !a.alpha && !a.Ct;
+            if (force == 256 ? (a.N >= BIG && !a.alpha && !a.Ct) : (fits && force != 128)) {
+                const int tiles_m8 = (tiles_m + 7) / 8 * 8;
+                static const bool big2 = [] { const char* e = getenv("OG_GEMM_BIG2"); return !e || atoi(e) != 0; }();   // experiments: 0 = first generation
+                if (big2 && nz == 1 && !a.rag) {
+                    hipLaunchKernelGGL(gemm_nt_f16x3_big2_kernel, dim3(tiles_m8 * tiles_n), dim3(512), 0, stream, g, tiles_m, tiles_n);
+                    return og_launch_status();
+                }
+                hipLaunchKernelGGL(gemm_nt_f16x3_big_kernel<RD>, dim3(tiles_m8 * tiles_n, nz), dim3(512), 0, stream, g, tiles_m, tiles_n, rd);
+                return og_launch_status();
+            }
         }
-    }
-    const int tiles_m = (a.M + TOK - 1) / TOK;
-    const int tiles_m8 = (tiles_m + 7) / 8 * 8;
-    if (a.N > 64) {
-        const int tiles_n = (a.N + 127) / 128;
-        hipLaunchKernelGGL((gemm_nt_f16x3_kernel<128, 2>), dim3(tiles_m8 * tiles_n, nz), dim3(256), 0, stream, g, tiles_m, tiles_n, rd);
-    } else {
-        hipLaunchKernelGGL((gemm_nt_f16x3_kernel<64, 2>), dim3(tiles_m8, nz), dim3(256), 0, stream, g, tiles_m, 1, rd);
-    }
-    return og_launch_status();
+        const int tiles_m = (a.M + TOK - 1) / TOK;
+        const int tiles_m8 = (tiles_m + 7) / 8 * 8;
+        if (a.N > 64) {
+            const int tiles_n = (a.N + 127) / 128;
+            hipLaunchKernelGGL((gemm_nt_f16x3_kernel<128, 2, RD>), dim3(tiles_m8 * tiles_n, nz), dim3(256), 0, stream, g, tiles_m, tiles_n, rd);
+        } else {
+            hipLaunchKernelGGL((gemm_nt_f16x3_kernel<64, 2, RD>), dim3(tiles_m8, nz), dim3(256), 0, stream, g, tiles_m, 1, rd);
+        }
+        return og_launch_status();
+    };
+    return a.rag ? launch(*a.rag) : launch(RaggedNone{});
 }
 
 int og_launch_split_f16(const float* x, int64_t n, void* hi, void* lo, hipStream_t stream) {
@@ -713,6 +964,13 @@ int og_launch_split_f16_hl(const float* x, int64_t rows, int cols, int64_t ldx, 
                        (_Float16*)out, ldo);
     return og_launch_status();
 }
+
+#if OG_GEMM_TRACE
+extern "C" int og_debug_gemm_trace(void* host_dst, size_t bytes) {
+    if (bytes > sizeof(og_gemm_trace_buf)) bytes = sizeof(og_gemm_trace_buf);
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(og_gemm_trace_buf), bytes);
+}
+#endif
 
 extern "C" int og_split_f16(const float* x, int64_t n, void* hi, void* lo, void* stream) {
     og_clear_status();

@@ -24,8 +24,8 @@ constexpr int BM = 128;
 constexpr int BK = 32;
 constexpr int LDSW = BK + 4;   // padded LDS row, floats
 
-template <int BN>
-__global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g, int tiles_m, int tiles_n, RaggedDesc rd) {
+template <int BN, class RD>
+__global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g, int tiles_m, int tiles_n, RD rd) {
     constexpr int TN = BN / 64;            // MFMA tiles per wave along N
     constexpr int BROWS = BN / 32;         // staging passes for B
     __shared__ __attribute__((aligned(16))) float As[BM * LDSW];
@@ -161,19 +161,20 @@ int og_launch_gemm(const GemmArgs& a, hipStream_t stream) {
     if ((a.strideA & 3) || (a.strideB & 3)) return OG_E_ALIGN;
     const int tiles_m = (a.M + BM - 1) / BM;
     const int tiles_m8 = (tiles_m + 7) / 8 * 8;
-    RaggedDesc rd;
-    rd.B = 0;
-    if (a.rag) rd = *a.rag;
     GemmArgs k = a;
     k.rag = nullptr;
-    if (a.N > 64) {
-        const int tiles_n = (a.N + 127) / 128;
-        hipLaunchKernelGGL(gemm_nt_f32_kernel<128>, dim3(tiles_m8 * tiles_n, a.batch), dim3(256), 0, stream,
-                           k, tiles_m, tiles_n, rd);
-    } else {
-        hipLaunchKernelGGL(gemm_nt_f32_kernel<64>, dim3(tiles_m8, a.batch), dim3(256), 0, stream, k, tiles_m, 1, rd);
-    }
-    return og_launch_status();
+    auto launch = [&](auto rd) -> int {       // the per-pair descriptor is a kernel argument only for ragged launches (og_common.h)
+        using RD = decltype(rd);
+        if (a.N > 64) {
+            const int tiles_n = (a.N + 127) / 128;
+            hipLaunchKernelGGL((gemm_nt_f32_kernel<128, RD>), dim3(tiles_m8 * tiles_n, a.batch), dim3(256), 0, stream,
+                               k, tiles_m, tiles_n, rd);
+        } else {
+            hipLaunchKernelGGL((gemm_nt_f32_kernel<64, RD>), dim3(tiles_m8, a.batch), dim3(256), 0, stream, k, tiles_m, 1, rd);
+        }
+        return og_launch_status();
+    };
+    return a.rag ? launch(*a.rag) : launch(RaggedNone{});
 }
 
 extern "C" int og_gemm_nt(const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,

@@ -36,8 +36,9 @@ __device__ __forceinline__ float unorderable(unsigned int k) {
 }
 
 // one wave per row i < m
+template <class RD>
 __global__ __launch_bounds__(256) void row_argmax_kernel(const float* __restrict__ scores, int M, int N,
-                                                         int* __restrict__ idx0, float* __restrict__ max0, RaggedDesc rd) {
+                                                         int* __restrict__ idx0, float* __restrict__ max0, RD rd) {
     const int b = blockIdx.y;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -62,8 +63,9 @@ __global__ __launch_bounds__(256) void row_argmax_kernel(const float* __restrict
 }
 
 // grid (ceil(n/256), ceil(m/64), B): thread = one column over a 64-row slab, then one 64-bit atomicMax
+template <class RD>
 __global__ __launch_bounds__(256) void col_argmax_kernel(const float* __restrict__ scores, int M, int N,
-                                                         unsigned long long* __restrict__ colbest, RaggedDesc rd) {
+                                                         unsigned long long* __restrict__ colbest, RD rd) {
     const int b = blockIdx.z;
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int Nmax = N;
@@ -83,11 +85,12 @@ __global__ __launch_bounds__(256) void col_argmax_kernel(const float* __restrict
     atomicMax(colbest + (int64_t)b * Nmax + j, key);
 }
 
+template <class RD>
 __global__ __launch_bounds__(256) void mutual_kernel(int M, int N, float thr, const int* __restrict__ idx0,
                                                      const float* __restrict__ max0,
                                                      const unsigned long long* __restrict__ colbest,
                                                      int64_t* __restrict__ matches0, float* __restrict__ ms0,
-                                                     int64_t* __restrict__ matches1, float* __restrict__ ms1, RaggedDesc rd) {
+                                                     int64_t* __restrict__ matches1, float* __restrict__ ms1, RD rd) {
     const int b = blockIdx.y;
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int Mmax = M, Nmax = N;                    // workspace strides
@@ -150,23 +153,32 @@ extern "C" size_t og_matches_workspace_bytes(int32_t batch, int32_t m, int32_t n
     return sizeof(unsigned long long) * (size_t)batch * n + (sizeof(int) + sizeof(float)) * (size_t)batch * m + 16;
 }
 
-int og_launch_matches(const float* scores, int B, int m, int n, float thr, int64_t* matches0, float* ms0,
-                      int64_t* matches1, float* ms1, void* workspace, hipStream_t st, const RaggedDesc* rag) {
-    RaggedDesc rd;
-    rd.B = 0;
-    if (rag) { if (rag->B != B) return OG_E_INVALID; rd = *rag; }
+namespace {
+template <class RD>
+int matches_run(const float* scores, int B, int m, int n, float thr, int64_t* matches0, float* ms0,
+                int64_t* matches1, float* ms1, void* workspace, hipStream_t st, const RD& rd) {
     if (!scores || !matches0 || !ms0 || !workspace || B <= 0 || m <= 0 || n <= 0) return OG_E_INVALID;
     if ((matches1 == nullptr) != (ms1 == nullptr)) return OG_E_INVALID;
     if ((uintptr_t)workspace & 15) return OG_E_ALIGN;
     const MatchWs w = mw_layout(workspace, B, m, n);
     hipError_t e = hipMemsetAsync(w.colbest, 0, sizeof(unsigned long long) * (size_t)B * n, st);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(row_argmax_kernel, dim3((m + 3) / 4, B), dim3(256), 0, st, scores, m, n, w.idx0, w.max0, rd);
-    hipLaunchKernelGGL(col_argmax_kernel, dim3((n + 255) / 256, (m + 63) / 64, B), dim3(256), 0, st, scores, m, n, w.colbest, rd);
+    hipLaunchKernelGGL(row_argmax_kernel<RD>, dim3((m + 3) / 4, B), dim3(256), 0, st, scores, m, n, w.idx0, w.max0, rd);
+    hipLaunchKernelGGL(col_argmax_kernel<RD>, dim3((n + 255) / 256, (m + 63) / 64, B), dim3(256), 0, st, scores, m, n, w.colbest, rd);
     const int mx = m > n ? m : n;
-    hipLaunchKernelGGL(mutual_kernel, dim3((mx + 255) / 256, B), dim3(256), 0, st, m, n, thr, w.idx0, w.max0, w.colbest,
+    hipLaunchKernelGGL(mutual_kernel<RD>, dim3((mx + 255) / 256, B), dim3(256), 0, st, m, n, thr, w.idx0, w.max0, w.colbest,
                        matches0, ms0, matches1, ms1, rd);
     return og_launch_status();
+}
+}  // namespace
+
+int og_launch_matches(const float* scores, int B, int m, int n, float thr, int64_t* matches0, float* ms0,
+                      int64_t* matches1, float* ms1, void* workspace, hipStream_t st, const RaggedDesc* rag) {
+    if (rag) {
+        if (rag->B != B) return OG_E_INVALID;
+        return matches_run<RaggedDesc>(scores, B, m, n, thr, matches0, ms0, matches1, ms1, workspace, st, *rag);
+    }
+    return matches_run<RaggedNone>(scores, B, m, n, thr, matches0, ms0, matches1, ms1, workspace, st, RaggedNone{});
 }
 
 extern "C" int og_extract_matches(const float* scores, int32_t batch, int32_t m, int32_t n, float match_threshold,

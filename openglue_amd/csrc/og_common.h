@@ -93,6 +93,16 @@ struct RaggedDesc {                    // OG_MAX_RAGGED: include/openglue_amd.h
     int64_t soff[OG_MAX_RAGGED + 1];   // float offsets of the [m_b+1][n_b+1] blocks in the packed scores output
 };
 
+// Uniform batches pass this empty stand-in instead of the 1.3 KB descriptor (kernels are templates on the descriptor type).
+// [Measured with the per-block entry stamps of scripts/trace_gemm.py: with the full descriptor in the kernarg segment the
+// 256 workgroups of a GEMM launch entered over 12-14 us; with a small kernarg segment they all enter within 0.3 us.]
+struct RaggedNone {
+    static constexpr int B = 0;
+    static constexpr int off0[2] = {0, 0};
+    static constexpr int off1[2] = {0, 0};
+    static constexpr int64_t soff[2] = {0, 0};
+};
+
 // ---- internal launchers shared between api.hip and the per-stage entry points ----
 struct GemmArgs {
     const float* A; int64_t lda, strideA;
@@ -159,6 +169,13 @@ int og_launch_linear_attention(const AttnArgs& a, hipStream_t stream);   // atte
 // m, n are the (maximum) sizes; with `rag` pair b uses m_b, n_b, S stays at stride m*lds per pair, scores are packed
 int og_launch_sinkhorn(const float* S, int64_t lds, const float* dustbin_dev /*or null*/, float dustbin_host, int batch, int m, int n, int iters,
                        float reg, float* scores, void* workspace, hipStream_t stream, const RaggedDesc* rag = nullptr);
+// sinkhorn_resident.hip: the dual-stabilised iterations with the score matrices resident in registers + LDS (one launch)
+bool og_sinkhorn_resident_shape_ok(int B, int m, int n);
+size_t og_sinkhorn_resident_ws_bytes(int B, int m, int n);            // exchange granules + status word (0: shape never resident)
+bool og_sinkhorn_resident_wanted(int B, int m, int n, int mode);      // mode 1: co-resident and large enough, 2: co-resident
+int og_launch_sinkhorn_resident(const float* S, int64_t lds, const float* zdev, float zhost, int B, int m, int n, int iters,
+                                float inv_reg, float la, float la_bin, float lb, float lb_bin, float* u, int ldu, const float* v_in,
+                                float* v_out, int ldv, void* xws, hipStream_t st);
 int og_launch_matches(const float* scores, int batch, int m, int n, float thr, int64_t* matches0,
                       float* ms0, int64_t* matches1, float* ms1, void* workspace, hipStream_t stream,
                       const RaggedDesc* rag = nullptr);

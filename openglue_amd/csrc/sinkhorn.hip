@@ -18,6 +18,7 @@
 // geometry is chosen for bytes in flight: 32 rows per workgroup, 2 rows per group, <= 1024 columns per wave.
 // Numerics: max-subtracted LSEs like torch.logsumexp, fp32, v_exp_f32 / v_log_f32.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "og_common.h"
 
@@ -82,13 +83,13 @@ __device__ __forceinline__ float exp_rel(float a, float b) { return a == OG_NEG_
 
 // Sweep of rows [32 rb, 32 rb + 32) of pair b.  Block = 4 waves = (4/WPR) row streams x WPR column parts;
 // a wave streams its rows in groups of RG, lane l holds columns cpart*256*CPL + 4l + 256k + e (k < CPL).
-template <int CPL, int RG, int WPR>
+template <int CPL, int RG, int WPR, class RD>
 __global__ __launch_bounds__(256) void sinkhorn_sweep_kernel(const float* __restrict__ S, int64_t lds, int M, int N,
                                                              const float* __restrict__ zdev, float zhost, float inv_reg,
                                                              float la, const float* __restrict__ v_in, int ldv,
                                                              float* __restrict__ u, int ldu, float* __restrict__ pm,
                                                              float* __restrict__ ps, int ldp, int RB, int64_t strideS,
-                                                             RaggedDesc rd) {
+                                                             RD rd) {
     constexpr int NRS = 4 / WPR;                 // row streams
     constexpr int RW = SK_ROWS / NRS;            // rows per stream
     constexpr int NCW = 256 * CPL;               // columns per wave
@@ -265,13 +266,14 @@ __global__ __launch_bounds__(256) void sinkhorn_sweep_kernel(const float* __rest
 }
 
 // Combine: grid (ceil((N+1)/256), B).  Finishes iteration t: dustbin-row u, all v.
+template <class RD>
 __global__ __launch_bounds__(256) void sinkhorn_combine_kernel(int M, int N, const float* __restrict__ zdev,
                                                                float zhost, float inv_reg, float la_bin, float lb,
                                                                float lb_bin, const float* __restrict__ v_in,
                                                                float* __restrict__ v_out, int ldv,
                                                                float* __restrict__ u, int ldu,
                                                                const float* __restrict__ pm,
-                                                               const float* __restrict__ ps, int ldp, int RB, RaggedDesc rd) {
+                                                               const float* __restrict__ ps, int ldp, int RB, RD rd) {
     __shared__ float sm[4];
     const int b = blockIdx.y, tid = threadIdx.x;
     int RBv = RB;                                // row blocks that hold valid partials for this pair
@@ -351,13 +353,13 @@ __global__ __launch_bounds__(256) void sinkhorn_combine_kernel(int M, int N, con
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
-template <int CPL, int RG, int WPR>
+template <int CPL, int RG, int WPR, class RD>
 __global__ __launch_bounds__(256) void sinkhorn_sweep_fast_kernel(const float* __restrict__ S, int64_t lds, int M, int N,
                                                                   const float* __restrict__ zdev, float zhost, float inv_reg,
                                                                   float la, const float* __restrict__ v_in, int ldv,
                                                                   float* __restrict__ u, int ldu, float* __restrict__ ps,
                                                                   int ldp, int RB, int64_t strideS, float in_scale,
-                                                                  float out_scale, RaggedDesc rd) {
+                                                                  float out_scale, RD rd) {
     // u, v in memory: base-2 units between two dual-stabilised iterations (no per-iteration unit conversion: at
     // convergence the increments vanish and the duals stop moving, instead of random-walking by an ulp per round trip);
     // in_scale = log2(e) when the previous iteration left natural units, out_scale = ln 2 on the last iteration.
@@ -495,12 +497,13 @@ __global__ __launch_bounds__(256) void sinkhorn_sweep_fast_kernel(const float* _
 }
 
 // Combine of a dual-stabilised iteration: dustbin-row u, all v from the per-row-block partial column sums.
+template <class RD>
 __global__ __launch_bounds__(256) void sinkhorn_combine_fast_kernel(int M, int N, const float* __restrict__ zdev, float zhost,
                                                                     float inv_reg, float la_bin, float lb, float lb_bin,
                                                                     const float* __restrict__ v_in, float* __restrict__ v_out,
                                                                     int ldv, float* __restrict__ u, int ldu,
                                                                     const float* __restrict__ ps, int ldp, int RB, float in_scale,
-                                                                    float out_scale, RaggedDesc rd) {
+                                                                    float out_scale, RD rd) {
     const int b = blockIdx.y, tid = threadIdx.x;
     const float u_scale = out_scale == 1.f ? 1.f : LOG2E;      // the sweep of this iteration stored u * out_scale
     int RBv = RB;
@@ -574,12 +577,13 @@ __global__ __launch_bounds__(256) void sinkhorn_combine_fast_kernel(int M, int N
 }
 
 // scores[b][i][j] = ((S~_ij + u_i) + v_j) - norm   (same association as optimal_transport.py:28, superglue.py:111)
+template <class RD>
 __global__ __launch_bounds__(256) void sinkhorn_scores_kernel(const float* __restrict__ S, int64_t lds, int M, int N,
                                                               const float* __restrict__ zdev, float zhost,
                                                               float inv_reg, float norm,
                                                               const float* __restrict__ u, int ldu,
                                                               const float* __restrict__ v, int ldv,
-                                                              float* __restrict__ scores, int64_t strideS, RaggedDesc rd) {
+                                                              float* __restrict__ scores, int64_t strideS, RD rd) {
     const int b = blockIdx.y;
     int64_t so = (int64_t)b * (M + 1) * (N + 1);
     if (rd.B > 0) {
@@ -605,21 +609,21 @@ __global__ __launch_bounds__(256) void sinkhorn_scores_kernel(const float* __res
     if (lane == 0) out[N] = ((zr + ui) + vb[N]) - norm;
 }
 
-template <int CPL, int RG, int WPR>
+template <int CPL, int RG, int WPR, class RD>
 void launch_sweep(const float* S, int64_t lds, int B, int m, int n, const float* zdev, float zhost, float inv_reg, float la,
-                  const float* v_in, const SinkhornWs& w, hipStream_t st, const RaggedDesc& rd) {
+                  const float* v_in, const SinkhornWs& w, hipStream_t st, const RD& rd) {
     constexpr int NRS = 4 / WPR;
     const size_t shmem = sizeof(float) * ((size_t)NRS * 2 * 256 * CPL * WPR + 2 * NRS * RG * WPR * 2);
-    hipLaunchKernelGGL((sinkhorn_sweep_kernel<CPL, RG, WPR>), dim3(w.RB, B), dim3(256), shmem, st, S, lds, m, n, zdev, zhost,
+    hipLaunchKernelGGL((sinkhorn_sweep_kernel<CPL, RG, WPR, RD>), dim3(w.RB, B), dim3(256), shmem, st, S, lds, m, n, zdev, zhost,
                        inv_reg, la, v_in, w.ldv, w.u, w.ldu, w.pm, w.ps, w.ldp, w.RB, (int64_t)m * lds, rd);
 }
 
-template <int CPL, int RG, int WPR>
+template <int CPL, int RG, int WPR, class RD>
 void launch_sweep_fast(const float* S, int64_t lds, int B, int m, int n, const float* zdev, float zhost, float inv_reg, float la,
-                       const float* v_in, const SinkhornWs& w, hipStream_t st, const RaggedDesc& rd, float in_scale, float out_scale) {
+                       const float* v_in, const SinkhornWs& w, hipStream_t st, const RD& rd, float in_scale, float out_scale) {
     constexpr int NRS = 4 / WPR;
     const size_t shmem = sizeof(float) * ((size_t)NRS * 256 * CPL * WPR + 2 * NRS * RG * WPR);
-    hipLaunchKernelGGL((sinkhorn_sweep_fast_kernel<CPL, RG, WPR>), dim3(w.RB, B), dim3(256), shmem, st, S, lds, m, n, zdev, zhost,
+    hipLaunchKernelGGL((sinkhorn_sweep_fast_kernel<CPL, RG, WPR, RD>), dim3(w.RB, B), dim3(256), shmem, st, S, lds, m, n, zdev, zhost,
                        inv_reg, la, v_in, w.ldv, w.u, w.ldu, w.ps, w.ldp, w.RB, (int64_t)m * lds, in_scale, out_scale, rd);
 }
 
@@ -630,14 +634,22 @@ extern "C" size_t og_sinkhorn_workspace_bytes(int32_t batch, int32_t m, int32_t 
     const int64_t RB = (m + SK_ROWS - 1) / SK_ROWS;
     const int64_t ldu = og_round_up(m + 1, 4), ldv = og_round_up(n + 1, 4), ldp = og_round_up(n, 4);
     const int64_t floats = (int64_t)batch * (ldu + 2 * ldv) + 4 + 2 * (int64_t)batch * RB * ldp;
-    return (size_t)floats * sizeof(float);
+    // + the exchange area of the on-chip-resident iteration kernel (sinkhorn_resident.hip), 256-byte aligned
+    return (size_t)og_round_up(floats * (int64_t)sizeof(float), 256) + og_sinkhorn_resident_ws_bytes(batch, m, n);
 }
 
-int og_launch_sinkhorn(const float* S, int64_t lds, const float* zdev, float dustbin, int B, int m, int n, int iters, float reg,
-                       float* scores, void* workspace, hipStream_t st, const RaggedDesc* rag) {
-    RaggedDesc rd;
-    rd.B = 0;
-    if (rag) { if (rag->B != B) return OG_E_INVALID; rd = *rag; }
+static inline void* sk_resident_ws(void* ws, int B, int m, int n) {
+    const int64_t RB = (m + SK_ROWS - 1) / SK_ROWS;
+    const int64_t ldu = og_round_up(m + 1, 4), ldv = og_round_up(n + 1, 4), ldp = og_round_up(n, 4);
+    const int64_t floats = (int64_t)B * (ldu + 2 * ldv) + 4 + 2 * (int64_t)B * RB * ldp;
+    return (char*)ws + og_round_up(floats * (int64_t)sizeof(float), 256);
+}
+
+namespace {
+// RD = RaggedDesc (per-pair sizes by value in the kernarg segment) or RaggedNone (uniform batch: nothing; og_common.h)
+template <class RD>
+int sinkhorn_run(const float* S, int64_t lds, const float* zdev, float dustbin, int B, int m, int n, int iters, float reg,
+                 float* scores, void* workspace, hipStream_t st, const RD& rd) {
     if (!S || !scores || !workspace || B <= 0 || m <= 0 || n <= 0 || iters < 0 || !(reg > 0.f)) return OG_E_INVALID;
     if (n > 8192) return OG_E_SHAPE;
     if ((lds & 3) || ((uintptr_t)S & 15) || ((uintptr_t)workspace & 15)) return OG_E_ALIGN;
@@ -653,8 +665,20 @@ int og_launch_sinkhorn(const float* S, int64_t lds, const float* zdev, float dus
     const SinkhornGeom g = sk_geom(n);
     int cur = 0;
     static const bool robust_only = [] { const char* e = getenv("OG_SINKHORN_ROBUST"); return e && atoi(e) != 0; }();   // experiments
+    // 0: streaming kernels only; 1 (default): on-chip-resident iterations when the batch is co-resident and big enough to pay
+    // off; 2: whenever it is co-resident (tests)
+    const char* rm_env = getenv("OG_SINKHORN_RESIDENT");          // read per call: the parity tests switch it
+    const int resident_mode = rm_env ? atoi(rm_env) : 1;
+    const bool resident = std::is_same<RD, RaggedNone>::value && !robust_only && iters > 1 && og_sinkhorn_resident_wanted(B, m, n, resident_mode);
     for (int it = 0; it < iters; ++it) {
         const float* vin = w.v[cur];
+        if (it > 0 && resident) {         // iterations 2 .. iters in ONE launch, S read once (sinkhorn_resident.hip)
+            if (int rc = og_launch_sinkhorn_resident(S, lds, zdev, dustbin, B, m, n, iters - 1, inv_reg, la, la_bin, lb, lb_bin, w.u, w.ldu,
+                                                     w.v[cur], w.v[cur ^ 1], w.ldv, sk_resident_ws(workspace, B, m, n), st))
+                return rc;
+            cur ^= 1;
+            break;
+        }
         if (it > 0 && !robust_only) {     // dual-stabilised form: valid once one max-subtracted iteration has been done
             const float is = it == 1 ? LOG2E : 1.f, os = it == iters - 1 ? LN2 : 1.f;     // duals stay in base 2 in between
             if (g.CPL == 1) launch_sweep_fast<1, 4, 1>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd, is, os);
@@ -663,7 +687,7 @@ int og_launch_sinkhorn(const float* S, int64_t lds, const float* zdev, float dus
             else if (g.WPR == 1) launch_sweep_fast<4, 2, 1>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd, is, os);
             else if (g.WPR == 2) launch_sweep_fast<4, 2, 2>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd, is, os);
             else launch_sweep_fast<4, 2, 4>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd, is, os);
-            hipLaunchKernelGGL(sinkhorn_combine_fast_kernel, dim3((n + 1 + 255) / 256, B), dim3(256), 0, st, m, n, zdev, dustbin,
+            hipLaunchKernelGGL(sinkhorn_combine_fast_kernel<RD>, dim3((n + 1 + 255) / 256, B), dim3(256), 0, st, m, n, zdev, dustbin,
                                inv_reg, la_bin, lb, lb_bin, w.v[cur], w.v[cur ^ 1], w.ldv, w.u, w.ldu, w.ps, w.ldp, w.RB, is, os, rd);
             cur ^= 1;
             continue;
@@ -674,13 +698,32 @@ int og_launch_sinkhorn(const float* S, int64_t lds, const float* zdev, float dus
         else if (g.WPR == 1) launch_sweep<4, 2, 1>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd);
         else if (g.WPR == 2) launch_sweep<4, 2, 2>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd);
         else launch_sweep<4, 2, 4>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd);
-        hipLaunchKernelGGL(sinkhorn_combine_kernel, dim3((n + 1 + 255) / 256, B), dim3(256), 0, st, m, n, zdev, dustbin, inv_reg, la_bin,
+        hipLaunchKernelGGL(sinkhorn_combine_kernel<RD>, dim3((n + 1 + 255) / 256, B), dim3(256), 0, st, m, n, zdev, dustbin, inv_reg, la_bin,
                            lb, lb_bin, w.v[cur], w.v[cur ^ 1], w.ldv, w.u, w.ldu, w.pm, w.ps, w.ldp, w.RB, rd);
         cur ^= 1;
     }
-    hipLaunchKernelGGL(sinkhorn_scores_kernel, dim3((m + 1 + 3) / 4, B), dim3(256), 0, st, S, lds, m, n, zdev, dustbin, inv_reg,
+    hipLaunchKernelGGL(sinkhorn_scores_kernel<RD>, dim3((m + 1 + 3) / 4, B), dim3(256), 0, st, S, lds, m, n, zdev, dustbin, inv_reg,
                        (float)norm, w.u, w.ldu, w.v[cur], w.ldv, scores, (int64_t)m * lds, rd);
     return og_launch_status();
+}
+}  // namespace
+
+int og_launch_sinkhorn(const float* S, int64_t lds, const float* zdev, float dustbin, int B, int m, int n, int iters, float reg,
+                       float* scores, void* workspace, hipStream_t st, const RaggedDesc* rag) {
+    if (rag) {
+        if (rag->B != B) return OG_E_INVALID;
+        return sinkhorn_run<RaggedDesc>(S, lds, zdev, dustbin, B, m, n, iters, reg, scores, workspace, st, *rag);
+    }
+    return sinkhorn_run<RaggedNone>(S, lds, zdev, dustbin, B, m, n, iters, reg, scores, workspace, st, RaggedNone{});
+}
+
+extern "C" int og_sinkhorn_status(const void* workspace_dev, int32_t batch, int32_t m, int32_t n) {
+    if (!workspace_dev || batch <= 0 || m <= 0 || n <= 0 || n > 8192) return -1;
+    if (og_sinkhorn_resident_ws_bytes(batch, m, n) == 0) return 0;
+    unsigned st = 0;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpy(&st, sk_resident_ws(const_cast<void*>(workspace_dev), batch, m, n), sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return st == 0 ? 0 : 1;
 }
 
 extern "C" int og_sinkhorn(const float* S, int64_t lds, float dustbin, int32_t batch, int32_t m, int32_t n,

@@ -135,7 +135,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int)
     return merge_f16(oh, ol)
 
 
-def sinkhorn(S: torch.Tensor, dustbin: float, iters: int, reg: float = 1.0) -> torch.Tensor:
+def sinkhorn(S: torch.Tensor, dustbin: float, iters: int, reg: float = 1.0, return_status: bool = False):
     """S [B,m,n] raw scores -> log-assignment [B,m+1,n+1] (superglue.py:88-111)."""
     lib = _lib.load()
     S = _req(S, "S")
@@ -150,6 +150,8 @@ def sinkhorn(S: torch.Tensor, dustbin: float, iters: int, reg: float = 1.0) -> t
     rc = lib.og_sinkhorn(S.data_ptr(), lds, float(dustbin), B, m, n, int(iters), float(reg), out.data_ptr(),
                          ws.data_ptr(), _stream())
     _lib.check(rc, "og_sinkhorn")
+    if return_status:        # 0 = ok / streaming kernels; 1 = a cross-workgroup wait of the on-chip-resident kernel timed out
+        return out, int(lib.og_sinkhorn_status(ws.data_ptr(), B, m, n))
     return out
 
 
