@@ -243,6 +243,20 @@ int og_sinkhorn(const float* S, int64_t lds, float dustbin, int32_t batch, int32
  * the size threshold) iterations 2..iters run in ONE launch with the score matrices held in registers + LDS. */
 int og_sinkhorn_status(const void* sinkhorn_workspace_dev, int32_t batch, int32_t m, int32_t n);
 
+/* ---- training slice of the optimal-transport layer (reference: autograd through superglue.py:88-111 +
+ * optimal_transport.py:20-28, consumed by the NLL of utils/losses.py:7-53) ----
+ * og_sinkhorn_train_forward: like og_sinkhorn (max-subtracted iterations only) but keeps the duals of every iteration in
+ * the training workspace; og_sinkhorn_backward: given grad_scores = dL/dscores [B][m+1][n+1] it back-propagates through the
+ * `iters` unrolled iterations and writes dS [B][m][ldds] (gradient w.r.t. the raw score matrix) and *d_dustbin (device
+ * scalar, may be NULL; gradient w.r.t. dustbin_score).  n <= 4159, iters >= 1.  fp32 atomics: gradients reproducible to
+ * rounding, not bit for bit.  The same workspace must be passed to both calls. */
+size_t og_sinkhorn_train_workspace_bytes(int32_t batch, int32_t m, int32_t n, int32_t iters);
+int og_sinkhorn_train_forward(const float* S, int64_t lds, float dustbin, int32_t batch, int32_t m, int32_t n, int32_t iters,
+                              float reg, float* scores, void* train_workspace_dev, void* stream);
+int og_sinkhorn_backward(const float* S, int64_t lds, float dustbin, int32_t batch, int32_t m, int32_t n, int32_t iters,
+                         float reg, const float* grad_scores, void* train_workspace_dev, float* dS, int64_t ldds,
+                         float* d_dustbin, void* stream);
+
 /* mutual-NN match extraction from a scores tensor [B][m+1][n+1] (matching_module.py:174-187;
  * matches1/matching_scores1 as inference.py:183-188, may be NULL).  First maximal index wins.
  * workspace: og_matches_workspace_bytes. */

@@ -30,6 +30,7 @@ constexpr int RS_RW = 16;              // row slots per wave
 constexpr int RS_RR = 8;               //   slots 0..7: rows held in registers (the 128 accumulator registers of the wave)
 constexpr int RS_LR = 4;               //   slots 8..11: rows held in LDS
 constexpr int RS_SR = 4;               //   slots 12..15: re-read from memory every iteration (prefetched under the exchange)
+static_assert(RS_RR + RS_LR + RS_SR == RS_RW, "sixteen row slots per wave");
 constexpr int RS_NW = 8;               // waves per workgroup
 constexpr int RS_ROWS = RS_NW * RS_RW; // 128 rows per workgroup
 constexpr int RS_NCOL = 1024;          // columns per row held on chip (16 per lane)

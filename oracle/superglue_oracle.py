@@ -314,3 +314,19 @@ def compact_matches(matches0: torch.Tensor, matching_scores0: torch.Tensor, lafs
         ml0, ml1 = lafs0[batch_idxs0, idx0][None], lafs1[batch_idxs0, idx1][None]
         out.update(lafs0=ml0, lafs1=ml1, keypoints0=ml0[0][..., 2], keypoints1=ml1[0][..., 2])   # kornia get_laf_center
     return out
+
+
+def nll_criterion(scores: torch.Tensor, gt_matches0: torch.Tensor, gt_matches1: torch.Tensor) -> torch.Tensor:
+    """The 'loss' entry of utils/losses.py:7-53 (margin=None): per pair, the mean negative log-assignment of the matched
+    keypoints (gt >= 0), plus half the mean over the unmatched (gt == -1) keypoints of image 0 at the dustbin column and of
+    image 1 at the dustbin row; IGNORE labels (-2) take no part; divided by the batch size."""
+    def mean_w(batch_idx):
+        _, inv, counts = torch.unique_consecutive(batch_idx, return_inverse=True, return_counts=True)
+        return (1 / counts)[inv]
+    b, i0 = torch.where(gt_matches0 >= 0)
+    matched = (-scores[b, i0, gt_matches0[b, i0]] * mean_w(b)).sum()
+    b, i0 = torch.where(gt_matches0 == -1)
+    un0 = (-scores[b, i0, -1] * mean_w(b)).sum()
+    b, i1 = torch.where(gt_matches1 == -1)
+    un1 = (-scores[b, -1, i1] * mean_w(b)).sum()
+    return (matched + 0.5 * (un0 + un1)) / scores.size(0)

@@ -12,6 +12,8 @@ lib.og_debug_gemm_trace.restype = C.c_int
 lib.og_debug_gemm_trace.argtypes = [C.c_void_p, C.c_size_t]
 T = 65536
 shapes = [("qkv", T, 768, 256, True), ("fc0", T, 512, 512, False), ("fc3", T, 256, 512, False)]
+if os.environ.get("OG_TRACE_SMALL"):      # few blocks: is the epilogue store rate a per-CU or a whole-chip limit?
+    shapes = [("fc3_32blocks", 8192, 256, 512, False), ("fc3_64blocks", 16384, 256, 512, False), ("fc3_128blocks", 32768, 256, 512, False)]
 g = torch.Generator().manual_seed(0)
 W = 64
 for name, M, N, K, planes in shapes:

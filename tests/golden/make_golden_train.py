@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Training fixtures FROM THE REFERENCE under torch autograd (build container only: needs /root/reference).
+
+    python tests/golden/make_golden_train.py        # writes tests/golden/train_ot.npz
+
+train_ot: the optimal-transport layer of the reference (SuperGlue.get_matching_probs, superglue.py:88-111, calling
+log_otp_solver, optimal_transport.py:20-28) on seeded score matrices, differentiated by autograd through two losses:
+  (a) a dense random cotangent  L = sum(scores * R)        -> dS, d dustbin_score
+  (b) the NLL of the reference's own criterion (utils/losses.py:7-53, margin=None) on synthetic gt_matches0/1
+      (MATCHED >= 0, UNMATCHED -1, IGNORE -2)               -> loss value, dS, d dustbin_score
+The losses module imports only torch + numpy + utils.misc, so it is imported unchanged."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, ROOT)
+
+from models.superglue.superglue import SuperGlue as RefSuperGlue           # noqa: E402
+from utils.losses import criterion                                        # noqa: E402
+from openglue_amd import synthetic as syn                                 # noqa: E402
+
+CASES = [  # name, B, m, n, iters, reg, dustbin
+    ("a", 2, 37, 53, 5, 1.0, 1.0),
+    ("b", 1, 64, 64, 20, 0.7, 0.3),
+    ("c", 2, 130, 97, 10, 1.0, -0.5),
+]
+
+
+def gt_matches(B, m, n, g):
+    """synthetic labels: a random partial matching, the rest unmatched (-1) or ignored (-2) (gt_matches_generation.py:60-91)"""
+    gt0 = torch.full((B, m), -1, dtype=torch.long)
+    gt1 = torch.full((B, n), -1, dtype=torch.long)
+    for b in range(B):
+        k = min(m, n) // 2
+        i = torch.randperm(m, generator=g)[:k]
+        j = torch.randperm(n, generator=g)[:k]
+        gt0[b, i] = j
+        gt1[b, j] = i
+        gt0[b, torch.randperm(m, generator=g)[:3]] = -2        # may overwrite a match on side 0 only: criterion handles each side separately
+        free1 = (gt1[b] == -1).nonzero()[:, 0]
+        gt1[b, free1[:2]] = -2
+    return gt0, gt1
+
+
+def main():
+    out = {}
+    for name, B, m, n, iters, reg, z in CASES:
+        g = torch.Generator().manual_seed(ord(name) * 7 + 17)
+        cfg = syn.make_config(descriptor_dim=64, num_stages=1, num_heads=4, num_iters=iters, reg=reg, dustbin_score_init=z)
+        ref = RefSuperGlue(cfg)
+        S = (torch.randn(B, m, n, generator=g) * 3.0).requires_grad_(True)
+        R = torch.randn(B, m + 1, n + 1, generator=g)
+        scores = ref.get_matching_probs(S)
+        (scores * R).sum().backward()
+        out[f"{name}_S"] = S.detach().numpy(); out[f"{name}_R"] = R.numpy(); out[f"{name}_scores"] = scores.detach().numpy()
+        out[f"{name}_dS_dense"] = S.grad.numpy().copy(); out[f"{name}_dz_dense"] = ref.dustbin_score.grad.numpy().copy()
+        S.grad = None; ref.dustbin_score.grad = None
+        gt0, gt1 = gt_matches(B, m, n, g)
+        scores = ref.get_matching_probs(S)
+        y_pred = {"context_descriptors0": torch.zeros(B, 64, m), "context_descriptors1": torch.zeros(B, 64, n), "scores": scores}
+        loss = criterion({"gt_matches0": gt0, "gt_matches1": gt1}, y_pred, margin=None)["loss"]
+        loss.backward()
+        out[f"{name}_gt0"] = gt0.numpy(); out[f"{name}_gt1"] = gt1.numpy(); out[f"{name}_nll"] = np.float32(loss.item())
+        out[f"{name}_dS_nll"] = S.grad.numpy().copy(); out[f"{name}_dz_nll"] = ref.dustbin_score.grad.numpy().copy()
+        out[f"{name}_meta"] = np.array([B, m, n, iters], np.int64); out[f"{name}_reg_z"] = np.array([reg, z], np.float32)
+        print(name, "nll", loss.item(), "|dS|max", float(np.abs(out[f'{name}_dS_nll']).max()), "dz", float(out[f'{name}_dz_nll']))
+    np.savez_compressed(os.path.join(HERE, "train_ot.npz"), **out)
+
+
+if __name__ == "__main__":
+    main()
