@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """gpurun_out/traffic/{FETCH_SIZE,WRITE_SIZE}/p_counter_collection.csv (scripts/gpu_traffic.sh) -> the per-kernel-class HBM
-traffic summary bench.py reads (profiles/r01_traffic_c2.json).  FETCH_SIZE counts 64 B per 128-B request on gfx950
+traffic summary bench.py reads (profiles/r02_traffic_c2.json).  FETCH_SIZE counts 64 B per 128-B request on gfx950
 (MI355X_MICROARCH.md): read bytes = 2 x FETCH_SIZE KB; WRITE_SIZE is 1:1 (calibrated on the 134 MB torch copy in the driver)."""
 import collections, csv, json, os, sys
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/traffic"
-out = sys.argv[2] if len(sys.argv) > 2 else "profiles/r01_traffic_c2.json"
-CLASSES = [("gemm_f16x3", "gemm_nt_f16x3"), ("attention", "attention_kernel"), ("sinkhorn_sweep", "sinkhorn_sweep"),
+out = sys.argv[2] if len(sys.argv) > 2 else "profiles/r02_traffic_c2.json"
+CLASSES = [("gemm_f16x3", "gemm_nt_f16x3"), ("attention", "attention_kernel"), ("sinkhorn_resident", "sinkhorn_resident_kernel"), ("sinkhorn_sweep", "sinkhorn_sweep"),
            ("sinkhorn_combine", "sinkhorn_combine"), ("gemm_f32", "gemm_nt_f32")]
 vals = {c: collections.defaultdict(list) for c, _ in CLASSES}
 cal = {}

@@ -320,7 +320,23 @@ def test_full_size_c2_batch_properties(gpu_device):
     # (2) pairs are independent: pair 5 alone gives the same scores as inside the batch (eval-mode BN)
     one = {k: (v[5:6] if torch.is_tensor(v) else v) for k, v in data.items()}
     s1 = model(to_device(one, gpu_device))["scores"]
-    assert (s1[0] - s[5]).abs().max() < 1e-5
+    # B=32 runs the resident Sinkhorn schedule and the 256x256 GEMM tile, B=1 the streaming schedule and
+    # a smaller tile: same arithmetic, different reduction orders, so rounding noise only (scores ~ -26,
+    # 100 iterations); both sit inside TOL_SCORES of the oracle, see (5)
+    assert (s1[0] - s[5]).abs().max() < 2e-4
+    # with the schedule pinned the only batch-size dependence left is the GEMM tile choice
+    import os
+    prev = os.environ.get("OG_SINKHORN_RESIDENT")
+    os.environ["OG_SINKHORN_RESIDENT"] = "0"
+    try:
+        sb = model(to_device(data, gpu_device))["scores"]
+        sa = model(to_device(one, gpu_device))["scores"]
+    finally:
+        if prev is None:
+            os.environ.pop("OG_SINKHORN_RESIDENT")
+        else:
+            os.environ["OG_SINKHORN_RESIDENT"] = prev
+    assert (sa[0] - sb[5]).abs().max() < 5e-5
     # (3) permuting the keypoints of image 1 permutes the columns of scores
     perm = torch.randperm(n, generator=torch.Generator().manual_seed(3))
     dp = dict(one)
