@@ -28,6 +28,7 @@
 // exponent arguments s - m_run come straight from the matrix pipe (no per-element subtract).
 // I/O: q, k, v arrive as f16 (hi, lo) PLANES written by the producing GEMM's epilogue and O leaves as planes
 // (it is the A operand of the fc.0 GEMM), so no conversion sits on the load path of either kernel.
+#include <cstdlib>
 #include <type_traits>
 
 #include "og_common.h"
@@ -36,6 +37,8 @@ namespace {
 
 typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
 typedef __attribute__((address_space(3))) s16x4 og_lds_s16x4;
+typedef __attribute__((address_space(3))) void og_lds_void;
+typedef __attribute__((address_space(1))) const void og_glb_void;
 
 constexpr int KV_TILE = 64;
 constexpr int Q_TILE = 128;
@@ -61,6 +64,27 @@ __device__ unsigned og_attn_trace_buf[2][4][16][8];
 #else
 #define OG_TP(i) do {} while (0)
 #endif
+
+
+// Compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>); the index feeds asm immediates.
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+// LDS fragment reads as inline asm with an immediate offset: the compiler's waitcnt insertion treats an LDS read it
+// knows about as a possible alias of every LDS-DMA in flight and drains vmcnt(0) in front of it (which would serialise
+// the next tile's DMA with this tile's PV); the waits for these reads are counted by hand (LDS returns in order).
+template <int OFF>
+__device__ __forceinline__ void lds_read_b128(f16x8& d, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read_tr16_b64(s16x4& d, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
 
 template <int DH, class RD>
 __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a, RD rd) {
@@ -402,6 +426,330 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a, RD rd) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// dh = 64 (the configuration of BASELINE configs 1-3, 5): a head row of K or V is exactly one 128-byte line, so the
+// tiles travel global -> LDS by LDS-DMA (global_load_lds, 16 B per lane, 8 rows x 128 B per wave instruction) with no
+// staging registers, no ds_write and no second barrier.  LDS rows are unpadded; bank conflicts are removed by an XOR
+// of the 16-byte chunk index applied on the SOURCE address of the DMA (the LDS side of a DMA is always contiguous)
+// and again on the fragment reads:
+//   K (ds_read_b128, 16 lanes = 16 keys per pass, all reading the same logical chunk):  chunk ^ ((key >> 1) & 7)
+//   V (ds_read_b64_tr_b16, a pass = [4 keys][32 dv] blocks):                             chunk ^ (((key >> 1) & 1) << 2)
+// Per tile t (buffer t & 1):  issue the DMA of tile t+1 into the other buffer | QK^T(t) | softmax(t) | PV(t) |
+// s_waitcnt vmcnt(0) + ONE barrier (tile t+1 landed, everybody is done with tile t).  The matrix pipe of a SIMD is kept
+// busy by the second workgroup of the CU (two independent 4-wave workgroups, 64 KB of LDS each): inside one in-order
+// wave a lagged PV(t-1) never overlapped softmax(t) anyway, the MFMA issue stalls the wave for the length of the burst.
+template <class RD>
+__global__ __launch_bounds__(256, 2) void attention64_kernel(AttnArgs a, RD rd) {
+    constexpr int DH = 64, NDV = 2, NCH = 4;
+    constexpr int PLANE = KV_TILE * 128;            // bytes: 64 keys x one 128-byte head row
+    constexpr int BUFB = 4 * PLANE;                 // Kh | Kl | Vh | Vl
+    __shared__ __attribute__((aligned(1024))) char smem[2 * BUFB];
+
+    const int id = blockIdx.x;
+    const int xcd = id & 7, local = id >> 3;
+    const int grp = (local / a.qtiles) * 8 + xcd;          // (problem, head) group: all its query tiles on one XCD
+    if (grp >= a.nz * a.num_heads) return;
+    const int z = grp / a.num_heads, h = grp - z * a.num_heads;
+    const int gsel = z < a.split ? 0 : 1;
+    const int zz = gsel ? z - a.split : z;
+    int nq = a.nq[gsel], nk = a.nk[gsel];
+    int64_t q_row0 = a.q_base[gsel] + (int64_t)zz * a.q_step[gsel];
+    int64_t kv_row0 = a.kv_base[gsel] + (int64_t)zz * a.kv_step[gsel];
+    if (rd.B > 0) {          // ragged batch: per-pair row ranges of the packed token matrix
+        const int T0 = rd.off0[rd.B];
+        const int b = z < rd.B ? z : z - rd.B;
+        const int r0 = rd.off0[b], m_b = rd.off0[b + 1] - r0;
+        const int r1 = T0 + rd.off1[b], n_b = rd.off1[b + 1] - rd.off1[b];
+        const bool q_is0 = a.rag_mode == 1 ? z < rd.B : a.rag_mode == 2;
+        const bool kv_is0 = a.rag_mode == 1 ? q_is0 : !q_is0;
+        q_row0 = q_is0 ? r0 : r1; nq = q_is0 ? m_b : n_b;
+        kv_row0 = kv_is0 ? r0 : r1; nk = kv_is0 ? m_b : n_b;
+    }
+    const int q0 = (local % a.qtiles) * Q_TILE;
+    if (q0 >= nq) return;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    // ---- DMA pieces: wave w fills rows [16w, 16w+16) of each of the four planes, two 8-row pieces each ----
+    const int rl = lane >> 3, pc = lane & 7;
+    const int ldkb = (int)a.ldk * 2, ldvb = (int)a.ldv * 2;          // row strides in bytes
+    unsigned ksw[2], vsw;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ksw[i] = (unsigned)(pc ^ ((lane >> 4) | (i << 2))) * 16u;
+    vsw = (unsigned)(pc ^ (((lane >> 4) & 1) << 2)) * 16u;
+    const int64_t k_tile0 = (kv_row0 * a.ldk + h * DH) * 2, v_tile0 = (kv_row0 * a.ldv + h * DH) * 2;   // bytes, uniform
+    // one tile = 8 DMA instructions per wave, issued in pairs (plane pair pp: 0 = K hi/lo, 1 = V hi/lo of piece i) so that
+    // the main loop can spread them under its MFMA bursts: the vector-memory path takes 64 B/clk per CU, a burst of 8 per
+    // wave right after the barrier stalls every wave of the workgroup for ~700 cycles (scripts/trace_attention.py)
+    auto issue_pair = [&](int kt, auto BUF, auto I, auto PP) {
+        constexpr int b = decltype(BUF)::value, i = decltype(I)::value, pp = decltype(PP)::value;
+        const int key0 = kt * KV_TILE;
+        const int last = nk - 1 - key0;                  // rows past the last key are clamped (masked in the softmax)
+        int r = wave * 16 + i * 8 + rl;
+        r = r < last ? r : last;
+        char* dst = smem + b * BUFB + (wave * 16 + i * 8) * 128 + pp * 2 * PLANE;
+        if constexpr (pp == 0) {
+            const int64_t o = k_tile0 + (int64_t)key0 * ldkb + (unsigned)(r * ldkb) + ksw[i];
+            __builtin_amdgcn_global_load_lds((og_glb_void*)(reinterpret_cast<const char*>(a.kh) + o), (og_lds_void*)(dst), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((og_glb_void*)(reinterpret_cast<const char*>(a.kl) + o), (og_lds_void*)(dst + PLANE), 16, 0, 0);
+        } else {
+            const int64_t o = v_tile0 + (int64_t)key0 * ldvb + (unsigned)(r * ldvb) + vsw;
+            __builtin_amdgcn_global_load_lds((og_glb_void*)(reinterpret_cast<const char*>(a.vh) + o), (og_lds_void*)(dst), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((og_glb_void*)(reinterpret_cast<const char*>(a.vl) + o), (og_lds_void*)(dst + PLANE), 16, 0, 0);
+        }
+    };
+    auto issue_tile = [&](int kt, auto BUF) {
+        static_for<4>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            issue_pair(kt, BUF, std::integral_constant<int, (j >> 1)>{}, std::integral_constant<int, (j & 1)>{});
+        });
+    };
+    issue_tile(0, std::integral_constant<int, 0>{});
+
+    // ---- Q fragments (B operand): lane (query l31, k-group hi) holds Q[q][16c + 8hi + e] ----
+    f16x8 qh[NCH], ql[NCH];
+    {
+        int qi = q0 + wave * 32 + l31;
+        if (qi >= nq) qi = nq - 1;     // clamp: computed but never stored
+        const int64_t qo = (q_row0 + qi) * a.ldq + h * DH + 8 * hi;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            qh[c] = *reinterpret_cast<const f16x8*>(a.qh + qo + 16 * c);
+            ql[c] = *reinterpret_cast<const f16x8*>(a.ql + qo + 16 * c);
+        }
+    }
+    f32x16 oacc[NDV];
+#pragma unroll
+    for (int d = 0; d < NDV; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+    float m_run = 0.f, l_run = 0.f;
+    f32x16 negm;                                   // -m_run in every element: the C operand that opens each QK^T chain
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+
+    // fragment addresses of this lane (bytes inside a plane); everything else is an immediate
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    unsigned kf[NCH], va[NDV];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) kf[c] = lds0 + l31 * 128 + (((2 * c + hi) ^ ((l31 >> 1) & 7)) * 16);
+    {
+        const int vrow = (4 * hi + ((lane & 15) >> 2)) * 128 + 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
+#pragma unroll
+        for (int d = 0; d < NDV; ++d) va[d] = lds0 + vrow + 64 * (d ^ ((lane >> 3) & 1));
+    }
+    // fragment registers, double-buffered by hand: K [buf][key block], V [buf][dv block] as two transposed halves
+    f16x8 kh[2][2], kl[2][2];
+    s16x4 vh0[2][NDV], vh1[2][NDV], vl0[2][NDV], vl1[2][NDV];
+    const int ntiles = (nk + KV_TILE - 1) / KV_TILE;
+
+#if OG_ATTN_TRACE
+    const int tsel = blockIdx.x == 8 * 40 ? 0 : blockIdx.x == 8 * 41 + 3 ? 1 : -1;     // two workgroups somewhere in the middle
+    unsigned tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    auto tile_step = [&](int kt, auto BUF) {
+        constexpr int b = decltype(BUF)::value;
+        const int key0 = kt * KV_TILE;
+        OG_TP(0);
+        const bool more = kt + 1 < ntiles;
+        OG_TP(1);
+
+        // K fragments of chunk c (both key blocks, hi and lo planes) -> buffer c & 1; V fragments of group g = 2kb + t
+        auto read_k = [&](auto C) {
+            constexpr int c = decltype(C)::value;
+            static_for<2>([&](auto KB) {
+                constexpr int kb = decltype(KB)::value;
+                lds_read_b128<b * BUFB + kb * 32 * 128>(kh[c & 1][kb], kf[c]);
+                lds_read_b128<b * BUFB + PLANE + kb * 32 * 128>(kl[c & 1][kb], kf[c]);
+            });
+        };
+        auto read_v = [&](auto G) {
+            constexpr int g = decltype(G)::value;
+            static_for<NDV>([&](auto D) {
+                constexpr int d = decltype(D)::value;
+                constexpr int off = b * BUFB + 2 * PLANE + g * 16 * 128;
+                lds_read_tr16_b64<off>(vh0[g & 1][d], va[d]);
+                lds_read_tr16_b64<off + 8 * 128>(vh1[g & 1][d], va[d]);
+                lds_read_tr16_b64<off + PLANE>(vl0[g & 1][d], va[d]);
+                lds_read_tr16_b64<off + PLANE + 8 * 128>(vl1[g & 1][d], va[d]);
+            });
+        };
+
+        // ---- S' = K Q^T - m_run for the two 32-key blocks (independent accumulator chains, interleaved) ----
+        float s[2][16];
+        {
+            f32x16 sacc[2];
+            __builtin_amdgcn_sched_barrier(0);
+            read_k(std::integral_constant<int, 0>{});
+            static_for<NCH>([&](auto C) {
+                constexpr int c = decltype(C)::value;
+                constexpr int cb = c & 1;
+                if constexpr (c + 1 < NCH) {
+                    read_k(std::integral_constant<int, c + 1>{});
+                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(kh[cb][0]), "+v"(kh[cb][1]), "+v"(kl[cb][0]), "+v"(kl[cb][1]) :: "memory");
+                } else {
+                    read_v(std::integral_constant<int, 0>{});       // the first V fragments fly under the softmax
+                    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(kh[cb][0]), "+v"(kh[cb][1]), "+v"(kl[cb][0]), "+v"(kl[cb][1]) :: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // the first MFMA of a chain takes -m_run (negm) as its C operand: no accumulator initialisation
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[cb][kb], qh[c], c == 0 ? negm : sacc[kb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                // two DMA instructions of tile t+1 in the shadow of the matrix pipe (its buffer was last read before the barrier)
+                if (more) issue_pair(kt + 1, std::integral_constant<int, b ^ 1>{}, std::integral_constant<int, (c >> 1)>{}, std::integral_constant<int, (c & 1)>{});
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[cb][kb], ql[c], sacc[kb], 0, 0, 0);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[cb][kb], qh[c], sacc[kb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                if (key0 + KV_TILE > nk) {                  // only the last tile can hold padded keys (block-uniform)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = key0 + kb * 32 + mfma32_row(r, lane);
+                        s[kb][r] = key < nk ? sacc[kb][r] : OG_NEG_INF;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[kb][r] = sacc[kb][r];
+                }
+            }
+        }
+
+        OG_TP(2);
+        // ---- online softmax over keys, base 2 (this lane: 32 of the tile's 64 keys of ONE query) ----
+        float mt = s[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[kb][r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));          // max of s - m_run over the tile; finite: every tile holds >= 1 valid key
+        if (kt == 0 || __any(mt > RESCALE_THR)) {        // wave-uniform; rare after the first tile
+            const float delta = kt == 0 ? mt : fmaxf(mt, 0.f);       // new running max = m_run + delta
+            m_run += delta;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) negm[r] = -m_run;
+            if (kt > 0) {
+                const float alpha = __builtin_amdgcn_exp2f(-delta);  // rows that did not grow: 2^0 = 1
+                l_run *= alpha;
+#pragma unroll
+                for (int d = 0; d < NDV; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+            }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kb][r] -= delta;
+        }
+        f16x8 pf[2][2], pl[2][2];
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; r += 4) {
+                const float p0 = __builtin_amdgcn_exp2f(s[kb][r]);       // <= 2^RESCALE_THR
+                const float p1 = __builtin_amdgcn_exp2f(s[kb][r + 1]);
+                const float p2 = __builtin_amdgcn_exp2f(s[kb][r + 2]);
+                const float p3 = __builtin_amdgcn_exp2f(s[kb][r + 3]);
+                psum += (p0 + p1) + (p2 + p3);
+                unsigned ha, la, hb, lb;
+                og_split4(p0, p1, p2, p3, ha, la, hb, lb);      // og_common.h: 3 instructions per pair, hazard-safe
+                unsigned* pfw = reinterpret_cast<unsigned*>(&pf[kb][r >> 3]);
+                unsigned* plw = reinterpret_cast<unsigned*>(&pl[kb][r >> 3]);
+                pfw[(r & 7) >> 1] = ha; pfw[((r & 7) >> 1) + 1] = hb;
+                plw[(r & 7) >> 1] = la; plw[((r & 7) >> 1) + 1] = lb;
+            }
+        l_run += psum;
+
+        OG_TP(3);
+        // ---- O^T += V^T P^T of the same tile: group g = (key block kb, half t); A operand element e of lane (dv, hi) is
+        //      key kb*32 + 16t + 8(e>>2) + 4hi + (e&3) -> two transposing reads per plane ----
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<4>([&](auto G) {
+            constexpr int g = decltype(G)::value;
+            constexpr int gb = g & 1, kb = g >> 1, t = g & 1;
+            if constexpr (g + 1 < 4) {
+                read_v(std::integral_constant<int, g + 1>{});
+                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(vh0[gb][0]), "+v"(vh1[gb][0]), "+v"(vl0[gb][0]), "+v"(vl1[gb][0]),
+                             "+v"(vh0[gb][1]), "+v"(vh1[gb][1]), "+v"(vl0[gb][1]), "+v"(vl1[gb][1]) :: "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vh0[gb][0]), "+v"(vh1[gb][0]), "+v"(vl0[gb][0]), "+v"(vl1[gb][0]),
+                             "+v"(vh0[gb][1]), "+v"(vh1[gb][1]), "+v"(vl0[gb][1]), "+v"(vl1[gb][1]) :: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            f16x8 vh[NDV], vl[NDV];
+#pragma unroll
+            for (int d = 0; d < NDV; ++d) {
+                vh[d] = __builtin_bit_cast(f16x8, __builtin_shufflevector(vh0[gb][d], vh1[gb][d], 0, 1, 2, 3, 4, 5, 6, 7));
+                vl[d] = __builtin_bit_cast(f16x8, __builtin_shufflevector(vl0[gb][d], vl1[gb][d], 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int d = 0; d < NDV; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[d], pf[kb][t], oacc[d], 0, 0, 0);
+#pragma unroll
+            for (int d = 0; d < NDV; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[d], pl[kb][t], oacc[d], 0, 0, 0);
+#pragma unroll
+            for (int d = 0; d < NDV; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[d], pf[kb][t], oacc[d], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+
+        OG_TP(4);
+        if (kt + 1 < ntiles) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my pieces of tile t+1 landed
+            OG_TP(5);
+            __syncthreads();                                      // ... everybody's did, and everybody is done with tile t
+        }
+        OG_TP(6);
+#if OG_ATTN_TRACE
+        tp[7] = tp[6];
+        if (tsel >= 0 && lane == 0 && kt < 16)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) og_attn_trace_buf[tsel][wave][kt][i] = tp[i];
+#endif
+    };
+    for (int kt = 0; kt < ntiles; kt += 2) {
+        tile_step(kt, std::integral_constant<int, 0>{});
+        if (kt + 1 < ntiles) tile_step(kt + 1, std::integral_constant<int, 1>{});
+    }
+
+    // ---- normalise and store O[q][h*DH + dv] ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.f / l_tot;
+    const int qi = q0 + wave * 32 + l31;
+    if (qi < nq) {
+        const int64_t orow = (q_row0 + qi) * a.ldo;
+#pragma unroll
+        for (int d = 0; d < NDV; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int dv = d * 32 + 8 * g4 + 4 * hi;
+                f16x4 vh, vl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float o = oacc[d][4 * g4 + e] * inv;
+                    asm("" : "+v"(o));          // one materialised product for both halves of og_split (og_common.h)
+                    _Float16 th, tl;
+                    og_split(o, th, tl);
+                    vh[e] = th; vl[e] = tl;
+                }
+                const int64_t oo = orow + (a.o_hl ? og_hl_col(h * DH + dv) : (int64_t)(h * DH + dv));
+                *reinterpret_cast<f16x4*>(a.oh + oo) = vh;
+                *reinterpret_cast<f16x4*>(a.ol + oo) = vl;
+            }
+    }
+}
+
 }  // namespace
 
 int og_launch_attention(const AttnArgs& a, hipStream_t stream) {
@@ -423,20 +771,29 @@ int og_launch_attention(const AttnArgs& a, hipStream_t stream) {
     rd.B = 0;
     if (a.rag) rd = *a.rag;
     a2.rag = nullptr;
+    // dh = 64 with full-line head rows: the LDS-DMA kernel (OG_ATTN_DMA=0 keeps the register-staged one, for A/B runs)
+    static const bool dma_on = [] { const char* e = getenv("OG_ATTN_DMA"); return !(e && e[0] == '0'); }();
+    const bool dma64 = dma_on && a.dh == 64;
     const int groups8 = (a.nz * a.num_heads + 7) / 8 * 8;
     dim3 grid(groups8 * a2.qtiles), block(256);
     if (a.rag) {
         switch (a.dh) {
             case 16: hipLaunchKernelGGL((attention_kernel<16, RaggedDesc>), grid, block, 0, stream, a2, rd); break;
             case 32: hipLaunchKernelGGL((attention_kernel<32, RaggedDesc>), grid, block, 0, stream, a2, rd); break;
-            case 64: hipLaunchKernelGGL((attention_kernel<64, RaggedDesc>), grid, block, 0, stream, a2, rd); break;
+            case 64:
+                if (dma64) hipLaunchKernelGGL((attention64_kernel<RaggedDesc>), grid, block, 0, stream, a2, rd);
+                else hipLaunchKernelGGL((attention_kernel<64, RaggedDesc>), grid, block, 0, stream, a2, rd);
+                break;
             default: return OG_E_SHAPE;
         }
     } else {          // uniform batch: no descriptor in the kernarg segment (og_common.h: RaggedNone)
         switch (a.dh) {
             case 16: hipLaunchKernelGGL((attention_kernel<16, RaggedNone>), grid, block, 0, stream, a2, RaggedNone{}); break;
             case 32: hipLaunchKernelGGL((attention_kernel<32, RaggedNone>), grid, block, 0, stream, a2, RaggedNone{}); break;
-            case 64: hipLaunchKernelGGL((attention_kernel<64, RaggedNone>), grid, block, 0, stream, a2, RaggedNone{}); break;
+            case 64:
+                if (dma64) hipLaunchKernelGGL((attention64_kernel<RaggedNone>), grid, block, 0, stream, a2, RaggedNone{});
+                else hipLaunchKernelGGL((attention_kernel<64, RaggedNone>), grid, block, 0, stream, a2, RaggedNone{});
+                break;
             default: return OG_E_SHAPE;
         }
     }

@@ -22,7 +22,8 @@ buf = np.zeros((2, 4, 16, 8), np.uint32)
 lib.og_debug_attn_trace.restype = C.c_int
 lib.og_debug_attn_trace.argtypes = [C.c_void_p, C.c_size_t]
 assert lib.og_debug_attn_trace(buf.ctypes.data, buf.nbytes) == 0
-names = ["issue global loads", "QK^T + S ready", "PV(t-1) issue", "softmax + split", "barrier 1", "LDS staging stores", "barrier 2"]
+names = (["issue DMA", "QK^T + S ready", "softmax + split", "PV", "vmcnt(0)", "barrier", "-"] if os.environ.get("OG_ATTN_DMA", "1") != "0" else
+         ["issue global loads", "QK^T + S ready", "PV(t-1) issue", "softmax + split", "barrier 1", "LDS staging stores", "barrier 2"])
 for wg in range(2):
     for w in range(4):
         t = buf[wg, w].astype(np.int64)
