@@ -55,7 +55,6 @@ constexpr float RESCALE_THR = 11.f;          // base-2 exponent headroom before 
 #endif
 #if OG_ATTN_TRACE
 __device__ unsigned og_attn_trace_buf[2][4][16][8];
-__device__ unsigned og_attn_trace_pp[2][8][32][8];
 #define OG_TP(i)                                                                                         \
     do {                                                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                               \
@@ -440,6 +439,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a, RD rd) {
 // s_waitcnt vmcnt(0) + ONE barrier (tile t+1 landed, everybody is done with tile t).  The matrix pipe of a SIMD is kept
 // busy by the second workgroup of the CU (two independent 4-wave workgroups, 64 KB of LDS each): inside one in-order
 // wave a lagged PV(t-1) never overlapped softmax(t) anyway, the MFMA issue stalls the wave for the length of the burst.
+// Measured alternative (git history): one 8-wave workgroup whose two halves alternate matrix and softmax
+// phases between barriers, sharing the K/V ring -- 30 % slower: on this part the MFMA and VALU issue of the two waves of a
+// SIMD add up (tile period ~ 2 x (1536 MFMA + ~1200 VALU cycles)) whatever the phase alignment.
 template <class RD>
 __global__ __launch_bounds__(256, 2) void attention64_kernel(AttnArgs a, RD rd) {
     constexpr int DH = 64, NDV = 2, NCH = 4;
@@ -754,350 +756,6 @@ __global__ __launch_bounds__(256, 2) void attention64_kernel(AttnArgs a, RD rd) 
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------
-// dh = 64, more than 128 queries per problem: ONE 8-wave workgroup per CU owns 256 queries and the two wave groups
-// (waves 0-3 / 4-7; wave w and w+4 share a SIMD) run half a tile out of phase, separated by workgroup barriers:
-//     interval 2t  :  group A  matrix phase  M(t) = PV(t-1) + QK^T(t)     |  group B  softmax(t-1)       (VALU)
-//     interval 2t+1:  group A  softmax(t)                       (VALU)    |  group B  matrix phase M(t)
-// so that on every SIMD a pure-MFMA stream always sits beside a pure-VALU stream.  With two INDEPENDENT 4-wave
-// workgroups per CU (attention64_kernel) the phases of the two waves of a SIMD drift: matrix beside matrix serialises,
-// VALU beside VALU leaves the matrix pipe idle (tile period 5600 cycles for 3072 cycles of MFMA issue per SIMD,
-// scripts/trace_attention.py).  The K/V tiles are shared by all 256 queries (half the DMA and L2 traffic per query) in a
-// ring of four 32 KB slots (tile t in slot t & 3): group A fetches the K planes of tile t+2 during M(t), group B the V
-// planes during its M(t); a wave waits for its own pieces of tile t+1 at the end of M(t) (vmcnt(4): the four newest are
-// tile t+2), the interval barriers publish them long before their first reader.
-template <class RD>
-__global__ __launch_bounds__(512, 1) void attention64_pp_kernel(AttnArgs a, RD rd) {
-    constexpr int DH = 64, NDV = 2, NCH = 4, QT = 256;
-    constexpr int PLANE = KV_TILE * 128;            // bytes: 64 keys x one 128-byte head row
-    constexpr int SLOT = 4 * PLANE;                 // Kh | Kl | Vh | Vl
-    __shared__ __attribute__((aligned(1024))) char smem[4 * SLOT];
-
-    const int id = blockIdx.x;
-    const int xcd = id & 7, local = id >> 3;
-    const int grp = (local / a.qtiles) * 8 + xcd;          // (problem, head) group: all its query tiles on one XCD
-    if (grp >= a.nz * a.num_heads) return;
-    const int z = grp / a.num_heads, h = grp - z * a.num_heads;
-    const int gsel = z < a.split ? 0 : 1;
-    const int zz = gsel ? z - a.split : z;
-    int nq = a.nq[gsel], nk = a.nk[gsel];
-    int64_t q_row0 = a.q_base[gsel] + (int64_t)zz * a.q_step[gsel];
-    int64_t kv_row0 = a.kv_base[gsel] + (int64_t)zz * a.kv_step[gsel];
-    if (rd.B > 0) {          // ragged batch: per-pair row ranges of the packed token matrix
-        const int T0 = rd.off0[rd.B];
-        const int b = z < rd.B ? z : z - rd.B;
-        const int r0 = rd.off0[b], m_b = rd.off0[b + 1] - r0;
-        const int r1 = T0 + rd.off1[b], n_b = rd.off1[b + 1] - rd.off1[b];
-        const bool q_is0 = a.rag_mode == 1 ? z < rd.B : a.rag_mode == 2;
-        const bool kv_is0 = a.rag_mode == 1 ? q_is0 : !q_is0;
-        q_row0 = q_is0 ? r0 : r1; nq = q_is0 ? m_b : n_b;
-        kv_row0 = kv_is0 ? r0 : r1; nk = kv_is0 ? m_b : n_b;
-    }
-    const int q0 = (local % a.qtiles) * QT;
-    if (q0 >= nq) return;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // 0..7: query block of 32
-    const int wgrp = wave >> 2, w4 = wave & 3;
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int ntiles = (nk + KV_TILE - 1) / KV_TILE;
-
-    // ---- DMA: group A moves the K planes, group B the V planes; wave w4 of a group fills rows [16 w4, 16 w4 + 16) of both
-    //      planes (hi, lo) as two 8-row pieces = four instructions per tile ----
-    const int rl = lane >> 3, pc = lane & 7;
-    const int ldb = __builtin_amdgcn_readfirstlane((int)(wgrp ? a.ldv : a.ldk) * 2);       // row stride in bytes of my planes
-    auto uniform_ptr = [](const char* p) {          // wave-uniform by construction: pin it to scalar registers
-        const uint64_t v = (uint64_t)(uintptr_t)p;
-        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi32 = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-        return reinterpret_cast<const char*>((uintptr_t)(((uint64_t)hi32 << 32) | lo));
-    };
-    const char* plane_h = uniform_ptr(reinterpret_cast<const char*>(wgrp ? a.vh : a.kh) + (kv_row0 * (wgrp ? a.ldv : a.ldk) + h * DH) * 2);
-    const char* plane_l = uniform_ptr(reinterpret_cast<const char*>(wgrp ? a.vl : a.kl) + (kv_row0 * (wgrp ? a.ldv : a.ldk) + h * DH) * 2);
-    unsigned sw[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)          // K: chunk ^ ((row >> 1) & 7); V: chunk ^ (((row >> 1) & 1) << 2)   (attention64_kernel)
-        sw[i] = (unsigned)(pc ^ (wgrp ? (((lane >> 4) & 1) << 2) : ((lane >> 4) | (i << 2)))) * 16u;
-    unsigned doff[2];                                    // per-lane byte offsets of my two pieces inside a full tile
-#pragma unroll
-    for (int i = 0; i < 2; ++i) doff[i] = (unsigned)((w4 * 16 + i * 8 + rl) * ldb) + sw[i];
-    auto issue_tile = [&](int kt) {
-        const int key0 = kt * KV_TILE;
-        char* dst0 = smem + (kt & 3) * SLOT + wgrp * 2 * PLANE + (w4 * 16) * 128;
-        const char* th = plane_h + (int64_t)key0 * ldb;  // scalar tile bases
-        const char* tl = plane_l + (int64_t)key0 * ldb;
-        if (key0 + KV_TILE <= nk) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                __builtin_amdgcn_global_load_lds((og_glb_void*)(th + doff[i]), (og_lds_void*)(dst0 + i * 8 * 128), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((og_glb_void*)(tl + doff[i]), (og_lds_void*)(dst0 + i * 8 * 128 + PLANE), 16, 0, 0);
-            }
-        } else {                                         // last, partial tile: rows past the last key are clamped (masked in the softmax)
-            const int last = nk - 1 - key0;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                int r = w4 * 16 + i * 8 + rl;
-                r = r < last ? r : last;
-                const unsigned o = (unsigned)(r * ldb) + sw[i];
-                __builtin_amdgcn_global_load_lds((og_glb_void*)(th + o), (og_lds_void*)(dst0 + i * 8 * 128), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((og_glb_void*)(tl + o), (og_lds_void*)(dst0 + i * 8 * 128 + PLANE), 16, 0, 0);
-            }
-        }
-    };
-    issue_tile(0);
-    if (ntiles > 1) issue_tile(1);
-
-    // ---- Q fragments (B operand): lane (query l31, k-group hi) holds Q[q][16c + 8hi + e] ----
-    f16x8 qh[NCH], ql[NCH];
-    {
-        int qi = q0 + wave * 32 + l31;
-        if (qi >= nq) qi = nq - 1;     // clamp: computed but never stored
-        const int64_t qo = (q_row0 + qi) * a.ldq + h * DH + 8 * hi;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            qh[c] = *reinterpret_cast<const f16x8*>(a.qh + qo + 16 * c);
-            ql[c] = *reinterpret_cast<const f16x8*>(a.ql + qo + 16 * c);
-        }
-    }
-    f32x16 oacc[NDV];
-#pragma unroll
-    for (int d = 0; d < NDV; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
-    float m_run = 0.f, l_run = 0.f;
-
-    // fragment addresses of this lane inside a slot (bytes); the slot base is added per phase, the rest are immediates
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    // (relative to smem; they are rotated in place from slot to slot at the start of every matrix phase: K of tile t, V of t-1)
-    unsigned kf[NCH], va[NDV];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) kf[c] = 3 * SLOT + l31 * 128 + (((2 * c + hi) ^ ((l31 >> 1) & 7)) * 16);              // "tile -1"
-    {
-        const int vrow = (4 * hi + ((lane & 15) >> 2)) * 128 + 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
-#pragma unroll
-        for (int d = 0; d < NDV; ++d) va[d] = 2 * SLOT + 2 * PLANE + vrow + 64 * (d ^ ((lane >> 3) & 1));               // "tile -2"
-    }
-    float s[2][16];                                 // S'(t) of this lane: QK^T(t) -> softmax(t)
-    f16x8 pf[2][2], pl[2][2];                       // P(t) as (hi, lo): softmax(t) -> PV(t)
-
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    // ---- matrix phase M(t) = PV(t-1) [HAS_PV] then QK^T(t) [HAS_QK]; fragment reads one group ahead of the MFMAs ----
-    auto matrix_phase = [&](int t, auto HAS_PV, auto HAS_QK) __attribute__((always_inline)) {
-        constexpr bool has_pv = decltype(HAS_PV)::value, has_qk = decltype(HAS_QK)::value;
-        const bool issue = t + 2 < ntiles;
-        // fragment registers, local to the phase (declared outside they would be carried around the interval loop)
-        f16x8 kh[2][2], kl[2][2];                       // K fragments [buf][key block]
-        s16x4 vh0[2][NDV], vh1[2][NDV], vl0[2][NDV], vl1[2][NDV];      // V fragments [buf][dv block], two transposed halves
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) kf[c] = (kf[c] + SLOT) & (4 * SLOT - 1);
-#pragma unroll
-        for (int d = 0; d < NDV; ++d) va[d] = (va[d] + SLOT) & (4 * SLOT - 1);
-        // One LDS read per call, so that the reads of the NEXT group can be slotted between the MFMAs of the current one: a
-        // wave issues at most one ds_read_b128 per ~26 cycles / one ds_read_b64_tr_b16 per ~14 (scripts/probes/
-        // lds_read_patterns.hip); issued as a burst in front of the group's MFMAs they delay the matrix pipe by their whole
-        // issue time, issued one or two per MFMA they vanish behind its 32 cycles.
-        auto read_k1 = [&](auto C, auto J) {             // piece j of chunk c: key block j >> 1, plane j & 1
-            constexpr int c = decltype(C)::value, j = decltype(J)::value, kb = j >> 1;
-            if constexpr ((j & 1) == 0) lds_read_b128<kb * 32 * 128>(kh[c & 1][kb], lds0 + kf[c]);
-            else lds_read_b128<PLANE + kb * 32 * 128>(kl[c & 1][kb], lds0 + kf[c]);
-        };
-        auto read_v1 = [&](auto G, auto J) {             // piece j of group g: dv block j >> 2, (plane, half) j & 3
-            constexpr int g = decltype(G)::value, j = decltype(J)::value, d = j >> 2, off = g * 16 * 128;
-            if constexpr ((j & 3) == 0) lds_read_tr16_b64<off>(vh0[g & 1][d], lds0 + va[d]);
-            else if constexpr ((j & 3) == 1) lds_read_tr16_b64<off + 8 * 128>(vh1[g & 1][d], lds0 + va[d]);
-            else if constexpr ((j & 3) == 2) lds_read_tr16_b64<off + PLANE>(vl0[g & 1][d], lds0 + va[d]);
-            else lds_read_tr16_b64<off + PLANE + 8 * 128>(vl1[g & 1][d], lds0 + va[d]);
-        };
-        auto fence = [] { __builtin_amdgcn_sched_barrier(0); };
-        fence();
-        if constexpr (has_pv) {
-            static_for<8>([&](auto J) { read_v1(std::integral_constant<int, 0>{}, J); });
-            static_for<4>([&](auto G) {
-                constexpr int g = decltype(G)::value;
-                constexpr int gb = g & 1, kb = g >> 1, tt = g & 1;
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vh0[gb][0]), "+v"(vh1[gb][0]), "+v"(vl0[gb][0]), "+v"(vl1[gb][0]),
-                             "+v"(vh0[gb][1]), "+v"(vh1[gb][1]), "+v"(vl0[gb][1]), "+v"(vl1[gb][1]) :: "memory");
-                fence();
-                f16x8 vh[NDV], vl[NDV];
-#pragma unroll
-                for (int d = 0; d < NDV; ++d) {
-                    vh[d] = __builtin_bit_cast(f16x8, __builtin_shufflevector(vh0[gb][d], vh1[gb][d], 0, 1, 2, 3, 4, 5, 6, 7));
-                    vl[d] = __builtin_bit_cast(f16x8, __builtin_shufflevector(vl0[gb][d], vl1[gb][d], 0, 1, 2, 3, 4, 5, 6, 7));
-                }
-                // MFMA m of the group, then the next group's (or the first K chunk's) reads 2m, 2m+1
-                static_for<6>([&](auto M) {
-                    constexpr int m = decltype(M)::value, d = m & 1, pass = m >> 1;
-                    if constexpr (pass == 0) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[d], pf[kb][tt], oacc[d], 0, 0, 0);
-                    else if constexpr (pass == 1) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[d], pl[kb][tt], oacc[d], 0, 0, 0);
-                    else oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[d], pf[kb][tt], oacc[d], 0, 0, 0);
-                    fence();
-                    if constexpr (m < 4) {
-                        if constexpr (g + 1 < 4) {
-                            read_v1(std::integral_constant<int, g + 1>{}, std::integral_constant<int, 2 * m>{});
-                            read_v1(std::integral_constant<int, g + 1>{}, std::integral_constant<int, 2 * m + 1>{});
-                        } else if constexpr (has_qk) {
-                            read_k1(std::integral_constant<int, 0>{}, std::integral_constant<int, m>{});
-                        }
-                        fence();
-                    }
-                });
-            });
-        }
-        if constexpr (has_qk) {
-            const int key0 = t * KV_TILE;
-            f32x16 sacc[2];                         // starts at -m_run (VALU slots are free beside the matrix phase)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sacc[kb][r] = -m_run;
-            if constexpr (!has_pv) static_for<4>([&](auto J) { read_k1(std::integral_constant<int, 0>{}, J); });
-            static_for<NCH>([&](auto C) {
-                constexpr int c = decltype(C)::value;
-                constexpr int cb = c & 1;
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kh[cb][0]), "+v"(kh[cb][1]), "+v"(kl[cb][0]), "+v"(kl[cb][1]) :: "memory");
-                fence();
-                static_for<6>([&](auto M) {
-                    constexpr int m = decltype(M)::value, kb = m & 1, pass = m >> 1;
-                    if constexpr (pass == 0) sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[cb][kb], qh[c], sacc[kb], 0, 0, 0);
-                    else if constexpr (pass == 1) sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[cb][kb], ql[c], sacc[kb], 0, 0, 0);
-                    else sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[cb][kb], qh[c], sacc[kb], 0, 0, 0);
-                    fence();
-                    if constexpr (m < 4 && c + 1 < NCH) {
-                        read_k1(std::integral_constant<int, c + 1>{}, std::integral_constant<int, m>{});
-                        fence();
-                    }
-                    // my four DMA instructions of tile t+2 behind the last MFMAs of the chunk, one wave of the group per chunk
-                    if constexpr (m == 4) {
-                        if (issue && w4 == c) issue_tile(t + 2);
-                        fence();
-                    }
-                });
-            });
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                if (key0 + KV_TILE > nk) {                  // only the last tile can hold padded keys (block-uniform)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = key0 + kb * 32 + mfma32_row(r, lane);
-                        s[kb][r] = key < nk ? sacc[kb][r] : OG_NEG_INF;
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s[kb][r] = sacc[kb][r];
-                }
-            }
-        }
-        // my pieces of tile t+1 landed (everything but the four newest, tile t+2); the interval barriers publish them
-        if (issue) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-
-    // ---- softmax(t): online softmax over keys, base 2 (this lane: 32 of the tile's 64 keys of ONE query) -> P(t) ----
-    auto softmax_phase = [&](int t) __attribute__((always_inline)) {
-        float mt = s[0][0];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[kb][r]);
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));          // max of s - m_run over the tile; finite: every tile holds >= 1 valid key
-        if (t == 0 || __any(mt > RESCALE_THR)) {         // wave-uniform; rare after the first tile
-            const float delta = t == 0 ? mt : fmaxf(mt, 0.f);        // new running max = m_run + delta
-            m_run += delta;
-            if (t > 0) {                                 // O and l are complete up to tile t-1 (PV(t-1) ran in the last matrix phase)
-                const float alpha = __builtin_amdgcn_exp2f(-delta);  // rows that did not grow: 2^0 = 1
-                l_run *= alpha;
-#pragma unroll
-                for (int d = 0; d < NDV; ++d)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
-            }
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[kb][r] -= delta;
-        }
-        float psum = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; r += 4) {
-                const float p0 = __builtin_amdgcn_exp2f(s[kb][r]);       // <= 2^RESCALE_THR
-                const float p1 = __builtin_amdgcn_exp2f(s[kb][r + 1]);
-                const float p2 = __builtin_amdgcn_exp2f(s[kb][r + 2]);
-                const float p3 = __builtin_amdgcn_exp2f(s[kb][r + 3]);
-                psum += (p0 + p1) + (p2 + p3);
-                unsigned ha, la, hb, lb;
-                og_split4(p0, p1, p2, p3, ha, la, hb, lb);      // og_common.h: 3 instructions per pair, hazard-safe
-                unsigned* pfw = reinterpret_cast<unsigned*>(&pf[kb][r >> 3]);
-                unsigned* plw = reinterpret_cast<unsigned*>(&pl[kb][r >> 3]);
-                pfw[(r & 7) >> 1] = ha; pfw[((r & 7) >> 1) + 1] = hb;
-                plw[(r & 7) >> 1] = la; plw[((r & 7) >> 1) + 1] = lb;
-            }
-        l_run += psum;
-    };
-
-    using T_ = std::true_type;
-    using F_ = std::false_type;
-#if OG_ATTN_TRACE
-    const int tsel = blockIdx.x == 8 * 20 ? 0 : blockIdx.x == 8 * 21 + 3 ? 1 : -1;
-    unsigned tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define OG_TPW(t)                                                                                          \
-    if (tsel >= 0 && lane == 0 && (t) < 32) {                                                             \
-        tp[5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));        /* HW_ID */               \
-        for (int i_ = 0; i_ < 8; ++i_) og_attn_trace_pp[tsel][wave][(t)][i_] = tp[i_];                      \
-    }
-#else
-#define OG_TPW(t) do {} while (0)
-#endif
-    // interval i: the group with (i & 1) == wgrp runs its matrix phase, the other one its softmax (one code path for both
-    // groups, so every phase body is instantiated once)
-    for (int i = 0; i < 2 * ntiles + 2; ++i) {
-        OG_TP(0);
-        if ((i & 1) == wgrp) {
-            const int t = (i - wgrp) >> 1;
-            if (t == 0) matrix_phase(t, F_{}, T_{});
-            else if (t < ntiles) matrix_phase(t, T_{}, T_{});
-            else matrix_phase(t, T_{}, F_{});
-        } else {
-            const int t = (i - 1 - wgrp) >> 1;
-            if (t >= 0 && t < ntiles) softmax_phase(t);
-        }
-        OG_TP(1);
-        // no __syncthreads(): its release fence drains vmcnt(0), i.e. the DMA of tile t+2 that was issued a moment ago; the
-        // matrix phase waited for exactly the pieces that must be visible (vmcnt(4)), LDS reads are all complete
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        OG_TP(2);
-        OG_TPW(i);
-    }
-
-    // ---- normalise and store O[q][h*DH + dv] ----
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.f / l_tot;
-    const int qi = q0 + wave * 32 + l31;
-    if (qi < nq) {
-        const int64_t orow = (q_row0 + qi) * a.ldo;
-#pragma unroll
-        for (int d = 0; d < NDV; ++d)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int dv = d * 32 + 8 * g4 + 4 * hi;
-                f16x4 vh, vl;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float o = oacc[d][4 * g4 + e] * inv;
-                    asm("" : "+v"(o));          // one materialised product for both halves of og_split (og_common.h)
-                    _Float16 th, tl;
-                    og_split(o, th, tl);
-                    vh[e] = th; vl[e] = tl;
-                }
-                const int64_t oo = orow + (a.o_hl ? og_hl_col(h * DH + dv) : (int64_t)(h * DH + dv));
-                *reinterpret_cast<f16x4*>(a.oh + oo) = vh;
-                *reinterpret_cast<f16x4*>(a.ol + oo) = vl;
-            }
-    }
-}
-
 }  // namespace
 
 int og_launch_attention(const AttnArgs& a, hipStream_t stream) {
@@ -1123,15 +781,6 @@ int og_launch_attention(const AttnArgs& a, hipStream_t stream) {
     static const bool dma_on = [] { const char* e = getenv("OG_ATTN_DMA"); return !(e && e[0] == '0'); }();
     const bool dma64 = dma_on && a.dh == 64;
     const int groups8 = (a.nz * a.num_heads + 7) / 8 * 8;
-    // more than one 128-query tile per problem: the 8-wave two-phase kernel (OG_ATTN_PP=0 keeps the 4-wave one, for A/B runs)
-    static const bool pp_on = [] { const char* e = getenv("OG_ATTN_PP"); return e && e[0] == '1'; }();      // experiment, off by default
-    if (dma64 && pp_on && nqmax > Q_TILE) {
-        a2.qtiles = (nqmax + 255) / 256;
-        dim3 grid_pp(groups8 * a2.qtiles), block_pp(512);
-        if (a.rag) hipLaunchKernelGGL((attention64_pp_kernel<RaggedDesc>), grid_pp, block_pp, 0, stream, a2, rd);
-        else hipLaunchKernelGGL((attention64_pp_kernel<RaggedNone>), grid_pp, block_pp, 0, stream, a2, RaggedNone{});
-        return og_launch_status();
-    }
     dim3 grid(groups8 * a2.qtiles), block(256);
     if (a.rag) {
         switch (a.dh) {
@@ -1158,10 +807,6 @@ int og_launch_attention(const AttnArgs& a, hipStream_t stream) {
 }
 
 #if OG_ATTN_TRACE
-extern "C" int og_debug_attn_trace_pp(void* host_dst, size_t bytes) {
-    if (bytes > sizeof(og_attn_trace_pp)) bytes = sizeof(og_attn_trace_pp);
-    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(og_attn_trace_pp), bytes);
-}
 extern "C" int og_debug_attn_trace(void* host_dst, size_t bytes) {
     if (bytes > sizeof(og_attn_trace_buf)) bytes = sizeof(og_attn_trace_buf);
     return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(og_attn_trace_buf), bytes);

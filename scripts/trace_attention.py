@@ -32,18 +32,3 @@ for wg in range(2):
         mid = slice(4, 12)
         print(f"wg {wg} wave {w}: tile period {tile[mid].mean():7.0f} cyc | " + " | ".join(f"{names[i]} {seg[mid, i].mean():6.0f}" for i in range(7)))
 
-if hasattr(lib, "og_debug_attn_trace_pp") and os.environ.get("OG_ATTN_PP", "1") != "0":
-    buf = np.zeros((2, 8, 32, 8), np.uint32)
-    lib.og_debug_attn_trace_pp.restype = C.c_int
-    lib.og_debug_attn_trace_pp.argtypes = [C.c_void_p, C.c_size_t]
-    assert lib.og_debug_attn_trace_pp(buf.ctypes.data, buf.nbytes) == 0
-    print("8-wave two-phase kernel, per interval: [phase body | barrier wait]; even intervals: waves 0-3 matrix phase, 4-7 softmax; odd: swapped")
-    for wg in range(2):
-        for w in range(8):
-            t_ = buf[wg, w].astype(np.int64)
-            body = (t_[:, 1] - t_[:, 0]) & 0xFFFFFFFF
-            bar = (t_[:, 2] - t_[:, 1]) & 0xFFFFFFFF
-            per = (t_[1:, 0] - t_[:-1, 0]) & 0xFFFFFFFF
-            hw = int(t_[5, 5])
-            ev, od = slice(8, 24, 2), slice(9, 25, 2)
-            print(f"wg {wg} wave {w} (simd {(hw >> 4) & 3}): interval {per[8:24].mean():6.0f} | even: body {body[ev].mean():6.0f} barrier {bar[ev].mean():5.0f} | odd: body {body[od].mean():6.0f} barrier {bar[od].mean():5.0f}")
