@@ -44,3 +44,8 @@ if [ "${2:-pmc}" = "pmc" ]; then
   bash scripts/gpu_traffic.sh > $OUT/traffic.log 2>&1
   python scripts/parse_traffic.py gpurun_out/traffic gpurun_out/traffic_c2.json > /dev/null 2>&1; head -c 1500 gpurun_out/traffic_c2.json
 fi
+echo "== probes"
+for p in lds_read_patterns mfma_valu_interleave store_pattern dispatch_ramp; do
+  [ -x openglue_amd/lib/probe_$p ] && timeout 60 openglue_amd/lib/probe_$p > $OUT/probe_$p.log 2>&1
+done
+tail -4 $OUT/probe_lds_read_patterns.log 2>/dev/null
