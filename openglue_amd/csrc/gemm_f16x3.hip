@@ -278,6 +278,64 @@ __device__ __forceinline__ void gemm_f16x3_epilogue_store(const GemmHArgs& g, f3
     }
 }
 
+// Fast path of the 256-tile kernels: the whole 64-channel x 128-token wave tile is inside the matrix, the output is hl32
+// rows (HL) or (hi, lo) planes, no fp32 / channel-first copy.  Per 32-token slice both channel blocks go through TWO slabs
+// (HL: one per channel block; planes: one per plane) -- 16 LDS writes, 8 LDS reads, 8 stores with no predicate, no per-store
+// address arithmetic: the row/column part of a store address is a scalar base, the lane part one 32-bit offset computed once.
+// [The generic path above costs ~13k cycles per tile (scripts/trace_gemm.py): every store sits under its own exec-mask branch
+// with a 64-bit multiply for its row, and each of the 8 (slice, channel block) passes waits for its own LDS round trip.]
+template <bool HL>
+__device__ __forceinline__ void gemm_f16x3_epilogue_fast(const GemmHArgs& g, f32x16 (&acc)[2][4], int tok0, int oc0, int lane, char* slab2) {
+#pragma clang fp contract(off)                  // og_split: hi and lo must see the same rounded value (og_common.h)
+    constexpr int ROWB = 128 + 16;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const unsigned voff = (unsigned)((lane >> 3) * (int)g.ldch * 2 + (lane & 7) * 16);       // 8 rows x 128 B per store instruction
+    const unsigned rd_off = (unsigned)((lane >> 3) * ROWB + (lane & 7) * 16);
+    char* const out_h = reinterpret_cast<char*>(g.Ch);
+    char* const out_l = reinterpret_cast<char*>(g.Cl);
+    og_u32x4 raw[2][4];
+    gemm_f16x3_load_residual<2>(g, raw, tok0, oc0, lane);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f32x16 a[2];
+        a[0] = acc[0][j]; a[1] = acc[1][j];
+        gemm_f16x3_epilogue_finish<2, false>(g, a, raw, oc0, lane);
+        if (j + 1 < 4) gemm_f16x3_load_residual<2>(g, raw, tok0 + (j + 1) * 32, oc0, lane);
+        // registers -> slabs.  HL: slab i = [32 tok][hi 64 B | lo 64 B] of channel block i; planes: slab 0 = hi, slab 1 = lo of [32 tok][64 ch]
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned ha, la, hb, lb;
+                og_split4(a[i][4 * q], a[i][4 * q + 1], a[i][4 * q + 2], a[i][4 * q + 3], ha, la, hb, lb);
+                if (HL) {
+                    char* d = slab2 + i * EPI_SLAB + l31 * ROWB + (8 * q + 4 * hi) * 2;
+                    *reinterpret_cast<uint2*>(d) = make_uint2(ha, hb);
+                    *reinterpret_cast<uint2*>(d + 64) = make_uint2(la, lb);
+                } else {
+                    char* d = slab2 + l31 * ROWB + (i * 32 + 8 * q + 4 * hi) * 2;
+                    *reinterpret_cast<uint2*>(d) = make_uint2(ha, hb);
+                    *reinterpret_cast<uint2*>(d + EPI_SLAB) = make_uint2(la, lb);
+                }
+            }
+        // slabs -> whole 128-byte lines
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f16x8 t[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) t[it] = *reinterpret_cast<const f16x8*>(slab2 + i * EPI_SLAB + it * 8 * ROWB + rd_off);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int64_t row = (int64_t)(tok0 + j * 32 + it * 8) * g.ldch;          // scalar
+                if (!(OG_GEMM_ABL & 1)) {
+                    if (HL) *reinterpret_cast<f16x8*>(out_h + (row + og_hl_col(oc0 + i * 32)) * 2 + voff) = t[it];
+                    else *reinterpret_cast<f16x8*>((i == 0 ? out_h : out_l) + (row + oc0) * 2 + voff) = t[it];
+                }
+            }
+        }
+    }
+}
+
 // Experiment builds only (scripts/build_ablation.sh gemm_trace -DOG_GEMM_TRACE=1): shader-cycle stamps of every wave of every
 // block of the 256-tile kernel at the stage hand-overs (read back by og_debug_gemm_trace, scripts/trace_gemm.py).  The stamps
 // sit where the LDS queue is already drained; they cost an SMEM round trip each (compare the traced build's time first).
@@ -675,6 +733,9 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_big_kernel(GemmHArgs g, int
 //     Counted waits: LDS-DMA completes in issue order, every stage issues W(kt+1) first and X(kt+2) second, so at the
 //     end of stage kt `s_waitcnt vmcnt(4)` = "everything but the four X(kt+2) pieces has landed" = X(kt+1), W(kt+1).
 // One problem per launch (no batch, no ragged descriptor): the per-pair score GEMM stays on the kernel above.
+// EPI: 0 = generic epilogue, 1 = fast hl32 rows, 2 = fast planes (every tile inside the matrix; chosen by the launcher -- one
+// epilogue per instantiation keeps the kernel inside its 256 registers)
+template <int EPI>
 __global__ __launch_bounds__(512) void gemm_nt_f16x3_big2_kernel(GemmHArgs g, int tiles_m, int tiles_n) {
     constexpr int XS = BIG * 128;              // one stage of one operand: 256 rows x 128 B (hi 64 B | lo 64 B)
     constexpr int WOFF = 3 * XS;
@@ -830,18 +891,24 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_big2_kernel(GemmHArgs g, in
 
     __builtin_amdgcn_s_barrier();      // every wave is past its last fragment reads, no DMA is in flight: the rings are free
     {
-        og_u32x4 raw[2][4];
         const int tok0 = t0 + wt * 128, oc0 = n0 + wo * 64;
-        char* slab = smem + wave * EPI_SLAB;
-        const RaggedNone no_rd{};                   // FULL = false: the channel-first copy (the only user of the descriptor) is compiled out
-        gemm_f16x3_load_residual<2>(g, raw, tok0, oc0, lane);
+        if constexpr (EPI == 1) {
+            gemm_f16x3_epilogue_fast<true>(g, acc, tok0, oc0, lane, smem + wave * 2 * EPI_SLAB);
+        } else if constexpr (EPI == 2) {
+            gemm_f16x3_epilogue_fast<false>(g, acc, tok0, oc0, lane, smem + wave * 2 * EPI_SLAB);
+        } else {
+            og_u32x4 raw[2][4];
+            char* slab = smem + wave * EPI_SLAB;
+            const RaggedNone no_rd{};               // FULL = false: the channel-first copy (the only user of the descriptor) is compiled out
+            gemm_f16x3_load_residual<2>(g, raw, tok0, oc0, lane);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f32x16 a[2];
-            a[0] = acc[0][j]; a[1] = acc[1][j];
-            gemm_f16x3_epilogue_finish<2, false>(g, a, raw, oc0, lane);
-            if (j + 1 < 4) gemm_f16x3_load_residual<2>(g, raw, tok0 + (j + 1) * 32, oc0, lane);
-            gemm_f16x3_epilogue_store<2, false>(g, a, tok0 + j * 32, oc0, lane, slab, no_rd);
+            for (int j = 0; j < 4; ++j) {
+                f32x16 a[2];
+                a[0] = acc[0][j]; a[1] = acc[1][j];
+                gemm_f16x3_epilogue_finish<2, false>(g, a, raw, oc0, lane);
+                if (j + 1 < 4) gemm_f16x3_load_residual<2>(g, raw, tok0 + (j + 1) * 32, oc0, lane);
+                gemm_f16x3_epilogue_store<2, false>(g, a, tok0 + j * 32, oc0, lane, slab, no_rd);
+            }
         }
     }
 #if OG_GEMM_TRACE
@@ -927,7 +994,12 @@ int og_launch_gemm_f16x3(const GemmHArgs& a, hipStream_t stream) {
                 const int tiles_m8 = (tiles_m + 7) / 8 * 8;
                 static const bool big2 = [] { const char* e = getenv("OG_GEMM_BIG2"); return !e || atoi(e) != 0; }();   // experiments: 0 = first generation
                 if (big2 && nz == 1 && !a.rag) {
-                    hipLaunchKernelGGL(gemm_nt_f16x3_big2_kernel, dim3(tiles_m8 * tiles_n), dim3(512), 0, stream, g, tiles_m, tiles_n);
+                    const bool whole = g.M % 256 == 0 && g.N % 256 == 0 && g.Ch && !g.C32;      // every tile inside, split-f16 output only
+                    static const bool fast_epi = [] { const char* e = getenv("OG_GEMM_FAST_EPI"); return !e || atoi(e) != 0; }();   // experiments
+                    const dim3 grid2(tiles_m8 * tiles_n), block2(512);
+                    if (whole && fast_epi && g.c_hl) hipLaunchKernelGGL(gemm_nt_f16x3_big2_kernel<1>, grid2, block2, 0, stream, g, tiles_m, tiles_n);
+                    else if (whole && fast_epi && g.Cl) hipLaunchKernelGGL(gemm_nt_f16x3_big2_kernel<2>, grid2, block2, 0, stream, g, tiles_m, tiles_n);
+                    else hipLaunchKernelGGL(gemm_nt_f16x3_big2_kernel<0>, grid2, block2, 0, stream, g, tiles_m, tiles_n);
                     return og_launch_status();
                 }
                 hipLaunchKernelGGL(gemm_nt_f16x3_big_kernel<RD>, dim3(tiles_m8 * tiles_n, nz), dim3(512), 0, stream, g, tiles_m, tiles_n, rd);
