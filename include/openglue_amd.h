@@ -257,6 +257,19 @@ int og_sinkhorn_backward(const float* S, int64_t lds, float dustbin, int32_t bat
                          float reg, const float* grad_scores, void* train_workspace_dev, float* dS, int64_t ldds,
                          float* d_dustbin, void* stream);
 
+/* ---- training slice: train-mode BatchNorm of the MLPs (reference models/utils.py:48-58, FeedForwardNet = Conv1d -> ReLU ->
+ * nn.BatchNorm1d, in training mode: torch.nn.functional.batch_norm(training=True)) on TOKEN-MAJOR activations
+ * x [rows][channels] (row stride ldx floats; the reference's [B, C, N] tensor with rows = B*N): batch statistics per channel
+ * over all rows, y = (x - mean) / sqrt(biased var + eps) * weight + bias, running_mean / running_var updated in place with
+ * `momentum` (running_var takes the unbiased variance), all like torch.  weight / bias / running_* / save_* may be NULL;
+ * save_mean / save_invstd [channels] are what a backward pass needs.  channels % 4 == 0, ldx % 4 == 0, ldy % 4 == 0,
+ * 16-byte aligned pointers; y may alias x.  workspace: og_batchnorm_train_workspace_bytes (0 = unsupported shape). */
+size_t og_batchnorm_train_workspace_bytes(int64_t rows, int32_t channels);
+int og_batchnorm_train_forward(const float* x, int64_t ldx, int64_t rows, int32_t channels, const float* weight,
+                               const float* bias, float eps, float momentum, float* running_mean, float* running_var,
+                               float* y, int64_t ldy, float* save_mean, float* save_invstd, void* workspace_dev,
+                               void* stream);
+
 /* mutual-NN match extraction from a scores tensor [B][m+1][n+1] (matching_module.py:174-187;
  * matches1/matching_scores1 as inference.py:183-188, may be NULL).  First maximal index wins.
  * workspace: og_matches_workspace_bytes. */

@@ -1,0 +1,119 @@
+// Train-mode BatchNorm statistics + normalisation for the token-major activations of the MLPs (training slice).
+//
+// Replaces nn.BatchNorm1d in training mode inside FeedForwardNet (reference models/utils.py:48-58: Conv1d -> ReLU ->
+// BatchNorm1d): per channel c over all tokens t of the call (the reference's [B, C, N] tensor: statistics over B and N)
+//     mean_c = E_t x[t][c]      var_c = E_t (x[t][c] - mean_c)^2  (biased)      y = (x - mean) / sqrt(var + eps) * w + b
+//     running_mean = (1 - mom) running_mean + mom mean        running_var = (1 - mom) running_var + mom var * T / (T - 1)
+// (torch.nn.functional.batch_norm semantics).  Eval mode needs none of this: the running statistics are folded into the next
+// 1x1 conv at pack time (api.hip).
+// HBM-bound, three passes over x: (1) per-row-slab partial sums of (x - k) and (x - k)^2 with k = x[0][c] (a per-channel shift
+// removes the cancellation of E x^2 - (E x)^2 for channels whose mean dominates their spread), coalesced along the channel
+// axis; (2) one block folds the partials in double, updates the running statistics and emits scale = w * invstd,
+// shift = b - mean * scale (+ mean / invstd for a later backward); (3) y = x * scale + shift, 16 bytes per lane.
+#include "og_common.h"
+
+namespace {
+
+constexpr int BN_ROWS_PER_BLOCK = 256;      // rows folded by one block of pass 1
+
+// grid (ceil(rows / BN_ROWS_PER_BLOCK), ceil(C / 64)), 256 threads = 4 row groups x 64 channels
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int C, float* __restrict__ part) {
+    __shared__ float red[2][4][64];
+    const int c = blockIdx.y * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * BN_ROWS_PER_BLOCK;
+    float s1 = 0.f, s2 = 0.f;
+    if (c < C) {
+        const float k = x[c];                                   // shift: row 0 of the channel
+        const int64_t r1 = r0 + BN_ROWS_PER_BLOCK < rows ? r0 + BN_ROWS_PER_BLOCK : rows;
+        for (int64_t r = r0 + rg; r < r1; r += 4) {
+            const float d = x[r * ldx + c] - k;
+            s1 += d;
+            s2 = fmaf(d, d, s2);
+        }
+    }
+    red[0][rg][threadIdx.x & 63] = s1;
+    red[1][rg][threadIdx.x & 63] = s2;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        const int l = threadIdx.x;
+        const float t1 = (red[0][0][l] + red[0][1][l]) + (red[0][2][l] + red[0][3][l]);
+        const float t2 = (red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l]);
+        part[((int64_t)blockIdx.x * C + c) * 2] = t1;
+        part[((int64_t)blockIdx.x * C + c) * 2 + 1] = t2;
+    }
+}
+
+// one thread per channel
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ x, const float* __restrict__ part, int nblk, int64_t rows, int C,
+                                                          const float* __restrict__ w, const float* __restrict__ b, float eps, float momentum,
+                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                          float* __restrict__ scale_shift, float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < nblk; ++i) {
+        s1 += (double)part[((int64_t)i * C + c) * 2];
+        s2 += (double)part[((int64_t)i * C + c) * 2 + 1];
+    }
+    const double n = (double)rows;
+    const double dm = s1 / n;                                   // mean - k
+    const double mean = (double)x[c] + dm;
+    double var = s2 / n - dm * dm;                              // biased
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const float sc = (float)((w ? (double)w[c] : 1.0) * invstd);
+    scale_shift[c] = sc;
+    scale_shift[C + c] = (float)((b ? (double)b[c] : 0.0) - mean * (double)sc);
+    if (save_mean) save_mean[c] = (float)mean;
+    if (save_invstd) save_invstd[c] = (float)invstd;
+    if (running_mean) running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+    if (running_var) {
+        const double unbiased = rows > 1 ? var * n / (n - 1.0) : var;
+        running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+    }
+}
+
+// C % 4 == 0, 16-byte aligned rows: one float4 per thread
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int C4, const float* __restrict__ scale_shift,
+                                                       float* __restrict__ y, int64_t ldy) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * C4) return;
+    const int64_t r = i / C4;
+    const int c = (int)(i - r * C4) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + c);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale_shift + c);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(scale_shift + 4 * C4 + c);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = fmaf(v[e], sc[e], sh[e]);
+    *reinterpret_cast<f32x4*>(y + r * ldy + c) = o;
+}
+
+}  // namespace
+
+// include/openglue_amd.h
+extern "C" size_t og_batchnorm_train_workspace_bytes(int64_t rows, int32_t channels) {
+    if (rows < 1 || channels < 4 || (channels & 3)) return 0;
+    const int64_t nblk = (rows + BN_ROWS_PER_BLOCK - 1) / BN_ROWS_PER_BLOCK;
+    return (size_t)((nblk * channels * 2 + 2 * channels) * (int64_t)sizeof(float));
+}
+
+extern "C" int og_batchnorm_train_forward(const float* x, int64_t ldx, int64_t rows, int32_t channels, const float* weight, const float* bias, float eps,
+                                          float momentum, float* running_mean, float* running_var, float* y, int64_t ldy, float* save_mean,
+                                          float* save_invstd, void* workspace, void* stream) {
+    og_clear_status();
+    if (!x || !y || !workspace || rows < 1 || channels < 4 || !(eps > 0.f) || !(momentum >= 0.f && momentum <= 1.f)) return OG_E_INVALID;
+    if ((channels & 3) || (ldx & 3) || (ldy & 3) || ldx < channels || ldy < channels) return OG_E_SHAPE;
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)workspace & 15)) return OG_E_ALIGN;
+    if (rows * (int64_t)(channels / 4) > ((int64_t)1 << 40)) return OG_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = (int)((rows + BN_ROWS_PER_BLOCK - 1) / BN_ROWS_PER_BLOCK);
+    float* part = reinterpret_cast<float*>(workspace);
+    float* scale_shift = part + (int64_t)nblk * channels * 2;
+    hipLaunchKernelGGL(bn_partial_kernel, dim3(nblk, (channels + 63) / 64), dim3(256), 0, st, x, ldx, rows, channels, part);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((channels + 255) / 256), dim3(256), 0, st, x, part, nblk, rows, channels, weight, bias, eps, momentum,
+                       running_mean, running_var, scale_shift, save_mean, save_invstd);
+    const int64_t n4 = rows * (channels / 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x, ldx, rows, channels / 4, scale_shift, y, ldy);
+    return og_launch_status();
+}

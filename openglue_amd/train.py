@@ -6,8 +6,11 @@ the dual trajectory), backward = og_sinkhorn_backward (unrolled iterations, reve
 utils/losses.py:7-53 computed on its result back-propagates into the score matrix S and into `dustbin_score` without any
 torch math on the way.  PyTorch is used for what it is here: autograd bookkeeping, device memory, the current stream.
 
-Not yet built (stated in DESIGN.md): backward of the GNN / encoder GEMMs and of attention, train-mode BatchNorm statistics;
-`SuperGlue.forward` therefore still refuses `train()` mode.
+`batch_norm_train` / `feed_forward_train` are the train-mode forward of the reference's MLP building block (models/utils.py:48-58:
+Conv1d -> ReLU -> BatchNorm1d with batch statistics and running-statistics update) on token-major activations.
+
+Not yet built (stated in DESIGN.md): backward of the GEMMs, of attention and of BatchNorm; `SuperGlue.forward` therefore still
+refuses `train()` mode.
 """
 from __future__ import annotations
 
@@ -68,3 +71,49 @@ class SinkhornOT(torch.autograd.Function):
 def matching_log_probs(S: torch.Tensor, dustbin_score: torch.Tensor, num_iters: int, reg: float = 1.0) -> torch.Tensor:
     """Differentiable `scores` [B, m+1, n+1] from the raw score matrix S [B, m, n] (superglue.py:88-111)."""
     return SinkhornOT.apply(S, dustbin_score, num_iters, reg)
+
+
+def batch_norm_train(x: torch.Tensor, weight, bias, running_mean, running_var, momentum: float = 0.1, eps: float = 1e-5,
+                     return_stats: bool = False):
+    """nn.BatchNorm1d in training mode on TOKEN-MAJOR activations x [T, C] (T = B*N rows of the reference's [B, C, N] tensor):
+    batch statistics per channel, `running_mean` / `running_var` updated IN PLACE like torch.  Returns y [T, C] (and the saved
+    mean / inverse std when `return_stats`).  Forward only."""
+    if not x.is_cuda:
+        raise RuntimeError("openglue_amd.train: x must be on the MI355X; there is no CPU fallback")
+    if x.dim() != 2 or x.dtype != torch.float32 or x.stride(1) != 1:
+        raise ValueError("x must be a float32 [T, C] tensor with contiguous channels")
+    lib = _lib.load()
+    T, C = x.shape
+    nbytes = lib.og_batchnorm_train_workspace_bytes(T, C)
+    if nbytes == 0:
+        raise ValueError("og_batchnorm_train_workspace_bytes: channels must be a multiple of 4, rows >= 1")
+    for name, t in (("weight", weight), ("bias", bias), ("running_mean", running_mean), ("running_var", running_var)):
+        if t is not None and (t.device != x.device or t.dtype != torch.float32 or t.numel() != C or not t.is_contiguous()):
+            raise ValueError(f"{name} must be a contiguous float32 [C] tensor on the device of x")
+    ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+    y = torch.empty(T, C, device=x.device, dtype=torch.float32)
+    mean = torch.empty(C, device=x.device, dtype=torch.float32) if return_stats else None
+    invstd = torch.empty(C, device=x.device, dtype=torch.float32) if return_stats else None
+    p = lambda t: None if t is None else t.data_ptr()       # noqa: E731
+    with torch.cuda.device(x.device):
+        _lib.check(lib.og_batchnorm_train_forward(x.data_ptr(), x.stride(0), T, C, p(weight), p(bias), float(eps), float(momentum),
+                                                  p(running_mean), p(running_var), y.data_ptr(), y.stride(0), p(mean), p(invstd),
+                                                  ws.data_ptr(), _stream(x)), "og_batchnorm_train_forward")
+    return (y, mean, invstd) if return_stats else y
+
+
+def feed_forward_train(x: torch.Tensor, state_dict, prefix: str = "", momentum: float = 0.1) -> torch.Tensor:
+    """The reference's FeedForwardNet (models/utils.py:48-58) in TRAINING mode on token-major x [T, C_in]: for every hidden layer
+    the exact-fp32 MFMA GEMM with fused bias + ReLU (og_gemm_nt), then train-mode BatchNorm (og_batchnorm_train_forward: batch
+    statistics, the running statistics inside `state_dict` are updated in place), then the last 1x1 conv.  Parameter names are
+    the nn.Sequential ones: `{prefix}{3i}.weight|bias` (Conv1d, weight [out, in, 1]), `{prefix}{3i+2}.*` (BatchNorm1d)."""
+    from . import ops
+    n_conv = len({k for k in state_dict if k.startswith(prefix) and k.endswith(".weight") and state_dict[k].dim() == 3})
+    for i in range(n_conv):
+        w = state_dict[f"{prefix}{3 * i}.weight"]
+        x = ops.gemm_nt(x, w.reshape(w.shape[0], w.shape[1]).contiguous(), state_dict[f"{prefix}{3 * i}.bias"], relu=i + 1 < n_conv)
+        if i + 1 < n_conv:
+            bn = f"{prefix}{3 * i + 2}"
+            x = batch_norm_train(x, state_dict[bn + ".weight"], state_dict[bn + ".bias"], state_dict[bn + ".running_mean"],
+                                 state_dict[bn + ".running_var"], momentum)
+    return x

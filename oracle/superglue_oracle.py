@@ -330,3 +330,38 @@ def nll_criterion(scores: torch.Tensor, gt_matches0: torch.Tensor, gt_matches1: 
     b, i1 = torch.where(gt_matches1 == -1)
     un1 = (-scores[b, -1, i1] * mean_w(b)).sum()
     return (matched + 0.5 * (un0 + un1)) / scores.size(0)
+
+
+def batchnorm_train(x: torch.Tensor, weight, bias, running_mean, running_var, momentum: float = 0.1, eps: float = 1e-5):
+    """nn.BatchNorm1d in training mode (reference models/utils.py:55 inside FeedForwardNet; semantics of
+    torch.nn.functional.batch_norm(training=True), restated with plain tensor ops) on token-major x [..., C] like the rest of
+    this file (the reference's [B, C, N] tensor transposed): batch statistics over every token, biased variance for the
+    normalisation, unbiased for the running estimate.  Returns (y, new_running_mean, new_running_var)."""
+    xt = x.reshape(-1, x.shape[-1])
+    n = xt.shape[0]
+    mean = xt.mean(dim=0)
+    var = ((xt - mean) ** 2).mean(dim=0)
+    y = (x - mean) / torch.sqrt(var + eps)
+    if weight is not None:
+        y = y * weight
+    if bias is not None:
+        y = y + bias
+    new_rm = (1 - momentum) * running_mean + momentum * mean
+    new_rv = (1 - momentum) * running_var + momentum * var * (n / max(n - 1, 1))
+    return y, new_rm, new_rv
+
+
+def feed_forward_train(x: torch.Tensor, sd, prefix: str, n_conv: int, momentum: float = 0.1):
+    """FeedForwardNet (models/utils.py:48-58) in TRAINING mode on token-major x [..., C]: (Conv1d -> ReLU -> BatchNorm1d[batch
+    stats]) x (n_conv-1) -> Conv1d.  `prefix` like feed_forward ("" for a bare nn.Sequential state dict).  Returns
+    (y, {running-stat name: new value}); `sd` is not modified."""
+    dtype = x.dtype
+    dot = prefix + "." if prefix else ""
+    new_stats = {}
+    for i in range(n_conv - 1):
+        x = torch.relu(conv1x1(x, sd, f"{dot}{3 * i}"))
+        bn = f"{dot}{3 * i + 2}"
+        x, rm, rv = batchnorm_train(x, _w(sd, bn + ".weight", dtype), _w(sd, bn + ".bias", dtype), _w(sd, bn + ".running_mean", dtype),
+                                    _w(sd, bn + ".running_var", dtype), momentum)
+        new_stats[bn + ".running_mean"], new_stats[bn + ".running_var"] = rm, rv
+    return conv1x1(x, sd, f"{dot}{3 * (n_conv - 1)}"), new_stats

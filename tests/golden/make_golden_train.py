@@ -70,6 +70,45 @@ def main():
         out[f"{name}_meta"] = np.array([B, m, n, iters], np.int64); out[f"{name}_reg_z"] = np.array([reg, z], np.float32)
         print(name, "nll", loss.item(), "|dS|max", float(np.abs(out[f'{name}_dS_nll']).max()), "dz", float(out[f'{name}_dz_nll']))
     np.savez_compressed(os.path.join(HERE, "train_ot.npz"), **out)
+    main_mlp()
+
+
+MLP_CASES = [  # name, channel sizes, B, N, number of train-mode steps
+    ("enc", (8, 32, 64, 128, 64), 3, 50, 2),       # shape of the keypoint-encoder MLP (superglue.py:74-78), two steps: running stats move twice
+    ("msg", (128, 128, 64), 2, 77, 1),             # shape of the message MLP of a GNN layer (attention_gnn.py:41-44)
+]
+
+
+def main_mlp():
+    """train_mlp: the reference's FeedForwardNet (models/utils.py:48-58) in TRAINING mode (batch statistics, running
+    statistics updated with momentum 0.1): inputs, the state dict before, outputs of every step, the state dict after."""
+    from models.utils import FeedForwardNet
+    out = {}
+    for name, sizes, B, N, steps in MLP_CASES:
+        g = torch.Generator().manual_seed(len(name) * 131 + 7)
+        net = FeedForwardNet(*sizes)
+        with torch.no_grad():
+            for k_, v_ in net.state_dict().items():        # seeded, non-trivial parameters (incl. BN affine and running stats)
+                if v_.dtype.is_floating_point:
+                    if "running_var" in k_:
+                        v_.copy_(torch.rand(v_.shape, generator=g) + 0.5)
+                    elif k_.endswith("weight") and v_.dim() == 1:
+                        v_.copy_(torch.rand(v_.shape, generator=g) + 0.5)
+                    else:
+                        v_.copy_(torch.randn(v_.shape, generator=g) * (0.3 if v_.dim() > 1 else 0.1))
+        for k_, v_ in net.state_dict().items():
+            out[f"{name}_before_{k_}"] = v_.numpy().copy()
+        net.train()
+        for st in range(steps):
+            x = torch.randn(B, sizes[0], N, generator=g) * 2.0 + 0.5
+            with torch.no_grad():
+                y = net(x)
+            out[f"{name}_x{st}"] = x.numpy(); out[f"{name}_y{st}"] = y.numpy()
+        for k_, v_ in net.state_dict().items():
+            out[f"{name}_after_{k_}"] = v_.numpy().copy()
+        out[f"{name}_meta"] = np.array(list(sizes) + [B, N, steps], np.int64)
+        print(name, "train-mode MLP", sizes, "y range", float(y.min()), float(y.max()))
+    np.savez_compressed(os.path.join(HERE, "train_mlp.npz"), **out)
 
 
 if __name__ == "__main__":

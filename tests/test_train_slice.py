@@ -75,3 +75,83 @@ def test_sinkhorn_backward_c2_sized(gpu_device):
     print(f"[train_ot C2-sized] nll {loss.item():.5f} vs {ref.item():.5f}; dS err {err:.2e} (max {scale:.2e}); d dustbin {dg.grad.item():.6f} vs {dust.grad.item():.6f}")
     assert err < 1e-3 * scale
     assert abs(dg.grad.item() - dust.grad.item()) < 1e-3 * abs(dust.grad.item()) + 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# train-mode BatchNorm / FeedForwardNet forward (tests/golden/train_mlp.npz: the reference's FeedForwardNet in train() mode)
+M = dict(np.load(os.path.join(GOLDEN, "train_mlp.npz")))
+MLP_CASES = ["enc", "msg"]
+
+
+def _mlp_state(name, which, device=None):
+    pre = f"{name}_{which}_"
+    sd = {k[len(pre):]: torch.from_numpy(v.copy()) for k, v in M.items() if k.startswith(pre)}
+    return {k: (v.to(device) if device is not None else v) for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("name", MLP_CASES)
+def test_oracle_train_mode_mlp_matches_the_reference(name):
+    """CPU: the restated train-mode BatchNorm inside FeedForwardNet reproduces the reference's outputs step by step and its
+    running statistics after the last step."""
+    meta = [int(v) for v in M[f"{name}_meta"]]
+    sizes, (B, N, steps) = meta[:-3], meta[-3:]
+    sd = _mlp_state(name, "before")
+    for st in range(steps):
+        x = torch.from_numpy(M[f"{name}_x{st}"]).permute(0, 2, 1)                   # [B, C, N] -> token-major [B, N, C]
+        y, new_stats = orc.feed_forward_train(x, sd, "", len(sizes) - 1)
+        assert np.abs(y.permute(0, 2, 1).numpy() - M[f"{name}_y{st}"]).max() < 2e-5
+        sd.update(new_stats)
+    after = _mlp_state(name, "after")
+    for k, v in after.items():
+        if "running" in k:
+            assert np.abs(sd[k].numpy() - v.numpy()).max() < 1e-6, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", MLP_CASES)
+def test_train_mode_mlp_forward_against_reference(gpu_device, name):
+    """HIP: exact-fp32 GEMM (+bias, ReLU) -> og_batchnorm_train_forward chain on token-major activations vs the reference's
+    FeedForwardNet in train() mode; the running statistics are updated in place like torch's."""
+    from openglue_amd.train import feed_forward_train
+    meta = [int(v) for v in M[f"{name}_meta"]]
+    sizes, (B, N, steps) = meta[:-3], meta[-3:]
+    sd = _mlp_state(name, "before", gpu_device)
+    for st in range(steps):
+        x = torch.from_numpy(M[f"{name}_x{st}"]).to(gpu_device)                       # [B, C, N]
+        xt = x.permute(0, 2, 1).reshape(B * N, sizes[0]).contiguous()                  # token-major
+        y = feed_forward_train(xt, sd).reshape(B, N, sizes[-1]).permute(0, 2, 1)
+        err = (y.cpu() - torch.from_numpy(M[f"{name}_y{st}"])).abs().max().item()
+        print(f"[train_mlp {name} step {st}] y err {err:.2e} (|y| up to {np.abs(M[f'{name}_y{st}']).max():.1f})")
+        assert err < 1e-4
+    after = _mlp_state(name, "after")
+    for k, v in after.items():
+        if "running" in k:
+            e = (sd[k].cpu() - v).abs().max().item()
+            assert e < 1e-5, (k, e)
+
+
+@pytest.mark.gpu
+def test_batchnorm_train_large_and_offset_channels(gpu_device):
+    """65536 tokens x 256 channels (the C2 activation shape), channels whose mean is 1000x their spread: the shifted sums keep
+    the variance; statistics against float64."""
+    from openglue_amd.train import batch_norm_train
+    g = torch.Generator().manual_seed(5)
+    T, C = 65536, 256
+    x = torch.randn(T, C, generator=g)
+    x[:, :16] = x[:, :16] * 1e-2 + 10.0                      # mean >> std
+    w, b = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    xd = x.to(gpu_device)
+    rmd, rvd = rm.to(gpu_device), rv.to(gpu_device)
+    y, mean, invstd = batch_norm_train(xd, w.to(gpu_device), b.to(gpu_device), rmd, rvd, 0.1, 1e-5, return_stats=True)
+    x64 = x.double()
+    m64, v64 = x64.mean(0), x64.var(0, unbiased=False)
+    want = (x64 - m64) / torch.sqrt(v64 + 1e-5) * w.double() + b.double()
+    assert (mean.cpu().double() - m64).abs().max() < 1e-5
+    assert ((invstd.cpu().double() - 1 / torch.sqrt(v64 + 1e-5)) * torch.sqrt(v64 + 1e-5)).abs().max() < 1e-4
+    err = (y.cpu().double() - want).abs().max().item()
+    print(f"[batchnorm_train 65536 x 256] y err {err:.2e}")
+    assert err < 2e-3                                         # offset channels: (x - mean) carries fp32 rounding of x itself (1e-6 * 10 / 1e-2)
+    assert (y.cpu().double()[:, 16:] - want[:, 16:]).abs().max() < 2e-5
+    assert (rmd.cpu().double() - 0.1 * m64).abs().max() < 1e-5
+    assert (rvd.cpu().double() - (0.9 + 0.1 * x64.var(0, unbiased=True))).abs().max() < 1e-5
