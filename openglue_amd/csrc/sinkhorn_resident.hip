@@ -40,6 +40,7 @@ constexpr float RS_LOG2E = 1.4426950408889634f;
 constexpr float RS_LN2 = 0.6931471805599453f;
 
 typedef unsigned long long rs_u64;
+typedef float rs_f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) rs_u64 rs_gu64;
 typedef __attribute__((address_space(1))) unsigned rs_gu32;
 
@@ -232,17 +233,22 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a) {
         auto mem_row = [&](f32x4 (&x)[4], int slot) {      // a row fetched from LDS / memory: its plan entries overwrite it
             if (slot < nvalid) {                           // wave-uniform: rows past the end of the workgroup's range are skipped
                 const float u = ur[slot];
-                float sum = 0.f;
+                // packed fp32 adds (two elements per VALU instruction); the association (s + v) + u and the pairing of the row sum
+                // are part of the arithmetic contract with the streaming kernels' tests (fixed, lane-local)
+                const rs_f32x2 uu = {u, u};
+                rs_f32x2 sum2 = {0.f, 0.f};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const f32x4 vk = *reinterpret_cast<const f32x4*>(vLl + 256 * k);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        x[k][e] = __builtin_amdgcn_exp2f((x[k][e] + vk[e]) + u);
-                        sum += x[k][e];
+                    for (int e = 0; e < 4; e += 2) {
+                        const rs_f32x2 t = (rs_f32x2{x[k][e], x[k][e + 1]} + rs_f32x2{vk[e], vk[e + 1]}) + uu;
+                        x[k][e] = __builtin_amdgcn_exp2f(t[0]);
+                        x[k][e + 1] = __builtin_amdgcn_exp2f(t[1]);
+                        sum2 += rs_f32x2{x[k][e], x[k][e + 1]};
                     }
                 }
-                finish_row(x, sum, slot);
+                finish_row(x, sum2[0] + sum2[1], slot);
             }
             __builtin_amdgcn_sched_barrier(0);             // one row at a time
         };
@@ -257,17 +263,20 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a) {
             if (r < nvalid) {
                 const float u = ur[r];
                 f32x4 x[4];
-                float sum = 0.f;
+                const rs_f32x2 uu = {u, u};
+                rs_f32x2 sum2 = {0.f, 0.f};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const f32x4 vk = *reinterpret_cast<const f32x4*>(vLl + 256 * k);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        x[k][e] = __builtin_amdgcn_exp2f((sr[r][k][e] + vk[e]) + u);
-                        sum += x[k][e];
+                    for (int e = 0; e < 4; e += 2) {
+                        const rs_f32x2 t = (rs_f32x2{sr[r][k][e], sr[r][k][e + 1]} + rs_f32x2{vk[e], vk[e + 1]}) + uu;
+                        x[k][e] = __builtin_amdgcn_exp2f(t[0]);
+                        x[k][e + 1] = __builtin_amdgcn_exp2f(t[1]);
+                        sum2 += rs_f32x2{x[k][e], x[k][e + 1]};
                     }
                 }
-                finish_row(x, sum, r);
+                finish_row(x, sum2[0] + sum2[1], r);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
