@@ -54,8 +54,14 @@ def algorithmic_counts(cfg_kw, m, n):
     sink_one = 4.0 * (m * n * (it + 1) + 2 * rb * n * it + (m + 1) * (n + 1))
     # kernel classes: the encoder MLP runs on the exact-fp32 MFMA kernel; the GNN 1x1 convs, the final projection and the
     # score matrix on the split-f16 kernel
+    # the on-chip-resident schedule (sinkhorn_resident.hip; m <= ..., n <= 1024): iteration 1 streams S once, the resident kernel
+    # loads S once, re-reads the quarter of the rows that does not fit on chip every iteration and exchanges the column partials
+    # of the G = ceil(m/128) workgroups of a pair as 8-byte granules (written once, read by all G), then the scores are written
+    G = (m + 127) // 128
+    sink_res = 4.0 * (2 * m * n + 2 * rb * n + 0.25 * m * n * (it - 1) + (m + 1) * (n + 1)) + 8.0 * (n + 1) * G * (G + 1) * (it - 1)
     return {"gemm_f32_flops": enc, "gemm_f16x3_flops": proj + final + score, "attention_flops": attn,
-            "total_flops": enc + proj + attn + final + score, "sinkhorn_bytes": sink_one, "sinkhorn_bytes_survey": sink_survey}
+            "total_flops": enc + proj + attn + final + score, "sinkhorn_bytes": sink_one, "sinkhorn_bytes_survey": sink_survey,
+            "sinkhorn_bytes_resident": sink_res}
 
 
 def _sum_counts(cfg_kw, lens):
@@ -89,6 +95,8 @@ def roofline_block(counts_per_step, stages, launches, num_iters, measured_on_thi
     elif "sinkhorn_sweep" in tj and "sinkhorn_combine" in tj:
         traffic["sinkhorn"] = {"hbm_bytes_per_launch": (tj["sinkhorn_sweep"]["hbm_bytes_per_launch"]
                                                         + tj["sinkhorn_combine"]["hbm_bytes_per_launch"]) * num_iters // nl_sk}
+    resident = nl_sk <= 4 and stages.get("sinkhorn", 0) > 0       # one resident launch instead of 2 x iters streaming launches
+    sk_bytes = counts_per_step["sinkhorn_bytes_resident"] if resident else counts_per_step["sinkhorn_bytes"]
     per_step = {  # kernel class -> (algorithmic work per step, unit scale, bound, peak, unit, kernels)
         "gemm_f16x3": (counts_per_step["gemm_f16x3_flops"], 1e12, "mfma", PEAK_F16_MFMA_TFLOPS, "TFLOP/s",
                        "gemm_nt_f16x3_big_kernel / gemm_nt_f16x3_kernel (GNN 1x1 convs, final projection, score matrix; split-f16 3-pass MFMA: executes 3x the algorithmic flops)"),
@@ -96,10 +104,14 @@ def roofline_block(counts_per_step, stages, launches, num_iters, measured_on_thi
                      "gemm_nt_f32_kernel (keypoint-encoder MLP; exact fp32 MFMA)"),
         "attention": (counts_per_step["attention_flops"], 1e12, "mfma", PEAK_F16_MFMA_TFLOPS, "TFLOP/s",
                       "attention_kernel (split-f16 flash attention: executes 3x the algorithmic flops)"),
-        "sinkhorn": (counts_per_step["sinkhorn_bytes"], 1e9, "hbm", PEAK_HBM_GBS, "GB/s",
-                     "sinkhorn_resident_kernel (B*m*n >= 4M elements and the grid co-resident) or sinkhorn_sweep + sinkhorn_combine, "
-                     "then sinkhorn_scores; one stage bracket incl. launch gaps; algorithmic bytes = ONE read of S per iteration + "
-                     "column partials + scores write (what a streaming schedule must move; the resident schedule keeps 3/4 of S on chip)"),
+        "sinkhorn": (sk_bytes, 1e9, "hbm", PEAK_HBM_GBS, "GB/s",
+                     ("sinkhorn_resident_kernel (+ first iteration sweep/combine, sinkhorn_scores), one stage bracket: the score matrices "
+                      "stay in registers + LDS; algorithmic bytes = what THIS schedule must move (S twice, the non-resident quarter of the "
+                      "rows once per iteration, the column-partial granules, the scores).  The kernel is VALU-bound on chip (about 10 VALU "
+                      "per element per iteration), not HBM-bound: the fraction is low by design")
+                     if resident else
+                     ("sinkhorn_sweep + sinkhorn_combine per iteration, then sinkhorn_scores; one stage bracket incl. launch gaps; "
+                      "algorithmic bytes = ONE read of S per iteration + column partials + scores write")),
     }
     roofs = {}
     for k, (work, scale, bound, peak, unit, kern) in per_step.items():
@@ -115,7 +127,9 @@ def roofline_block(counts_per_step, stages, launches, num_iters, measured_on_thi
             roofs[k]["mfma_busy_frac"] = pmc[k].get("mfma_busy_frac")
             roofs[k]["pmc"] = {kk: vv for kk, vv in pmc[k].items() if kk != "mfma_busy_frac"}
     ms = stages["sinkhorn"]
-    if ms > 0:   # the SURVEY §8d accounting (two sweeps per iteration), for comparison only: NOT a roofline fraction
+    if ms > 0:   # other accountings, for comparison only: NOT roofline fractions
+        roofs["sinkhorn"]["schedule"] = "resident" if resident else "streaming"
+        roofs["sinkhorn"]["streaming_one_sweep_equivalent_gbs"] = round(counts_per_step["sinkhorn_bytes"] / (ms * 1e-3) / 1e9, 1)
         roofs["sinkhorn"]["survey_two_sweep_equivalent_gbs"] = round(counts_per_step["sinkhorn_bytes_survey"] / (ms * 1e-3) / 1e9, 1)
     dominant = max(per_step, key=lambda k: stages[k])
     roof = roofs.pop(dominant)

@@ -13,7 +13,7 @@ import collections, csv, glob, json, os, sys
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
 out = sys.argv[2] if len(sys.argv) > 2 else "profiles/r02_pmc_summary.json"
-CLASSES = [("gemm_f16x3", "gemm_nt_f16x3"), ("attention", "attention_kernel"), ("sinkhorn", "sinkhorn_resident_kernel"), ("sinkhorn_sweep", "sinkhorn_sweep"),
+CLASSES = [("gemm_f16x3", "gemm_nt_f16x3"), ("attention", "attention"), ("sinkhorn", "sinkhorn_resident_kernel"), ("sinkhorn_sweep", "sinkhorn_sweep"),
            ("gemm_f32", "gemm_nt_f32")]
 N_SIMD = 256 * 4
 

@@ -6,7 +6,7 @@ import collections, csv, json, os, sys
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/traffic"
 out = sys.argv[2] if len(sys.argv) > 2 else "profiles/r02_traffic_c2.json"
-CLASSES = [("gemm_f16x3", "gemm_nt_f16x3"), ("attention", "attention_kernel"), ("sinkhorn_resident", "sinkhorn_resident_kernel"), ("sinkhorn_sweep", "sinkhorn_sweep"),
+CLASSES = [("gemm_f16x3", "gemm_nt_f16x3"), ("attention", "attention"), ("sinkhorn_resident", "sinkhorn_resident_kernel"), ("sinkhorn_sweep", "sinkhorn_sweep"),
            ("sinkhorn_combine", "sinkhorn_combine"), ("gemm_f32", "gemm_nt_f32")]
 vals = {c: collections.defaultdict(list) for c, _ in CLASSES}
 cal = {}

@@ -107,13 +107,13 @@ __global__ __launch_bounds__(256, WPS) void k(const f16x8* in, float* out, unsig
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s[q][j][r] = MODE == 3 ? sn[q][j][r] : sn[q][j][r] * 1e-3f - 1.f;     // stand-in for the max bookkeeping
+                for (int r = 0; r < 16; ++r) s[q][j][r] = MODE == 3 ? s[q][j][r] + sn[q][j][r] : sn[q][j][r] * 1e-3f - 1.f;     // stand-in for the max bookkeeping
         }
     }
     const unsigned t1 = (unsigned)__builtin_amdgcn_s_memtime();
     float acc = 0.f;
 #pragma unroll
-    for (int q = 0; q < QB; ++q) { acc += l[q]; for (int d = 0; d < 2; ++d) for (int r = 0; r < 16; ++r) acc += o[q][d][r]; }
+    for (int q = 0; q < QB; ++q) { acc += l[q]; for (int d = 0; d < 2; ++d) for (int r = 0; r < 16; ++r) acc += o[q][d][r] + s[q][d][r]; }
     out[blockIdx.x * 256 + threadIdx.x] = acc;
     if (lane == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
 }
@@ -127,27 +127,26 @@ void run(const char* name) {
     const size_t lds = WPS == 1 ? 100 * 1024 : 60 * 1024;        // pins the number of workgroups per CU
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k<QB, MODE, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL((k<QB, MODE, WPS>), dim3(blocks), dim3(256), lds, 0, in, out, cyc, iters); CHECK(hipDeviceSynchronize()); }
+    int occ = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(&k<QB, MODE, WPS>), 256, lds);
     unsigned h[64];
     CHECK(hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost));
     double avg = 0; for (int i = 0; i < 64; ++i) avg += h[i]; avg /= 64.0 * iters;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, 0);
     hipLaunchKernelGGL((k<QB, MODE, WPS>), dim3(blocks), dim3(256), lds, 0, in, out, cyc, iters); hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-    printf("%-64s %7.0f cycles / tile / wave; MFMA issue alone %5d; per SIMD %.0f%% of the matrix pipe; kernel %.1f us = %.0f TFLOP/s f16\n", name, avg, 48 * QB * 32, 100.0 * 48 * QB * 32 * WPS / avg, ms * 1e3, (double)blocks * 4 * iters * 48 * QB * 32768 / (ms * 1e-3) / 1e12);
+    printf("%-64s [%d workgroup(s)/CU] %7.0f cycles / tile / wave; MFMA issue alone %5d; per SIMD %.0f%% of the matrix pipe; kernel %.1f us = %.0f TFLOP/s f16\n", name, occ, avg, 48 * QB * 32, 100.0 * 48 * QB * 32 * WPS / avg, ms * 1e3, (double)blocks * 4 * iters * 48 * QB * 32768 / (ms * 1e-3) / 1e12);
     hipFree(in); hipFree(out); hipFree(cyc);
 }
 
 int main() {
     run<1, 3, 1>("1 wave/SIMD, 32 q/wave, MFMAs only");
-    run<1, 3, 2>("2 waves/SIMD, 32 q/wave, MFMAs only");
     run<1, 0, 1>("1 wave/SIMD, 32 q/wave, phases (MFMA | VALU | MFMA)");
     run<1, 1, 1>("1 wave/SIMD, 32 q/wave, compiler-scheduled");
     run<1, 2, 1>("1 wave/SIMD, 32 q/wave, sched_group_barrier 1 MFMA + 6 VALU");
     run<2, 0, 1>("1 wave/SIMD, 64 q/wave, phases");
     run<2, 1, 1>("1 wave/SIMD, 64 q/wave, compiler-scheduled");
     run<2, 2, 1>("1 wave/SIMD, 64 q/wave, sched_group_barrier 1 MFMA + 6 VALU");
-    run<1, 0, 2>("2 waves/SIMD, 32 q/wave, phases");
-    run<1, 1, 2>("2 waves/SIMD, 32 q/wave, compiler-scheduled");
-    run<1, 2, 2>("2 waves/SIMD, 32 q/wave, sched_group_barrier 1 MFMA + 6 VALU");
+    // (two workgroups per CU are not reliably co-scheduled by this launch pattern -- scripts/probes/clock_calibration.hip shows the
+    //  second set running after the first -- so no 2-waves-per-SIMD rows here; the attention kernel trace covers that case)
     return 0;
 }

@@ -98,7 +98,8 @@ def _attn_ref(q, k, v, H):
 
 
 @pytest.mark.parametrize("H,dh,nq,nk", [(4, 16, 50, 70), (4, 32, 129, 64), (4, 64, 300, 257), (2, 64, 128, 1024), (1, 32, 1, 1),
-                                        (4, 32, 300, 257), (4, 16, 300, 257), (2, 32, 40, 65)])    # several key tiles at every head size
+                                        (4, 32, 300, 257), (4, 16, 300, 257), (2, 32, 40, 65),    # several key tiles at every head size
+                                        (1, 64, 1, 1), (2, 64, 70, 63), (3, 64, 129, 65), (1, 64, 33, 128)])   # dh=64 = the LDS-DMA kernel: single / partial / odd tiles
 def test_attention_vs_oracle(gpu_device, H, dh, nq, nk):
     g = torch.Generator().manual_seed(H * 100 + dh + nq)
     D = H * dh
