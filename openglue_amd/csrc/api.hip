@@ -17,6 +17,7 @@ struct PackedLayout {
     int enc_k[OG_MAX_HIDDEN + 1];               // padded input width of layer i
     int enc_out[OG_MAX_HIDDEN + 1];             // padded output width of layer i
     int64_t enc_w[OG_MAX_HIDDEN + 1], enc_b[OG_MAX_HIDDEN + 1];
+    int64_t enc_whl;                            // last encoder conv once more, as hl32 rows of 256*w (split-f16 kernel), -1: none
     int64_t layer0, layer_stride;               // per GNN layer block
     // offsets inside a layer block (float units); weights in the hl32 row format: [N][2K] halves = N*K floats
     int64_t o_wqkv, o_bqkv, o_w0, o_b0, o_w3, o_b3;
@@ -42,6 +43,10 @@ PackedLayout packed_layout(const og_shape& s) {
         if (i < s.num_hidden && out > L.enc_maxw) L.enc_maxw = out;
         k = out;
     }
+    // the last conv (no activation behind it) runs on the split-f16 kernel when its input is a hidden activation that fits the G
+    // buffer as hl32 rows (api.hip: forward_impl)
+    L.enc_whl = -1;
+    if (L.n_enc >= 2 && L.enc_k[L.n_enc - 1] <= D) { L.enc_whl = off; off = al64(off + D * (int64_t)L.enc_k[L.n_enc - 1]); }
     int64_t lo = 0;
     L.o_wqkv = lo; lo = al64(lo + 3 * D * D);
     L.o_bqkv = lo; lo = al64(lo + 3 * D);
@@ -190,6 +195,12 @@ extern "C" int og_pack_weights(const og_shape* shape, const og_params* P, void* 
                     else { W[(int64_t)o * L.enc_k[i] + k] = (float)(w * g[k]); bb += w * c[k]; }
                 }
                 b[o] = (float)bb;
+            }
+            if (i == L.n_enc - 1 && L.enc_whl >= 0) {        // the same folded weights as hl32 rows of 256*w
+                _Float16* Whl = (_Float16*)(out + L.enc_whl);
+                for (int o = 0; o < out_real; ++o)
+                    for (int k = 0; k < in_real; ++k)
+                        if (!put_split(Whl, o, k, L.enc_k[i], (double)W[(int64_t)o * L.enc_k[i] + k])) return OG_E_RANGE;
             }
             if (i < s.num_hidden) {
                 if (s.flags & OG_FLAG_SIREN_ENCODER) {       // no BatchNorm between the layers: identity fold
@@ -377,18 +388,41 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
             if ((rc = og_launch_encoder_input(in->keypoints1, in->side_info1, T1, s.side_info, in->image1_wh[0], in->image1_wh[1], EI + T0 * 32, st, er1))) return rc;
         }
         const float* cur = EI; int64_t ldcur = 32;
+        // The last conv carries 3/4 of the encoder's FLOPs and has no activation behind it: it runs on the split-f16 kernel
+        // (fp32-class accuracy, 16x the matrix rate of exact fp32).  Its input, the last hidden activation, is written as hl32
+        // rows by the epilogue of the conv before it -- into G, which is free until the final projection.
+        const bool tail_f16 = L.enc_whl >= 0;
+        const int last = L.n_enc - 1;
+        _Float16* Ehl = (_Float16*)G;
         for (int i = 0; i < L.n_enc; ++i) {
             const float* Wi = pk + L.enc_w[i]; const float* bi = pk + L.enc_b[i];
-            if (i + 1 < L.n_enc) {
+            if (i < last) {
                 float* dst = (i & 1) ? Eb : Ea;
                 const int act = (s.flags & OG_FLAG_SIREN_ENCODER) ? 2 : 1;      // sin(30 x) or ReLU (+ folded BatchNorm)
-                if ((rc = gemm(cur, ldcur, Wi, L.enc_k[i], dst, L.enc_maxw, T, L.enc_out[i], L.enc_k[i], bi, act, nullptr, 0, nullptr, 0))) return rc;
+                const bool to_hl = tail_f16 && i == last - 1;                   // only the hl32 rows are read again
+                if ((rc = gemm(cur, ldcur, Wi, L.enc_k[i], to_hl ? nullptr : dst, L.enc_maxw, T, L.enc_out[i], L.enc_k[i], bi, act, nullptr, 0,
+                               to_hl ? Ehl : nullptr, to_hl ? 2 * L.enc_out[i] : 0))) return rc;
                 cur = dst; ldcur = L.enc_maxw;
             } else {
                 const bool nd = s.flags & OG_FLAG_NO_DESCRIPTORS;
-                if ((rc = gemm(cur, ldcur, Wi, L.enc_k[i], X32, D, T0, D, L.enc_k[i], bi, 0, nd ? nullptr : in->descriptors0, D, XO, D4))) return rc;
-                if ((rc = gemm(cur + T0 * ldcur, ldcur, Wi, L.enc_k[i], X32 + T0 * D, D, T1, D, L.enc_k[i], bi, 0,
-                               nd ? nullptr : in->descriptors1, D, XO + T0 * D4, D4))) return rc;
+                const float* res[2] = {nd ? nullptr : in->descriptors0, nd ? nullptr : in->descriptors1};
+                const int64_t r0[2] = {0, T0}, R[2] = {T0, T1};
+                for (int side = 0; side < 2; ++side) {
+                    if (tail_f16) {
+                        const int K = L.enc_k[i];
+                        GemmHArgs g{};
+                        g.A = Ehl + r0[side] * 2 * K; g.lda = 2 * K;
+                        g.B = (const _Float16*)(pk + L.enc_whl); g.ldb = 2 * K;
+                        g.M = (int)R[side]; g.N = D; g.K = K; g.scale = (float)(1.0 / OG_W_SCALE); g.bias = bi; g.relu = 0;
+                        g.res = res[side]; g.ldr = D; g.res_hl = nullptr; g.ldrh = 0;
+                        g.C32 = nullptr; g.ldc = D; g.Ch = XO + r0[side] * D4; g.Cl = g.Ch + 32; g.ldch = D4; g.c_hl = 1;
+                        Scope sc(prof, OG_STAGE_GEMM_F16X3);
+                        if ((rc = og_launch_gemm_f16x3(g, st))) return rc;
+                    } else {
+                        if ((rc = gemm(cur + r0[side] * ldcur, ldcur, Wi, L.enc_k[i], X32 + r0[side] * D, D, R[side], D, L.enc_k[i], bi, 0, res[side], D,
+                                       XO + r0[side] * D4, D4))) return rc;
+                    }
+                }
             }
         }
     }

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g, int tiles_
                     v = g.alpha ? al * v + (1.f - al) * rr : v + rr;
                 }
                 v *= g.scale;
-                C[(int64_t)row * g.ldc + col] = v;
+                if (g.C) C[(int64_t)row * g.ldc + col] = v;
                 if (g.Ch) {     // split-f16 copy for the f16x3 consumers (x = hi + lo)
                     const int64_t o = (int64_t)row * g.ldch + (g.c_hl ? og_hl_col(col) : (int64_t)col);
                     og_split(v, g.Ch[o], g.Cl[o]);
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g, int tiles_
 }  // namespace
 
 int og_launch_gemm(const GemmArgs& a, hipStream_t stream) {
-    if (!a.A || !a.B || !a.C || a.M <= 0 || a.N <= 0 || a.K <= 0 || a.batch <= 0) return OG_E_INVALID;
+    if (!a.A || !a.B || !(a.C || a.Ch) || a.M <= 0 || a.N <= 0 || a.K <= 0 || a.batch <= 0) return OG_E_INVALID;
     if ((a.lda & 3) || (a.ldb & 3) || (a.K & 3)) return OG_E_ALIGN;
     if (((uintptr_t)a.A & 15) || ((uintptr_t)a.B & 15)) return OG_E_ALIGN;
     if ((a.strideA & 3) || (a.strideB & 3)) return OG_E_ALIGN;
