@@ -8,14 +8,15 @@ from openglue_amd import _lib, ops
 lib = _lib.load()
 dev = torch.device("cuda:0")
 T = 65536
-shapes = [("qkv", T, 768, 256), ("fc0", T, 512, 512), ("fc3", T, 256, 512), ("q_cross", T // 2, 256, 256), ("kv_cross", T // 2, 512, 256)]
+shapes = [("qkv", T, 768, 256), ("fc0", T, 512, 512), ("fc3", T, 256, 512), ("q_cross", T // 2, 256, 256), ("kv_cross", T // 2, 512, 256),
+          ("qkv_cross", T // 2, 768, 256), ("fc0_cross", T // 2, 512, 512), ("fc3_cross", T // 2, 256, 512)]
 g = torch.Generator().manual_seed(0)
 tot = 0.0
 for name, M, N, K in shapes:
     a = torch.randn(M, K, generator=g).to(dev); b = (torch.randn(N, K, generator=g) * 0.05).to(dev)
     a_hl, b_hl = ops.split_f16_hl(a), ops.split_f16_hl(b * 256.0)
     bias = torch.randn(N, generator=g).to(dev)
-    planes = name in ('qkv', 'q_cross', 'kv_cross')       # as in og_forward: q/k/v leave as planes, the MLP as hl32 rows
+    planes = name in ('qkv', 'q_cross', 'kv_cross', 'qkv_cross')       # as in og_forward: q/k/v leave as planes, the MLP as hl32 rows
     ch = torch.empty(M, N if planes else 2 * N, device=dev, dtype=torch.float16); cl = torch.empty_like(ch) if planes else None
     st = torch.cuda.current_stream().cuda_stream
     def run():
