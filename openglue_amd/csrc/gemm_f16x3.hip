@@ -761,26 +761,40 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_big2_kernel(GemmHArgs g, in
     const int l31 = lane & 31, hi = lane >> 5;
 
     // ---- DMA pieces (1 KiB = 8 rows x 128 B): wave w fills rows [32w, 32w+32) of the token tile and of the W tile ----
-    const char* src[8];
+    // per-lane 32-bit byte offsets from the block's (scalar) tile bases: the DMA address of a stage is base + kt * 128 (SALU) + offset,
+    // no vector arithmetic per stage
+    unsigned soff[8];
+    const char* const baseA = reinterpret_cast<const char*>(g.A + (int64_t)t0 * g.lda);
+    const char* const baseB = reinterpret_cast<const char*>(g.B + (int64_t)n0 * g.ldb);
     {
         const int rl = lane >> 3, pc = lane & 7;
+        const int lastA = g.M - 1 - t0, lastB = g.N - 1 - n0;           // rows past the matrix are clamped (computed, never stored)
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
             const int rt = wave * 32 + h * 8 + rl;
-            const int sw = (pc ^ ((rt >> 1) & 7)) * 16;
-            int row = t0 + rt; if (row >= g.M) row = g.M - 1;
-            src[h] = reinterpret_cast<const char*>(g.A + (int64_t)row * g.lda) + sw;
-            row = n0 + rt; if (row >= g.N) row = g.N - 1;
-            src[4 + h] = reinterpret_cast<const char*>(g.B + (int64_t)row * g.ldb) + sw;
+            const unsigned sw = (unsigned)(pc ^ ((rt >> 1) & 7)) * 16u;
+            soff[h] = (unsigned)((rt < lastA ? rt : lastA) * (int)g.lda * 2) + sw;
+            soff[4 + h] = (unsigned)((rt < lastB ? rt : lastB) * (int)g.ldb * 2) + sw;
+            asm volatile("" : "+v"(soff[h]), "+v"(soff[4 + h]));        // opaque: computed once, never rematerialised inside the stage loop
         }
     }
+    auto scalar_ptr = [](const char* p) {        // wave-uniform by construction: pinned to an SGPR pair so that the DMA takes the
+        const uint64_t v = (uint64_t)(uintptr_t)p;   // (scalar base + 32-bit lane offset) addressing form
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi32 = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        return reinterpret_cast<const char*>((uintptr_t)(((uint64_t)hi32 << 32) | lo));
+    };
     // piece h of the token / weight operand of stage kt
+    auto lane_off = [&](int i) {                  // re-launder per use: keeps the zero-extension next to the address add (else the
+        unsigned o = soff[i];                      // hoisted 64-bit copy hides that the lane part is 32 bits wide)
+        asm volatile("" : "+v"(o));
+        return o;
+    };
     auto issue_x = [&](int kt, int h) {
-        __builtin_amdgcn_global_load_lds((og_glb_void*)(src[h] + (int64_t)kt * 128),
+        __builtin_amdgcn_global_load_lds((og_glb_void*)(scalar_ptr(baseA + (int64_t)kt * 128) + lane_off(h)),
                                          (og_lds_void*)(smem + (kt % 3) * XS + (wave * 32 + h * 8) * 128), 16, 0, 0);
     };
     auto issue_w = [&](int kt, int h) {
-        __builtin_amdgcn_global_load_lds((og_glb_void*)(src[4 + h] + (int64_t)kt * 128),
+        __builtin_amdgcn_global_load_lds((og_glb_void*)(scalar_ptr(baseB + (int64_t)kt * 128) + lane_off(4 + h)),
                                          (og_lds_void*)(smem + WOFF + (kt & 1) * XS + (wave * 32 + h * 8) * 128), 16, 0, 0);
     };
 
