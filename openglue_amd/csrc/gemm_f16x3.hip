@@ -806,19 +806,37 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_big2_kernel(GemmHArgs g, in
     // fragment pipeline as in the kernel above (hand-counted lgkmcnt: LDS-DMA does not touch that counter)
     f16x8 wh[2][2], wl[2][2], xh[2], xl[2];
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    auto lds_read = [&](f16x8& dst, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr)); };
-    auto read_w = [&](unsigned wb, int ks, int buf) {
-        const unsigned a = wb + w_row + (((2 * ks + hi) ^ swz) * 16);
+    // Fragment addresses: the lane part (row, swizzled chunk of k-step ks, hi or lo half = chunk ^ 4) is loop invariant -- four
+    // registers per operand; a stage adds its ring-slot base once (8 VALU per stage), token / channel block offsets are immediates.
+    unsigned xk[2][2], wk[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl) {
+            const unsigned c = (unsigned)(((2 * ks + hi) ^ swz) * 16) ^ (hl ? 64u : 0u);
+            xk[ks][hl] = (unsigned)x_row + c;
+            wk[ks][hl] = (unsigned)w_row + c;
+        }
+    auto lds_read = [&](f16x8& dst, unsigned addr, int imm) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm)); };
+    unsigned xa[2][2], wa[2][2];                   // the addresses of the stage being read (and, at the hand-over, of the next one)
+    auto set_x = [&](unsigned xb) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) { xa[ks][0] = xb + xk[ks][0]; xa[ks][1] = xb + xk[ks][1]; }
+    };
+    auto set_w = [&](unsigned wb) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) { wa[ks][0] = wb + wk[ks][0]; wa[ks][1] = wb + wk[ks][1]; }
+    };
+    auto read_w = [&](int ks, int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            lds_read(wh[buf][i], a + i * 32 * 128);
-            lds_read(wl[buf][i], (a + i * 32 * 128) ^ 64);
+            lds_read(wh[buf][i], wa[ks][0], i * 32 * 128);
+            lds_read(wl[buf][i], wa[ks][1], i * 32 * 128);
         }
     };
-    auto read_x = [&](unsigned xb, int ks, int j, int buf) {
-        const unsigned a = xb + x_row + j * 32 * 128 + (((2 * ks + hi) ^ swz) * 16);
-        lds_read(xh[buf], a);
-        lds_read(xl[buf], a ^ 64);
+    auto read_x = [&](int ks, int j, int buf) {
+        lds_read(xh[buf], xa[ks][0], j * 32 * 128);
+        lds_read(xl[buf], xa[ks][1], j * 32 * 128);
     };
     auto wait_frags = [&](int wb, int xb, int newer) {
         if (newer == 0)
@@ -844,11 +862,11 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_big2_kernel(GemmHArgs g, in
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     OG_GT(7);
-    read_x(lds0, 0, 0, 0);
-    read_w(lds0 + WOFF, 0, 0);
+    set_x(lds0); set_w(lds0 + WOFF);
+    read_x(0, 0, 0);
+    read_w(0, 0);
     int xs = 0;                                     // kt % 3
     for (int kt = 0; kt < nk; ++kt) {
-        const unsigned xb = lds0 + xs * XS, wb = lds0 + WOFF + (kt & 1) * XS;
         const int xs1 = xs == 2 ? 0 : xs + 1;
         const unsigned xbn = lds0 + xs1 * XS, wbn = lds0 + WOFF + ((kt + 1) & 1) * XS;
         const bool iw = kt + 1 < nk, ix = kt + 2 < nk;      // W(kt+1) / X(kt+2) exist
@@ -857,8 +875,8 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_big2_kernel(GemmHArgs g, in
             const int ks = grp >> 2, j = grp & 3;
             if (grp < 7) {
                 const int ks1 = (grp + 1) >> 2, j1 = (grp + 1) & 3;
-                read_x(xb, ks1, j1, (grp + 1) & 1);
-                if (j1 == 0) read_w(wb, ks1, ks1 & 1);
+                read_x(ks1, j1, (grp + 1) & 1);
+                if (j1 == 0) read_w(ks1, ks1 & 1);
                 wait_frags(ks & 1, grp & 1, j1 == 0 ? 6 : 2);
             } else {
                 wait_frags(ks & 1, grp & 1, 0);                                // all my reads of stage kt are done
@@ -870,8 +888,9 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_big2_kernel(GemmHArgs g, in
                     OG_GT(9 + 3 * kt);
                     __builtin_amdgcn_s_barrier();
                     OG_GT(10 + 3 * kt);
-                    read_x(xbn, 0, 0, 0);
-                    read_w(wbn, 0, 0);
+                    set_x(xbn); set_w(wbn);              // my reads of stage kt are complete: the address registers move on
+                    read_x(0, 0, 0);
+                    read_w(0, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
