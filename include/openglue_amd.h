@@ -270,6 +270,18 @@ int og_batchnorm_train_forward(const float* x, int64_t ldx, int64_t rows, int32_
                                float* y, int64_t ldy, float* save_mean, float* save_invstd, void* workspace_dev,
                                void* stream);
 
+/* Backward of the same block (autograd of relu + torch.nn.functional.batch_norm(training=True), i.e. of models/utils.py:53-55
+ * during MatchingTrainingModule.training_step): a = the block's BatchNorm INPUT (the ReLU output), dy = dL/dy, save_mean /
+ * save_invstd from the forward.  Writes dz = dL/d(pre-ReLU conv output) when relu_mask != 0 (else dL/da), dweight, dbias
+ * (may be NULL).  Same shape rules and workspace size as the forward; dz may alias dy. */
+int og_batchnorm_train_backward(const float* a, int64_t lda, const float* dy, int64_t lddy, int64_t rows, int32_t channels,
+                                const float* weight, const float* save_mean, const float* save_invstd, int32_t relu_mask,
+                                float* dz, int64_t lddz, float* dweight, float* dbias, void* workspace_dev, void* stream);
+/* Helpers of the 1x1-conv backward on token-major activations (dW = dZ^T X as og_gemm_nt(dZ^T, X^T); db = column sums of dZ):
+ * dst[c][r] = src[r][c]; out[c] = sum_r x[r][c] (workspace: og_batchnorm_train_workspace_bytes(rows, channels) is enough). */
+int og_transpose_f32(const float* src, int64_t ld_src, int64_t rows, int32_t cols, float* dst, int64_t ld_dst, void* stream);
+int og_colsum_f32(const float* x, int64_t ldx, int64_t rows, int32_t channels, float* out, void* workspace_dev, void* stream);
+
 /* mutual-NN match extraction from a scores tensor [B][m+1][n+1] (matching_module.py:174-187;
  * matches1/matching_scores1 as inference.py:183-188, may be NULL).  First maximal index wins.
  * workspace: og_matches_workspace_bytes. */

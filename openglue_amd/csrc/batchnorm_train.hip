@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 extern "C" size_t og_batchnorm_train_workspace_bytes(int64_t rows, int32_t channels) {
     if (rows < 1 || channels < 4 || (channels & 3)) return 0;
     const int64_t nblk = (rows + BN_ROWS_PER_BLOCK - 1) / BN_ROWS_PER_BLOCK;
-    return (size_t)((nblk * channels * 2 + 2 * channels) * (int64_t)sizeof(float));
+    return (size_t)((nblk * channels * 2 + 3 * channels) * (int64_t)sizeof(float));     // partials + scale/shift (forward) or 3 coefficient rows (backward)
 }
 
 extern "C" int og_batchnorm_train_forward(const float* x, int64_t ldx, int64_t rows, int32_t channels, const float* weight, const float* bias, float eps,
@@ -115,5 +115,164 @@ extern "C" int og_batchnorm_train_forward(const float* x, int64_t ldx, int64_t r
                        running_mean, running_var, scale_shift, save_mean, save_invstd);
     const int64_t n4 = rows * (channels / 4);
     hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x, ldx, rows, channels / 4, scale_shift, y, ldy);
+    return og_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward of the train-mode block  a = relu(z) ; y = batchnorm_train(a)  (models/utils.py:52-56, autograd of
+// torch.nn.functional.batch_norm(training=True) and relu):
+//     xhat = (a - mean) invstd        dbias_c = sum_t dy        dweight_c = sum_t dy xhat
+//     da = (w invstd / T) (T dy - dbias - xhat dweight)         dz = da * [a > 0]   (relu_mask: `a` IS the ReLU output)
+// Same three passes as the forward: partial sums per row slab, one fold in double, one elementwise pass.
+namespace {
+
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ dy, int64_t lddy,
+                                                             int64_t rows, int C, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             float* __restrict__ part) {
+    __shared__ float red[2][4][64];
+    const int c = blockIdx.y * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * BN_ROWS_PER_BLOCK;
+    float s1 = 0.f, s2 = 0.f;
+    if (c < C) {
+        const float mu = mean[c], is = invstd[c];
+        const int64_t r1 = r0 + BN_ROWS_PER_BLOCK < rows ? r0 + BN_ROWS_PER_BLOCK : rows;
+        for (int64_t r = r0 + rg; r < r1; r += 4) {
+            const float g = dy[r * lddy + c];
+            s1 += g;
+            s2 = fmaf(g, (a[r * lda + c] - mu) * is, s2);
+        }
+    }
+    red[0][rg][threadIdx.x & 63] = s1;
+    red[1][rg][threadIdx.x & 63] = s2;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        const int l = threadIdx.x;
+        part[((int64_t)blockIdx.x * C + c) * 2] = (red[0][0][l] + red[0][1][l]) + (red[0][2][l] + red[0][3][l]);
+        part[((int64_t)blockIdx.x * C + c) * 2 + 1] = (red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l]);
+    }
+}
+
+// coef[c] = w invstd, coef[C + c] = dbias / T, coef[2C + c] = dweight / T
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int64_t rows, int C, const float* __restrict__ w,
+                                                              const float* __restrict__ invstd, float* __restrict__ dweight, float* __restrict__ dbias,
+                                                              float* __restrict__ coef) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < nblk; ++i) {
+        s1 += (double)part[((int64_t)i * C + c) * 2];
+        s2 += (double)part[((int64_t)i * C + c) * 2 + 1];
+    }
+    if (dbias) dbias[c] = (float)s1;
+    if (dweight) dweight[c] = (float)s2;
+    coef[c] = (w ? w[c] : 1.f) * invstd[c];
+    coef[C + c] = (float)(s1 / (double)rows);
+    coef[2 * C + c] = (float)(s2 / (double)rows);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ dy, int64_t lddy, int64_t rows,
+                                                           int C4, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ coef, int relu_mask, float* __restrict__ dz, int64_t lddz) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * C4) return;
+    const int64_t r = i / C4;
+    const int c = (int)(i - r * C4) * 4, C = 4 * C4;
+    const f32x4 av = *reinterpret_cast<const f32x4*>(a + r * lda + c);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(dy + r * lddy + c);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
+    const f32x4 k0 = *reinterpret_cast<const f32x4*>(coef + c), k1 = *reinterpret_cast<const f32x4*>(coef + C + c);
+    const f32x4 k2 = *reinterpret_cast<const f32x4*>(coef + 2 * C + c);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float xhat = (av[e] - mu[e]) * is[e];
+        const float d = k0[e] * (g[e] - k1[e] - xhat * k2[e]);
+        o[e] = (relu_mask && !(av[e] > 0.f)) ? 0.f : d;
+    }
+    *reinterpret_cast<f32x4*>(dz + r * lddz + c) = o;
+}
+
+// dst[c][r] = src[r][c]: 64 x 64 tiles through LDS (the weight-gradient GEMM wants both operands K-contiguous: dW = dZ^T X)
+__global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ src, int64_t lds_, int64_t rows, int cols, float* __restrict__ dst,
+                                                            int64_t ldd) {
+    __shared__ float tile[64][65];
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int64_t r = r0 + i;
+        const int c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? src[r * lds_ + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i;
+        const int64_t r = r0 + tx;
+        if (c < cols && r < rows) dst[(int64_t)c * ldd + r] = tile[tx][i];
+    }
+}
+
+// out[c] = sum_r x[r][c] (bias gradient): per-slab partials + one fold in double
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int C, float* __restrict__ part) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.y * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * BN_ROWS_PER_BLOCK;
+    float s1 = 0.f;
+    if (c < C) {
+        const int64_t r1 = r0 + BN_ROWS_PER_BLOCK < rows ? r0 + BN_ROWS_PER_BLOCK : rows;
+        for (int64_t r = r0 + rg; r < r1; r += 4) s1 += x[r * ldx + c];
+    }
+    red[rg][threadIdx.x & 63] = s1;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        const int l = threadIdx.x;
+        part[(int64_t)blockIdx.x * C + c] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+    }
+}
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int i = 0; i < nblk; ++i) s += (double)part[(int64_t)i * C + c];
+    out[c] = (float)s;
+}
+
+}  // namespace
+
+extern "C" int og_batchnorm_train_backward(const float* a, int64_t lda, const float* dy, int64_t lddy, int64_t rows, int32_t channels, const float* weight,
+                                           const float* save_mean, const float* save_invstd, int32_t relu_mask, float* dz, int64_t lddz,
+                                           float* dweight, float* dbias, void* workspace, void* stream) {
+    og_clear_status();
+    if (!a || !dy || !dz || !save_mean || !save_invstd || !workspace || rows < 1 || channels < 4) return OG_E_INVALID;
+    if ((channels & 3) || (lda & 3) || (lddy & 3) || (lddz & 3) || lda < channels || lddy < channels || lddz < channels) return OG_E_SHAPE;
+    if (((uintptr_t)a & 15) || ((uintptr_t)dy & 15) || ((uintptr_t)dz & 15) || ((uintptr_t)workspace & 15) || ((uintptr_t)save_mean & 15) ||
+        ((uintptr_t)save_invstd & 15)) return OG_E_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = (int)((rows + BN_ROWS_PER_BLOCK - 1) / BN_ROWS_PER_BLOCK);
+    float* part = reinterpret_cast<float*>(workspace);
+    float* coef = part + (int64_t)nblk * channels * 2;       // 3 * channels floats: og_batchnorm_train_workspace_bytes reserves them
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblk, (channels + 63) / 64), dim3(256), 0, st, a, lda, dy, lddy, rows, channels, save_mean, save_invstd, part);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((channels + 255) / 256), dim3(256), 0, st, part, nblk, rows, channels, weight, save_invstd, dweight,
+                       dbias, coef);
+    const int64_t n4 = rows * (channels / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, a, lda, dy, lddy, rows, channels / 4, save_mean,
+                       save_invstd, coef, relu_mask, dz, lddz);
+    return og_launch_status();
+}
+
+extern "C" int og_transpose_f32(const float* src, int64_t ld_src, int64_t rows, int32_t cols, float* dst, int64_t ld_dst, void* stream) {
+    og_clear_status();
+    if (!src || !dst || rows < 1 || cols < 1 || ld_src < cols || ld_dst < rows) return OG_E_INVALID;
+    hipLaunchKernelGGL(transpose_f32_kernel, dim3((unsigned)((rows + 63) / 64), (cols + 63) / 64), dim3(256), 0, (hipStream_t)stream, src, ld_src, rows, cols,
+                       dst, ld_dst);
+    return og_launch_status();
+}
+
+extern "C" int og_colsum_f32(const float* x, int64_t ldx, int64_t rows, int32_t channels, float* out, void* workspace, void* stream) {
+    og_clear_status();
+    if (!x || !out || !workspace || rows < 1 || channels < 1 || ldx < channels) return OG_E_INVALID;
+    const int nblk = (int)((rows + BN_ROWS_PER_BLOCK - 1) / BN_ROWS_PER_BLOCK);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, (channels + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, channels, (float*)workspace);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((channels + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nblk, channels, out);
     return og_launch_status();
 }

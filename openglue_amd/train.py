@@ -9,7 +9,10 @@ torch math on the way.  PyTorch is used for what it is here: autograd bookkeepin
 `batch_norm_train` / `feed_forward_train` are the train-mode forward of the reference's MLP building block (models/utils.py:48-58:
 Conv1d -> ReLU -> BatchNorm1d with batch statistics and running-statistics update) on token-major activations.
 
-Not yet built (stated in DESIGN.md): backward of the GEMMs, of attention and of BatchNorm; `SuperGlue.forward` therefore still
+`feed_forward_train_autograd` adds the backward of that block (1x1 conv: dX, dW, db on the exact-fp32 GEMM; ReLU + train-mode
+BatchNorm: og_batchnorm_train_backward), so the keypoint-encoder MLP / a message MLP can be trained end to end on HIP kernels.
+
+Not yet built (stated in DESIGN.md): backward of attention and of the split-f16 GNN GEMMs; `SuperGlue.forward` therefore still
 refuses `train()` mode.
 """
 from __future__ import annotations
@@ -116,4 +119,101 @@ def feed_forward_train(x: torch.Tensor, state_dict, prefix: str = "", momentum: 
             bn = f"{prefix}{3 * i + 2}"
             x = batch_norm_train(x, state_dict[bn + ".weight"], state_dict[bn + ".bias"], state_dict[bn + ".running_mean"],
                                  state_dict[bn + ".running_var"], momentum)
+    return x
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# backward of the MLP block
+def _ws(x: torch.Tensor, rows: int, C: int) -> torch.Tensor:
+    lib = _lib.load()
+    n = lib.og_batchnorm_train_workspace_bytes(rows, max(4, (C + 3) // 4 * 4))
+    return torch.empty(max(n, 256), device=x.device, dtype=torch.uint8)
+
+
+def _transpose_pad(x: torch.Tensor) -> torch.Tensor:
+    """[R, C] -> [C, round_up(R, 4)] (zero tail): both operands of the weight-gradient GEMM must be K-contiguous, K = R."""
+    lib = _lib.load()
+    R, C = x.shape
+    R4 = (R + 3) // 4 * 4
+    out = torch.zeros(C, R4, device=x.device, dtype=torch.float32) if R4 != R else torch.empty(C, R, device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.og_transpose_f32(x.data_ptr(), x.stride(0), R, C, out.data_ptr(), R4, _stream(x)), "og_transpose_f32")
+    return out
+
+
+def _conv_backward(x: torch.Tensor, W: torch.Tensor, dz: torch.Tensor, need_dx: bool):
+    """1x1 conv on token rows, z = x W^T + b:  dx = dz W,  dW = dz^T x,  db = column sums of dz -- all on HIP kernels."""
+    from . import ops
+    lib = _lib.load()
+    T, Cout = dz.shape
+    dx = ops.gemm_nt(dz, _transpose_pad(W)) if need_dx else None              # [T, Cout] x [Cin, Cout]^T
+    dW = ops.gemm_nt(_transpose_pad(dz), _transpose_pad(x))                   # [Cout, T] x [Cin, T]^T
+    db = torch.empty(Cout, device=dz.device, dtype=torch.float32)
+    ws = _ws(dz, T, Cout)
+    with torch.cuda.device(dz.device):
+        _lib.check(lib.og_colsum_f32(dz.data_ptr(), dz.stride(0), T, Cout, db.data_ptr(), ws.data_ptr(), _stream(dz)), "og_colsum_f32")
+    return dx, dW, db
+
+
+class Conv1x1(torch.autograd.Function):
+    """y = x W^T + b on token-major x [T, Cin] (nn.Conv1d(kernel_size=1) of the reference on [B, Cin, N])."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        from . import ops
+        ctx.save_for_backward(x, W)
+        return ops.gemm_nt(x.detach(), W.detach().contiguous(), b.detach())
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dx, dW, db = _conv_backward(x.detach(), W.detach().contiguous(), dy.detach().contiguous(), ctx.needs_input_grad[0])
+        return dx, dW, db
+
+
+class ConvReluBNTrain(torch.autograd.Function):
+    """The hidden block of FeedForwardNet in training mode (models/utils.py:52-56): y = BatchNorm_train(relu(x W^T + b)); running
+    statistics are updated in place in forward."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, gamma, beta, running_mean, running_var, momentum, eps):
+        from . import ops
+        a = ops.gemm_nt(x.detach(), W.detach().contiguous(), b.detach(), relu=True)
+        y, mean, invstd = batch_norm_train(a, gamma.detach(), beta.detach(), running_mean, running_var, momentum, eps, return_stats=True)
+        ctx.save_for_backward(x, W, gamma, a, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, W, gamma, a, mean, invstd = ctx.saved_tensors
+        T, C = a.shape
+        dy = dy.detach().contiguous()
+        dz = torch.empty_like(a)
+        dgamma = torch.empty(C, device=a.device, dtype=torch.float32)
+        dbeta = torch.empty(C, device=a.device, dtype=torch.float32)
+        ws = _ws(a, T, C)
+        with torch.cuda.device(a.device):
+            _lib.check(lib.og_batchnorm_train_backward(a.data_ptr(), a.stride(0), dy.data_ptr(), dy.stride(0), T, C, gamma.detach().data_ptr(),
+                                                       mean.data_ptr(), invstd.data_ptr(), 1, dz.data_ptr(), dz.stride(0), dgamma.data_ptr(),
+                                                       dbeta.data_ptr(), ws.data_ptr(), _stream(a)), "og_batchnorm_train_backward")
+        dx, dW, db = _conv_backward(x.detach(), W.detach().contiguous(), dz, ctx.needs_input_grad[0])
+        return dx, dW, db, dgamma, dbeta, None, None, None, None
+
+
+def feed_forward_train_autograd(x: torch.Tensor, net_params, buffers, prefix: str = "", momentum: float = 0.1, eps: float = 1e-5) -> torch.Tensor:
+    """FeedForwardNet (models/utils.py:48-58) in TRAINING mode with gradients: `net_params` maps the nn.Sequential parameter names
+    (`{prefix}{3i}.weight|bias`, `{prefix}{3i+2}.weight|bias`) to tensors (requires_grad as wanted; conv weights [out, in, 1] or
+    [out, in]), `buffers` the BatchNorm running statistics (updated in place).  x: token-major [T, C_in]."""
+    n_conv = len({k for k in net_params if k.startswith(prefix) and k.endswith(".weight") and net_params[k].dim() >= 2})
+    for i in range(n_conv):
+        W = net_params[f"{prefix}{3 * i}.weight"]
+        W = W.reshape(W.shape[0], W.shape[1])
+        b = net_params[f"{prefix}{3 * i}.bias"]
+        if i + 1 < n_conv:
+            bn = f"{prefix}{3 * i + 2}"
+            x = ConvReluBNTrain.apply(x, W, b, net_params[bn + ".weight"], net_params[bn + ".bias"], buffers[bn + ".running_mean"],
+                                      buffers[bn + ".running_var"], momentum, eps)
+        else:
+            x = Conv1x1.apply(x, W, b)
     return x

@@ -33,7 +33,8 @@ BN_EPS = 1e-5  # nn.BatchNorm1d default, models/utils.py:55
 
 
 def _w(sd: Mapping[str, torch.Tensor], name: str, dtype) -> torch.Tensor:
-    t = sd[name].detach().to("cpu", dtype)
+    t = sd[name]
+    t = (t if t.requires_grad else t.detach()).to("cpu", dtype)       # parameters under autograd (training fixtures) stay attached
     return t[:, :, 0] if t.dim() == 3 else t  # Conv1d k=1 weight [out, in, 1] -> [out, in]
 
 

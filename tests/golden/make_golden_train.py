@@ -106,6 +106,16 @@ def main_mlp():
             out[f"{name}_x{st}"] = x.numpy(); out[f"{name}_y{st}"] = y.numpy()
         for k_, v_ in net.state_dict().items():
             out[f"{name}_after_{k_}"] = v_.numpy().copy()
+        # one more train-mode step under autograd: L = sum(y * R) -> gradients w.r.t. the input and every parameter
+        xg = (torch.randn(B, sizes[0], N, generator=g) * 2.0 + 0.5).requires_grad_(True)
+        Rg = torch.randn(B, sizes[-1], N, generator=g)
+        net.zero_grad()
+        yg = net(xg)
+        (yg * Rg).sum().backward()
+        out[f"{name}_gx"] = xg.detach().numpy(); out[f"{name}_gR"] = Rg.numpy(); out[f"{name}_gy"] = yg.detach().numpy()
+        out[f"{name}_grad_x"] = xg.grad.numpy().copy()
+        for k_, p_ in net.named_parameters():
+            out[f"{name}_grad_{k_}"] = p_.grad.numpy().copy()
         out[f"{name}_meta"] = np.array(list(sizes) + [B, N, steps], np.int64)
         print(name, "train-mode MLP", sizes, "y range", float(y.min()), float(y.max()))
     np.savez_compressed(os.path.join(HERE, "train_mlp.npz"), **out)

@@ -155,3 +155,55 @@ def test_batchnorm_train_large_and_offset_channels(gpu_device):
     assert (y.cpu().double()[:, 16:] - want[:, 16:]).abs().max() < 2e-5
     assert (rmd.cpu().double() - 0.1 * m64).abs().max() < 1e-5
     assert (rvd.cpu().double() - (0.9 + 0.1 * x64.var(0, unbiased=True))).abs().max() < 1e-5
+
+
+def _grad_case(name, device=None):
+    meta = [int(v) for v in M[f"{name}_meta"]]
+    sizes, (B, N, steps) = meta[:-3], meta[-3:]
+    sd = _mlp_state(name, "after", device)                   # parameters are the same before / after; only running statistics moved
+    x = torch.from_numpy(M[f"{name}_gx"]).permute(0, 2, 1).contiguous()       # token-major [B, N, C]
+    R = torch.from_numpy(M[f"{name}_gR"]).permute(0, 2, 1).contiguous()
+    return sizes, B, N, sd, x, R
+
+
+@pytest.mark.parametrize("name", MLP_CASES)
+def test_oracle_train_mode_mlp_gradients_match_the_reference(name):
+    """CPU: autograd through the restated train-mode block reproduces the reference's gradients (input and every parameter)."""
+    sizes, B, N, sd, x, R = _grad_case(name)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if "running" not in k and "num_batches" not in k}
+    full = dict(sd); full.update(params)
+    xr = x.clone().requires_grad_(True)
+    y, _ = orc.feed_forward_train(xr, full, "", len(sizes) - 1)
+    assert np.abs(y.detach().permute(0, 2, 1).numpy() - M[f"{name}_gy"]).max() < 2e-5
+    (y * R).sum().backward()
+    want = M[f"{name}_grad_x"]
+    assert np.abs(xr.grad.permute(0, 2, 1).numpy() - want).max() < 1e-4 * np.abs(want).max() + 1e-6
+    for k, p in params.items():
+        want = M[f"{name}_grad_{k}"]
+        assert np.abs(p.grad.numpy() - want).max() < 1e-4 * np.abs(want).max() + 1e-5, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", MLP_CASES)
+def test_train_mode_mlp_backward_against_reference_autograd(gpu_device, name):
+    """HIP: conv / ReLU / train-mode BatchNorm backward (exact-fp32 GEMMs, og_batchnorm_train_backward) vs the gradients the
+    reference's FeedForwardNet produced under torch autograd."""
+    from openglue_amd.train import feed_forward_train_autograd
+    sizes, B, N, sd, x, R = _grad_case(name, gpu_device)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if "running" not in k and "num_batches" not in k}
+    buffers = {k: v.clone() for k, v in sd.items() if "running" in k}
+    xr = x.reshape(B * N, sizes[0]).to(gpu_device).requires_grad_(True)
+    y = feed_forward_train_autograd(xr, params, buffers)
+    err_y = (y.detach().reshape(B, N, sizes[-1]).permute(0, 2, 1).cpu() - torch.from_numpy(M[f"{name}_gy"])).abs().max().item()
+    assert err_y < 1e-4
+    (y * R.reshape(B * N, sizes[-1]).to(gpu_device)).sum().backward()
+    want = M[f"{name}_grad_x"]
+    got = xr.grad.reshape(B, N, sizes[0]).permute(0, 2, 1).cpu().numpy()
+    worst = np.abs(got - want).max() / np.abs(want).max()
+    for k, p in params.items():
+        want = M[f"{name}_grad_{k}"]
+        e = np.abs(p.grad.cpu().numpy().reshape(want.shape) - want).max() / max(np.abs(want).max(), 1e-6)
+        worst = max(worst, e)
+        assert e < 1e-3, (k, e)                                  # VERDICT r1 item 7: gradients to rel. 1e-3
+    print(f"[train_mlp {name} backward] forward err {err_y:.2e}; worst relative gradient error {worst:.2e}")
+    assert worst < 1e-3
