@@ -282,6 +282,14 @@ int og_batchnorm_train_backward(const float* a, int64_t lda, const float* dy, in
 int og_transpose_f32(const float* src, int64_t ld_src, int64_t rows, int32_t cols, float* dst, int64_t ld_dst, void* stream);
 int og_colsum_f32(const float* x, int64_t ldx, int64_t rows, int32_t channels, float* out, void* workspace_dev, void* stream);
 
+int og_transpose_f32_batched(const float* src, int64_t ld_src, int64_t stride_src, int64_t rows, int32_t cols, float* dst,
+                             int64_t ld_dst, int64_t stride_dst, int32_t batch, void* stream);
+/* Training-mode softmax attention keeps the attention matrix, like the reference (models/superglue/attention.py:8-19; autograd
+ * needs it): og_softmax_rows turns S [rows][ld] (= scale * Q K^T from og_gemm_nt) into P in place, og_softmax_rows_backward turns
+ * dP (= dO V^T) into dS = scale * P o (dP - rowsum(dP o P)) in place.  Columns [cols, ld) are zeroed. */
+int og_softmax_rows(float* S, int64_t ld, int64_t rows, int32_t cols, void* stream);
+int og_softmax_rows_backward(const float* P, float* dP, int64_t ld, int64_t rows, int32_t cols, float scale, void* stream);
+
 /* mutual-NN match extraction from a scores tensor [B][m+1][n+1] (matching_module.py:174-187;
  * matches1/matching_scores1 as inference.py:183-188, may be NULL).  First maximal index wins.
  * workspace: og_matches_workspace_bytes. */

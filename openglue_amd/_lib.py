@@ -105,6 +105,9 @@ SYMBOLS = {
     "og_batchnorm_train_backward": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _vp]),
     "og_transpose_f32": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _i64, _vp]),
     "og_colsum_f32": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp]),
+    "og_transpose_f32_batched": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _vp, _i64, _i64, _i32, _vp]),
+    "og_softmax_rows": (C.c_int, [_vp, _i64, _i64, _i32, _vp]),
+    "og_softmax_rows_backward": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _f, _vp]),
     "og_sinkhorn": (C.c_int, [_vp, _i64, _f, _i32, _i32, _i32, _i32, _f, _vp, _vp, _vp]),
     "og_matches_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "og_prepare_features": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),

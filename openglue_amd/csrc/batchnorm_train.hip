@@ -194,8 +194,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 
 // dst[c][r] = src[r][c]: 64 x 64 tiles through LDS (the weight-gradient GEMM wants both operands K-contiguous: dW = dZ^T X)
 __global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ src, int64_t lds_, int64_t rows, int cols, float* __restrict__ dst,
-                                                            int64_t ldd) {
+                                                            int64_t ldd, int64_t stride_src, int64_t stride_dst) {
     __shared__ float tile[64][65];
+    src += (int64_t)blockIdx.z * stride_src;
+    dst += (int64_t)blockIdx.z * stride_dst;
     const int64_t r0 = (int64_t)blockIdx.x * 64;
     const int c0 = blockIdx.y * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -263,8 +265,17 @@ extern "C" int og_batchnorm_train_backward(const float* a, int64_t lda, const fl
 extern "C" int og_transpose_f32(const float* src, int64_t ld_src, int64_t rows, int32_t cols, float* dst, int64_t ld_dst, void* stream) {
     og_clear_status();
     if (!src || !dst || rows < 1 || cols < 1 || ld_src < cols || ld_dst < rows) return OG_E_INVALID;
-    hipLaunchKernelGGL(transpose_f32_kernel, dim3((unsigned)((rows + 63) / 64), (cols + 63) / 64), dim3(256), 0, (hipStream_t)stream, src, ld_src, rows, cols,
-                       dst, ld_dst);
+    hipLaunchKernelGGL(transpose_f32_kernel, dim3((unsigned)((rows + 63) / 64), (cols + 63) / 64, 1), dim3(256), 0, (hipStream_t)stream, src, ld_src, rows,
+                       cols, dst, ld_dst, (int64_t)0, (int64_t)0);
+    return og_launch_status();
+}
+
+extern "C" int og_transpose_f32_batched(const float* src, int64_t ld_src, int64_t stride_src, int64_t rows, int32_t cols, float* dst, int64_t ld_dst,
+                                        int64_t stride_dst, int32_t batch, void* stream) {
+    og_clear_status();
+    if (!src || !dst || rows < 1 || cols < 1 || batch < 1 || batch > 65535 || ld_src < cols || ld_dst < rows) return OG_E_INVALID;
+    hipLaunchKernelGGL(transpose_f32_kernel, dim3((unsigned)((rows + 63) / 64), (cols + 63) / 64, batch), dim3(256), 0, (hipStream_t)stream, src, ld_src,
+                       rows, cols, dst, ld_dst, stride_src, stride_dst);
     return og_launch_status();
 }
 
@@ -274,5 +285,73 @@ extern "C" int og_colsum_f32(const float* x, int64_t ldx, int64_t rows, int32_t 
     const int nblk = (int)((rows + BN_ROWS_PER_BLOCK - 1) / BN_ROWS_PER_BLOCK);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, (channels + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, channels, (float*)workspace);
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3((channels + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nblk, channels, out);
+    return og_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Training-mode attention with the attention matrix MATERIALISED, like the reference (attention.py:8-19) -- autograd needs P:
+//   forward   P = softmax_rows(S)                  (S = scale * Q K^T from the batched exact-fp32 GEMM, in place)
+//   backward  dS = scale * P o (dP - sum_j dP o P) (dP = dO V^T from the same GEMM, in place)
+// One wave per row, columns [cols, ld) are zeroed (the matrices are the K operand of the next GEMM, K padded to a multiple of 4).
+namespace {
+
+__device__ __forceinline__ float bn_wave_sum(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+__device__ __forceinline__ float bn_wave_max(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o, 64));
+    return x;
+}
+
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ S, int64_t ld, int64_t rows, int cols) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float* row = S + r * ld;
+    float mx = OG_NEG_INF;
+    for (int j = lane; j < cols; j += 64) mx = fmaxf(mx, row[j]);
+    mx = bn_wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < cols; j += 64) {
+        const float e = expf(row[j] - mx);
+        row[j] = e;
+        sum += e;
+    }
+    sum = bn_wave_sum(sum);
+    const float inv = 1.f / sum;
+    for (int j = lane; j < cols; j += 64) row[j] *= inv;
+    for (int j = cols + lane; j < ld; j += 64) row[j] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void softmax_rows_backward_kernel(const float* __restrict__ P, float* __restrict__ dP, int64_t ld, int64_t rows, int cols,
+                                                                    float scale) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* p = P + r * ld;
+    float* d = dP + r * ld;
+    float dot = 0.f;
+    for (int j = lane; j < cols; j += 64) dot = fmaf(d[j], p[j], dot);
+    dot = bn_wave_sum(dot);
+    for (int j = lane; j < cols; j += 64) d[j] = scale * p[j] * (d[j] - dot);
+    for (int j = cols + lane; j < ld; j += 64) d[j] = 0.f;
+}
+
+}  // namespace
+
+extern "C" int og_softmax_rows(float* S, int64_t ld, int64_t rows, int32_t cols, void* stream) {
+    og_clear_status();
+    if (!S || rows < 1 || cols < 1 || ld < cols) return OG_E_INVALID;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, S, ld, rows, cols);
+    return og_launch_status();
+}
+
+extern "C" int og_softmax_rows_backward(const float* P, float* dP, int64_t ld, int64_t rows, int32_t cols, float scale, void* stream) {
+    og_clear_status();
+    if (!P || !dP || rows < 1 || cols < 1 || ld < cols) return OG_E_INVALID;
+    hipLaunchKernelGGL(softmax_rows_backward_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, P, dP, ld, rows, cols, scale);
     return og_launch_status();
 }

@@ -12,7 +12,8 @@ MatchingTrainingModule.forward / OpenGlueMatcher.forward run on `scores`
 The torch.nn modules below are PARAMETER CONTAINERS only (they give identical names, shapes and
 default initialisation); none of their forward() methods is ever called.  All arithmetic is in
 libopenglue_amd.so, reached through the C ABI of include/openglue_amd.h.  There is no CPU or
-eager-PyTorch fallback: off-GPU inputs or a missing library raise.
+eager-PyTorch fallback: off-GPU inputs or a missing library raise.  eval(): the fused inference path (og_forward);
+train(): openglue_amd.train (the same forward in training mode under autograd, HIP forward/backward kernels).
 """
 from __future__ import annotations
 
@@ -408,10 +409,14 @@ class SuperGlue(nn.Module):
         + 'context_descriptors{0,1}' [D, m_i] on request)."""
         return self.match_ragged_packed(self.pack_ragged(pairs), match_threshold, both_sides, context_descriptors)
 
-    @torch.no_grad()
     def forward(self, data: Mapping) -> Dict[str, torch.Tensor]:
-        """Same contract as the reference SuperGlue.forward (superglue.py:29-72)."""
-        return self._run(data, want_matches=False, match_threshold=0.0, both_sides=False)
+        """Same contract as the reference SuperGlue.forward (superglue.py:29-72).  eval(): the fused inference path (og_forward);
+        train(): the training path of openglue_amd.train (batch-statistics BatchNorm, autograd through HIP forward/backward kernels)."""
+        if self.training:
+            from . import train
+            return train.superglue_forward_train(self, data)
+        with torch.no_grad():
+            return self._run(data, want_matches=False, match_threshold=0.0, both_sides=False)
 
     @torch.no_grad()
     def match(self, data: Mapping, match_threshold: float = 0.2, both_sides: bool = True, _profile=None) -> Dict[str, torch.Tensor]:

@@ -217,3 +217,213 @@ def feed_forward_train_autograd(x: torch.Tensor, net_params, buffers, prefix: st
         else:
             x = Conv1x1.apply(x, W, b)
     return x
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# training-mode softmax attention (attention matrix materialised like the reference, attention.py:8-19) and the score matrix
+def _gemm_raw(dev, A, lda, sA, Bp, ldb, sB, Cp, ldc, sC, M, N, K, batch, scale=1.0):
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        _lib.check(lib.og_gemm_nt(A, lda, sA, Bp, ldb, sB, Cp, ldc, sC, M, N, K, batch, None, 0, None, 0, None, float(scale),
+                                  torch.cuda.current_stream(dev).cuda_stream), "og_gemm_nt")
+
+
+def _transpose_raw(dev, src, ld_src, s_src, rows, cols, dst, ld_dst, s_dst, batch):
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        _lib.check(lib.og_transpose_f32_batched(src, ld_src, s_src, rows, cols, dst, ld_dst, s_dst, batch,
+                                                torch.cuda.current_stream(dev).cuda_stream), "og_transpose_f32_batched")
+
+
+def _r4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
+class SoftmaxAttention(torch.autograd.Function):
+    """out[b, i, h*d:(h+1)*d] = softmax_j(q_h[b, i] . k_h[b, j] / sqrt(d)) v_h[b, j]  on token-major q [B, Nq, D], k, v [B, Nk, D]
+    (heads = contiguous channel blocks, attention_gnn.py:24-26).  Every product is an exact-fp32 MFMA GEMM (og_gemm_nt), the
+    softmax and its backward are HIP kernels; P is kept for the backward, as the reference's autograd does."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, num_heads):
+        lib = _lib.load()
+        q, k, v = (t.detach().to(torch.float32).contiguous() for t in (q, k, v))
+        B, Nq, D = q.shape
+        Nk = k.shape[1]
+        H, d = num_heads, D // num_heads
+        dev = q.device
+        st = torch.cuda.current_stream(dev).cuda_stream
+        Nk4 = _r4(Nk)
+        P = torch.empty(H, B, Nq, Nk4, device=dev, dtype=torch.float32)
+        vt = torch.zeros(H, B, d, Nk4, device=dev, dtype=torch.float32)
+        out = torch.empty(B, Nq, D, device=dev, dtype=torch.float32)
+        for h in range(H):
+            o4 = h * d * 4
+            _gemm_raw(dev, q.data_ptr() + o4, D, Nq * D, k.data_ptr() + o4, D, Nk * D, P[h].data_ptr(), Nk4, Nq * Nk4, Nq, Nk, d, B, d ** -0.5)
+            with torch.cuda.device(dev):
+                _lib.check(lib.og_softmax_rows(P[h].data_ptr(), Nk4, B * Nq, Nk, st), "og_softmax_rows")
+            _transpose_raw(dev, v.data_ptr() + o4, D, Nk * D, Nk, d, vt[h].data_ptr(), Nk4, d * Nk4, B)
+            _gemm_raw(dev, P[h].data_ptr(), Nk4, Nq * Nk4, vt[h].data_ptr(), Nk4, d * Nk4, out.data_ptr() + o4, D, Nq * D, Nq, d, Nk4, B)
+        ctx.save_for_backward(q, k, v, P)
+        ctx.num_heads = H
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        q, k, v, P = ctx.saved_tensors
+        B, Nq, D = q.shape
+        Nk = k.shape[1]
+        H, d = ctx.num_heads, D // ctx.num_heads
+        dev = q.device
+        st = torch.cuda.current_stream(dev).cuda_stream
+        Nk4, Nq4 = _r4(Nk), _r4(Nq)
+        dout = dout.detach().to(torch.float32).contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        dS = torch.empty(B, Nq, Nk4, device=dev, dtype=torch.float32)
+        Pt = torch.zeros(B, Nk, Nq4, device=dev, dtype=torch.float32)          # P^T, then dS^T
+        xt = torch.zeros(B, d, max(Nq4, Nk4), device=dev, dtype=torch.float32)  # dO_h^T / K_h^T / Q_h^T, K-contiguous
+        for h in range(H):
+            o4 = h * d * 4
+            # dV_h = P^T dO_h
+            _transpose_raw(dev, P[h].data_ptr(), Nk4, Nq * Nk4, Nq, Nk, Pt.data_ptr(), Nq4, Nk * Nq4, B)
+            xt.zero_()
+            _transpose_raw(dev, dout.data_ptr() + o4, D, Nq * D, Nq, d, xt.data_ptr(), Nq4, d * xt.shape[2], B)
+            _gemm_raw(dev, Pt.data_ptr(), Nq4, Nk * Nq4, xt.data_ptr(), Nq4, d * xt.shape[2], dv.data_ptr() + o4, D, Nk * D, Nk, d, Nq4, B)
+            # dP = dO_h V_h^T  ->  dS = scale * P o (dP - rowsum(dP o P))
+            _gemm_raw(dev, dout.data_ptr() + o4, D, Nq * D, v.data_ptr() + o4, D, Nk * D, dS.data_ptr(), Nk4, Nq * Nk4, Nq, Nk, d, B)
+            with torch.cuda.device(dev):
+                _lib.check(lib.og_softmax_rows_backward(P[h].data_ptr(), dS.data_ptr(), Nk4, B * Nq, Nk, d ** -0.5, st), "og_softmax_rows_backward")
+            # dQ_h = dS K_h
+            xt.zero_()
+            _transpose_raw(dev, k.data_ptr() + o4, D, Nk * D, Nk, d, xt.data_ptr(), Nk4, d * xt.shape[2], B)
+            _gemm_raw(dev, dS.data_ptr(), Nk4, Nq * Nk4, xt.data_ptr(), Nk4, d * xt.shape[2], dq.data_ptr() + o4, D, Nq * D, Nq, d, Nk4, B)
+            # dK_h = dS^T Q_h
+            _transpose_raw(dev, dS.data_ptr(), Nk4, Nq * Nk4, Nq, Nk, Pt.data_ptr(), Nq4, Nk * Nq4, B)
+            xt.zero_()
+            _transpose_raw(dev, q.data_ptr() + o4, D, Nq * D, Nq, d, xt.data_ptr(), Nq4, d * xt.shape[2], B)
+            _gemm_raw(dev, Pt.data_ptr(), Nq4, Nk * Nq4, xt.data_ptr(), Nq4, d * xt.shape[2], dk.data_ptr() + o4, D, Nk * D, Nk, d, Nq4, B)
+        return dq, dk, dv, None
+
+
+class MatchingScores(torch.autograd.Function):
+    """S[b] = g0[b] g1[b]^T * scale on token-major g0 [B, m, D], g1 [B, n, D] (superglue.py:81-86 with its D^-1/2 factor)."""
+
+    @staticmethod
+    def forward(ctx, g0, g1, scale):
+        g0, g1 = g0.detach().to(torch.float32).contiguous(), g1.detach().to(torch.float32).contiguous()
+        B, m, D = g0.shape
+        n = g1.shape[1]
+        S = torch.empty(B, m, n, device=g0.device, dtype=torch.float32)
+        _gemm_raw(g0.device, g0.data_ptr(), D, m * D, g1.data_ptr(), D, n * D, S.data_ptr(), n, m * n, m, n, D, B, scale)
+        ctx.save_for_backward(g0, g1)
+        ctx.scale = float(scale)
+        return S
+
+    @staticmethod
+    def backward(ctx, dS):
+        g0, g1 = ctx.saved_tensors
+        B, m, D = g0.shape
+        n = g1.shape[1]
+        dev = g0.device
+        n4, m4 = _r4(n), _r4(m)
+        dSp = torch.zeros(B, m, n4, device=dev, dtype=torch.float32)
+        dSp[:, :, :n] = dS.detach()
+        g1t = torch.zeros(B, D, n4, device=dev, dtype=torch.float32)
+        _transpose_raw(dev, g1.data_ptr(), D, n * D, n, D, g1t.data_ptr(), n4, D * n4, B)
+        dg0 = torch.empty_like(g0)
+        _gemm_raw(dev, dSp.data_ptr(), n4, m * n4, g1t.data_ptr(), n4, D * n4, dg0.data_ptr(), D, m * D, m, D, n4, B, ctx.scale)
+        dSt = torch.zeros(B, n, m4, device=dev, dtype=torch.float32)
+        _transpose_raw(dev, dSp.data_ptr(), n4, m * n4, m, n, dSt.data_ptr(), m4, n * m4, B)
+        g0t = torch.zeros(B, D, m4, device=dev, dtype=torch.float32)
+        _transpose_raw(dev, g0.data_ptr(), D, m * D, m, D, g0t.data_ptr(), m4, D * m4, B)
+        dg1 = torch.empty_like(g1)
+        _gemm_raw(dev, dSt.data_ptr(), m4, n * m4, g0t.data_ptr(), m4, D * m4, dg1.data_ptr(), D, n * D, n, D, m4, B, ctx.scale)
+        return dg0, dg1, None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the whole module in training mode (superglue.py:29-72 under autograd)
+def _pad_k4(x2d: torch.Tensor, W: torch.Tensor):
+    """The exact-fp32 GEMM wants K % 4 == 0: zero-pad the 2 + side_info input columns of the first encoder conv (and its weight)."""
+    K = x2d.shape[1]
+    if K % 4 == 0:
+        return x2d, W
+    pad = 4 - K % 4
+    return torch.nn.functional.pad(x2d, (0, pad)), torch.nn.functional.pad(W.reshape(W.shape[0], K), (0, pad))
+
+
+def _seq_state(seq: torch.nn.Module):
+    return dict(seq.named_parameters()), dict(seq.named_buffers())
+
+
+def _mlp_train(x2d: torch.Tensor, seq: torch.nn.Module, momentum: float = 0.1, eps: float = 1e-5) -> torch.Tensor:
+    params, buffers = _seq_state(seq)
+    W0 = params["0.weight"]
+    x2d, W0p = _pad_k4(x2d, W0.reshape(W0.shape[0], W0.shape[1]))
+    params = dict(params)
+    params["0.weight"] = W0p
+    y = feed_forward_train_autograd(x2d.contiguous(), params, buffers, "", momentum, eps)
+    for k, b in buffers.items():                      # nn.BatchNorm1d bookkeeping (unused by the arithmetic: momentum is fixed)
+        if k.endswith("num_batches_tracked"):
+            b.add_(1)
+    return y
+
+
+def superglue_forward_train(model, data):
+    """`SuperGlue.forward` in training mode (reference superglue.py:29-72 with the modules in train()): batch-statistics BatchNorm
+    (running statistics updated like torch's), every 1x1 conv / attention product / score matrix on the exact-fp32 MFMA GEMM,
+    softmax + its backward, BatchNorm + ReLU backward and the optimal-transport layer on HIP kernels, all wired through
+    torch.autograd.Functions -- loss.backward() reaches every parameter.  Glue that stays torch tensor algebra: keypoint
+    normalisation, concatenations, residual adds, the sigmoid mix.  Supported: encoder FeedForwardNet, softmax attention,
+    use_offset, residual, no_descriptors."""
+    if model.siren or model.linear_attention:
+        raise NotImplementedError("training mode: FeedForwardNet encoder and softmax attention only")
+    D, H = model.descriptor_dim, model.num_heads
+    k0, k1 = data["keypoints0"], data["keypoints1"]
+    d0, d1 = data["local_descriptors0"], data["local_descriptors1"]                # [B, N, D] token-major as they arrive
+    s0, s1 = data["side_info0"], data["side_info1"]
+    for t in (k0, k1, d0, d1, s0, s1):
+        if not t.is_cuda:
+            raise RuntimeError("openglue_amd.SuperGlue: inputs must be on the MI355X; there is no CPU fallback")
+    B, m, n = k0.shape[0], k0.shape[1], k1.shape[1]
+    from .superglue import _get_wh
+
+    def encode(k, s, wh):
+        wh1 = torch.tensor([wh[0] - 1.0, wh[1] - 1.0], device=k.device, dtype=torch.float32)
+        kn = 2.0 * k.to(torch.float32) / wh1 - 1.0                                  # superglue.py:74-78
+        inp = torch.cat([kn, s.to(torch.float32).reshape(k.shape[0], k.shape[1], -1)], dim=-1)
+        return _mlp_train(inp.reshape(-1, inp.shape[-1]), model.positional_encoding.encoder)
+
+    pe0, pe1 = encode(k0, s0, _get_wh(data, 0)), encode(k1, s1, _get_wh(data, 1))
+    d0f, d1f = d0.to(torch.float32).reshape(B * m, D), d1.to(torch.float32).reshape(B * n, D)
+    x0, x1 = (pe0, pe1) if model.no_descriptors else (d0f + pe0, d1f + pe1)
+
+    def conv(x2d, c):
+        return Conv1x1.apply(x2d.contiguous(), c.weight.reshape(c.weight.shape[0], c.weight.shape[1]), c.bias)
+
+    def propagate(layer, xq, nq, xkv, nk):                                         # attention_gnn.py:45-55
+        mha = layer.module.mha
+        q, k, v = conv(xq, mha.in_proj_q), conv(xkv, mha.in_proj_k), conv(xkv, mha.in_proj_v)
+        o = SoftmaxAttention.apply(q.reshape(B, nq, D), k.reshape(B, nk, D), v.reshape(B, nk, D), H)
+        msg = conv(o.reshape(B * nq, D), mha.out_proj)
+        y = torch.cat([xq - msg if model.use_offset else xq, msg], dim=-1)
+        return xq + _mlp_train(y, layer.module.fc)
+
+    for li, layer in enumerate(model.attention_gnn.layers):
+        if li % 2 == 0:                                                            # self (attention_gnn.py:63-66)
+            x0 = propagate(layer, x0, m, x0, m)
+            x1 = propagate(layer, x1, n, x1, n)
+        else:                                                                      # cross: image 1 sees the UPDATED image 0 (:74-77)
+            x0 = propagate(layer, x0, m, x1, n)
+            x1 = propagate(layer, x1, n, x0, m)
+    g0, g1 = conv(x0, model.linear_proj), conv(x1, model.linear_proj)
+    if model.residual:
+        alpha = torch.sigmoid(model.mix_coefs).reshape(1, D)
+        g0 = alpha * g0 + (1.0 - alpha) * d0f
+        g1 = alpha * g1 + (1.0 - alpha) * d1f
+    S = MatchingScores.apply(g0.reshape(B, m, D), g1.reshape(B, n, D), D ** -0.5)
+    otp = model.config["otp"]
+    scores = SinkhornOT.apply(S, model.dustbin_score, int(otp["num_iters"]), float(otp["reg"]))
+    return {"context_descriptors0": g0.reshape(B, m, D).transpose(1, 2), "context_descriptors1": g1.reshape(B, n, D).transpose(1, 2),
+            "scores": scores}

@@ -51,9 +51,19 @@ def batchnorm_eval(x: torch.Tensor, sd, prefix: str) -> torch.Tensor:
     return (x - mean) / torch.sqrt(var + BN_EPS) * gamma + beta
 
 
+# training-mode restatement (tests only): when this is a dict, every FeedForwardNet uses batch statistics
+# (feed_forward_train below) and records the updated running statistics in it -- see superglue_forward(train_stats=...)
+_TRAIN_STATS = None
+
+
 def feed_forward(x: torch.Tensor, sd, prefix: str, n_conv: int) -> torch.Tensor:
     """FeedForwardNet: [Conv1d, ReLU, BatchNorm1d] * (n_conv-1) + Conv1d, in THAT order
     (models/utils.py:48-58).  Sequential indices: conv 3i, relu 3i+1, bn 3i+2."""
+    if _TRAIN_STATS is not None:
+        y, stats = feed_forward_train(x, {**sd, **_TRAIN_STATS}, prefix, n_conv)      # the second call of a module continues from the first
+        for k, v in stats.items():          # a module called twice per step (image 0, image 1) updates its statistics twice
+            _TRAIN_STATS[k] = v
+        return y
     for i in range(n_conv - 1):
         x = conv1x1(x, sd, f"{prefix}.{3 * i}")
         x = torch.relu(x)
@@ -188,10 +198,18 @@ def _image_wh(data: Mapping, idx: int) -> Tuple[float, float]:
 
 def superglue_forward(sd: Mapping[str, torch.Tensor], config: Mapping, data: Mapping,
                       dtype: torch.dtype = torch.float32, attn_operand_dtype=None,
-                      return_intermediates: bool = False) -> Dict[str, torch.Tensor]:
-    """SuperGlue.forward, superglue.py:29-72 (eval mode).  Returns the reference's dict:
-    'context_descriptors{0,1}' CHANNEL-FIRST [B, D, n] and 'scores' [B, m+1, n+1]."""
-    cvt = lambda t: t.detach().to("cpu", dtype)
+                      return_intermediates: bool = False, train_stats: Optional[dict] = None) -> Dict[str, torch.Tensor]:
+    """SuperGlue.forward, superglue.py:29-72.  Returns the reference's dict: 'context_descriptors{0,1}' CHANNEL-FIRST [B, D, n]
+    and 'scores' [B, m+1, n+1].  Eval mode by default; with `train_stats` (a dict) the MLPs run in TRAINING mode (batch-statistics
+    BatchNorm), the updated running statistics are returned in it, and tensors that require grad stay attached to autograd."""
+    global _TRAIN_STATS
+    if train_stats is not None:
+        _TRAIN_STATS = train_stats
+        try:
+            return superglue_forward(sd, config, data, dtype, attn_operand_dtype, return_intermediates, None)
+        finally:
+            _TRAIN_STATS = None
+    cvt = lambda t: (t if t.requires_grad else t.detach()).to("cpu", dtype)
     k0, k1 = cvt(data["keypoints0"]), cvt(data["keypoints1"])
     d0, d1 = cvt(data["local_descriptors0"]), cvt(data["local_descriptors1"])
     s0, s1 = cvt(data["side_info0"]), cvt(data["side_info1"])

@@ -119,6 +119,44 @@ def main_mlp():
         out[f"{name}_meta"] = np.array(list(sizes) + [B, N, steps], np.int64)
         print(name, "train-mode MLP", sizes, "y range", float(y.min()), float(y.max()))
     np.savez_compressed(os.path.join(HERE, "train_mlp.npz"), **out)
+    main_model()
+
+
+MODEL_CASES = [  # name, config overrides, B, m, n
+    ("base", dict(descriptor_dim=64, num_stages=2, num_heads=4, num_iters=8), 2, 37, 53),
+    ("flags", dict(descriptor_dim=64, num_stages=1, num_heads=2, num_iters=5, use_offset=True, residual=True), 2, 40, 33),
+]
+
+
+def main_model():
+    """train_model: the reference SuperGlue in train() mode on seeded weights / inputs, L = criterion NLL (utils/losses.py, margin
+    None): scores, loss, gradients w.r.t. EVERY parameter and the local descriptors, BatchNorm running statistics after the step."""
+    out = {}
+    for name, kw, B, m, n in MODEL_CASES:
+        cfg = syn.make_config(**kw)
+        sd = syn.make_state_dict(cfg, seed=len(name))
+        ref = RefSuperGlue(cfg)
+        ref.load_state_dict(sd)
+        ref.train()
+        data = syn.make_batch(B, m, n, cfg["descriptor_dim"], 1, seed=3 + len(name))
+        data["local_descriptors0"].requires_grad_(True); data["local_descriptors1"].requires_grad_(True)
+        g = torch.Generator().manual_seed(11)
+        gt0, gt1 = gt_matches(B, m, n, g)
+        y = ref(data)
+        loss = criterion({"gt_matches0": gt0, "gt_matches1": gt1}, y, margin=None)["loss"]
+        loss.backward()
+        out[f"{name}_scores"] = y["scores"].detach().numpy(); out[f"{name}_loss"] = np.float32(loss.item())
+        out[f"{name}_ctx0"] = y["context_descriptors0"].detach().numpy()
+        out[f"{name}_gt0"] = gt0.numpy(); out[f"{name}_gt1"] = gt1.numpy()
+        out[f"{name}_grad_desc0"] = data["local_descriptors0"].grad.numpy().copy()
+        out[f"{name}_grad_desc1"] = data["local_descriptors1"].grad.numpy().copy()
+        for k_, p_ in ref.named_parameters():
+            out[f"{name}_grad_{k_}"] = (p_.grad if p_.grad is not None else torch.zeros_like(p_)).numpy().copy()
+        for k_, b_ in ref.named_buffers():
+            out[f"{name}_buf_{k_}"] = b_.numpy().copy()
+        out[f"{name}_meta"] = np.array([B, m, n], np.int64)
+        print(name, "train-mode model: loss", loss.item(), "params", sum(1 for _ in ref.named_parameters()))
+    np.savez_compressed(os.path.join(HERE, "train_model.npz"), **out)
 
 
 if __name__ == "__main__":

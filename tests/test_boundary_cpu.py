@@ -99,8 +99,9 @@ def test_error_behaviour():
     data = syn.make_batch(1, 16, 16, 64, 1, seed=0)
     with pytest.raises(RuntimeError, match="no CPU fallback"):      # product path never computes on the CPU
         model(data)
-    with pytest.raises(RuntimeError, match="eval"):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):      # ... in training mode neither (openglue_amd.train)
         model.train()(data)
+    model.eval()
     lib = _lib.load()
     s = model._shape(1, 16, 16)
     assert lib.og_check_shape(C.byref(s)) == 0
