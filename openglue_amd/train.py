@@ -239,71 +239,83 @@ def _r4(n: int) -> int:
     return (n + 3) // 4 * 4
 
 
+def _heads_first(x: torch.Tensor, H: int) -> torch.Tensor:
+    """[B, N, H*d] -> [B*H, N, d] contiguous (pure data movement): one uniformly strided batch of B*H problems per GEMM launch."""
+    B, N, D = x.shape
+    return x.reshape(B, N, H, D // H).permute(0, 2, 1, 3).reshape(B * H, N, D // H).contiguous()
+
+
+def _heads_last(x: torch.Tensor, B: int) -> torch.Tensor:
+    """[B*H, N, d] -> [B, N, H*d] contiguous."""
+    BH, N, d = x.shape
+    H = BH // B
+    return x.reshape(B, H, N, d).permute(0, 2, 1, 3).reshape(B, N, H * d).contiguous()
+
+
 class SoftmaxAttention(torch.autograd.Function):
     """out[b, i, h*d:(h+1)*d] = softmax_j(q_h[b, i] . k_h[b, j] / sqrt(d)) v_h[b, j]  on token-major q [B, Nq, D], k, v [B, Nk, D]
-    (heads = contiguous channel blocks, attention_gnn.py:24-26).  Every product is an exact-fp32 MFMA GEMM (og_gemm_nt), the
-    softmax and its backward are HIP kernels; P is kept for the backward, as the reference's autograd does."""
+    (heads = contiguous channel blocks, attention_gnn.py:24-26).  Every product is an exact-fp32 MFMA GEMM (og_gemm_nt, one
+    launch over the B*H (pair, head) problems), the softmax and its backward are HIP kernels; P is kept for the backward, as the
+    reference's autograd does."""
 
     @staticmethod
     def forward(ctx, q, k, v, num_heads):
         lib = _lib.load()
-        q, k, v = (t.detach().to(torch.float32).contiguous() for t in (q, k, v))
         B, Nq, D = q.shape
         Nk = k.shape[1]
         H, d = num_heads, D // num_heads
+        qh, kh, vh = (_heads_first(t.detach().to(torch.float32), H) for t in (q, k, v))      # [B*H, N, d]
         dev = q.device
         st = torch.cuda.current_stream(dev).cuda_stream
-        Nk4 = _r4(Nk)
-        P = torch.empty(H, B, Nq, Nk4, device=dev, dtype=torch.float32)
-        vt = torch.zeros(H, B, d, Nk4, device=dev, dtype=torch.float32)
-        out = torch.empty(B, Nq, D, device=dev, dtype=torch.float32)
-        for h in range(H):
-            o4 = h * d * 4
-            _gemm_raw(dev, q.data_ptr() + o4, D, Nq * D, k.data_ptr() + o4, D, Nk * D, P[h].data_ptr(), Nk4, Nq * Nk4, Nq, Nk, d, B, d ** -0.5)
-            with torch.cuda.device(dev):
-                _lib.check(lib.og_softmax_rows(P[h].data_ptr(), Nk4, B * Nq, Nk, st), "og_softmax_rows")
-            _transpose_raw(dev, v.data_ptr() + o4, D, Nk * D, Nk, d, vt[h].data_ptr(), Nk4, d * Nk4, B)
-            _gemm_raw(dev, P[h].data_ptr(), Nk4, Nq * Nk4, vt[h].data_ptr(), Nk4, d * Nk4, out.data_ptr() + o4, D, Nq * D, Nq, d, Nk4, B)
-        ctx.save_for_backward(q, k, v, P)
-        ctx.num_heads = H
-        return out
+        Z, Nk4 = B * H, _r4(Nk)
+        P = torch.empty(Z, Nq, Nk4, device=dev, dtype=torch.float32)
+        _gemm_raw(dev, qh.data_ptr(), d, Nq * d, kh.data_ptr(), d, Nk * d, P.data_ptr(), Nk4, Nq * Nk4, Nq, Nk, d, Z, d ** -0.5)
+        with torch.cuda.device(dev):
+            _lib.check(lib.og_softmax_rows(P.data_ptr(), Nk4, Z * Nq, Nk, st), "og_softmax_rows")
+        vt = torch.zeros(Z, d, Nk4, device=dev, dtype=torch.float32) if Nk4 != Nk else torch.empty(Z, d, Nk4, device=dev, dtype=torch.float32)
+        _transpose_raw(dev, vh.data_ptr(), d, Nk * d, Nk, d, vt.data_ptr(), Nk4, d * Nk4, Z)
+        oh = torch.empty(Z, Nq, d, device=dev, dtype=torch.float32)
+        _gemm_raw(dev, P.data_ptr(), Nk4, Nq * Nk4, vt.data_ptr(), Nk4, d * Nk4, oh.data_ptr(), d, Nq * d, Nq, d, Nk4, Z)
+        ctx.save_for_backward(qh, kh, vh, P)
+        ctx.dims = (B, H)
+        return _heads_last(oh, B)
 
     @staticmethod
     def backward(ctx, dout):
         lib = _lib.load()
-        q, k, v, P = ctx.saved_tensors
-        B, Nq, D = q.shape
-        Nk = k.shape[1]
-        H, d = ctx.num_heads, D // ctx.num_heads
-        dev = q.device
+        qh, kh, vh, P = ctx.saved_tensors
+        B, H = ctx.dims
+        Z, Nq, d = qh.shape
+        Nk = kh.shape[1]
+        dev = qh.device
         st = torch.cuda.current_stream(dev).cuda_stream
         Nk4, Nq4 = _r4(Nk), _r4(Nq)
-        dout = dout.detach().to(torch.float32).contiguous()
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        dS = torch.empty(B, Nq, Nk4, device=dev, dtype=torch.float32)
-        Pt = torch.zeros(B, Nk, Nq4, device=dev, dtype=torch.float32)          # P^T, then dS^T
-        xt = torch.zeros(B, d, max(Nq4, Nk4), device=dev, dtype=torch.float32)  # dO_h^T / K_h^T / Q_h^T, K-contiguous
-        for h in range(H):
-            o4 = h * d * 4
-            # dV_h = P^T dO_h
-            _transpose_raw(dev, P[h].data_ptr(), Nk4, Nq * Nk4, Nq, Nk, Pt.data_ptr(), Nq4, Nk * Nq4, B)
-            xt.zero_()
-            _transpose_raw(dev, dout.data_ptr() + o4, D, Nq * D, Nq, d, xt.data_ptr(), Nq4, d * xt.shape[2], B)
-            _gemm_raw(dev, Pt.data_ptr(), Nq4, Nk * Nq4, xt.data_ptr(), Nq4, d * xt.shape[2], dv.data_ptr() + o4, D, Nk * D, Nk, d, Nq4, B)
-            # dP = dO_h V_h^T  ->  dS = scale * P o (dP - rowsum(dP o P))
-            _gemm_raw(dev, dout.data_ptr() + o4, D, Nq * D, v.data_ptr() + o4, D, Nk * D, dS.data_ptr(), Nk4, Nq * Nk4, Nq, Nk, d, B)
-            with torch.cuda.device(dev):
-                _lib.check(lib.og_softmax_rows_backward(P[h].data_ptr(), dS.data_ptr(), Nk4, B * Nq, Nk, d ** -0.5, st), "og_softmax_rows_backward")
-            # dQ_h = dS K_h
-            xt.zero_()
-            _transpose_raw(dev, k.data_ptr() + o4, D, Nk * D, Nk, d, xt.data_ptr(), Nk4, d * xt.shape[2], B)
-            _gemm_raw(dev, dS.data_ptr(), Nk4, Nq * Nk4, xt.data_ptr(), Nk4, d * xt.shape[2], dq.data_ptr() + o4, D, Nq * D, Nq, d, Nk4, B)
-            # dK_h = dS^T Q_h
-            _transpose_raw(dev, dS.data_ptr(), Nk4, Nq * Nk4, Nq, Nk, Pt.data_ptr(), Nq4, Nk * Nq4, B)
-            xt.zero_()
-            _transpose_raw(dev, q.data_ptr() + o4, D, Nq * D, Nq, d, xt.data_ptr(), Nq4, d * xt.shape[2], B)
-            _gemm_raw(dev, Pt.data_ptr(), Nq4, Nk * Nq4, xt.data_ptr(), Nq4, d * xt.shape[2], dk.data_ptr() + o4, D, Nk * D, Nk, d, Nq4, B)
-        return dq, dk, dv, None
+        doh = _heads_first(dout.detach().to(torch.float32), H)                                  # [Z, Nq, d]
+
+        def tr(x, rows, cols, ld):      # [Z, rows, cols] (row stride ld) -> [Z, cols, r4(rows)], zero tail
+            r4 = _r4(rows)
+            out = torch.zeros(Z, cols, r4, device=dev, dtype=torch.float32) if r4 != rows else torch.empty(Z, cols, r4, device=dev, dtype=torch.float32)
+            _transpose_raw(dev, x.data_ptr(), ld, rows * ld, rows, cols, out.data_ptr(), r4, cols * r4, Z)
+            return out
+
+        # dV = P^T dO
+        Pt, dot = tr(P, Nq, Nk, Nk4), tr(doh, Nq, d, d)
+        dvh = torch.empty(Z, Nk, d, device=dev, dtype=torch.float32)
+        _gemm_raw(dev, Pt.data_ptr(), Nq4, Nk * Nq4, dot.data_ptr(), Nq4, d * Nq4, dvh.data_ptr(), d, Nk * d, Nk, d, Nq4, Z)
+        # dP = dO V^T  ->  dS = scale * P o (dP - rowsum(dP o P))
+        dS = torch.empty(Z, Nq, Nk4, device=dev, dtype=torch.float32)
+        _gemm_raw(dev, doh.data_ptr(), d, Nq * d, vh.data_ptr(), d, Nk * d, dS.data_ptr(), Nk4, Nq * Nk4, Nq, Nk, d, Z)
+        with torch.cuda.device(dev):
+            _lib.check(lib.og_softmax_rows_backward(P.data_ptr(), dS.data_ptr(), Nk4, Z * Nq, Nk, d ** -0.5, st), "og_softmax_rows_backward")
+        # dQ = dS K
+        kt = tr(kh, Nk, d, d)
+        dqh = torch.empty(Z, Nq, d, device=dev, dtype=torch.float32)
+        _gemm_raw(dev, dS.data_ptr(), Nk4, Nq * Nk4, kt.data_ptr(), Nk4, d * Nk4, dqh.data_ptr(), d, Nq * d, Nq, d, Nk4, Z)
+        # dK = dS^T Q
+        dSt, qt = tr(dS, Nq, Nk, Nk4), tr(qh, Nq, d, d)
+        dkh = torch.empty(Z, Nk, d, device=dev, dtype=torch.float32)
+        _gemm_raw(dev, dSt.data_ptr(), Nq4, Nk * Nq4, qt.data_ptr(), Nq4, d * Nq4, dkh.data_ptr(), d, Nk * d, Nk, d, Nq4, Z)
+        return _heads_last(dqh, B), _heads_last(dkh, B), _heads_last(dvh, B), None
 
 
 class MatchingScores(torch.autograd.Function):
