@@ -181,17 +181,11 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a) {
     load_row(row0 + RS_RR + RS_LR, xs0);
     load_row(row0 + RS_RR + RS_LR + 1, xs1);
     bool failed = false;
-#pragma unroll 1
-    for (int it = 0; it < a.iters; ++it) {
-        const unsigned epoch = (unsigned)it + 1u;
-        rs_gu64* xg = (rs_gu64*)a.xg + (((int64_t)(it & 1) * B + b) * G) * RS_NG;      // this pair's granules of this parity
-
-        // (v is re-read from LDS chunk by chunk inside the rows: 16 more live registers would not fit beside the 176 of S)
+    // ---- dustbin row dual from the INITIAL v: u_M' = log2 a_M - (z + LSE2_{j<=N} v_j)   (every workgroup, identically).  Inside the
+    //      loop the same quantity for the next iteration falls out of the new-v phase, where the new v are still in registers ----
+    float uM2;
+    {
         const float vN2 = vL[RS_NCOL];
-        const float dcol2 = zr2 + vN2;
-
-        RS_TP(0);
-        // ---- (1) dustbin row from the OLD v: u_M' = log2 a_M - (z + LSE2_{j<=N} v_j)   (every workgroup, identically) ----
         float mx = vN2;
         for (int j = tid; j < N; j += 512) mx = fmaxf(mx, vL[j]);
         mx = rs_wave_max(mx);
@@ -208,8 +202,19 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a) {
         float svt = red[8];
 #pragma unroll
         for (int w = 1; w < RS_NW; ++w) svt += red[8 + w];
-        const float uM2 = la_bin2 - (zr2 + mx + __builtin_amdgcn_logf(svt));
+        uM2 = la_bin2 - (zr2 + mx + __builtin_amdgcn_logf(svt));
+        __syncthreads();                                   // red[] is reused by the loop
+    }
+#pragma unroll 1
+    for (int it = 0; it < a.iters; ++it) {
+        const unsigned epoch = (unsigned)it + 1u;
+        rs_gu64* xg = (rs_gu64*)a.xg + (((int64_t)(it & 1) * B + b) * G) * RS_NG;      // this pair's granules of this parity
 
+        // (v is re-read from LDS chunk by chunk inside the rows: 16 more live registers would not fit beside the 176 of S)
+        const float vN2 = vL[RS_NCOL];
+        const float dcol2 = zr2 + vN2;
+
+        RS_TP(0);
         RS_TP(1);
         // ---- (2) row pass over my 16 rows: new u, column partials with the new u, dustbin-column partial ----
         f32x4 cs[4];
@@ -368,18 +373,41 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a) {
             }
         }
         RS_TP(6);
-        // ---- (6) new v for my columns (every workgroup of the pair computes the same bits) ----
+        // ---- (6) new v for my columns (every workgroup of the pair computes the same bits), and -- while they are in registers --
+        //      the dustbin-row dual of the NEXT iteration, u_M' = log2 a_M - (z + LSE2 of the new v): per-wave (max, sum) first,
+        //      one LDS round for each ----
+        float vnew[2] = {OG_NEG_INF, OG_NEG_INF};
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int j = tid + 512 * c;
             if (j < N) {
                 const float vo = vL[j];
-                vL[j] = vo + lb2 - __builtin_amdgcn_logf(colsum[c] + __builtin_amdgcn_exp2f(zr2 + vo + uM2));
+                vnew[c] = vo + lb2 - __builtin_amdgcn_logf(colsum[c] + __builtin_amdgcn_exp2f(zr2 + vo + uM2));
+                vL[j] = vnew[c];
             }
         }
-        if (tid == 0) vL[RS_NCOL] = vN2 + lb_bin2 - __builtin_amdgcn_logf(colsum[2] + __builtin_amdgcn_exp2f(zr2 + vN2 + uM2));
-        if (tid == 0) red[32] = uM2;
-        __syncthreads();
+        float vNn = OG_NEG_INF;
+        if (tid == 0) {
+            vNn = vN2 + lb_bin2 - __builtin_amdgcn_logf(colsum[2] + __builtin_amdgcn_exp2f(zr2 + vN2 + uM2));
+            vL[RS_NCOL] = vNn;
+            red[32] = uM2;
+        }
+        {
+            float mx = rs_wave_max(fmaxf(fmaxf(vnew[0], vnew[1]), vNn));
+            if (lane == 0) red[wave] = mx;
+            __syncthreads();
+            mx = red[0];
+#pragma unroll
+            for (int w = 1; w < RS_NW; ++w) mx = fmaxf(mx, red[w]);
+            float sv = __builtin_amdgcn_exp2f(vnew[0] - mx) + __builtin_amdgcn_exp2f(vnew[1] - mx) + __builtin_amdgcn_exp2f(vNn - mx);   // 2^-inf = 0
+            sv = rs_wave_sum(sv);
+            if (lane == 0) red[8 + wave] = sv;
+            __syncthreads();
+            float svt = red[8];
+#pragma unroll
+            for (int w = 1; w < RS_NW; ++w) svt += red[8 + w];
+            uM2 = la_bin2 - (zr2 + mx + __builtin_amdgcn_logf(svt));
+        }
         RS_TP(7);
         if (__syncthreads_or(failed)) break;               // a peer never arrived: leave together (status = 1)
         RS_TP(8);
