@@ -177,9 +177,10 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a) {
 #endif
     // the first two streamed rows of an iteration are fetched before the exchange of the previous one (nothing they need
     // depends on it), the other two while the LDS rows are processed
-    f32x4 xs0[4], xs1[4];
+    // ONE prefetch buffer: with two of them live over the register rows the allocator spilled part of a resident row, and every
+    // reload (s_waitcnt vmcnt(0)) also waited for the prefetches in flight -- thousands of cycles per iteration
+    f32x4 xs0[4];
     load_row(row0 + RS_RR + RS_LR, xs0);
-    load_row(row0 + RS_RR + RS_LR + 1, xs1);
     bool failed = false;
     // ---- dustbin row dual from the INITIAL v: u_M' = log2 a_M - (z + LSE2_{j<=N} v_j)   (every workgroup, identically).  Inside the
     //      loop the same quantity for the next iteration falls out of the new-v phase, where the new v are still in registers ----
@@ -257,14 +258,11 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);             // one row at a time
         };
-        // streamed rows 12, 13 (fetched under the previous exchange), then 14, 15 in flight under the register rows
-        mem_row(xs0, RS_RR + RS_LR);
-        mem_row(xs1, RS_RR + RS_LR + 1);
-        load_row(row0 + RS_RR + RS_LR + 2, xs0);
-        load_row(row0 + RS_RR + RS_LR + 3, xs1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int r = 0; r < RS_RR; ++r) {
+        // streamed rows 12..15 through the one buffer, each requested three resident rows (~3-4k cycles) before it is consumed:
+        //   row 12 (fetched under the previous exchange) | load 13 | reg 0-2 | row 13 | load 14 | reg 3-5 | row 14 | load 15 |
+        //   reg 6-7, LDS 0-1 | row 15 | load 12 of the next iteration | LDS 2-3
+        auto reg_row = [&](auto R) {
+            constexpr int r = decltype(R)::value;
             if (r < nvalid) {
                 const float u = ur[r];
                 f32x4 x[4];
@@ -284,22 +282,34 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a) {
                 finish_row(x, sum2[0] + sum2[1], r);
             }
             __builtin_amdgcn_sched_barrier(0);
-        }
-        RS_TP(2);
-        mem_row(xs0, RS_RR + RS_LR + 2);
-        mem_row(xs1, RS_RR + RS_LR + 3);
-        if (it + 1 < a.iters) {                            // next iteration's first two streamed rows: under the LDS rows and the exchange
-            load_row(row0 + RS_RR + RS_LR, xs0);
-            load_row(row0 + RS_RR + RS_LR + 1, xs1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < RS_LR; ++s) {
+        };
+        auto lds_row = [&](auto Sl) {
+            constexpr int sl = decltype(Sl)::value;
             f32x4 x[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) x[k] = *reinterpret_cast<const f32x4*>(Sw + s * RS_NCOL + 256 * k);
-            mem_row(x, RS_RR + s);
-        }
+            for (int k = 0; k < 4; ++k) x[k] = *reinterpret_cast<const f32x4*>(Sw + sl * RS_NCOL + 256 * k);
+            mem_row(x, RS_RR + sl);
+        };
+        static_assert(RS_RR == 8 && RS_LR == 4 && RS_SR == 4, "the row schedule below is written out for 8 + 4 + 4 rows");
+        using std::integral_constant;
+        mem_row(xs0, RS_RR + RS_LR);
+        load_row(row0 + RS_RR + RS_LR + 1, xs0);
+        __builtin_amdgcn_sched_barrier(0);
+        reg_row(integral_constant<int, 0>{}); reg_row(integral_constant<int, 1>{}); reg_row(integral_constant<int, 2>{});
+        mem_row(xs0, RS_RR + RS_LR + 1);
+        load_row(row0 + RS_RR + RS_LR + 2, xs0);
+        __builtin_amdgcn_sched_barrier(0);
+        reg_row(integral_constant<int, 3>{}); reg_row(integral_constant<int, 4>{}); reg_row(integral_constant<int, 5>{});
+        mem_row(xs0, RS_RR + RS_LR + 2);
+        load_row(row0 + RS_RR + RS_LR + 3, xs0);
+        __builtin_amdgcn_sched_barrier(0);
+        reg_row(integral_constant<int, 6>{}); reg_row(integral_constant<int, 7>{});
+        RS_TP(2);
+        lds_row(integral_constant<int, 0>{}); lds_row(integral_constant<int, 1>{});
+        mem_row(xs0, RS_RR + RS_LR + 3);
+        if (it + 1 < a.iters) load_row(row0 + RS_RR + RS_LR, xs0);      // next iteration's first streamed row: under the LDS rows and the exchange
+        __builtin_amdgcn_sched_barrier(0);
+        lds_row(integral_constant<int, 2>{}); lds_row(integral_constant<int, 3>{});
 
         RS_TP(3);
         // ---- (3) workgroup column partials: two rounds of four waves through LDS, fixed summation order ----
