@@ -226,14 +226,15 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a) {
         // LDS / memory are overwritten in place
         auto finish_row = [&](f32x4 (&p)[4], float sum, int s) {
             const float u = ur[s];
-            const float rowsum = rs_wave_sum(sum) + __builtin_amdgcn_exp2f(dcol2 + u);
+            const float pd = __builtin_amdgcn_exp2f(dcol2 + u);            // the row's dustbin-column entry with the old u
+            const float rowsum = rs_wave_sum(sum) + pd;
             const float un = u + la2 - __builtin_amdgcn_logf(rowsum);
             const float f = __builtin_amdgcn_exp2f(un - u);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) cs[k][e] = __builtin_fmaf(p[k][e], f, cs[k][e]);
-            usum += __builtin_amdgcn_exp2f(zr2 + vN2 + un);
+            usum += pd * f;                                                 // = 2^(z + v_N + u'), one transcendental less per row
             ur[s] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, un)));   // wave-uniform: an SGPR
         };
         auto mem_row = [&](f32x4 (&x)[4], int slot) {      // a row fetched from LDS / memory: its plan entries overwrite it
