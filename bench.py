@@ -99,11 +99,11 @@ def roofline_block(counts_per_step, stages, launches, num_iters, measured_on_thi
     sk_bytes = counts_per_step["sinkhorn_bytes_resident"] if resident else counts_per_step["sinkhorn_bytes"]
     per_step = {  # kernel class -> (algorithmic work per step, unit scale, bound, peak, unit, kernels)
         "gemm_f16x3": (counts_per_step["gemm_f16x3_flops"], 1e12, "mfma", PEAK_F16_MFMA_TFLOPS, "TFLOP/s",
-                       "gemm_nt_f16x3_big_kernel / gemm_nt_f16x3_kernel (GNN 1x1 convs, final projection, score matrix; split-f16 3-pass MFMA: executes 3x the algorithmic flops)"),
+                       "gemm_nt_f16x3_big2_kernel (256x256 tiles) / gemm_nt_f16x3_kernel (128-token tiles) / gemm_nt_f16x3_big_kernel (batched score matrix): GNN 1x1 convs, last encoder conv, final projection, score matrix; split-f16 3-pass MFMA: executes 3x the algorithmic flops"),
         "gemm_f32": (counts_per_step["gemm_f32_flops"], 1e12, "mfma", PEAK_F32_MFMA_TFLOPS, "TFLOP/s",
-                     "gemm_nt_f32_kernel (keypoint-encoder MLP; exact fp32 MFMA)"),
+                     "gemm_nt_f32_kernel (keypoint-encoder MLP without its last conv; exact fp32 MFMA)"),
         "attention": (counts_per_step["attention_flops"], 1e12, "mfma", PEAK_F16_MFMA_TFLOPS, "TFLOP/s",
-                      "attention_kernel (split-f16 flash attention: executes 3x the algorithmic flops)"),
+                      "attention64_kernel (dh = 64: K/V tiles by LDS-DMA) / attention_kernel (dh = 16, 32): split-f16 flash attention, executes 3x the algorithmic flops"),
         "sinkhorn": (sk_bytes, 1e9, "hbm", PEAK_HBM_GBS, "GB/s",
                      ("sinkhorn_resident_kernel (+ first iteration sweep/combine, sinkhorn_scores), one stage bracket: the score matrices "
                       "stay in registers + LDS; algorithmic bytes = what THIS schedule must move (S twice, the non-resident quarter of the "
