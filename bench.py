@@ -103,7 +103,7 @@ def roofline_block(counts_per_step, stages, launches, num_iters, measured_on_thi
         "gemm_f32": (counts_per_step["gemm_f32_flops"], 1e12, "mfma", PEAK_F32_MFMA_TFLOPS, "TFLOP/s",
                      "gemm_nt_f32_kernel (keypoint-encoder MLP without its last conv; exact fp32 MFMA)"),
         "attention": (counts_per_step["attention_flops"], 1e12, "mfma", PEAK_F16_MFMA_TFLOPS, "TFLOP/s",
-                      "attention64_kernel (dh = 64: K/V tiles by LDS-DMA) / attention_kernel (dh = 16, 32): split-f16 flash attention, executes 3x the algorithmic flops"),
+                      "attention_dma_kernel (dh = 64, 32: K/V tiles by LDS-DMA) / attention_kernel (dh = 16): split-f16 flash attention, executes 3x the algorithmic flops"),
         "sinkhorn": (sk_bytes, 1e9, "hbm", PEAK_HBM_GBS, "GB/s",
                      ("sinkhorn_resident_kernel (+ first iteration sweep/combine, sinkhorn_scores), one stage bracket: the score matrices "
                       "stay in registers + LDS; algorithmic bytes = what THIS schedule must move (S twice, the non-resident quarter of the "

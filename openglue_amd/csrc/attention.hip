@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a, RD rd) {
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// dh = 64 (the configuration of BASELINE configs 1-3, 5): a head row of K or V is exactly one 128-byte line, so the
+// dh = 64 (BASELINE configs 1-3, 5) and dh = 32 (config 4): a head row of K or V is exactly one 128-byte line (or half of one), so the
 // tiles travel global -> LDS by LDS-DMA (global_load_lds, 16 B per lane, 8 rows x 128 B per wave instruction) with no
 // staging registers, no ds_write and no second barrier.  LDS rows are unpadded; bank conflicts are removed by an XOR
 // of the 16-byte chunk index applied on the SOURCE address of the DMA (the LDS side of a DMA is always contiguous)
@@ -442,10 +442,15 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a, RD rd) {
 // Measured alternative (git history): one 8-wave workgroup whose two halves alternate matrix and softmax
 // phases between barriers, sharing the K/V ring -- 30 % slower: on this part the MFMA and VALU issue of the two waves of a
 // SIMD add up (tile period ~ 2 x (1536 MFMA + ~1200 VALU cycles)) whatever the phase alignment.
-template <class RD>
-__global__ __launch_bounds__(256, 2) void attention64_kernel(AttnArgs a, RD rd) {
-    constexpr int DH = 64, NDV = 2, NCH = 4;
-    constexpr int PLANE = KV_TILE * 128;            // bytes: 64 keys x one 128-byte head row
+template <int DH, class RD>
+__global__ __launch_bounds__(256, 2) void attention_dma_kernel(AttnArgs a, RD rd) {      // (dh = 32 would fit three workgroups per CU: measured 4 % slower)
+    static_assert(DH == 64 || DH == 32, "head rows of 128 or 64 bytes");
+    constexpr int NDV = DH / 32, NCH = DH / 16;
+    constexpr int ROWB = DH * 2;                    // bytes of a head row of one plane: a full 128-byte line (dh = 64) or half of one
+    constexpr int RPI = 1024 / ROWB;                // rows per DMA instruction (8 or 16), LPR lanes per row
+    constexpr int LPR = ROWB / 16;
+    constexpr int NPI = 16 / RPI;                   // DMA pieces per wave and plane: the wave fills rows [16w, 16w + 16)
+    constexpr int PLANE = KV_TILE * ROWB;           // bytes: 64 keys x one head row
     constexpr int BUFB = 4 * PLANE;                 // Kh | Kl | Vh | Vl
     __shared__ __attribute__((aligned(1024))) char smem[2 * BUFB];
 
@@ -476,13 +481,18 @@ __global__ __launch_bounds__(256, 2) void attention64_kernel(AttnArgs a, RD rd) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
 
-    // ---- DMA pieces: wave w fills rows [16w, 16w+16) of each of the four planes, two 8-row pieces each ----
-    const int rl = lane >> 3, pc = lane & 7;
+    // ---- DMA pieces: wave w fills rows [16w, 16w+16) of each of the four planes, NPI pieces of RPI rows each.  Chunk swizzles
+    //      (on the LDS row r): dh = 64: K chunk ^ ((r >> 1) & 7), V chunk ^ (((r >> 1) & 1) << 2); dh = 32 (64-byte rows, four
+    //      chunks): K chunk ^ ((r >> 2) & 3), V none (a [4 keys][32 dv] transposing pass already covers all banks) ----
+    const int rl = lane / LPR, pc = lane % LPR;
     const int ldkb = (int)a.ldk * 2, ldvb = (int)a.ldv * 2;          // row strides in bytes
     unsigned ksw[2], vsw;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) ksw[i] = (unsigned)(pc ^ ((lane >> 4) | (i << 2))) * 16u;
-    vsw = (unsigned)(pc ^ (((lane >> 4) & 1) << 2)) * 16u;
+    for (int i = 0; i < 2; ++i) {
+        const int r = i * RPI + rl;                                   // + 16 w: a multiple of 16, invisible to either swizzle
+        ksw[i] = (unsigned)(pc ^ (DH == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3))) * 16u;
+    }
+    vsw = (unsigned)(pc ^ (DH == 64 ? (((rl >> 1) & 1) << 2) : 0)) * 16u;
     const int64_t k_tile0 = (kv_row0 * a.ldk + h * DH) * 2, v_tile0 = (kv_row0 * a.ldv + h * DH) * 2;   // bytes, uniform
     // one tile = 8 DMA instructions per wave, issued in pairs (plane pair pp: 0 = K hi/lo, 1 = V hi/lo of piece i) so that
     // the main loop can spread them under its MFMA bursts: the vector-memory path takes 64 B/clk per CU, a burst of 8 per
@@ -491,9 +501,9 @@ __global__ __launch_bounds__(256, 2) void attention64_kernel(AttnArgs a, RD rd) 
         constexpr int b = decltype(BUF)::value, i = decltype(I)::value, pp = decltype(PP)::value;
         const int key0 = kt * KV_TILE;
         const int last = nk - 1 - key0;                  // rows past the last key are clamped (masked in the softmax)
-        int r = wave * 16 + i * 8 + rl;
+        int r = wave * 16 + i * RPI + rl;
         r = r < last ? r : last;
-        char* dst = smem + b * BUFB + (wave * 16 + i * 8) * 128 + pp * 2 * PLANE;
+        char* dst = smem + b * BUFB + (wave * 16 + i * RPI) * ROWB + pp * 2 * PLANE;
         if constexpr (pp == 0) {
             const int64_t o = k_tile0 + (int64_t)key0 * ldkb + (unsigned)(r * ldkb) + ksw[i];
             __builtin_amdgcn_global_load_lds((og_glb_void*)(reinterpret_cast<const char*>(a.kh) + o), (og_lds_void*)(dst), 16, 0, 0);
@@ -505,7 +515,7 @@ __global__ __launch_bounds__(256, 2) void attention64_kernel(AttnArgs a, RD rd) 
         }
     };
     auto issue_tile = [&](int kt, auto BUF) {
-        static_for<4>([&](auto J) {
+        static_for<2 * NPI>([&](auto J) {
             constexpr int j = decltype(J)::value;
             issue_pair(kt, BUF, std::integral_constant<int, (j >> 1)>{}, std::integral_constant<int, (j & 1)>{});
         });
@@ -538,11 +548,11 @@ __global__ __launch_bounds__(256, 2) void attention64_kernel(AttnArgs a, RD rd) 
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     unsigned kf[NCH], va[NDV];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) kf[c] = lds0 + l31 * 128 + (((2 * c + hi) ^ ((l31 >> 1) & 7)) * 16);
+    for (int c = 0; c < NCH; ++c) kf[c] = lds0 + l31 * ROWB + (((2 * c + hi) ^ (DH == 64 ? ((l31 >> 1) & 7) : ((l31 >> 2) & 3))) * 16);
     {
-        const int vrow = (4 * hi + ((lane & 15) >> 2)) * 128 + 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
+        const int vrow = (4 * hi + ((lane & 15) >> 2)) * ROWB + 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
 #pragma unroll
-        for (int d = 0; d < NDV; ++d) va[d] = lds0 + vrow + 64 * (d ^ ((lane >> 3) & 1));
+        for (int d = 0; d < NDV; ++d) va[d] = lds0 + vrow + (DH == 64 ? 64 * (d ^ ((lane >> 3) & 1)) : 0);
     }
     // fragment registers, double-buffered by hand: K [buf][key block], V [buf][dv block] as two transposed halves
     f16x8 kh[2][2], kl[2][2];
@@ -569,15 +579,15 @@ __global__ __launch_bounds__(256, 2) void attention64_kernel(AttnArgs a, RD rd) 
         // lds_read_patterns.hip); as a burst in front of the group's MFMAs they delay the matrix pipe by their whole issue time.
         auto read_k1 = [&](auto C, auto J) {             // piece j of chunk c: key block j >> 1, plane j & 1 -> buffer c & 1
             constexpr int c = decltype(C)::value, j = decltype(J)::value, kb = j >> 1;
-            if constexpr ((j & 1) == 0) lds_read_b128<b * BUFB + kb * 32 * 128>(kh[c & 1][kb], kf[c]);
-            else lds_read_b128<b * BUFB + PLANE + kb * 32 * 128>(kl[c & 1][kb], kf[c]);
+            if constexpr ((j & 1) == 0) lds_read_b128<b * BUFB + kb * 32 * ROWB>(kh[c & 1][kb], kf[c]);
+            else lds_read_b128<b * BUFB + PLANE + kb * 32 * ROWB>(kl[c & 1][kb], kf[c]);
         };
         auto read_v1 = [&](auto G, auto J) {             // piece j of group g = 2kb + t: dv block j >> 2, (plane, half) j & 3
-            constexpr int g = decltype(G)::value, j = decltype(J)::value, d = j >> 2, off = b * BUFB + 2 * PLANE + g * 16 * 128;
+            constexpr int g = decltype(G)::value, j = decltype(J)::value, d = j >> 2, off = b * BUFB + 2 * PLANE + g * 16 * ROWB;
             if constexpr ((j & 3) == 0) lds_read_tr16_b64<off>(vh0[g & 1][d], va[d]);
-            else if constexpr ((j & 3) == 1) lds_read_tr16_b64<off + 8 * 128>(vh1[g & 1][d], va[d]);
+            else if constexpr ((j & 3) == 1) lds_read_tr16_b64<off + 8 * ROWB>(vh1[g & 1][d], va[d]);
             else if constexpr ((j & 3) == 2) lds_read_tr16_b64<off + PLANE>(vl0[g & 1][d], va[d]);
-            else lds_read_tr16_b64<off + PLANE + 8 * 128>(vl1[g & 1][d], va[d]);
+            else lds_read_tr16_b64<off + PLANE + 8 * ROWB>(vl1[g & 1][d], va[d]);
         };
         auto fence = [] { __builtin_amdgcn_sched_barrier(0); };
 
@@ -602,18 +612,18 @@ __global__ __launch_bounds__(256, 2) void attention64_kernel(AttnArgs a, RD rd) 
                     if constexpr (m < 4) {
                         if constexpr (c + 1 < NCH) {
                             read_k1(std::integral_constant<int, c + 1>{}, std::integral_constant<int, m>{});
-                        } else {                         // last chunk: the first V fragments, they fly under the softmax
+                        } else if constexpr (2 * m < 4 * NDV) {          // last chunk: the first V fragments, they fly under the softmax
                             read_v1(std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * m>{});
                             read_v1(std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * m + 1>{});
                         }
                         fence();
                     }
                     // the DMA of tile t+1 in the shadow of the matrix pipe (its buffer was last read before the barrier), STAGGERED:
-                    // wave w issues its eight instructions during chunk w.  The vector-memory path serves ~18 cycles per 1 KB
+                    // wave w issues its instructions (eight at dh = 64) during chunk w % NCH.  The vector-memory path serves ~18 cycles per 1 KB
                     // instruction per CU; when all waves of the workgroup issue at the same point each instruction queues behind
                     // the others' (~125 cycles each in the trace), one wave at a time pays only its own service time.
                     if constexpr (m == 4) {
-                        if (more && wave == c) issue_tile(kt + 1, std::integral_constant<int, b ^ 1>{});
+                        if (more && wave % NCH == c) issue_tile(kt + 1, std::integral_constant<int, b ^ 1>{});
                         fence();
                     }
                 });
@@ -686,8 +696,11 @@ __global__ __launch_bounds__(256, 2) void attention64_kernel(AttnArgs a, RD rd) 
         static_for<4>([&](auto G) {
             constexpr int g = decltype(G)::value;
             constexpr int gb = g & 1, kb = g >> 1, t = g & 1;
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vh0[gb][0]), "+v"(vh1[gb][0]), "+v"(vl0[gb][0]), "+v"(vl1[gb][0]),
-                         "+v"(vh0[gb][1]), "+v"(vh1[gb][1]), "+v"(vl0[gb][1]), "+v"(vl1[gb][1]) :: "memory");
+            if constexpr (NDV == 2)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vh0[gb][0]), "+v"(vh1[gb][0]), "+v"(vl0[gb][0]), "+v"(vl1[gb][0]),
+                             "+v"(vh0[gb][NDV - 1]), "+v"(vh1[gb][NDV - 1]), "+v"(vl0[gb][NDV - 1]), "+v"(vl1[gb][NDV - 1]) :: "memory");
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vh0[gb][0]), "+v"(vh1[gb][0]), "+v"(vl0[gb][0]), "+v"(vl1[gb][0]) :: "memory");
             fence();
             f16x8 vh[NDV], vl[NDV];
 #pragma unroll
@@ -695,13 +708,13 @@ __global__ __launch_bounds__(256, 2) void attention64_kernel(AttnArgs a, RD rd) 
                 vh[d] = __builtin_bit_cast(f16x8, __builtin_shufflevector(vh0[gb][d], vh1[gb][d], 0, 1, 2, 3, 4, 5, 6, 7));
                 vl[d] = __builtin_bit_cast(f16x8, __builtin_shufflevector(vl0[gb][d], vl1[gb][d], 0, 1, 2, 3, 4, 5, 6, 7));
             }
-            static_for<6>([&](auto M) {
-                constexpr int m = decltype(M)::value, d = m & 1, pass = m >> 1;
+            static_for<3 * NDV>([&](auto M) {
+                constexpr int m = decltype(M)::value, d = m % NDV, pass = m / NDV;
                 if constexpr (pass == 0) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[d], pf[kb][t], oacc[d], 0, 0, 0);
                 else if constexpr (pass == 1) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[d], pl[kb][t], oacc[d], 0, 0, 0);
                 else oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[d], pf[kb][t], oacc[d], 0, 0, 0);
                 fence();
-                if constexpr (m < 4 && g + 1 < 4) {
+                if constexpr (2 * m < 4 * NDV && g + 1 < 4) {                  // the next group's 4 NDV reads, two behind each MFMA
                     read_v1(std::integral_constant<int, g + 1>{}, std::integral_constant<int, 2 * m>{});
                     read_v1(std::integral_constant<int, g + 1>{}, std::integral_constant<int, 2 * m + 1>{});
                     fence();
@@ -779,15 +792,18 @@ int og_launch_attention(const AttnArgs& a, hipStream_t stream) {
     a2.rag = nullptr;
     // dh = 64 with full-line head rows: the LDS-DMA kernel (OG_ATTN_DMA=0 keeps the register-staged one, for A/B runs)
     static const bool dma_on = [] { const char* e = getenv("OG_ATTN_DMA"); return !(e && e[0] == '0'); }();
-    const bool dma64 = dma_on && a.dh == 64;
+    const bool dma = dma_on && (a.dh == 64 || a.dh == 32);       // head rows of one or half a 128-byte line: the LDS-DMA kernel
     const int groups8 = (a.nz * a.num_heads + 7) / 8 * 8;
     dim3 grid(groups8 * a2.qtiles), block(256);
     if (a.rag) {
         switch (a.dh) {
             case 16: hipLaunchKernelGGL((attention_kernel<16, RaggedDesc>), grid, block, 0, stream, a2, rd); break;
-            case 32: hipLaunchKernelGGL((attention_kernel<32, RaggedDesc>), grid, block, 0, stream, a2, rd); break;
+            case 32:
+                if (dma) hipLaunchKernelGGL((attention_dma_kernel<32, RaggedDesc>), grid, block, 0, stream, a2, rd);
+                else hipLaunchKernelGGL((attention_kernel<32, RaggedDesc>), grid, block, 0, stream, a2, rd);
+                break;
             case 64:
-                if (dma64) hipLaunchKernelGGL((attention64_kernel<RaggedDesc>), grid, block, 0, stream, a2, rd);
+                if (dma) hipLaunchKernelGGL((attention_dma_kernel<64, RaggedDesc>), grid, block, 0, stream, a2, rd);
                 else hipLaunchKernelGGL((attention_kernel<64, RaggedDesc>), grid, block, 0, stream, a2, rd);
                 break;
             default: return OG_E_SHAPE;
@@ -795,9 +811,12 @@ int og_launch_attention(const AttnArgs& a, hipStream_t stream) {
     } else {          // uniform batch: no descriptor in the kernarg segment (og_common.h: RaggedNone)
         switch (a.dh) {
             case 16: hipLaunchKernelGGL((attention_kernel<16, RaggedNone>), grid, block, 0, stream, a2, RaggedNone{}); break;
-            case 32: hipLaunchKernelGGL((attention_kernel<32, RaggedNone>), grid, block, 0, stream, a2, RaggedNone{}); break;
+            case 32:
+                if (dma) hipLaunchKernelGGL((attention_dma_kernel<32, RaggedNone>), grid, block, 0, stream, a2, RaggedNone{});
+                else hipLaunchKernelGGL((attention_kernel<32, RaggedNone>), grid, block, 0, stream, a2, RaggedNone{});
+                break;
             case 64:
-                if (dma64) hipLaunchKernelGGL((attention64_kernel<RaggedNone>), grid, block, 0, stream, a2, RaggedNone{});
+                if (dma) hipLaunchKernelGGL((attention_dma_kernel<64, RaggedNone>), grid, block, 0, stream, a2, RaggedNone{});
                 else hipLaunchKernelGGL((attention_kernel<64, RaggedNone>), grid, block, 0, stream, a2, RaggedNone{});
                 break;
             default: return OG_E_SHAPE;
