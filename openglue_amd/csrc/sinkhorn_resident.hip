@@ -350,37 +350,43 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a) {
         // ---- (5) sweep the granules of all G workgroups of the pair (mine included: same code path, same rounding) ----
         float colsum[3] = {0.f, 0.f, 0.f};
         {
-            // all loads first (independent: G x 3 round trips in flight instead of one after the other), then re-read only
-            // what had not arrived; summation in the fixed order gg = 0 .. G-1
-            const int idx[3] = {tid, tid + 512, N};
-            const bool own[3] = {tid < N, tid + 512 < N, tid == 0};
-            constexpr int GMAX = 8;
-            for (int g0 = 0; g0 < G; g0 += GMAX) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    rs_u64 x[GMAX];
-#pragma unroll
-                    for (int q = 0; q < GMAX; ++q)
-                        if (own[c] && g0 + q < G)
-                            x[q] = __hip_atomic_load(xg + (int64_t)(g0 + q) * RS_NG + idx[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                    for (int q = 0; q < GMAX; ++q) {
-                        if (!(own[c] && g0 + q < G)) continue;
-                        rs_gu64* p = xg + (int64_t)(g0 + q) * RS_NG + idx[c];
-                        rs_u64 v = x[q];
-                        unsigned spins = 0;
-                        while ((unsigned)(v >> 32) != epoch) {
-                            if (++spins > RS_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-                                failed = true;
-                                __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                break;
-                            }
-                            __builtin_amdgcn_s_sleep(1);
-                            v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                        colsum[c] += __builtin_bit_cast(float, (unsigned)v);
+            // Two batches of loads per thread (one per column it owns, G granules each, all in flight together), then re-read only
+            // what had not arrived; the dustbin-column term rides in the second batch, one granule per thread 0..G-1 (as a third
+            // batch of thread 0 it cost every wave of the workgroup a third memory round trip at the next barrier).  Holding both
+            // columns in one batch needs 16 more registers and makes the allocator spill a resident row.  Fixed order gg = 0..G-1.
+            constexpr int GMAX = 8;                            // G <= 8: m <= 1024 rows per pair on chip
+            const bool own[2] = {tid < N, tid + 512 < N};
+            const bool ownd = tid < G;
+            auto arrived = [&](rs_gu64* p, rs_u64 v) -> float {             // spin (bounded) until the granule carries this epoch
+                unsigned spins = 0;
+                while ((unsigned)(v >> 32) != epoch) {
+                    if (++spins > RS_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                        failed = true;
+                        __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
                     }
+                    __builtin_amdgcn_s_sleep(1);
+                    v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+                return __builtin_bit_cast(float, (unsigned)v);
+            };
+            float dval = 0.f;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                rs_u64 x[GMAX], xd = 0;
+#pragma unroll
+                for (int q = 0; q < GMAX; ++q)
+                    if (own[c] && q < G) x[q] = __hip_atomic_load(xg + (int64_t)q * RS_NG + tid + 512 * c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (c == 1 && ownd) xd = __hip_atomic_load(xg + (int64_t)tid * RS_NG + N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int q = 0; q < GMAX; ++q)
+                    if (own[c] && q < G) colsum[c] += arrived(xg + (int64_t)q * RS_NG + tid + 512 * c, x[q]);
+                if (c == 1 && ownd) dval = arrived(xg + (int64_t)tid * RS_NG + N, xd);
+            }
+            if (wave == 0) {                                   // lanes 0..G-1 of wave 0 hold the G dustbin terms: ordered sum for thread 0
+#pragma unroll
+                for (int q = 0; q < GMAX; ++q)
+                    if (q < G) colsum[2] += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dval), q));
             }
         }
         RS_TP(6);
