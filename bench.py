@@ -423,6 +423,7 @@ def main():
         return out
 
     dt, out = _timed_steps(step, args, dist_on, dev)
+    model.check_status()          # outside the timed region: the resident Sinkhorn kernel of the last step completed (no time-out)
 
     if rank == 0:
         c1 = algorithmic_counts(kw, m, n)

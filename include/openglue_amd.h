@@ -242,6 +242,10 @@ int og_sinkhorn(const float* S, int64_t lds, float dustbin, int32_t batch, int32
  * When the batch fits (batch * ceil(m/128) <= #CUs, n <= 1024, >= 16 MB of scores; OG_SINKHORN_RESIDENT=0 disables, =2 drops
  * the size threshold) iterations 2..iters run in ONE launch with the score matrices held in registers + LDS. */
 int og_sinkhorn_status(const void* sinkhorn_workspace_dev, int32_t batch, int32_t m, int32_t n);
+/* The same check for the workspace of an og_forward / og_forward_ragged call with this shape (for ragged calls: the shape
+ * that was passed, i.e. the maxima).  SYNCHRONISES the device.  0 = the last call's optimal-transport stage completed,
+ * 1 = its resident kernel timed out waiting for a peer workgroup (scores invalid), -1 = bad arguments. */
+int og_forward_status(const og_shape* shape, const void* workspace_dev);
 
 /* ---- training slice of the optimal-transport layer (reference: autograd through superglue.py:88-111 +
  * optimal_transport.py:20-28, consumed by the NLL of utils/losses.py:7-53) ----

@@ -162,6 +162,15 @@ extern "C" int og_packed_layout(const og_shape* shape, og_packed_layout_t* o) {
     return 0;
 }
 
+extern "C" int og_sinkhorn_status(const void* workspace_dev, int32_t batch, int32_t m, int32_t n);      // sinkhorn.hip
+
+// include/openglue_amd.h
+extern "C" int og_forward_status(const og_shape* shape, const void* workspace_dev) {
+    if (!workspace_dev || check_shape(shape)) return -1;
+    const WorkspaceLayout W = workspace_layout(*shape);
+    return og_sinkhorn_status((const float*)workspace_dev + W.sink, shape->batch, shape->m, shape->n);
+}
+
 extern "C" size_t og_workspace_bytes(const og_shape* shape) {
     if (check_shape(shape)) return 0;
     return (size_t)workspace_layout(*shape).total * sizeof(float);

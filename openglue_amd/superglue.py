@@ -159,6 +159,18 @@ class SuperGlue(nn.Module):
         # in-place updates (optimizer steps, copy_) bump _version; moves re-create the tensors (_apply above)
         return (str(device), ts[0].data_ptr()) + tuple(t._version for t in ts)
 
+    def check_status(self) -> None:
+        """Synchronise and verify that the optimal-transport stage of the LAST forward / match call completed: its on-chip-resident
+        kernel (large co-resident batches) waits for peer workgroups with bounded spins and flags a time-out instead of hanging
+        (og_forward_status).  Raises RuntimeError on a time-out; a no-op before the first call."""
+        last = getattr(self, "_last_call", None)
+        if last is None:
+            return
+        shape, ws = last
+        rc = _lib.load().og_forward_status(C.byref(shape), ws.data_ptr())
+        if rc != 0:
+            raise RuntimeError(f"og_forward_status = {rc}: the last call's Sinkhorn stage did not complete (scores invalid)")
+
     def _get_workspace(self, dev, key, nbytes: int) -> torch.Tensor:
         """One live workspace (shapes rarely change between calls); re-used while it is large enough."""
         wkey = (str(dev),) + tuple(key)
@@ -255,6 +267,7 @@ class SuperGlue(nn.Module):
         with torch.cuda.device(dev):
             packed = self._pack(dev)
             ws = self._get_workspace(dev, (B, m, n), lib.og_workspace_bytes(C.byref(shape)))
+            self._last_call = (shape, ws)
             out = {
                 "context_descriptors0": torch.empty(B, D, m, device=dev, dtype=torch.float32),
                 "context_descriptors1": torch.empty(B, D, n, device=dev, dtype=torch.float32),
@@ -356,6 +369,7 @@ class SuperGlue(nn.Module):
             with torch.cuda.device(dev):
                 pk = self._pack(dev)
                 ws = self._get_workspace(dev, ("ragged", B, max(l0), max(l1)), lib.og_workspace_bytes(C.byref(shape)))
+                self._last_call = None            # ragged calls always take the streaming Sinkhorn schedule: nothing to check
                 scores = torch.empty(n_scores, device=dev, dtype=torch.float32)
                 m0 = torch.empty(T0, device=dev, dtype=torch.int64)
                 s0 = torch.empty(T0, device=dev, dtype=torch.float32)

@@ -308,6 +308,7 @@ def test_full_size_c2_batch_properties(gpu_device):
     B, m, n = 32, 1024, 1024
     data = syn.make_batch(B, m, n, 256, 1, seed=11)
     out = model.match(to_device(data, gpu_device), MATCH_THRESHOLD)
+    model.check_status()                 # B=32 x 1024 x 1024 takes the on-chip-resident Sinkhorn schedule: no peer time-out
     s = out["scores"]
     assert torch.isfinite(s).all()
     norm = -math.log(m + n)
