@@ -521,15 +521,18 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
     // ---- 5. Sinkhorn with dustbins -> scores (superglue.py:88-111) ----
     {
         Scope sc(prof, OG_STAGE_SINKHORN);
+        // with matches requested, the scores kernel also leaves every row's max / argmax in the extraction's workspace
+        RowBest rb{nullptr, nullptr, 0};
+        if (outp->matches0) rb = og_matches_row_best(ws + W.match, B, m, n);
         if ((rc = og_launch_sinkhorn(Sb, W.lds, pk + L.dustbin, 0.f, B, m, n, s.sinkhorn_iters, s.sinkhorn_reg, outp->scores,
-                                     ws + W.sink, st, rag))) return rc;
+                                     ws + W.sink, st, rag, outp->matches0 ? &rb : nullptr))) return rc;
     }
 
     // ---- 6. mutual-NN matches (matching_module.py:174-187) ----
     if (outp->matches0) {
         Scope sc(prof, OG_STAGE_MATCHES);
         if ((rc = og_launch_matches(outp->scores, B, m, n, s.match_threshold, outp->matches0, outp->matching_scores0,
-                                    outp->matches1, outp->matching_scores1, ws + W.match, st, rag))) return rc;
+                                    outp->matches1, outp->matching_scores1, ws + W.match, st, rag, true))) return rc;
     }
     return 0;
 }

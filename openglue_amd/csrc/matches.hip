@@ -156,14 +156,14 @@ extern "C" size_t og_matches_workspace_bytes(int32_t batch, int32_t m, int32_t n
 namespace {
 template <class RD>
 int matches_run(const float* scores, int B, int m, int n, float thr, int64_t* matches0, float* ms0,
-                int64_t* matches1, float* ms1, void* workspace, hipStream_t st, const RD& rd) {
+                int64_t* matches1, float* ms1, void* workspace, hipStream_t st, const RD& rd, bool rows_done) {
     if (!scores || !matches0 || !ms0 || !workspace || B <= 0 || m <= 0 || n <= 0) return OG_E_INVALID;
     if ((matches1 == nullptr) != (ms1 == nullptr)) return OG_E_INVALID;
     if ((uintptr_t)workspace & 15) return OG_E_ALIGN;
     const MatchWs w = mw_layout(workspace, B, m, n);
     hipError_t e = hipMemsetAsync(w.colbest, 0, sizeof(unsigned long long) * (size_t)B * n, st);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(row_argmax_kernel<RD>, dim3((m + 3) / 4, B), dim3(256), 0, st, scores, m, n, w.idx0, w.max0, rd);
+    if (!rows_done) hipLaunchKernelGGL(row_argmax_kernel<RD>, dim3((m + 3) / 4, B), dim3(256), 0, st, scores, m, n, w.idx0, w.max0, rd);
     hipLaunchKernelGGL(col_argmax_kernel<RD>, dim3((n + 255) / 256, (m + 63) / 64, B), dim3(256), 0, st, scores, m, n, w.colbest, rd);
     const int mx = m > n ? m : n;
     hipLaunchKernelGGL(mutual_kernel<RD>, dim3((mx + 255) / 256, B), dim3(256), 0, st, m, n, thr, w.idx0, w.max0, w.colbest,
@@ -173,12 +173,17 @@ int matches_run(const float* scores, int B, int m, int n, float thr, int64_t* ma
 }  // namespace
 
 int og_launch_matches(const float* scores, int B, int m, int n, float thr, int64_t* matches0, float* ms0,
-                      int64_t* matches1, float* ms1, void* workspace, hipStream_t st, const RaggedDesc* rag) {
+                      int64_t* matches1, float* ms1, void* workspace, hipStream_t st, const RaggedDesc* rag, bool rows_done) {
     if (rag) {
         if (rag->B != B) return OG_E_INVALID;
-        return matches_run<RaggedDesc>(scores, B, m, n, thr, matches0, ms0, matches1, ms1, workspace, st, *rag);
+        return matches_run<RaggedDesc>(scores, B, m, n, thr, matches0, ms0, matches1, ms1, workspace, st, *rag, rows_done);
     }
-    return matches_run<RaggedNone>(scores, B, m, n, thr, matches0, ms0, matches1, ms1, workspace, st, RaggedNone{});
+    return matches_run<RaggedNone>(scores, B, m, n, thr, matches0, ms0, matches1, ms1, workspace, st, RaggedNone{}, rows_done);
+}
+
+RowBest og_matches_row_best(void* matches_workspace, int B, int m, int n) {
+    const MatchWs w = mw_layout(matches_workspace, B, m, n);
+    return RowBest{w.idx0, w.max0, m};
 }
 
 extern "C" int og_extract_matches(const float* scores, int32_t batch, int32_t m, int32_t n, float match_threshold,
@@ -186,7 +191,7 @@ extern "C" int og_extract_matches(const float* scores, int32_t batch, int32_t m,
                                   float* matching_scores1, void* workspace_dev, void* stream) {
     og_clear_status();
     return og_launch_matches(scores, batch, m, n, match_threshold, matches0, matching_scores0, matches1,
-                             matching_scores1, workspace_dev, (hipStream_t)stream, nullptr);
+                             matching_scores1, workspace_dev, (hipStream_t)stream, nullptr, false);
 }
 
 int og_launch_encoder_input(const float* kpts, const float* side, int64_t tokens, int s, float wx, float wy,

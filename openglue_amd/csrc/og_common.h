@@ -167,8 +167,12 @@ int og_launch_attention(const AttnArgs& a, hipStream_t stream);
 int og_launch_linear_attention(const AttnArgs& a, hipStream_t stream);   // attention = 'linear' (elu+1 feature map)
 
 // m, n are the (maximum) sizes; with `rag` pair b uses m_b, n_b, S stays at stride m*lds per pair, scores are packed
+// row_best (optional): the kernel that writes the scores also leaves max / argmax_j<n of every row i<m there (the first half of the
+// mutual-NN extraction, matches.hip), so that the extraction need not read the rows again
+struct RowBest { int* idx; float* val; int stride; };      // [batch][stride]
 int og_launch_sinkhorn(const float* S, int64_t lds, const float* dustbin_dev /*or null*/, float dustbin_host, int batch, int m, int n, int iters,
-                       float reg, float* scores, void* workspace, hipStream_t stream, const RaggedDesc* rag = nullptr);
+                       float reg, float* scores, void* workspace, hipStream_t stream, const RaggedDesc* rag = nullptr,
+                       const RowBest* row_best = nullptr);
 // sinkhorn_resident.hip: the dual-stabilised iterations with the score matrices resident in registers + LDS (one launch)
 bool og_sinkhorn_resident_shape_ok(int B, int m, int n);
 size_t og_sinkhorn_resident_ws_bytes(int B, int m, int n);            // exchange granules + status word (0: shape never resident)
@@ -178,7 +182,8 @@ int og_launch_sinkhorn_resident(const float* S, int64_t lds, const float* zdev, 
                                 float* v_out, int ldv, void* xws, hipStream_t st);
 int og_launch_matches(const float* scores, int batch, int m, int n, float thr, int64_t* matches0,
                       float* ms0, int64_t* matches1, float* ms1, void* workspace, hipStream_t stream,
-                      const RaggedDesc* rag = nullptr);
+                      const RaggedDesc* rag = nullptr, bool rows_done = false);      // rows_done: og_matches_row_best() was filled already
+RowBest og_matches_row_best(void* matches_workspace, int batch, int m, int n);
 // per-pair image sizes of a ragged batch (keypoint normalisation, superglue.py:74-78): pair b owns tokens off[b] .. off[b+1]
 struct EncoderRagged {
     int B;                              // 0: uniform batch, one image size for every token

@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256) void sinkhorn_scores_kernel(const float* __res
                                                               float inv_reg, float norm,
                                                               const float* __restrict__ u, int ldu,
                                                               const float* __restrict__ v, int ldv,
-                                                              float* __restrict__ scores, int64_t strideS, RD rd) {
+                                                              float* __restrict__ scores, int64_t strideS, RD rd, RowBest rb) {
     const int b = blockIdx.y;
     int64_t so = (int64_t)b * (M + 1) * (N + 1);
     if (rd.B > 0) {
@@ -602,7 +602,24 @@ __global__ __launch_bounds__(256) void sinkhorn_scores_kernel(const float* __res
     float* out = scores + so + (int64_t)row * (N + 1);
     if (row < M) {
         const float* sp = S + (int64_t)row * lds;
-        for (int j = lane; j < N; j += 64) out[j] = ((sp[j] * inv_reg + ui) + vb[j]) - norm;
+        if (rb.idx) {        // + row max / argmax over j < N on the values just written ("first maximal index wins", matches.hip)
+            float best = OG_NEG_INF;
+            int bi = 0x7FFFFFFF;
+            for (int j = lane; j < N; j += 64) {
+                const float val = ((sp[j] * inv_reg + ui) + vb[j]) - norm;
+                out[j] = val;
+                if (val > best || bi == 0x7FFFFFFF) { best = val; bi = j; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(best, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+            }
+            if (lane == 0) { rb.idx[(int64_t)b * rb.stride + row] = bi; rb.val[(int64_t)b * rb.stride + row] = best; }
+        } else {
+            for (int j = lane; j < N; j += 64) out[j] = ((sp[j] * inv_reg + ui) + vb[j]) - norm;
+        }
     } else {
         for (int j = lane; j < N; j += 64) out[j] = ((zr + ui) + vb[j]) - norm;
     }
@@ -649,7 +666,7 @@ namespace {
 // RD = RaggedDesc (per-pair sizes by value in the kernarg segment) or RaggedNone (uniform batch: nothing; og_common.h)
 template <class RD>
 int sinkhorn_run(const float* S, int64_t lds, const float* zdev, float dustbin, int B, int m, int n, int iters, float reg,
-                 float* scores, void* workspace, hipStream_t st, const RD& rd) {
+                 float* scores, void* workspace, hipStream_t st, const RD& rd, const RowBest* row_best) {
     if (!S || !scores || !workspace || B <= 0 || m <= 0 || n <= 0 || iters < 0 || !(reg > 0.f)) return OG_E_INVALID;
     if (n > 8192) return OG_E_SHAPE;
     if ((lds & 3) || ((uintptr_t)S & 15) || ((uintptr_t)workspace & 15)) return OG_E_ALIGN;
@@ -703,7 +720,7 @@ int sinkhorn_run(const float* S, int64_t lds, const float* zdev, float dustbin, 
         cur ^= 1;
     }
     hipLaunchKernelGGL(sinkhorn_scores_kernel<RD>, dim3((m + 1 + 3) / 4, B), dim3(256), 0, st, S, lds, m, n, zdev, dustbin, inv_reg,
-                       (float)norm, w.u, w.ldu, w.v[cur], w.ldv, scores, (int64_t)m * lds, rd);
+                       (float)norm, w.u, w.ldu, w.v[cur], w.ldv, scores, (int64_t)m * lds, rd, row_best ? *row_best : RowBest{nullptr, nullptr, 0});
     return og_launch_status();
 }
 }  // namespace
@@ -737,17 +754,17 @@ int og_launch_sinkhorn_trajectory(const float* S, int64_t lds, float dustbin, in
     }
     hipLaunchKernelGGL(sinkhorn_scores_kernel<RaggedNone>, dim3((m + 1 + 3) / 4, B), dim3(256), 0, st, S, lds, m, n, (const float*)nullptr, dustbin,
                        inv_reg, (float)norm, U + (size_t)(iters - 1) * B * w.ldu, w.ldu, V + (size_t)iters * B * w.ldv, w.ldv, scores,
-                       (int64_t)m * lds, rd);
+                       (int64_t)m * lds, rd, RowBest{nullptr, nullptr, 0});
     return og_launch_status();
 }
 
 int og_launch_sinkhorn(const float* S, int64_t lds, const float* zdev, float dustbin, int B, int m, int n, int iters, float reg,
-                       float* scores, void* workspace, hipStream_t st, const RaggedDesc* rag) {
+                       float* scores, void* workspace, hipStream_t st, const RaggedDesc* rag, const RowBest* row_best) {
     if (rag) {
         if (rag->B != B) return OG_E_INVALID;
-        return sinkhorn_run<RaggedDesc>(S, lds, zdev, dustbin, B, m, n, iters, reg, scores, workspace, st, *rag);
+        return sinkhorn_run<RaggedDesc>(S, lds, zdev, dustbin, B, m, n, iters, reg, scores, workspace, st, *rag, row_best);
     }
-    return sinkhorn_run<RaggedNone>(S, lds, zdev, dustbin, B, m, n, iters, reg, scores, workspace, st, RaggedNone{});
+    return sinkhorn_run<RaggedNone>(S, lds, zdev, dustbin, B, m, n, iters, reg, scores, workspace, st, RaggedNone{}, row_best);
 }
 
 extern "C" int og_sinkhorn_status(const void* workspace_dev, int32_t batch, int32_t m, int32_t n) {
