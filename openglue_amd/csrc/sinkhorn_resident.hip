@@ -14,8 +14,9 @@
 // Rows are wave-local (one wave owns a row: lane-local exponentials + one DPP reduction), columns cross the G
 // workgroups of the pair: every workgroup publishes its 1024 column partials as 8-byte {epoch, value} granules
 // (cdna_hip_programming.md Guideline 16, form R2: the data is the flag -- agent-scope relaxed atomics on both sides, no
-// fence), sweeps the G x 1025 granules of its pair and computes ALL new v_j redundantly but bit-identically (fixed
-// summation order), so no second exchange is needed.  Granules are double-buffered by epoch parity: a workgroup can
+// fence), sweeps the 8 x 1025 granules of its pair (four 16-byte loads per column, see rs_granule_offset) and computes ALL
+// new v_j redundantly but bit-identically (fixed summation order), so no second exchange is needed.  Slots without a workgroup (G < 8) and columns >= n carry published zeros: the
+// sweep has no predicates.  Granules are double-buffered by epoch parity: a workgroup can
 // only reach epoch t+2 after it has seen every epoch-t+1 granule, i.e. after every peer has finished reading epoch t.
 // Every spin is bounded (status word: 0 ok, 1 = a wait timed out -> results invalid); all G x B workgroups must be
 // co-resident: one 512-thread workgroup per CU (148 KB of LDS), G x B <= number of CUs, checked by the launcher.
@@ -34,7 +35,8 @@ static_assert(RS_RR + RS_LR + RS_SR == RS_RW, "sixteen row slots per wave");
 constexpr int RS_NW = 8;               // waves per workgroup
 constexpr int RS_ROWS = RS_NW * RS_RW; // 128 rows per workgroup
 constexpr int RS_NCOL = 1024;          // columns per row held on chip (16 per lane)
-constexpr int RS_NG = RS_NCOL + 16;    // granules per (pair, workgroup): 1024 column partials + the dustbin-column term at index n
+constexpr int RS_NG = RS_NCOL + 16;    // columns with granules per pair: 1024 column partials + the dustbin-column term at index 1024
+constexpr int RS_GMAX = 8;             // slots per column = workgroups per pair at most (m <= 1024 rows on chip)
 constexpr unsigned RS_SPIN_LIMIT = 1u << 21;
 constexpr float RS_LOG2E = 1.4426950408889634f;
 constexpr float RS_LN2 = 0.6931471805599453f;
@@ -43,6 +45,49 @@ typedef unsigned long long rs_u64;
 typedef float rs_f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) rs_u64 rs_gu64;
 typedef __attribute__((address_space(1))) unsigned rs_gu32;
+typedef unsigned rs_u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) char rs_gchar;
+typedef __attribute__((address_space(1))) f32x4 rs_gf32x4;
+
+// ---- exchange area of one (parity, pair): 8-byte {epoch, value} granules, RS_GMAX slots (one per workgroup of the pair) for each
+// of the 1024 columns + the dustbin column.  Layout: blocks of 64 columns; inside a block four 1-KB rows, row k = slots 2k and
+// 2k+1 of the 64 columns (16 bytes per column).  A wave reads the eight slots of its 64 columns with four 16-byte loads per lane
+// whose lanes are contiguous (1 KB = 8 cache lines per instruction, one address + immediates 0/1024/2048/3072); laid out
+// [column][slot] the same loads touch 32 lines each and the sweep gets slower, laid out [slot][column] they are sixteen 8-byte
+// loads with their own addresses. ----
+constexpr int RS_XBLOCK = 4096;                              // bytes per block of 64 columns
+constexpr int RS_XPAIR = (RS_NCOL / 64 + 1) * RS_XBLOCK;     // bytes per (parity, pair): 16 column blocks + the dustbin column's block
+__device__ __forceinline__ unsigned rs_granule_offset(int col, int slot) {      // byte offset inside the exchange area of a (parity, pair)
+    return (unsigned)((col >> 6) * RS_XBLOCK + (slot >> 1) * 1024 + (col & 63) * 16 + (slot & 1) * 8);
+}
+
+// The eight granules of two columns + one granule of the dustbin column, read from the L2 -- never from this CU's vector L1 (an
+// aligned 8-byte granule cannot tear).  The wait is part of the block: the compiler does not count the loads of an asm statement.
+//   agent scope (sc1): coherent over the whole device -- on this multi-XCD part every such load goes to the fabric behind the
+//   per-XCD L2s (which are not coherent with each other): ~3k cycles per round trip, 11-12k cycles per sweep;
+//   XCD-local (LOCAL): the workgroups of a pair share one XCD = one L2 (verified at run time, kernel prologue).  Workgroup-scope
+//   streaming loads (sc0 nt) do not keep their line in the vector L1, so a re-poll reads the L2 again: 5-6k cycles per sweep.
+//   (sc0 alone may hit a stale L1 line for ever; buffer_inv sc0 does not help in non-tgsplit mode; buffer_inv sc1 is correct but
+//   costs 8k cycles per iteration -- it is the guaranteed-progress fallback of the poll loop, every 64th poll.)
+template <bool LOCAL>
+__device__ __forceinline__ void rs_load_columns(const rs_gu64* base0, const rs_gu64* base1, unsigned off, unsigned offd, rs_u32x4 (&a)[4],
+                                                rs_u32x4 (&b)[4], rs_u64& d) {
+#define RS_LOADS(M)                                                                                                                       \
+    asm volatile("global_load_dwordx4 %0, %9, %11 " M "\n\t"                                                                              \
+                 "global_load_dwordx4 %1, %9, %11 offset:1024 " M "\n\t"                                                                  \
+                 "global_load_dwordx4 %2, %9, %11 offset:2048 " M "\n\t"                                                                  \
+                 "global_load_dwordx4 %3, %9, %11 offset:3072 " M "\n\t"                                                                  \
+                 "global_load_dwordx4 %4, %9, %12 " M "\n\t"                                                                              \
+                 "global_load_dwordx4 %5, %9, %12 offset:1024 " M "\n\t"                                                                  \
+                 "global_load_dwordx4 %6, %9, %12 offset:2048 " M "\n\t"                                                                  \
+                 "global_load_dwordx4 %7, %9, %12 offset:3072 " M "\n\t"                                                                  \
+                 "global_load_dwordx2 %8, %10, %11 " M "\n\t"                                                                             \
+                 "s_waitcnt vmcnt(0)"                                                                                                     \
+                 : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]), "=&v"(d)       \
+                 : "v"(off), "v"(offd), "s"(base0), "s"(base1) : "memory")
+    if constexpr (LOCAL) RS_LOADS("sc0 nt"); else RS_LOADS("sc1");
+#undef RS_LOADS
+}
 
 // Experiment builds only (-DOG_SK_TRACE=1): shader-cycle stamps of the phases of iterations 8..15 of every wave of workgroups
 // (0,0) and (B/2, G-1), read back by og_debug_sk_trace (scripts/trace_sinkhorn.py)
@@ -61,8 +106,10 @@ struct SkResArgs {
     const float* S; int64_t lds, strideS;      // raw scores [B][m][lds]
     float* u; int ldu;                         // [B][ldu]: duals of the rows after the first (max-subtracted) iteration, natural units; updated in place
     const float* v_in; float* v_out; int ldv;  // [B][ldv]
-    rs_u64* xg;                                // [2][B][G][RS_NG] granules, zeroed before the launch
+    rs_u64* xg;                                // [2][B] exchange areas of RS_XPAIR bytes (parity, pair), zeroed before the launch
     unsigned* status;                          // zeroed before the launch
+    unsigned* xcc;                             // [B][8] XCC id + 1 of every workgroup, zeroed before the launch
+    int force_agent_scope;                     // experiments / tests: never take the XCD-local path
     const float* zdev; float zhost;
     float inv_reg, la, la_bin, lb, lb_bin;     // natural units (see og_launch_sinkhorn)
     int m, n, mb, iters;                       // mb = rows per workgroup (<= 128), iters = dual-stabilised iterations to run (>= 1)
@@ -145,13 +192,26 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a) {
         const float u0 = row < row_end ? ub[row] * RS_LOG2E : 0.f;
         ur[s] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, u0)));     // wave-uniform: SGPRs
     }
-    int ck[4];                                             // this lane's column chunks, clamped to valid addresses
+    unsigned ckb[4];                                       // this lane's column chunks (byte offsets), clamped to valid addresses
 #pragma unroll
-    for (int k = 0; k < 4; ++k) ck[k] = 4 * lane + 256 * k < N ? 4 * lane + 256 * k : 0;
-    auto load_row = [&](int row, f32x4 (&x)[4]) {          // raw scores of one row -> s2 = S * c2 (rows past the end: row 0's bytes, never used)
-        const float* rp = Sb + (int64_t)(row < row_end ? row : 0) * a.lds;
+    for (int k = 0; k < 4; ++k) ckb[k] = (unsigned)(4 * lane + 256 * k < N ? 4 * lane + 256 * k : 0) * 4u;
+    // raw scores of one row (rows past the end: row 0's bytes, never used).  (scalar row base + 32-bit lane offset) addressing: as
+    // 64-bit per-lane addresses the sixteen loop-invariant chunk addresses of the streamed rows took 32 registers and were spilled
+    auto load_row_raw = [&](int row, f32x4 (&x)[4]) {
+        const uint64_t v = (uint64_t)(uintptr_t)(Sb + (int64_t)(row < row_end ? row : 0) * a.lds);      // wave-uniform: pinned to an SGPR pair
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi32 = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        const rs_gchar* rp = (const rs_gchar*)(uintptr_t)(((uint64_t)hi32 << 32) | lo);                    // global address space: global_load, not flat_load
 #pragma unroll
-        for (int k = 0; k < 4; ++k) x[k] = *reinterpret_cast<const f32x4*>(rp + ck[k]) * c2;
+        for (int k = 0; k < 4; ++k) {
+            unsigned o = ckb[k];
+            asm volatile("" : "+v"(o));                    // re-launder per use: keeps the zero-extension next to the address add
+            x[k] = *(const rs_gf32x4*)(rp + o);
+        }
+    };
+    auto load_row = [&](int row, f32x4 (&x)[4]) {          // -> s2 = S * c2 (waits for the data: resident rows only)
+        load_row_raw(row, x);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] = x[k] * c2;
     };
     f32x4 sr[RS_RR][4];
 #pragma unroll
@@ -175,13 +235,36 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a) {
 #if OG_SK_TRACE
     const int tsel = (b == 0 && g == 0) ? 0 : (b == B / 2 && g == G - 1) ? 1 : -1;
 #endif
+    // ---- do the G workgroups of this pair sit on ONE XCD (one L2)?  Workgroups are dealt to the XCDs round-robin by linear id, so
+    //      with B a multiple of 8 they do -- but that is dispatcher behaviour, not a contract: every workgroup publishes its
+    //      XCC id (agent scope) and reads its peers'; all of them see the same table and take the same decision.  A pair that is
+    //      spread over XCDs exchanges its granules at agent scope (slower, always correct). ----
+    bool failed = false;
+    if (tid == 0) {
+        const unsigned mine = (__builtin_amdgcn_s_getreg(20 | (31 << 11)) & 0x00F0000Fu) + 1u;      // HW_REG_XCC_ID: XCC_ID [3:0], DIE_ID [23:20]
+        rs_gu32* tab = (rs_gu32*)a.xcc + (int64_t)b * RS_GMAX;
+        __hip_atomic_store(tab + g, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned same = 1u;
+        for (int q = 0; q < G; ++q) {
+            unsigned x = 0u, spins = 0u;
+            while ((x = __hip_atomic_load(tab + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
+                if (++spins > RS_SPIN_LIMIT) { same = 2u; __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (x != mine && same == 1u) same = 0u;
+        }
+        red[40] = __builtin_bit_cast(float, same);
+    }
+    __syncthreads();
+    const unsigned xcd_word = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, red[40]));
+    const bool xcd_local = xcd_word == 1u && !a.force_agent_scope;
+    failed = xcd_word == 2u;
     // the first two streamed rows of an iteration are fetched before the exchange of the previous one (nothing they need
     // depends on it), the other two while the LDS rows are processed
     // ONE prefetch buffer: with two of them live over the register rows the allocator spilled part of a resident row, and every
     // reload (s_waitcnt vmcnt(0)) also waited for the prefetches in flight -- thousands of cycles per iteration
-    f32x4 xs0[4];
-    load_row(row0 + RS_RR + RS_LR, xs0);
-    bool failed = false;
+    f32x4 xs0[4];                                          // RAW scores: scaled by c2 when consumed (a multiply here would wait for the data)
+    load_row_raw(row0 + RS_RR + RS_LR, xs0);
     // ---- dustbin row dual from the INITIAL v: u_M' = log2 a_M - (z + LSE2_{j<=N} v_j)   (every workgroup, identically).  Inside the
     //      loop the same quantity for the next iteration falls out of the new-v phase, where the new v are still in registers ----
     float uM2;
@@ -209,7 +292,7 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a) {
 #pragma unroll 1
     for (int it = 0; it < a.iters; ++it) {
         const unsigned epoch = (unsigned)it + 1u;
-        rs_gu64* xg = (rs_gu64*)a.xg + (((int64_t)(it & 1) * B + b) * G) * RS_NG;      // this pair's granules of this parity
+        char* xg = (char*)a.xg + ((int64_t)(it & 1) * B + b) * RS_XPAIR;                 // this pair's exchange area of this parity
 
         // (v is re-read from LDS chunk by chunk inside the rows: 16 more live registers would not fit beside the 176 of S)
         const float vN2 = vL[RS_NCOL];
@@ -237,19 +320,22 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a) {
             usum += pd * f;                                                 // = 2^(z + v_N + u'), one transcendental less per row
             ur[s] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, un)));   // wave-uniform: an SGPR
         };
-        auto mem_row = [&](f32x4 (&x)[4], int slot) {      // a row fetched from LDS / memory: its plan entries overwrite it
+        auto mem_row = [&](f32x4 (&x)[4], int slot, auto RAW_) {      // a row fetched from LDS (scaled) / memory (RAW): its plan entries overwrite it
+            constexpr bool RAW = decltype(RAW_)::value;
             if (slot < nvalid) {                           // wave-uniform: rows past the end of the workgroup's range are skipped
                 const float u = ur[slot];
                 // packed fp32 adds (two elements per VALU instruction); the association (s + v) + u and the pairing of the row sum
                 // are part of the arithmetic contract with the streaming kernels' tests (fixed, lane-local)
                 const rs_f32x2 uu = {u, u};
+                const rs_f32x2 cc = {c2, c2};
                 rs_f32x2 sum2 = {0.f, 0.f};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const f32x4 vk = *reinterpret_cast<const f32x4*>(vLl + 256 * k);
 #pragma unroll
                     for (int e = 0; e < 4; e += 2) {
-                        const rs_f32x2 t = (rs_f32x2{x[k][e], x[k][e + 1]} + rs_f32x2{vk[e], vk[e + 1]}) + uu;
+                        const rs_f32x2 xe = {x[k][e], x[k][e + 1]}, ve = {vk[e], vk[e + 1]};
+                        const rs_f32x2 t = (RAW ? xe * cc + ve : xe + ve) + uu;
                         x[k][e] = __builtin_amdgcn_exp2f(t[0]);
                         x[k][e + 1] = __builtin_amdgcn_exp2f(t[1]);
                         sum2 += rs_f32x2{x[k][e], x[k][e + 1]};
@@ -289,26 +375,26 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a) {
             f32x4 x[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) x[k] = *reinterpret_cast<const f32x4*>(Sw + sl * RS_NCOL + 256 * k);
-            mem_row(x, RS_RR + sl);
+            mem_row(x, RS_RR + sl, std::false_type{});
         };
         static_assert(RS_RR == 8 && RS_LR == 4 && RS_SR == 4, "the row schedule below is written out for 8 + 4 + 4 rows");
         using std::integral_constant;
-        mem_row(xs0, RS_RR + RS_LR);
-        load_row(row0 + RS_RR + RS_LR + 1, xs0);
+        mem_row(xs0, RS_RR + RS_LR, std::true_type{});
+        load_row_raw(row0 + RS_RR + RS_LR + 1, xs0);
         __builtin_amdgcn_sched_barrier(0);
         reg_row(integral_constant<int, 0>{}); reg_row(integral_constant<int, 1>{}); reg_row(integral_constant<int, 2>{});
-        mem_row(xs0, RS_RR + RS_LR + 1);
-        load_row(row0 + RS_RR + RS_LR + 2, xs0);
+        mem_row(xs0, RS_RR + RS_LR + 1, std::true_type{});
+        load_row_raw(row0 + RS_RR + RS_LR + 2, xs0);
         __builtin_amdgcn_sched_barrier(0);
         reg_row(integral_constant<int, 3>{}); reg_row(integral_constant<int, 4>{}); reg_row(integral_constant<int, 5>{});
-        mem_row(xs0, RS_RR + RS_LR + 2);
-        load_row(row0 + RS_RR + RS_LR + 3, xs0);
+        mem_row(xs0, RS_RR + RS_LR + 2, std::true_type{});
+        load_row_raw(row0 + RS_RR + RS_LR + 3, xs0);
         __builtin_amdgcn_sched_barrier(0);
         reg_row(integral_constant<int, 6>{}); reg_row(integral_constant<int, 7>{});
         RS_TP(2);
         lds_row(integral_constant<int, 0>{}); lds_row(integral_constant<int, 1>{});
-        mem_row(xs0, RS_RR + RS_LR + 3);
-        if (it + 1 < a.iters) load_row(row0 + RS_RR + RS_LR, xs0);      // next iteration's first streamed row: under the LDS rows and the exchange
+        mem_row(xs0, RS_RR + RS_LR + 3, std::true_type{});
+        if (it + 1 < a.iters) load_row_raw(row0 + RS_RR + RS_LR, xs0);      // next iteration's first streamed row: under the LDS rows and the exchange
         __builtin_amdgcn_sched_barrier(0);
         lds_row(integral_constant<int, 2>{}); lds_row(integral_constant<int, 3>{});
 
@@ -331,64 +417,69 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a) {
         if (lane == 0) red[16 + wave] = usum;
         __syncthreads();
         RS_TP(4);
-        // ---- (4) publish: 8-byte {epoch, value} granules, agent-scope relaxed stores (write-through) ----
-        {
-            rs_gu64* mine = xg + (int64_t)g * RS_NG;
+        // ---- (4) publish: 8-byte {epoch, value} granules, relaxed stores (the vector L1 is write-through: they land in the L2);
+        //      slot g of every column.  Columns >= n publish their (zero) partials too, and workgroup 0 fills the slots G..7
+        //      nobody owns with zeros.
+        //      (5) sweep the granules of the pair (mine included: same code path, same rounding).  Both columns of a thread in ONE
+        //      batch of eight 16-byte loads; the batch is polled as a whole until every granule carries this epoch, so a late peer
+        //      costs one more round trip (polled granule by granule, the stale ones of a batch cost up to G sequential round
+        //      trips: 7.7k cycles per iteration in the first trace of round 2).  Fixed summation order: slot 0..7. ----
+        float colsum[3] = {0.f, 0.f, 0.f};
+        auto exchange = [&](auto LOCAL_) __attribute__((always_inline)) {
+            constexpr bool LOCAL = decltype(LOCAL_)::value;
+            constexpr int SCOPE = LOCAL ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_AGENT;
+            const rs_u64 tag = (rs_u64)epoch << 32;
+            auto slot_ptr = [&](int col, int slot) { return (rs_gu64*)(xg + rs_granule_offset(col, slot)); };
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const int j = tid + 512 * c;
-                if (j < N) __hip_atomic_store(mine + j, ((rs_u64)epoch << 32) | __builtin_bit_cast(unsigned, tot[c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(slot_ptr(tid + 512 * c, g), tag | __builtin_bit_cast(unsigned, tot[c]), __ATOMIC_RELAXED, SCOPE);
+                if (g == 0)
+                    for (int q = G; q < RS_GMAX; ++q) __hip_atomic_store(slot_ptr(tid + 512 * c, q), tag, __ATOMIC_RELAXED, SCOPE);
             }
             if (tid == 0) {
                 float us = red[16];
 #pragma unroll
                 for (int w = 1; w < RS_NW; ++w) us += red[16 + w];
-                __hip_atomic_store(mine + N, ((rs_u64)epoch << 32) | __builtin_bit_cast(unsigned, us), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(slot_ptr(RS_NCOL, g), tag | __builtin_bit_cast(unsigned, us), __ATOMIC_RELAXED, SCOPE);
+                if (g == 0)
+                    for (int q = G; q < RS_GMAX; ++q) __hip_atomic_store(slot_ptr(RS_NCOL, q), tag, __ATOMIC_RELAXED, SCOPE);
             }
-        }
-        RS_TP(5);
-        // ---- (5) sweep the granules of all G workgroups of the pair (mine included: same code path, same rounding) ----
-        float colsum[3] = {0.f, 0.f, 0.f};
-        {
-            // Two batches of loads per thread (one per column it owns, G granules each, all in flight together), then re-read only
-            // what had not arrived; the dustbin-column term rides in the second batch, one granule per thread 0..G-1 (as a third
-            // batch of thread 0 it cost every wave of the workgroup a third memory round trip at the next barrier).  Holding both
-            // columns in one batch needs 16 more registers and makes the allocator spill a resident row.  Fixed order gg = 0..G-1.
-            constexpr int GMAX = 8;                            // G <= 8: m <= 1024 rows per pair on chip
-            const bool own[2] = {tid < N, tid + 512 < N};
-            const bool ownd = tid < G;
-            auto arrived = [&](rs_gu64* p, rs_u64 v) -> float {             // spin (bounded) until the granule carries this epoch
-                unsigned spins = 0;
-                while ((unsigned)(v >> 32) != epoch) {
-                    if (++spins > RS_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-                        failed = true;
-                        __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                    v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            RS_TP(5);
+            const rs_gu64* base0 = (const rs_gu64*)xg;                                     // columns tid ...
+            const rs_gu64* base1 = (const rs_gu64*)(xg + (512 / 64) * RS_XBLOCK);          // ... and tid + 512: eight blocks further
+            const unsigned off = rs_granule_offset(tid, 0);
+            const unsigned offd = rs_granule_offset(RS_NCOL, lane & (RS_GMAX - 1));         // lane q (mod 8) holds slot q of the dustbin column
+            rs_u32x4 ga[4], gb[4];
+            rs_u64 xd;
+            unsigned spins = 0;
+            for (;;) {
+                rs_load_columns<LOCAL>(base0, base1, off, offd, ga, gb, xd);
+                unsigned bad = (unsigned)(xd >> 32) ^ epoch;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) bad |= (ga[k][1] ^ epoch) | (ga[k][3] ^ epoch) | (gb[k][1] ^ epoch) | (gb[k][3] ^ epoch);
+                if (__builtin_amdgcn_ballot_w64(bad != 0u) == 0) break;
+                if (++spins > RS_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                    failed = true;
+                    __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
                 }
-                return __builtin_bit_cast(float, (unsigned)v);
-            };
-            float dval = 0.f;
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                rs_u64 x[GMAX], xd = 0;
-#pragma unroll
-                for (int q = 0; q < GMAX; ++q)
-                    if (own[c] && q < G) x[q] = __hip_atomic_load(xg + (int64_t)q * RS_NG + tid + 512 * c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (c == 1 && ownd) xd = __hip_atomic_load(xg + (int64_t)tid * RS_NG + N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                for (int q = 0; q < GMAX; ++q)
-                    if (own[c] && q < G) colsum[c] += arrived(xg + (int64_t)q * RS_NG + tid + 512 * c, x[q]);
-                if (c == 1 && ownd) dval = arrived(xg + (int64_t)tid * RS_NG + N, xd);
+                if (LOCAL && (spins & 63u) == 0u) asm volatile("buffer_inv sc1" ::: "memory");     // guaranteed progress: drop the L1 for real
+                __builtin_amdgcn_s_sleep(1);
             }
-            if (wave == 0) {                                   // lanes 0..G-1 of wave 0 hold the G dustbin terms: ordered sum for thread 0
 #pragma unroll
-                for (int q = 0; q < GMAX; ++q)
-                    if (q < G) colsum[2] += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dval), q));
+            for (int k = 0; k < 4; ++k) {
+                // (through scalars: __builtin_bit_cast applied to a vector ELEMENT reads element 0 whatever the index, hipcc 7.2)
+                const unsigned a0 = ga[k][0], a1 = ga[k][2], b0 = gb[k][0], b1 = gb[k][2];
+                colsum[0] += __builtin_bit_cast(float, a0);
+                colsum[0] += __builtin_bit_cast(float, a1);
+                colsum[1] += __builtin_bit_cast(float, b0);
+                colsum[1] += __builtin_bit_cast(float, b1);
             }
-        }
+            const int dval = (int)(unsigned)xd;                // ordered sum of the eight dustbin terms (used by thread 0)
+#pragma unroll
+            for (int q = 0; q < RS_GMAX; ++q) colsum[2] += __builtin_bit_cast(float, __builtin_amdgcn_readlane(dval, q));
+        };
+        if (xcd_local) exchange(std::true_type{}); else exchange(std::false_type{});
         RS_TP(6);
         // ---- (6) new v for my columns (every workgroup of the pair computes the same bits), and -- while they are in registers --
         //      the dustbin-row dual of the NEXT iteration, u_M' = log2 a_M - (z + LSE2 of the new v): per-wave (max, sum) first,
@@ -470,7 +561,7 @@ bool og_sinkhorn_resident_shape_ok(int B, int m, int n) {
 
 size_t og_sinkhorn_resident_ws_bytes(int B, int m, int n) {
     if (!og_sinkhorn_resident_shape_ok(B, m, n)) return 0;
-    return (size_t)2 * B * rs_groups(m) * RS_NG * sizeof(rs_u64) + 256;      // granules (two parities) + status word
+    return (size_t)2 * B * RS_XPAIR + 256 + (size_t)B * RS_GMAX * sizeof(unsigned);      // status word, exchange areas (two parities), XCC table
 }
 
 // mode: 1 = when the whole batch is co-resident AND large enough to pay off, 2 = whenever it is co-resident (tests)
@@ -494,6 +585,8 @@ int og_launch_sinkhorn_resident(const float* S, int64_t lds, const float* zdev, 
     a.S = S; a.lds = lds; a.strideS = (int64_t)m * lds;
     a.u = u; a.ldu = ldu; a.v_in = v_in; a.v_out = v_out; a.ldv = ldv;
     a.xg = (rs_u64*)((char*)xws + 256); a.status = (unsigned*)xws;
+    a.xcc = (unsigned*)((char*)xws + 256 + (size_t)2 * B * RS_XPAIR);
+    { const char* e = getenv("OG_SINKHORN_AGENT_SCOPE"); a.force_agent_scope = e && atoi(e) != 0; }       // read per call: the tests switch it
     a.zdev = zdev; a.zhost = zhost; a.inv_reg = inv_reg; a.la = la; a.la_bin = la_bin; a.lb = lb; a.lb_bin = lb_bin;
     a.m = m; a.n = n; a.mb = (m + G - 1) / G; a.iters = iters;
     hipLaunchKernelGGL(sinkhorn_resident_kernel, dim3(B, G), dim3(512), 0, st, a);

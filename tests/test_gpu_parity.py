@@ -523,6 +523,22 @@ def test_sinkhorn_resident_vs_oracle(gpu_device, monkeypatch, B, m, n, iters, re
     assert (torch.logsumexp(out.double() + norm, dim=1) - lb).abs().max() < 1e-4        # column marginals exact after the last v update
 
 
+@pytest.mark.parametrize("B,m,n,iters", [(8, 1024, 1024, 60), (2, 257, 1000, 10), (3, 640, 333, 25)])
+def test_sinkhorn_resident_exchange_scopes(gpu_device, monkeypatch, B, m, n, iters):
+    """The column partials travel between the workgroups of a pair either at agent scope or -- when the kernel finds all of them
+    on one XCD (B a multiple of 8 with the round-robin dispatch) -- through that XCD's L2 with workgroup-scope streaming loads.
+    Same arithmetic, same summation order: the two paths must agree bit for bit, and neither may time out."""
+    g = torch.Generator().manual_seed(B * 7 + m)
+    S = _rand(g, B, m, n, scale=4.0).to(gpu_device)
+    monkeypatch.setenv("OG_SINKHORN_RESIDENT", "2")
+    monkeypatch.setenv("OG_SINKHORN_AGENT_SCOPE", "0")
+    a, st_a = ops.sinkhorn(S, 0.7, iters, 1.0, return_status=True)
+    monkeypatch.setenv("OG_SINKHORN_AGENT_SCOPE", "1")
+    b2, st_b = ops.sinkhorn(S, 0.7, iters, 1.0, return_status=True)
+    assert st_a == 0 and st_b == 0
+    assert torch.equal(a, b2)
+
+
 def test_sinkhorn_resident_extreme_range_and_repeatability(gpu_device, monkeypatch):
     g = torch.Generator().manual_seed(5)
     B, m, n, iters = 2, 200, 900, 40
