@@ -219,6 +219,12 @@ int og_split_f16_hl(const float* x, int64_t rows, int32_t cols, int64_t ldx, voi
 int og_gemm_nt_f16x3(const void* A, int64_t lda, const void* B, int64_t ldb, int32_t M, int32_t N, int32_t K,
                      float scale, const float* bias, int32_t relu, const float* res, int64_t ldr, float* C32, int64_t ldc,
                      void* Ch, void* Cl, int64_t ldch, int32_t c_hl, void* stream);
+/* The same with the residual given as hl32 rows (res_hl, row stride ldrh halves; may alias Ch when c_hl != 0: every element is read
+ * before it is written by the same lane): v += hi + lo.  This is the form of the GNN's fc.3 (attention_gnn.py:55: desc_q + fc(message)):
+ * og_forward keeps the residual stream as (hi, lo) rows.  C32 may be NULL when a split-f16 output is given. */
+int og_gemm_nt_f16x3_reshl(const void* A, int64_t lda, const void* B, int64_t ldb, int32_t M, int32_t N, int32_t K,
+                           float scale, const float* bias, int32_t relu, const void* res_hl, int64_t ldrh, float* C32, int64_t ldc,
+                           void* Ch, void* Cl, int64_t ldch, int32_t c_hl, void* stream);
 
 /* softmax attention (attention.py:8-19) for `batch` independent problems and H heads, operands and
  * result as split-f16 planes: q [batch][nq][ldq] (columns h*dh.. of row i = head h, PRE-SCALED by

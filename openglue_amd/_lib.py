@@ -93,6 +93,8 @@ SYMBOLS = {
     "og_split_f16_hl": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i64, _vp]),
     "og_gemm_nt_f16x3": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _f, _vp, _i32, _vp, _i64, _vp, _i64,
                                    _vp, _vp, _i64, _i32, _vp]),
+    "og_gemm_nt_f16x3_reshl": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _f, _vp, _i32, _vp, _i64, _vp, _i64,
+                                         _vp, _vp, _i64, _i32, _vp]),
     "og_attention": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32,
                                _i32, _vp]),
     "og_sinkhorn_workspace_bytes": (_sz, [_i32, _i32, _i32]),

@@ -20,6 +20,7 @@
 // v_mfma_f32_32x32x16_f16; block tile 128 tokens x OC channels x 32 k, 4 waves as 2x2.
 #include <stdlib.h>
 #include <cmath>
+#include <type_traits>
 
 #include "og_common.h"
 
@@ -84,14 +85,16 @@ __device__ __forceinline__ void gemm_f16x3_acc_init(GemmHArgs& g, f32x16 (&acc)[
 
 // residual of the 32-token slice starting at tok0 (one 4-dword slot per group for either residual form: they are
 // mutually exclusive, og_launch_gemm_f16x3)
-template <int TI>
+// ONLY_HL: the caller knows that the residual is the (hi, lo) form (no run-time branch whose two sides would have to be merged
+// through 32 register copies)
+template <int TI, bool ONLY_HL = false>
 __device__ __forceinline__ void gemm_f16x3_load_residual(const GemmHArgs& g, og_u32x4 (&raw)[TI][4], int tok0, int oc0, int lane) {
     const int l31 = lane & 31, hi = lane >> 5;
     const int tok = tok0 + l31;
     const int tokc = tok < g.M ? tok : g.M - 1;              // clamped: rows past M are computed, never stored
     // N % 32 == 0 with either residual form (og_launch_gemm_f16x3): a 32-channel block is valid or not as a whole, so the
     // column clamp is wave-uniform and every load is one per-lane row pointer + a scalar block offset + an immediate
-    if (g.res) {
+    if (!ONLY_HL && g.res) {
         const float* rp = g.res + (int64_t)tokc * g.ldr + 4 * hi;
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
@@ -100,7 +103,7 @@ __device__ __forceinline__ void gemm_f16x3_load_residual(const GemmHArgs& g, og_
 #pragma unroll
             for (int q = 0; q < 4; ++q) raw[i][q] = *reinterpret_cast<const og_u32x4*>(p2 + 8 * q);
         }
-    } else if (g.res_hl) {                                   // residual carried as (hi, lo): 2^-22 relative
+    } else if (ONLY_HL || g.res_hl) {                        // residual carried as (hi, lo): 2^-22 relative
         const _Float16* rp = g.res_hl + (int64_t)tokc * g.ldrh + 4 * hi;
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
@@ -284,23 +287,75 @@ __device__ __forceinline__ void gemm_f16x3_epilogue_store(const GemmHArgs& g, f3
 // address arithmetic: the row/column part of a store address is a scalar base, the lane part one 32-bit offset computed once.
 // [The generic path above costs ~13k cycles per tile (scripts/trace_gemm.py): every store sits under its own exec-mask branch
 // with a 64-bit multiply for its row, and each of the 8 (slice, channel block) passes waits for its own LDS round trip.]
-template <bool HL>
-__device__ __forceinline__ void gemm_f16x3_epilogue_fast(const GemmHArgs& g, f32x16 (&acc)[2][4], int tok0, int oc0, int lane, char* slab2) {
+// EM: the arithmetic of the epilogue fixed at compile time (chosen by the launcher), 0 = decided at run time by the generic code
+// above.  [The run-time form costs, per 32-token slice and wave, 32 v_mul + 32 v_max whatever the activation, 3 VALU per element
+// for a (hi, lo) residual and ~32 v_mov: the wave-uniform branches on g.res / g.res_hl / g.alpha merge their results through
+// register copies.  VALU and MFMA issue do not overlap on this part, so these count.]
+//   1: v = acc * scale                  (q/k/v projections: packed multiplies, 0.5 VALU per element)
+//   2: v = max(acc * scale, 0)          (fc.0)
+//   3: v = acc * scale + rh + rl        (fc.3: the (hi, lo) residual enters through two mixed-precision FMAs, 2 VALU per element)
+enum { OG_EM_RUNTIME = 0, OG_EM_NONE = 1, OG_EM_RELU = 2, OG_EM_RES_HL = 3 };
+
+template <int EM>
+__device__ __forceinline__ void gemm_f16x3_epilogue_finish_spec(const GemmHArgs& g, f32x16 (&a)[2], const og_u32x4 (&raw)[2][4]) {
+    const float sc = g.scale;
+    if constexpr (EM == OG_EM_NONE) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = a[i] * sc;                    // vector form: v_pk_mul_f32
+    } else if constexpr (EM == OG_EM_RELU) {
+        // multiply first: the product is known to be canonical, so fmaxf is ONE v_max (on the raw accumulator it costs a second
+        // v_max that quiets a possible NaN)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = a[i] * sc;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[i][r] = fmaxf(a[i][r], 0.f);
+    } else {
+        static_assert(EM == OG_EM_RES_HL, "unknown epilogue mode");
+        // raw[i][q] = {h01, h23, l01, l23} (f16 pairs).  v_fma_mix_f32: f32 acc * f32 scale + f16 hi, then f16 lo * 1.0 + that.
+        // Full-register VALU writes (no op_sel partial-write hazard).  The hazard recognizer does not look inside inline asm: the only
+        // software-managed hazard in reach is "MFMA writes a VGPR -> VALU reads it" (up to 19 wait states); between the last MFMA and this
+        // block lie the block barrier, the residual loads and their s_waitcnt vmcnt -- hundreds of cycles.
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float x0 = a[i][4 * q], x1 = a[i][4 * q + 1], x2 = a[i][4 * q + 2], x3 = a[i][4 * q + 3];
+                asm("v_fma_mix_f32 %0, %0, %4, %5 op_sel_hi:[0,0,1]\n\t"
+                    "v_fma_mix_f32 %1, %1, %4, %5 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+                    "v_fma_mix_f32 %2, %2, %4, %6 op_sel_hi:[0,0,1]\n\t"
+                    "v_fma_mix_f32 %3, %3, %4, %6 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+                    "v_fma_mix_f32 %0, %7, 1.0, %0 op_sel_hi:[1,0,0]\n\t"
+                    "v_fma_mix_f32 %1, %7, 1.0, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                    "v_fma_mix_f32 %2, %8, 1.0, %2 op_sel_hi:[1,0,0]\n\t"
+                    "v_fma_mix_f32 %3, %8, 1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                    : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3)
+                    : "s"(sc), "v"(raw[i][q][0]), "v"(raw[i][q][1]), "v"(raw[i][q][2]), "v"(raw[i][q][3]));
+                a[i][4 * q] = x0; a[i][4 * q + 1] = x1; a[i][4 * q + 2] = x2; a[i][4 * q + 3] = x3;
+            }
+    }
+}
+
+template <bool HL, int EM, int NJ>
+__device__ __forceinline__ void gemm_f16x3_epilogue_fast(const GemmHArgs& g, f32x16 (&acc)[2][NJ], int tok0, int oc0, int lane, char* slab2) {
 #pragma clang fp contract(off)                  // og_split: hi and lo must see the same rounded value (og_common.h)
     constexpr int ROWB = 128 + 16;
+    constexpr bool HAS_RES = EM == OG_EM_RUNTIME || EM == OG_EM_RES_HL;
     const int l31 = lane & 31, hi = lane >> 5;
     const unsigned voff = (unsigned)((lane >> 3) * (int)g.ldch * 2 + (lane & 7) * 16);       // 8 rows x 128 B per store instruction
     const unsigned rd_off = (unsigned)((lane >> 3) * ROWB + (lane & 7) * 16);
     char* const out_h = reinterpret_cast<char*>(g.Ch);
     char* const out_l = reinterpret_cast<char*>(g.Cl);
     og_u32x4 raw[2][4];
-    gemm_f16x3_load_residual<2>(g, raw, tok0, oc0, lane);
+    if constexpr (HAS_RES) gemm_f16x3_load_residual<2, EM == OG_EM_RES_HL>(g, raw, tok0, oc0, lane);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         f32x16 a[2];
         a[0] = acc[0][j]; a[1] = acc[1][j];
-        gemm_f16x3_epilogue_finish<2, false>(g, a, raw, oc0, lane);
-        if (j + 1 < 4) gemm_f16x3_load_residual<2>(g, raw, tok0 + (j + 1) * 32, oc0, lane);
+        if constexpr (EM == OG_EM_RUNTIME) gemm_f16x3_epilogue_finish<2, false>(g, a, raw, oc0, lane);
+        else gemm_f16x3_epilogue_finish_spec<EM>(g, a, raw);
+        if constexpr (HAS_RES) { if (j + 1 < NJ) gemm_f16x3_load_residual<2, EM == OG_EM_RES_HL>(g, raw, tok0 + (j + 1) * 32, oc0, lane); }
         // registers -> slabs.  HL: slab i = [32 tok][hi 64 B | lo 64 B] of channel block i; planes: slab 0 = hi, slab 1 = lo of [32 tok][64 ch]
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -381,7 +436,9 @@ __device__ unsigned og_gemm_trace_buf[OG_GT_BLOCKS][8][OG_GT_WORDS];
 typedef __attribute__((address_space(3))) void og_lds_void;
 typedef __attribute__((address_space(1))) const void og_glb_void;
 
-template <int OC, int NS, class RD>
+// EPI / EM as in the 256-tile kernel below (EPI 0: the generic epilogue; 1 / 2: every tile inside the matrix, split-f16 output only,
+// OC == 128): the launcher picks them for the cross-layer launches over one image (q projection, fc.3)
+template <int OC, int NS, class RD, int EPI = 0, int EM = 0>
 __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void gemm_nt_f16x3_kernel(GemmHArgs g, int tiles_m, int tiles_n, RD rd) {
     constexpr int TI = OC / 64;                // MFMA tiles per wave along channels
     constexpr int XB = TOK * 128;              // bytes of the token tile per stage (hi|lo rows)
@@ -506,7 +563,10 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void gemm_nt_f16x3_kernel(G
     }
 
     __builtin_amdgcn_s_barrier();      // every wave is past its last fragment reads: the ring is free
-    {
+    if constexpr (EPI != 0) {
+        static_assert(TI == 2 && 4 * 2 * EPI_SLAB <= NS * STAGE, "fast epilogue: 64-channel wave tiles, two slabs per wave");
+        gemm_f16x3_epilogue_fast<EPI == 1, EM, 2>(g, acc, t0 + wt * 64, n0 + wo * (OC / 2), lane, smem + wave * 2 * EPI_SLAB);
+    } else {
         // two 32-token slices; the residual of slice 1 is fetched (into the same registers) as soon as slice 0 has consumed
         // its own, and is in flight while slice 0 is split, transposed and stored
         og_u32x4 raw[TI][4];
@@ -735,7 +795,7 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_big_kernel(GemmHArgs g, int
 // One problem per launch (no batch, no ragged descriptor): the per-pair score GEMM stays on the kernel above.
 // EPI: 0 = generic epilogue, 1 = fast hl32 rows, 2 = fast planes (every tile inside the matrix; chosen by the launcher -- one
 // epilogue per instantiation keeps the kernel inside its 256 registers)
-template <int EPI>
+template <int EPI, int EM>
 __global__ __launch_bounds__(512) void gemm_nt_f16x3_big2_kernel(GemmHArgs g, int tiles_m, int tiles_n) {
     constexpr int XS = BIG * 128;              // one stage of one operand: 256 rows x 128 B (hi 64 B | lo 64 B)
     constexpr int WOFF = 3 * XS;
@@ -926,9 +986,9 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_big2_kernel(GemmHArgs g, in
     {
         const int tok0 = t0 + wt * 128, oc0 = n0 + wo * 64;
         if constexpr (EPI == 1) {
-            gemm_f16x3_epilogue_fast<true>(g, acc, tok0, oc0, lane, smem + wave * 2 * EPI_SLAB);
+            gemm_f16x3_epilogue_fast<true, EM, 4>(g, acc, tok0, oc0, lane, smem + wave * 2 * EPI_SLAB);
         } else if constexpr (EPI == 2) {
-            gemm_f16x3_epilogue_fast<false>(g, acc, tok0, oc0, lane, smem + wave * 2 * EPI_SLAB);
+            gemm_f16x3_epilogue_fast<false, EM, 4>(g, acc, tok0, oc0, lane, smem + wave * 2 * EPI_SLAB);
         } else {
             og_u32x4 raw[2][4];
             char* slab = smem + wave * EPI_SLAB;
@@ -1030,9 +1090,25 @@ int og_launch_gemm_f16x3(const GemmHArgs& a, hipStream_t stream) {
                     const bool whole = g.M % 256 == 0 && g.N % 256 == 0 && g.Ch && !g.C32;      // every tile inside, split-f16 output only
                     static const bool fast_epi = [] { const char* e = getenv("OG_GEMM_FAST_EPI"); return !e || atoi(e) != 0; }();   // experiments
                     const dim3 grid2(tiles_m8 * tiles_n), block2(512);
-                    if (whole && fast_epi && g.c_hl) hipLaunchKernelGGL(gemm_nt_f16x3_big2_kernel<1>, grid2, block2, 0, stream, g, tiles_m, tiles_n);
-                    else if (whole && fast_epi && g.Cl) hipLaunchKernelGGL(gemm_nt_f16x3_big2_kernel<2>, grid2, block2, 0, stream, g, tiles_m, tiles_n);
-                    else hipLaunchKernelGGL(gemm_nt_f16x3_big2_kernel<0>, grid2, block2, 0, stream, g, tiles_m, tiles_n);
+                    // the epilogue arithmetic as a compile-time mode where the launch is one of the GNN's four forms (OG_GEMM_SPEC_EPI=0: experiments)
+                    static const bool spec_epi = [] { const char* e = getenv("OG_GEMM_SPEC_EPI"); return !e || atoi(e) != 0; }();
+                    int em = OG_EM_RUNTIME;
+                    if (spec_epi && !g.alpha) {
+                        if (!g.res && !g.res_hl) em = g.relu ? OG_EM_RELU : OG_EM_NONE;
+                        else if (!g.relu && g.res_hl) em = OG_EM_RES_HL;      // (an fp32 residual -- one launch per step -- stays on the run-time form:
+                                                                              //  its 32 prefetched residual registers spill in a specialised kernel)
+                    }
+#define OG_BIG2(EPI_, EM_) hipLaunchKernelGGL((gemm_nt_f16x3_big2_kernel<EPI_, EM_>), grid2, block2, 0, stream, g, tiles_m, tiles_n)
+                    if (whole && fast_epi && g.c_hl) {
+                        if (em == OG_EM_RELU) OG_BIG2(1, OG_EM_RELU);
+                        else if (em == OG_EM_RES_HL) OG_BIG2(1, OG_EM_RES_HL);
+                        else if (em == OG_EM_NONE) OG_BIG2(1, OG_EM_NONE);
+                        else OG_BIG2(1, OG_EM_RUNTIME);
+                    } else if (whole && fast_epi && g.Cl) {
+                        if (em == OG_EM_NONE) OG_BIG2(2, OG_EM_NONE);
+                        else OG_BIG2(2, OG_EM_RUNTIME);
+                    } else OG_BIG2(0, OG_EM_RUNTIME);
+#undef OG_BIG2
                     return og_launch_status();
                 }
                 hipLaunchKernelGGL(gemm_nt_f16x3_big_kernel<RD>, dim3(tiles_m8 * tiles_n, nz), dim3(512), 0, stream, g, tiles_m, tiles_n, rd);
@@ -1043,6 +1119,19 @@ int og_launch_gemm_f16x3(const GemmHArgs& a, hipStream_t stream) {
         const int tiles_m8 = (tiles_m + 7) / 8 * 8;
         if (a.N > 64) {
             const int tiles_n = (a.N + 127) / 128;
+            if constexpr (std::is_same<RD, RaggedNone>::value) {
+                static const bool spec128 = [] { const char* e = getenv("OG_GEMM_SPEC_EPI"); return !e || atoi(e) != 0; }();
+                const bool whole = spec128 && nz == 1 && g.M % TOK == 0 && g.N % 128 == 0 && g.Ch && !g.C32 && !g.Ct && !g.alpha && !g.res;
+                if (whole) {
+                    const dim3 grid(tiles_m8 * tiles_n), block(256);
+#define OG_T128(EPI_, EM_) hipLaunchKernelGGL((gemm_nt_f16x3_kernel<128, 2, RD, EPI_, EM_>), grid, block, 0, stream, g, tiles_m, tiles_n, rd)
+                    if (g.c_hl && !g.res_hl && g.relu) { OG_T128(1, OG_EM_RELU); return og_launch_status(); }
+                    if (g.c_hl && !g.res_hl && !g.relu) { OG_T128(1, OG_EM_NONE); return og_launch_status(); }
+                    if (g.c_hl && g.res_hl && !g.relu) { OG_T128(1, OG_EM_RES_HL); return og_launch_status(); }
+                    if (!g.c_hl && g.Cl && !g.res_hl && !g.relu) { OG_T128(2, OG_EM_NONE); return og_launch_status(); }
+#undef OG_T128
+                }
+            }
             hipLaunchKernelGGL((gemm_nt_f16x3_kernel<128, 2, RD>), dim3(tiles_m8 * tiles_n, nz), dim3(256), 0, stream, g, tiles_m, tiles_n, rd);
         } else {
             hipLaunchKernelGGL((gemm_nt_f16x3_kernel<64, 2, RD>), dim3(tiles_m8, nz), dim3(256), 0, stream, g, tiles_m, 1, rd);
@@ -1094,6 +1183,19 @@ extern "C" int og_gemm_nt_f16x3(const void* A, int64_t lda, const void* B, int64
     GemmHArgs g{};
     g.A = (const _Float16*)A; g.lda = lda; g.B = (const _Float16*)B; g.ldb = ldb;
     g.M = M; g.N = N; g.K = K; g.scale = scale; g.bias = bias; g.relu = relu; g.res = res; g.ldr = ldr;
+    g.C32 = C32; g.ldc = ldc; g.Ch = (_Float16*)Ch; g.Cl = c_hl ? (Ch ? (_Float16*)Ch + 32 : nullptr) : (_Float16*)Cl;
+    g.ldch = ldch; g.c_hl = c_hl ? 1 : 0;
+    return og_launch_gemm_f16x3(g, (hipStream_t)stream);
+}
+
+// the fc.3 form of the GNN: the residual arrives as hl32 rows (og_forward keeps the residual stream that way)
+extern "C" int og_gemm_nt_f16x3_reshl(const void* A, int64_t lda, const void* B, int64_t ldb, int32_t M, int32_t N, int32_t K,
+                                      float scale, const float* bias, int32_t relu, const void* res_hl, int64_t ldrh, float* C32, int64_t ldc,
+                                      void* Ch, void* Cl, int64_t ldch, int32_t c_hl, void* stream) {
+    og_clear_status();
+    GemmHArgs g{};
+    g.A = (const _Float16*)A; g.lda = lda; g.B = (const _Float16*)B; g.ldb = ldb;
+    g.M = M; g.N = N; g.K = K; g.scale = scale; g.bias = bias; g.relu = relu; g.res_hl = (const _Float16*)res_hl; g.ldrh = ldrh;
     g.C32 = C32; g.ldc = ldc; g.Ch = (_Float16*)Ch; g.Cl = c_hl ? (Ch ? (_Float16*)Ch + 32 : nullptr) : (_Float16*)Cl;
     g.ldch = ldch; g.c_hl = c_hl ? 1 : 0;
     return og_launch_gemm_f16x3(g, (hipStream_t)stream);

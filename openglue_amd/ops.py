@@ -117,6 +117,28 @@ def gemm_nt_f16x3(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor]
     return out
 
 
+def gemm_nt_f16x3_split_only(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False,
+                             res: Optional[torch.Tensor] = None, planes: bool = False) -> torch.Tensor:
+    """The forms the GNN launches (no fp32 output, so whole-tile shapes take the 256-tile kernel's compile-time epilogues):
+    q/k/v projections (planes=True), fc.0 (relu=True), fc.3 (res: fp32 here, handed to the kernel as hl32 rows like the
+    residual stream of og_forward).  Returns the output merged back to fp32."""
+    lib = _lib.load()
+    a, b = _req(a, "a"), _req(b, "b")
+    M, K = a.shape
+    N = b.shape[0]
+    a_hl, b_hl = split_f16_hl(a), split_f16_hl(b * 256.0)
+    if bias is not None: bias = _req(bias, "bias")
+    res_hl = split_f16_hl(_req(res, "res")) if res is not None else None
+    if planes:
+        ch = torch.empty(M, N, device=a.device, dtype=torch.float16); cl = torch.empty_like(ch); ldch = N
+    else:
+        ch = torch.empty(M, 2 * N, device=a.device, dtype=torch.float16); cl = None; ldch = 2 * N
+    rc = lib.og_gemm_nt_f16x3_reshl(a_hl.data_ptr(), 2 * K, b_hl.data_ptr(), 2 * K, M, N, K, 1.0 / 256.0, _ptr(bias), int(relu),
+                                    _ptr(res_hl), 2 * N, None, N, ch.data_ptr(), _ptr(cl), ldch, int(not planes), _stream())
+    _lib.check(rc, "og_gemm_nt_f16x3_reshl")
+    return merge_f16(ch, cl) if planes else merge_f16_hl(ch)
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int) -> torch.Tensor:
     """Multi-head softmax attention on token-major fp32 tensors q [Z,nq,D], k,v [Z,nk,D]; head h owns
     channels h*d..(h+1)*d-1.  q must already carry the d^-1/2 scale (the log2(e) factor of the kernel's

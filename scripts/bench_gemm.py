@@ -17,11 +17,14 @@ for name, M, N, K in shapes:
     a_hl, b_hl = ops.split_f16_hl(a), ops.split_f16_hl(b * 256.0)
     bias = torch.randn(N, generator=g).to(dev)
     planes = name in ('qkv', 'q_cross', 'kv_cross', 'qkv_cross')       # as in og_forward: q/k/v leave as planes, the MLP as hl32 rows
+    relu = name.startswith('fc0')                                      # fc.0: ReLU; fc.3: + the (hi, lo) residual stream; q/k/v: bias only
+    res = ops.split_f16_hl(torch.randn(M, N, generator=g).to(dev)) if name.startswith('fc3') else None
     ch = torch.empty(M, N if planes else 2 * N, device=dev, dtype=torch.float16); cl = torch.empty_like(ch) if planes else None
     st = torch.cuda.current_stream().cuda_stream
     def run():
-        rc = lib.og_gemm_nt_f16x3(a_hl.data_ptr(), 2 * K, b_hl.data_ptr(), 2 * K, M, N, K, 1.0 / 256.0, bias.data_ptr(), 1, None, N,
-                                  None, N, ch.data_ptr(), cl.data_ptr() if planes else None, N if planes else 2 * N, 0 if planes else 1, st)
+        rc = lib.og_gemm_nt_f16x3_reshl(a_hl.data_ptr(), 2 * K, b_hl.data_ptr(), 2 * K, M, N, K, 1.0 / 256.0, bias.data_ptr(), int(relu),
+                                        res.data_ptr() if res is not None else None, 2 * N,
+                                        None, N, ch.data_ptr(), cl.data_ptr() if planes else None, N if planes else 2 * N, 0 if planes else 1, st)
         assert rc == 0, rc
     for _ in range(3): run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -30,7 +33,9 @@ for name, M, N, K in shapes:
     for _ in range(reps): run()
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / reps * 1e3
-    ref = torch.relu(a[:256].double() @ b.double().T + bias.double())
+    ref = a[:256].double() @ b.double().T + bias.double()
+    if relu: ref = torch.relu(ref)
+    if res is not None: ref = ref + ops.merge_f16_hl(res[:256]).double()
     got = ops.merge_f16(ch[:256], cl[:256]) if planes else ops.merge_f16_hl(ch[:256])
     err = (got.double() - ref).abs().max().item()
     tf = 2.0 * M * N * K / us / 1e6

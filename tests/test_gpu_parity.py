@@ -79,6 +79,33 @@ def test_gemm_nt_f16x3_fp32_class_accuracy(gpu_device, M, N, K):
     assert torch.equal(ops.merge_f16_hl(chl).cpu(), merged)
 
 
+@pytest.mark.parametrize("M,N,K,form", [(49152, 768, 256, "planes"), (49152, 512, 512, "relu"), (49152, 256, 512, "res_hl"),
+                                        (49152, 256, 256, "relu_res_hl"), (24700, 512, 256, "res_hl"), (300, 192, 96, "res_hl")])
+def test_gemm_nt_f16x3_gnn_forms(gpu_device, M, N, K, form):
+    """The launch forms of the GNN (split-f16 output only): whole-tile shapes take the 256-tile kernel whose epilogue arithmetic is
+    fixed at compile time (q/k/v planes, fc.0 ReLU rows, fc.3 rows with the (hi, lo) residual); ragged / small shapes and
+    ReLU + residual take the run-time forms.  All must agree with float64 to fp32-GEMM accuracy, and with OG_GEMM_SPEC_EPI=0
+    the generic epilogue path (OG_GEMM_SPEC_EPI=0, exercised by scripts/gpu_gemm_epi.sh) must give the same bits."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a, b = _rand(g, M, K, scale=3.0), _rand(g, N, K, scale=0.05)
+    bias = _rand(g, N)
+    res = _rand(g, M, N, scale=5.0) if "res_hl" in form else None
+    relu = "relu" in form
+    dev = lambda t: t.to(gpu_device) if t is not None else None
+    out = ops.gemm_nt_f16x3_split_only(dev(a), dev(b), bias=dev(bias), relu=relu, res=dev(res), planes=form == "planes").cpu()
+    rows = torch.cat([torch.arange(0, 700), torch.arange(M - 300, M)]) if M > 1000 else torch.arange(M)     # float64 reference on a slice
+    ref = a[rows].double() @ b.double().T + bias.double()
+    if relu: ref = torch.relu(ref)
+    if res is not None:
+        res_hl = ops.merge_f16_hl(ops.split_f16_hl(dev(res))).cpu()      # what the kernel is given: the (hi, lo) representation
+        ref = ref + res_hl[rows].double()
+    fp32_err = ((a[rows] @ b.T).double() - a[rows].double() @ b.double().T).abs().max().item()
+    err = (out[rows].double() - ref).abs().max().item()
+    print(f"[f16x3 {form} {M}x{N}x{K}] err {err:.2e} (fp32 CPU GEMM err {fp32_err:.2e})")
+    assert err < max(2.0 * fp32_err, 1e-6) + 2e-6 * ref.abs().max().item()       # + the (hi, lo) output representation
+    assert torch.isfinite(out).all()
+
+
 def test_split_f16_roundtrip(gpu_device):
     g = torch.Generator().manual_seed(1)
     x = torch.cat([_rand(g, 1000, scale=s) for s in (1e-3, 1.0, 50.0, 3000.0)])
