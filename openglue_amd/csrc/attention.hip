@@ -567,8 +567,11 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(AttnArgs a, RD rd
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    auto tile_step = [&](int kt, auto BUF) {
+    // MASKED: this tile may hold padded keys (only the last tile of a problem can).  A compile-time flag: with the mask as a
+    // run-time branch the two sides of it merged the 32 score registers through register copies in EVERY tile.
+    auto tile_step = [&](int kt, auto BUF, auto MASKED) {
         constexpr int b = decltype(BUF)::value;
+        constexpr bool masked = decltype(MASKED)::value;
         const int key0 = kt * KV_TILE;
         OG_TP(0);
         const bool more = kt + 1 < ntiles;
@@ -630,7 +633,7 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(AttnArgs a, RD rd
             });
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
-                if (key0 + KV_TILE > nk) {                  // only the last tile can hold padded keys (block-uniform)
+                if (masked && key0 + KV_TILE > nk) {        // only the last tile can hold padded keys (block-uniform)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int key = key0 + kb * 32 + mfma32_row(r, lane);
@@ -736,9 +739,19 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(AttnArgs a, RD rd
             for (int i = 0; i < 8; ++i) og_attn_trace_buf[tsel][wave][kt][i] = tp[i];
 #endif
     };
-    for (int kt = 0; kt < ntiles; kt += 2) {
-        tile_step(kt, std::integral_constant<int, 0>{});
-        if (kt + 1 < ntiles) tile_step(kt + 1, std::integral_constant<int, 1>{});
+    {
+        using B0 = std::integral_constant<int, 0>; using B1 = std::integral_constant<int, 1>;
+        int kt = 0;
+        for (; kt + 2 < ntiles; kt += 2) {                 // pairs of tiles that are not the last one: no mask code at all
+            tile_step(kt, B0{}, std::false_type{});
+            tile_step(kt + 1, B1{}, std::false_type{});
+        }
+        if (kt + 1 < ntiles) {
+            tile_step(kt, B0{}, std::false_type{});
+            tile_step(kt + 1, B1{}, std::true_type{});
+        } else {
+            tile_step(kt, B0{}, std::true_type{});
+        }
     }
 
     // ---- normalise and store O[q][h*DH + dv] ----
