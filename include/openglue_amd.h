@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define OG_ABI_VERSION 3
+#define OG_ABI_VERSION 4
 
 #define OG_E_INVALID   (-1)  /* NULL pointer / non-positive size                         */
 #define OG_E_SHAPE     (-2)  /* unsupported shape (see og_check_shape)                   */
@@ -46,6 +46,11 @@ extern "C" {
 #define OG_FLAG_USE_OFFSET      2
 #define OG_FLAG_NO_DESCRIPTORS  4
 #define OG_FLAG_LINEAR_ATTENTION 16  /* attention_gnn.attention = 'linear': elu+1 linear attention (attention.py:22-40) instead of softmax */
+#define OG_FLAG_FAVOR_RELU      32  /* attention_gnn.attention = 'favor_relu': generalised FAVOR+ attention with ReLU random features
+                                       (attention.py:43-95, __init__.py:19-25): phi(x) = relu(P x d^-1/4) + 1e-8 on q and k, P the
+                                       [2D][D] buffer og_layer_params.favor_projection, then linear attention over the 2D features.
+                                       As in the reference this needs num_heads == 1 (its matmul of P with the per-head tensors only
+                                       type-checks when the head size equals D); D <= 256.  Not combinable with LINEAR_ATTENTION. */
 #define OG_FLAG_SIREN_ENCODER   8   /* positional_encoding.encoder_name = FeedForwardNetSiren: [Conv, sin(30x)]*h + Conv,
                                        no BatchNorm (models/utils.py:23-45); og_params.enc_bn is ignored */
 
@@ -58,7 +63,8 @@ typedef struct og_shape {
     int32_t batch;                  /* B image pairs                                             */
     int32_t m, n;                   /* keypoints per image 0 / image 1                           */
     int32_t desc_dim;               /* D = descriptor_dim = attention_gnn.embed_dim (mult. of 64) */
-    int32_t num_heads;              /* H; head h owns channels h*D/H .. (h+1)*D/H-1 (attention_gnn.py:24-26); D/H in {16,32,64} */
+    int32_t num_heads;              /* H; head h owns channels h*D/H .. (h+1)*D/H-1 (attention_gnn.py:24-26); D/H in {16,32,64}
+                                       (OG_FLAG_FAVOR_RELU: H == 1, any D <= 256) */
     int32_t num_stages;             /* L self+cross stages (attention_gnn.py:84-89)              */
     int32_t side_info;              /* s = positional_encoding.side_info_size (2+s <= 32)        */
     int32_t num_hidden;             /* len(positional_encoding.hidden_layers_sizes) <= OG_MAX_HIDDEN */
@@ -87,6 +93,8 @@ typedef struct og_layer_params {    /* attention_gnn.layers.{l}.module.*  (atten
     og_conv fc0;                                         /* fc.0   [2D][2D]        */
     og_bn   fc_bn;                                       /* fc.2   BatchNorm1d(2D) */
     og_conv fc3;                                         /* fc.3   [D][2D]         */
+    const float* favor_projection;                       /* mha.attention_func.projection_matrix [2D][D] (attention.py:53); read with
+                                                            OG_FLAG_FAVOR_RELU only, may be NULL otherwise (ABI v4)                  */
 } og_layer_params;
 
 typedef struct og_params {

@@ -11,8 +11,9 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OPENGLUE_AMD_LIB") or os.path.join(HERE, "lib", "libopenglue_amd.so")   # override: A/B builds
 
-OG_ABI_VERSION = 3
+OG_ABI_VERSION = 4
 OG_FLAG_RESIDUAL, OG_FLAG_USE_OFFSET, OG_FLAG_NO_DESCRIPTORS, OG_FLAG_SIREN_ENCODER, OG_FLAG_LINEAR_ATTENTION = 1, 2, 4, 8, 16
+OG_FLAG_FAVOR_RELU = 32
 OG_MAX_HIDDEN = 8
 OG_MAX_RAGGED = 64
 OG_STAGES = ("encoder_input", "gemm_f32", "attention", "sinkhorn", "matches", "gemm_f16x3")
@@ -42,7 +43,7 @@ class og_bn(C.Structure):
 
 class og_layer_params(C.Structure):
     _fields_ = [("in_proj_q", og_conv), ("in_proj_k", og_conv), ("in_proj_v", og_conv), ("out_proj", og_conv),
-                ("fc0", og_conv), ("fc_bn", og_bn), ("fc3", og_conv)]
+                ("fc0", og_conv), ("fc_bn", og_bn), ("fc3", og_conv), ("favor_projection", C.c_void_p)]
 
 
 class og_params(C.Structure):

@@ -28,6 +28,11 @@ struct PackedLayout {
 
 inline int64_t al64(int64_t x) { return og_round_up(x, 64); }   // 256-byte aligned sections
 
+// Width of the q (and k) block of the q | k | v planes and of the packed projection matrix: D channels, or with
+// attention = 'favor_relu' the 2D random features phi(q), phi(k) (the feature map's projection is folded into in_proj_q / in_proj_k).
+inline int qk_width(const og_shape& s) { return (s.flags & OG_FLAG_FAVOR_RELU) ? 2 * s.desc_dim : s.desc_dim; }
+inline int qkv_width(const og_shape& s) { return 2 * qk_width(s) + s.desc_dim; }
+
 PackedLayout packed_layout(const og_shape& s) {
     PackedLayout L{};
     const int64_t D = s.desc_dim;
@@ -48,8 +53,8 @@ PackedLayout packed_layout(const og_shape& s) {
     L.enc_whl = -1;
     if (L.n_enc >= 2 && L.enc_k[L.n_enc - 1] <= D) { L.enc_whl = off; off = al64(off + D * (int64_t)L.enc_k[L.n_enc - 1]); }
     int64_t lo = 0;
-    L.o_wqkv = lo; lo = al64(lo + 3 * D * D);
-    L.o_bqkv = lo; lo = al64(lo + 3 * D);
+    L.o_wqkv = lo; lo = al64(lo + qkv_width(s) * D);
+    L.o_bqkv = lo; lo = al64(lo + qkv_width(s));
     L.o_w0 = lo; lo = al64(lo + 4 * D * D);
     L.o_b0 = lo; lo = al64(lo + 2 * D);
     L.o_w3 = lo; lo = al64(lo + 2 * D * D);
@@ -79,8 +84,8 @@ WorkspaceLayout workspace_layout(const og_shape& s) {
     const int64_t ew = PL.enc_maxw > 0 ? PL.enc_maxw : 64;
     W.x32 = off; off = al64(off + T * D);
     W.xo = off; off = al64(off + T * 2 * D);       // [T] hl32 rows of [x | O]: 4D halves each
-    W.qkvh = off; off = al64(off + T * 3 * D / 2); // [T][3D] halves
-    W.qkvl = off; off = al64(off + T * 3 * D / 2);
+    W.qkvh = off; off = al64(off + T * qkv_width(s) / 2); // [T][3D] halves (favor_relu: [T][5D])
+    W.qkvl = off; off = al64(off + T * qkv_width(s) / 2);
     W.h = off; off = al64(off + T * 2 * D);        // [T] hl32 rows of the 2D hidden activations
     W.g = off; off = al64(off + T * D);
     W.ei = off; off = al64(off + T * 32);
@@ -99,7 +104,9 @@ int check_shape(const og_shape* s) {
     if (s->desc_dim <= 0 || s->desc_dim % 64) return OG_E_SHAPE;
     if (s->num_heads <= 0 || s->desc_dim % s->num_heads) return OG_E_SHAPE;
     const int dh = s->desc_dim / s->num_heads;
-    if (dh != 16 && dh != 32 && dh != 64) return OG_E_SHAPE;
+    if (s->flags & OG_FLAG_FAVOR_RELU) {      // the reference's FAVOR attention only runs with one head (openglue_amd.h)
+        if (s->num_heads != 1 || s->desc_dim > 256 || (s->flags & OG_FLAG_LINEAR_ATTENTION)) return OG_E_SHAPE;
+    } else if (dh != 16 && dh != 32 && dh != 64) return OG_E_SHAPE;
     if (s->num_stages < 0) return OG_E_SHAPE;
     if (s->side_info < 0 || 2 + s->side_info > 32) return OG_E_SHAPE;
     if (s->num_hidden < 0 || s->num_hidden > OG_MAX_HIDDEN) return OG_E_SHAPE;
@@ -107,7 +114,7 @@ int check_shape(const og_shape* s) {
         if (s->hidden[i] <= 0 || og_round_up(s->hidden[i], 64) > 2 * s->desc_dim) return OG_E_SHAPE;
     if (s->n > 8192) return OG_E_SHAPE;                 // Sinkhorn sweep geometry (sinkhorn.hip)
     if (s->sinkhorn_iters < 0 || !(s->sinkhorn_reg > 0.f)) return OG_E_SHAPE;
-    if (s->flags & ~(OG_FLAG_RESIDUAL | OG_FLAG_USE_OFFSET | OG_FLAG_NO_DESCRIPTORS | OG_FLAG_SIREN_ENCODER | OG_FLAG_LINEAR_ATTENTION)) return OG_E_FLAG;
+    if (s->flags & ~(OG_FLAG_RESIDUAL | OG_FLAG_USE_OFFSET | OG_FLAG_NO_DESCRIPTORS | OG_FLAG_SIREN_ENCODER | OG_FLAG_LINEAR_ATTENTION | OG_FLAG_FAVOR_RELU)) return OG_E_FLAG;
     return 0;
 }
 
@@ -230,6 +237,8 @@ extern "C" int og_pack_weights(const og_shape* shape, const og_params* P, void* 
     // Linear attention (attention.py:22-40) has no scale.
     const double qscale = (s.flags & OG_FLAG_LINEAR_ATTENTION) ? 1.0 : 1.4426950408889634 / sqrt((double)dh);
     const bool offset = s.flags & OG_FLAG_USE_OFFSET;
+    const bool favor = s.flags & OG_FLAG_FAVOR_RELU;
+    const int wq = qk_width(s);
     std::vector<double> Wm((size_t)D2 * D), prod((size_t)D2 * D), g, c;
     bool ok = true;                     // every split-f16 weight fits binary16 after the 256x pre-scale
     for (int l = 0; l < 2 * s.num_stages; ++l) {
@@ -241,10 +250,33 @@ extern "C" int og_pack_weights(const og_shape* shape, const og_params* P, void* 
         const og_conv* proj[3] = {&lp.in_proj_q, &lp.in_proj_k, &lp.in_proj_v};
         for (int p = 0; p < 3; ++p) {
             if (!proj[p]->weight || !proj[p]->bias) return OG_E_INVALID;
-            const double sc = p == 0 ? qscale : 1.0;
+            const int64_t row0 = p == 0 ? 0 : p == 1 ? wq : 2 * wq;      // q | k | v row blocks of the packed matrix
+            if (favor && p < 2) {
+                // randomized_kernel (attention.py:91-95): phi(x) = relu(P (x d^-1/4)) + eps on x = W t + b (d = D: one head)
+                //   => relu((d^-1/4 P W) t + d^-1/4 P b) + eps: the projection folds into the 1x1 conv, 2D output rows; the ReLU is
+                // the GEMM's epilogue, eps is added where the features are read (linear_attention.hip)
+                if (!lp.favor_projection) return OG_E_INVALID;
+                const double fs = pow((double)D, -0.25);
+                std::vector<double> row(D);
+                for (int f = 0; f < 2 * D; ++f) {
+                    const float* pf = lp.favor_projection + (int64_t)f * D;
+                    std::fill(row.begin(), row.end(), 0.0);
+                    double bb = 0.0;
+                    for (int o = 0; o < D; ++o) {
+                        const double pw = fs * (double)pf[o];
+                        const float* wr = proj[p]->weight + (int64_t)o * D;
+                        for (int k = 0; k < D; ++k) row[k] += pw * (double)wr[k];
+                        bb += pw * (double)proj[p]->bias[o];
+                    }
+                    for (int k = 0; k < D; ++k) ok &= put_split(Wqkv, row0 + f, k, D, row[k]);
+                    bqkv[row0 + f] = (float)bb;
+                }
+                continue;
+            }
+            const double sc = (p == 0 && !favor) ? qscale : 1.0;
             for (int o = 0; o < D; ++o)
-                for (int k = 0; k < D; ++k) ok &= put_split(Wqkv, (int64_t)p * D + o, k, D, proj[p]->weight[(int64_t)o * D + k] * sc);
-            for (int i = 0; i < D; ++i) bqkv[p * D + i] = (float)(proj[p]->bias[i] * sc);
+                for (int k = 0; k < D; ++k) ok &= put_split(Wqkv, row0 + o, k, D, proj[p]->weight[(int64_t)o * D + k] * sc);
+            for (int i = 0; i < D; ++i) bqkv[row0 + i] = (float)(proj[p]->bias[i] * sc);
         }
         // fc.0 on y = [x ; msg] (or [x - msg ; msg] with use_offset, attention_gnn.py:51-54), msg = Wo O + bo:
         //   W0 y = W0a x + Wm (Wo O + bo),  Wm = W0b (- W0a)   ->  [W0a | Wm Wo] [x ; O] + (b0 + Wm bo)
@@ -352,13 +384,15 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
     const WorkspaceLayout W = workspace_layout(s);
     const float* pk = (const float*)packed_dev;
     float* ws = (float*)workspace_dev;
-    const int D = s.desc_dim, D2 = 2 * D, D3 = 3 * D, B = s.batch, m = s.m, n = s.n;
+    const int D = s.desc_dim, D2 = 2 * D, B = s.batch, m = s.m, n = s.n;
+    const bool favor = s.flags & OG_FLAG_FAVOR_RELU;
+    const int WQ = qk_width(s), QW = qkv_width(s);      // q | k | v planes: columns [0, WQ) | [WQ, 2WQ) | [2WQ, QW); QW = 3D (5D: favor_relu)
     // uniform batch: B sets of m (n) tokens; ragged batch: packed sets, m and n are the maxima
     const int64_t T0 = rag ? rag->off0[B] : (int64_t)B * m, T1 = rag ? rag->off1[B] : (int64_t)B * n, T = T0 + T1;
     float* X32 = ws + W.x32; float* G = ws + W.g; float* Sb = ws + W.sbuf;
     const int D4 = 4 * D;
     _Float16* XO = (_Float16*)(ws + W.xo);             // [T] hl32 rows of [x | O]: 4D halves, x in the first 2D, O in the last 2D
-    _Float16* QKVh = (_Float16*)(ws + W.qkvh); _Float16* QKVl = (_Float16*)(ws + W.qkvl);  // planes [T][3D]: q | k | v
+    _Float16* QKVh = (_Float16*)(ws + W.qkvh); _Float16* QKVl = (_Float16*)(ws + W.qkvl);  // planes [T][QW]: q | k | v
     _Float16* Hb = (_Float16*)(ws + W.h);              // [T] hl32 rows of the hidden activations (4D halves)
     int rc;
 
@@ -442,14 +476,31 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
                          int64_t qb1, int64_t qs1, int nq1, int64_t kb1, int64_t ks1, int nk1, int rag_mode) -> int {
         AttnArgs a{};
         a.rag = rag; a.rag_mode = rag_mode;
-        a.qh = QKVh; a.ql = QKVl; a.ldq = D3; a.kh = QKVh + D; a.kl = QKVl + D; a.ldk = D3;
-        a.vh = QKVh + D2; a.vl = QKVl + D2; a.ldv = D3;
+        a.qh = QKVh; a.ql = QKVl; a.ldq = QW; a.kh = QKVh + WQ; a.kl = QKVl + WQ; a.ldk = QW;
+        a.vh = QKVh + 2 * WQ; a.vl = QKVl + 2 * WQ; a.ldv = QW;
+        a.feat = favor ? WQ : 0;
         a.oh = XO + D2; a.ol = XO + D2 + 32; a.ldo = D4; a.o_hl = 1;        // O = channels D..2D-1 of the [x | O] rows
         a.nz = nz; a.num_heads = s.num_heads; a.dh = dh; a.split = split;
         a.q_base[0] = qb0; a.q_step[0] = qs0; a.nq[0] = nq0; a.kv_base[0] = kb0; a.kv_step[0] = ks0; a.nk[0] = nk0;
         a.q_base[1] = qb1; a.q_step[1] = qs1; a.nq[1] = nq1; a.kv_base[1] = kb1; a.kv_step[1] = ks1; a.nk[1] = nk1;
         Scope sc(prof, OG_STAGE_ATTENTION);
+        if (favor) return og_launch_favor_attention(a, st);
         return (s.flags & OG_FLAG_LINEAR_ATTENTION) ? og_launch_linear_attention(a, st) : og_launch_attention(a, st);
+    };
+    // q / k / v projections of token rows [r0, r0 + R): columns [c0, c1) of the q | k | v planes = rows [c0, c1) of the packed
+    // projection matrix.  One launch; with favor_relu the feature blocks (columns < 2 WQ) carry the ReLU of the feature map and the
+    // value block does not, so a range that spans both is two launches.
+    auto qkv_proj = [&](const float* lw, int64_t r0, int64_t R, int c0, int c1) -> int {
+        const int cut = favor ? 2 * WQ : c1;
+        const int ca[2] = {c0, c0 < cut && cut < c1 ? cut : c1}, cb[2] = {ca[1], c1};
+        for (int part = 0; part < 2; ++part) {
+            const int a0 = part ? cb[0] : ca[0], a1 = part ? cb[1] : ca[1];
+            if (a1 <= a0) continue;
+            const int relu = favor && a0 < 2 * WQ;
+            if (int e = gemmh(XO + r0 * D4, lw, L.o_wqkv, a0, R, a1 - a0, D, lw + L.o_bqkv + a0, relu, nullptr, nullptr, QKVh + r0 * QW + a0,
+                              QKVl + r0 * QW + a0, QW, 0)) return e;
+        }
+        return 0;
     };
     // message MLP on token rows [r0, r0+R):  h = relu([x;O] W0'^T + b0') ; x += h W3'^T + b3'  (x kept in fp32 AND as planes)
     // message MLP on token rows [r0, r0+R):  h = relu([x;O] W0'^T + b0') ; x += h W3'^T + b3'.  x lives as hl32 (hi, lo)
@@ -462,7 +513,7 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
     for (int l = 0; l < s.num_stages; ++l) {
         // self layer 2l: both images through the same weights (attention_gnn.py:63-66)
         const float* lw = pk + L.layer0 + (int64_t)(2 * l) * L.layer_stride;
-        if ((rc = gemmh(XO, lw, L.o_wqkv, 0, T, D3, D, lw + L.o_bqkv, 0, nullptr, nullptr, QKVh, QKVl, D3, 0))) return rc;
+        if ((rc = qkv_proj(lw, 0, T, 0, QW))) return rc;
         if ((rc = attention(2 * B, B, 0, m, m, 0, m, m, T0, n, n, T0, n, n, 1))) return rc;
         if ((rc = mlp(lw, 0, T))) return rc;
         // cross layer 2l+1: image 0 first, then image 1 against the UPDATED image 0 (attention_gnn.py:74-77)
@@ -471,12 +522,11 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
             const int64_t qr0 = side ? T0 : 0, qR = side ? T1 : T0;       // query rows
             if (side == 0) {
                 // image 1 is still untouched: its k, v (for this half) and its q (for the second half) in ONE launch
-                if ((rc = gemmh(XO + T0 * D4, lw, L.o_wqkv, 0, T1, D3, D, lw + L.o_bqkv, 0, nullptr, nullptr, QKVh + T0 * D3,
-                                QKVl + T0 * D3, D3, 0))) return rc;
-                if ((rc = gemmh(XO, lw, L.o_wqkv, 0, T0, D, D, lw + L.o_bqkv, 0, nullptr, nullptr, QKVh, QKVl, D3, 0))) return rc;
+                if ((rc = qkv_proj(lw, T0, T1, 0, QW))) return rc;
+                if ((rc = qkv_proj(lw, 0, T0, 0, WQ))) return rc;
             } else {
                 // k, v of the UPDATED image 0
-                if ((rc = gemmh(XO, lw, L.o_wqkv, D, T0, D2, D, lw + L.o_bqkv + D, 0, nullptr, nullptr, QKVh + D, QKVl + D, D3, 0))) return rc;
+                if ((rc = qkv_proj(lw, 0, T0, WQ, QW))) return rc;
             }
             if (side == 0) rc = attention(B, B, 0, m, m, T0, n, n, 0, 0, 0, 0, 0, 0, 2);
             else rc = attention(B, B, T0, n, n, 0, m, m, 0, 0, 0, 0, 0, 0, 3);

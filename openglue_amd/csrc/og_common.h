@@ -162,9 +162,11 @@ struct AttnArgs {
     int qtiles;               // set by the launcher: query tiles per (problem, head)
     const RaggedDesc* rag;    // host pointer or null; with rag_mode: 1 = self (z < B image 0, else image 1),
     int rag_mode;             // 2 = cross, queries of image 0 attend image 1, 3 = cross, image 1 attends image 0
+    int feat;                 // og_launch_favor_attention only: random features per head (columns of q and k; v / out have dh columns)
 };
 int og_launch_attention(const AttnArgs& a, hipStream_t stream);
 int og_launch_linear_attention(const AttnArgs& a, hipStream_t stream);   // attention = 'linear' (elu+1 feature map)
+int og_launch_favor_attention(const AttnArgs& a, hipStream_t stream);    // attention = 'favor_relu': q, k hold relu(P x d^-1/4) (a.feat columns)
 
 // m, n are the (maximum) sizes; with `rag` pair b uses m_b, n_b, S stays at stride m*lds per pair, scores are packed
 // row_best (optional): the kernel that writes the scores also leaves max / argmax_j<n of every row i<m there (the first half of the

@@ -27,7 +27,7 @@ import torch.nn as nn
 from . import _lib
 
 _ENCODERS = ("FeedForwardNet", "FeedForwardNetSiren")
-_ATTENTIONS = ("softmax", "linear")      # FAVOR variants: out of scope ('favor_softmax' is unreachable upstream)
+_ATTENTIONS = ("softmax", "linear", "favor_relu")      # 'favor_softmax' is unreachable upstream (NameError, models/superglue/__init__.py:26)
 
 
 def _mlp_container(*sizes: int) -> nn.Sequential:
@@ -48,6 +48,25 @@ def _siren_container(*sizes: int) -> nn.Sequential:
         layers += [nn.Conv1d(sizes[i - 1], sizes[i], kernel_size=1), nn.Identity()]
     layers.append(nn.Conv1d(sizes[-2], sizes[-1], kernel_size=1))
     return nn.Sequential(*layers)
+
+
+class _FavorFeatures(nn.Module):
+    """Buffer container named like the reference's GeneralizedFavorAttention (attention.py:43-95; created by
+    get_attention_mechanism(embed_dim, 'favor_relu'), __init__.py:19-25, as `mha.attention_func`): `projection_matrix`
+    [2 * embed_dim, embed_dim], drawn like FavorAttention.sample_orthogonal_random_vectors, and `resample_projection()` for the
+    redraw callback (utils/lightning_callbacks.py:6-14)."""
+
+    def __init__(self, embed_dim: int):
+        super().__init__()
+        from .synthetic import orthogonal_random_features
+        self.embed_dim, self.num_orthogonal_features = embed_dim, 2 * embed_dim
+        self.register_buffer("projection_matrix", orthogonal_random_features(self.num_orthogonal_features, embed_dim))
+
+    @torch.no_grad()
+    def resample_projection(self) -> None:
+        from .synthetic import orthogonal_random_features
+        new = orthogonal_random_features(self.num_orthogonal_features, self.embed_dim)
+        self.projection_matrix.copy_(new.to(self.projection_matrix.device))      # in place: bumps _version, the packed weights re-pack
 
 
 class _Holder(nn.Module):
@@ -89,6 +108,11 @@ class SuperGlue(nn.Module):
         self.num_stages, self.num_heads = int(gnn["num_stages"]), int(gnn["num_heads"])
         self.use_offset = bool(gnn.get("use_offset", False))
         self.linear_attention = attn == "linear"
+        self.favor_relu = attn == "favor_relu"
+        if self.favor_relu and (self.num_heads != 1 or D > 256):
+            # the reference multiplies its [2D, D] feature buffer with per-head [B, H, D/H, N] tensors (attention.py:94): with more
+            # than one head torch.matmul raises inside forward; fail at construction instead
+            raise ValueError("attention 'favor_relu' runs with num_heads == 1 only (as in the reference) and descriptor_dim <= 256")
         self.residual = bool(config.get("residual", False))
         self.no_descriptors = bool(config.get("no_descriptors", False))
 
@@ -98,7 +122,8 @@ class SuperGlue(nn.Module):
         self.positional_encoding = _Holder(encoder=make_enc(2 + self.side_info_size, *self.hidden, D))
         layers = nn.ModuleList()
         for _ in range(2 * self.num_stages):       # even = self, odd = cross (attention_gnn.py:84-89)
-            mha = _Holder(in_proj_q=nn.Conv1d(D, D, 1), in_proj_k=nn.Conv1d(D, D, 1),
+            favor = dict(attention_func=_FavorFeatures(D)) if self.favor_relu else {}
+            mha = _Holder(**favor, in_proj_q=nn.Conv1d(D, D, 1), in_proj_k=nn.Conv1d(D, D, 1),
                           in_proj_v=nn.Conv1d(D, D, 1), out_proj=nn.Conv1d(D, D, 1))
             layers.append(_Holder(module=_Holder(mha=mha, fc=_mlp_container(2 * D, 2 * D, D))))
         self.attention_gnn = _Holder(layers=layers)
@@ -129,7 +154,8 @@ class SuperGlue(nn.Module):
         s.flags = ((_lib.OG_FLAG_RESIDUAL if self.residual else 0) | (_lib.OG_FLAG_USE_OFFSET if self.use_offset else 0)
                    | (_lib.OG_FLAG_NO_DESCRIPTORS if self.no_descriptors else 0)
                    | (_lib.OG_FLAG_SIREN_ENCODER if self.siren else 0)
-                   | (_lib.OG_FLAG_LINEAR_ATTENTION if self.linear_attention else 0))
+                   | (_lib.OG_FLAG_LINEAR_ATTENTION if self.linear_attention else 0)
+                   | (_lib.OG_FLAG_FAVOR_RELU if self.favor_relu else 0))
         s.match_threshold = float(match_threshold)
         return s
 
@@ -224,6 +250,7 @@ class SuperGlue(nn.Module):
             lp.in_proj_q, lp.in_proj_k = conv(mod.mha.in_proj_q), conv(mod.mha.in_proj_k)
             lp.in_proj_v, lp.out_proj = conv(mod.mha.in_proj_v), conv(mod.mha.out_proj)
             lp.fc0, lp.fc_bn, lp.fc3 = conv(mod.fc[0]), bn(mod.fc[2]), conv(mod.fc[3])
+            lp.favor_projection = host(mod.mha.attention_func.projection_matrix) if self.favor_relu else None
         P.layers = C.cast(layer_arr, C.POINTER(_lib.og_layer_params))
         P.linear_proj = conv(self.linear_proj)
         P.mix_coefs = host(self.mix_coefs) if self.residual else None

@@ -103,8 +103,12 @@ def state_dict_spec(config: dict) -> "OrderedDict[str, tuple]":
             bn(f"positional_encoding.encoder.{idx + 2}", sizes[i])
             idx += 3
         conv(f"positional_encoding.encoder.{idx}", sizes[-1], sizes[-2])
+    favor = config["attention_gnn"].get("attention", "softmax") == "favor_relu"
     for l in range(2 * L):
         p = f"attention_gnn.layers.{l}.module"
+        if favor:   # GeneralizedFavorAttention registers its random features as a buffer (attention.py:43-53; __init__.py:19-25:
+            #         num_orthogonal_features = 2 * embed_dim), created before the projections (attention_gnn.py:14)
+            spec[f"{p}.mha.attention_func.projection_matrix"] = ((2 * D, D), "favor_proj", D)
         for name in ("in_proj_q", "in_proj_k", "in_proj_v", "out_proj"):
             conv(f"{p}.mha.{name}", D, D)
         conv(f"{p}.fc.0", 2 * D, 2 * D)
@@ -112,6 +116,18 @@ def state_dict_spec(config: dict) -> "OrderedDict[str, tuple]":
         conv(f"{p}.fc.3", D, 2 * D)
     conv("linear_proj", D, D)
     return spec
+
+
+def orthogonal_random_features(num_rows: int, num_cols: int, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+    """FAVOR+ random features as the reference draws them (FavorAttention.sample_orthogonal_random_vectors, attention.py:62-78):
+    ceil(rows / cols) Gaussian blocks [cols, cols], each orthogonalised by QR, the unit rows rescaled by the norms of the
+    Gaussian rows."""
+    blocks = math.ceil(num_rows / num_cols)
+    unstructured = torch.randn(blocks, num_cols, num_cols, generator=generator)
+    norm = unstructured.norm(dim=-1).view(-1, 1)
+    q, _ = torch.linalg.qr(unstructured, mode="reduced")
+    q = q.transpose(-1, -2).reshape(-1, num_cols)
+    return q[:num_rows] * norm[:num_rows]
 
 
 def make_state_dict(config: dict, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
@@ -135,6 +151,8 @@ def make_state_dict(config: dict, seed: int = 0) -> "OrderedDict[str, torch.Tens
             t = 0.5 * torch.randn(shape, generator=g)
         elif kind == "dustbin":
             t = torch.tensor(float(config["dustbin_score_init"]))
+        elif kind == "favor_proj":
+            t = orthogonal_random_features(shape[0], shape[1], g)
         else:  # pragma: no cover
             raise AssertionError(kind)
         out[name] = t

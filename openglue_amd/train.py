@@ -389,7 +389,7 @@ def superglue_forward_train(model, data):
     torch.autograd.Functions -- loss.backward() reaches every parameter.  Glue that stays torch tensor algebra: keypoint
     normalisation, concatenations, residual adds, the sigmoid mix.  Supported: encoder FeedForwardNet, softmax attention,
     use_offset, residual, no_descriptors."""
-    if model.siren or model.linear_attention:
+    if model.siren or model.linear_attention or getattr(model, 'favor_relu', False):
         raise NotImplementedError("training mode: FeedForwardNet encoder and softmax attention only")
     D, H = model.descriptor_dim, model.num_heads
     k0, k1 = data["keypoints0"], data["keypoints1"]

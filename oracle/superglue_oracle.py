@@ -128,6 +128,21 @@ def linear_attention_elu(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_
     return o.transpose(1, 2).reshape(B, nq, D)
 
 
+def favor_relu_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, projection: torch.Tensor, eps: float = 1e-8) -> torch.Tensor:
+    """attention = 'favor_relu' (__init__.py:19-25: GeneralizedFavorAttention(embed_dim, ReLU, 2 * embed_dim features, eps = 1e-8)):
+    randomized_kernel (attention.py:91-95)  phi(x) = relu(P (x * d^-1/4)) + eps  with d = x.size(2) = the head size, applied to
+    q and k, then linear_attention (attention.py:29-40): out = phi(q) (phi(k)^T v) / (phi(q) . sum_keys phi(k)).
+    The reference multiplies the [2D, D] buffer with [B, H, d, N] tensors, which only type-checks for d == D: num_heads == 1
+    (a 4-head config raises inside torch.matmul).  q, k, v token-major [B, n, D]."""
+    d = q.shape[-1]
+    P = projection.to(q.dtype)
+    fq = torch.relu((q * d ** -0.25) @ P.T) + eps                # [B, nq, F]
+    fk = torch.relu((k * d ** -0.25) @ P.T) + eps                # [B, nk, F]
+    kv = fk.transpose(-1, -2) @ v                                # [B, F, D]
+    norm = fq @ fk.sum(1, keepdim=True).transpose(-1, -2)        # [B, nq, 1]
+    return (fq @ kv) / norm
+
+
 def message_passing(xq: torch.Tensor, xkv: torch.Tensor, sd, prefix: str, num_heads: int,
                     use_offset: bool, attn_operand_dtype=None, attention: str = "softmax") -> torch.Tensor:
     """ResidualAttentionMessagePropagation.forward, attention_gnn.py:43-55, with
@@ -135,7 +150,14 @@ def message_passing(xq: torch.Tensor, xkv: torch.Tensor, sd, prefix: str, num_he
     q = conv1x1(xq, sd, prefix + ".mha.in_proj_q")
     k = conv1x1(xkv, sd, prefix + ".mha.in_proj_k")
     v = conv1x1(xkv, sd, prefix + ".mha.in_proj_v")
-    att = linear_attention_elu(q, k, v, num_heads) if attention == "linear" else softmax_attention(q, k, v, num_heads, attn_operand_dtype)
+    if attention == "linear":
+        att = linear_attention_elu(q, k, v, num_heads)
+    elif attention == "favor_relu":
+        if num_heads != 1:
+            raise ValueError("favor_relu: the reference only runs with num_heads == 1")
+        att = favor_relu_attention(q, k, v, _w(sd, prefix + ".mha.attention_func.projection_matrix", q.dtype))
+    else:
+        att = softmax_attention(q, k, v, num_heads, attn_operand_dtype)
     msg = conv1x1(att, sd, prefix + ".mha.out_proj")
     y = torch.cat([xq - msg, msg], dim=-1) if use_offset else torch.cat([xq, msg], dim=-1)
     return xq + feed_forward(y, sd, prefix + ".fc", 2)
@@ -148,7 +170,7 @@ def attentional_gnn(x0: torch.Tensor, x1: torch.Tensor, sd, config, attn_operand
     g = config["attention_gnn"]
     H, off = g["num_heads"], g.get("use_offset", False)
     att = g.get("attention", "softmax")
-    if att not in ("softmax", "linear"):
+    if att not in ("softmax", "linear", "favor_relu"):
         raise ValueError(f"oracle: attention {att} not restated")
     for l in range(g["num_stages"]):
         ps, pc = f"attention_gnn.layers.{2 * l}.module", f"attention_gnn.layers.{2 * l + 1}.module"

@@ -46,6 +46,8 @@ CASES = {
                    encoder_name="FeedForwardNetSiren", hidden_layers_sizes=(32, 64)), 80, 75, 2, 6, "full"),
     "linear": (dict(descriptor_dim=128, num_stages=2, num_heads=4, num_iters=8, side_info_size=1, attention="linear"),
                150, 97, 2, 7, "full"),
+    "favor": (dict(descriptor_dim=128, num_stages=2, num_heads=1, num_iters=8, side_info_size=1, attention="favor_relu"),
+              140, 101, 2, 8, "full"),
     "c2": (dict(syn.CONFIGS["C2"]), 1024, 1024, 2, 5, "sub8"),
 }
 
@@ -135,7 +137,10 @@ def stage_cases():
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    only = sys.argv[1:]                      # e.g. `make_golden.py favor`: (re)generate the named cases only
     for name, (kw, m, n, batch, seed, store) in CASES.items():
-        full_case(name, kw, m, n, batch, seed, store)
-    stage_cases()
+        if not only or name in only:
+            full_case(name, kw, m, n, batch, seed, store)
+    if not only:
+        stage_cases()
     print("torch", torch.__version__)

@@ -65,10 +65,19 @@ def forward_from_packed(model, data, dtype=torch.float64):
 
     def prop(l, xq, xkv):
         base = L.layer0 + l * L.layer_stride
-        Wqkv, bqkv = planes(base + L.o_wqkv, 3 * D, D), vec(base + L.o_bqkv, 3 * D)
-        q = xq @ Wqkv[:D].T + bqkv[:D]
-        kv = xkv @ Wqkv[D:].T + bqkv[D:]
-        o = attn(q, kv[..., :D], kv[..., D:])
+        if getattr(model, "favor_relu", False):
+            # favor_relu (api.hip): rows [0, 2D) / [2D, 4D) = d^-1/4 P folded into in_proj_q / in_proj_k (ReLU in the GEMM epilogue,
+            # + eps where the features are read), rows [4D, 5D) = in_proj_v; then linear attention over the 2D features
+            Wqkv, bqkv = planes(base + L.o_wqkv, 5 * D, D), vec(base + L.o_bqkv, 5 * D)
+            fq = torch.relu(xq @ Wqkv[:2 * D].T + bqkv[:2 * D]) + 1e-8
+            fk = torch.relu(xkv @ Wqkv[2 * D:4 * D].T + bqkv[2 * D:4 * D]) + 1e-8
+            v = xkv @ Wqkv[4 * D:].T + bqkv[4 * D:]
+            o = (fq @ (fk.transpose(-1, -2) @ v)) / (fq @ fk.sum(1, keepdim=True).transpose(-1, -2))
+        else:
+            Wqkv, bqkv = planes(base + L.o_wqkv, 3 * D, D), vec(base + L.o_bqkv, 3 * D)
+            q = xq @ Wqkv[:D].T + bqkv[:D]
+            kv = xkv @ Wqkv[D:].T + bqkv[D:]
+            o = attn(q, kv[..., :D], kv[..., D:])
         h = torch.relu(torch.cat([xq, o], -1) @ planes(base + L.o_w0, 2 * D, 2 * D).T + vec(base + L.o_b0, 2 * D))
         return xq + h @ planes(base + L.o_w3, D, 2 * D).T + vec(base + L.o_b3, D)
 

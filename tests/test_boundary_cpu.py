@@ -33,7 +33,7 @@ def test_struct_sizes_match_header():
     # og_shape: 8 ints + 8 hidden + int + float + int + float = 20 * 4 bytes
     assert C.sizeof(_lib.og_shape) == 80
     assert C.sizeof(_lib.og_conv) == 16 and C.sizeof(_lib.og_bn) == 32
-    assert C.sizeof(_lib.og_layer_params) == 5 * 16 + 32 + 16
+    assert C.sizeof(_lib.og_layer_params) == 5 * 16 + 32 + 16 + 8     # + favor_projection (ABI v4)
     assert C.sizeof(_lib.og_inputs) == 6 * 8 + 16 and C.sizeof(_lib.og_outputs) == 7 * 8
 
 
@@ -55,13 +55,15 @@ def test_state_dict_layout_matches_reference_names():
 def test_state_dict_equals_live_reference():
     sys.path.insert(0, "/root/reference")
     from models.superglue.superglue import SuperGlue as Ref
-    cfg = syn.make_config(descriptor_dim=64, num_stages=2, num_heads=4, num_iters=3, side_info_size=6)
-    a, b = Ref(cfg).state_dict(), SuperGlue(cfg).state_dict()
-    assert list(a.keys()) == list(b.keys())          # same names in the same registration order
-    assert {k: tuple(v.shape) for k, v in a.items()} == {k: tuple(v.shape) for k, v in b.items()}
+    for kw in (dict(num_heads=4), dict(num_heads=1, attention="favor_relu")):      # favor_relu: + the projection_matrix buffers
+        cfg = syn.make_config(descriptor_dim=64, num_stages=2, num_iters=3, side_info_size=6, **kw)
+        a, b = Ref(cfg).state_dict(), SuperGlue(cfg).state_dict()
+        assert list(a.keys()) == list(b.keys())          # same names in the same registration order
+        assert {k: tuple(v.shape) for k, v in a.items()} == {k: tuple(v.shape) for k, v in b.items()}
+        assert list(syn.state_dict_spec(cfg)) == list(a.keys())
 
 
-@pytest.mark.parametrize("name", ["c1", "flags", "nodesc", "mid", "siren", "linear"])
+@pytest.mark.parametrize("name", ["c1", "flags", "nodesc", "mid", "siren", "linear", "favor"])
 def test_pack_weights_algebra_against_oracle(name):
     """og_pack_weights (BN folds, out_proj -> fc.0 fold, q pre-scale, padding) evaluated on the CPU in
     float64 must reproduce the oracle: proves the packed blob og_forward consumes is right."""
@@ -92,9 +94,17 @@ def test_error_behaviour():
     bad = dict(cfg); bad["positional_encoding"] = dict(cfg["positional_encoding"], encoder_name="Nope")
     with pytest.raises(NameError):           # reference: get_positional_encoder raises NameError (__init__.py:39-42)
         SuperGlue(bad)
-    bad = dict(cfg); bad["attention_gnn"] = dict(cfg["attention_gnn"], attention="favor_relu")
+    bad = dict(cfg); bad["attention_gnn"] = dict(cfg["attention_gnn"], attention="favor_relu")     # 4 heads: the reference's
+    with pytest.raises(ValueError):                                                                # forward raises in torch.matmul
+        SuperGlue(bad)
+    bad = dict(cfg); bad["attention_gnn"] = dict(cfg["attention_gnn"], attention="favor_softmax")  # unreachable upstream
     with pytest.raises(ValueError):
         SuperGlue(bad)
+    fav = dict(cfg); fav["attention_gnn"] = dict(cfg["attention_gnn"], attention="favor_relu", num_heads=1)
+    fm = SuperGlue(fav).eval()
+    k0 = fm._param_key("cpu")
+    fm.attention_gnn.layers[0].module.mha.attention_func.resample_projection()      # the redraw callback's hook: triggers a re-pack
+    assert fm._param_key("cpu") != k0
     model = SuperGlue(cfg).eval()
     data = syn.make_batch(1, 16, 16, 64, 1, seed=0)
     with pytest.raises(RuntimeError, match="no CPU fallback"):      # product path never computes on the CPU

@@ -274,7 +274,7 @@ def _index_agreement(got_matches0, scores_gpu, sd, cfg, data):
     return int(diff.sum()), 0, o64
 
 
-@pytest.mark.parametrize("name", ["c1", "mid", "flags", "nodesc", "siren", "linear"])
+@pytest.mark.parametrize("name", ["c1", "mid", "flags", "nodesc", "siren", "linear", "favor"])
 def test_forward_against_reference_fixture(gpu_device, name):
     z, cfg, sd, data = load_case(name)
     model = _build(cfg, sd, gpu_device)
@@ -521,6 +521,35 @@ def test_forward_edge_shapes(gpu_device, m, n, kw):
     amb_r, _ = orc.ambiguous_rows(ref["scores"].double(), 1e-3) if m > 1 and n > 1 else (torch.zeros(2, m, dtype=torch.bool), None)
     diff = (out["matches0"] != ref["matches0"]) & ~amb_r
     assert int(diff.sum()) == 0
+
+
+@pytest.mark.parametrize("D,m,n,B", [(256, 300, 170, 2), (64, 17, 40, 3), (192, 2, 33, 1)])
+def test_favor_relu_attention_whole_path(gpu_device, D, m, n, B):
+    """attention = 'favor_relu' (one head, 2D ReLU random features; attention.py:43-95) at the widest supported size (D = 256:
+    512 features, 8 column slices per problem, two features per thread), at a narrow one and with two queries -- against the
+    oracle, which tests/golden/favor.npz pins to the reference; uniform and token-packed (ragged) launches."""
+    cfg = syn.make_config(descriptor_dim=D, num_stages=2, num_heads=1, num_iters=6, side_info_size=1, attention="favor_relu")
+    sd = syn.make_state_dict(cfg, seed=2)
+    model = _build(cfg, sd, gpu_device)
+    data = syn.make_batch(B, m, n, D, 1, seed=11)
+    out = {k: v.cpu() for k, v in model.match(to_device(data, gpu_device), MATCH_THRESHOLD).items()}
+    with torch.no_grad():
+        ref = orc.match_pairs(sd, cfg, data, MATCH_THRESHOLD)
+    err = (out["scores"] - ref["scores"]).abs().max().item()
+    print(f"[favor_relu D={D} {m}x{n}] scores err {err:.2e}")
+    assert err < TOL_SCORES, err
+    assert (out["context_descriptors0"] - ref["context_descriptors0"]).abs().max() < TOL_SCORES
+    ndiff, unexplained, _ = _index_agreement(out["matches0"], out["scores"], sd, cfg, data)
+    assert unexplained == 0, (ndiff, unexplained)
+    # ragged launch of the same pairs (per-pair row ranges from the descriptor) = the uniform result
+    pairs = []
+    for b in range(B):
+        p = {k: v[b] for k, v in data.items() if torch.is_tensor(v)}
+        p["image0_size"] = data["image0_size"]; p["image1_size"] = data["image1_size"]
+        pairs.append(to_device(p, gpu_device))
+    for b, r in enumerate(model.match_ragged(pairs, MATCH_THRESHOLD)):
+        assert (r["scores"].cpu() - out["scores"][b]).abs().max() < 1e-4
+        assert torch.equal(r["matches0"].cpu(), out["matches0"][b])
 
 
 # ----------------------------------------------------------------------------- on-chip-resident Sinkhorn iterations

@@ -13,7 +13,7 @@ TOL_SCORES = 2e-4
 TOL_DESC = 2e-5
 
 
-@pytest.mark.parametrize("name", ["c1", "mid", "flags", "nodesc", "siren", "linear"])
+@pytest.mark.parametrize("name", ["c1", "mid", "flags", "nodesc", "siren", "linear", "favor"])
 def test_forward_matches_reference_fixture(name):
     z, cfg, sd, data = load_case(name)
     with torch.no_grad():
