@@ -522,8 +522,20 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
             const int64_t qr0 = side ? T0 : 0, qR = side ? T1 : T0;       // query rows
             if (side == 0) {
                 // image 1 is still untouched: its k, v (for this half) and its q (for the second half) in ONE launch
-                if ((rc = qkv_proj(lw, T0, T1, 0, QW))) return rc;
-                if ((rc = qkv_proj(lw, 0, T0, 0, WQ))) return rc;
+                // ... and the q of image 0 with them when the shapes allow it (whole 256-row / 256-column tiles): rows < T0 of the launch
+                // stop after the q columns.  [Two launches: 56 + 20 us at C2; one: the 512 tiles are exactly two rounds of the 256 CUs.]
+                GemmHArgs g{};
+                g.A = XO; g.lda = D4; g.B = (const _Float16*)(lw + L.o_wqkv); g.ldb = 2 * D;
+                g.M = (int)T; g.N = QW; g.K = D; g.scale = (float)(1.0 / OG_W_SCALE); g.bias = lw + L.o_bqkv;
+                g.Ch = QKVh; g.Cl = QKVl; g.ldch = QW; g.c_hl = 0; g.ldc = D; g.ldr = D; g.ldrh = D4;
+                g.split_row = (int)T0; g.split_n = WQ;
+                if (!favor && !rag && T < (int64_t)1 << 30 && og_gemm_f16x3_row_split_ok(g)) {
+                    Scope sc(prof, OG_STAGE_GEMM_F16X3);
+                    if ((rc = og_launch_gemm_f16x3(g, st))) return rc;
+                } else {
+                    if ((rc = qkv_proj(lw, T0, T1, 0, QW))) return rc;
+                    if ((rc = qkv_proj(lw, 0, T0, 0, WQ))) return rc;
+                }
             } else {
                 // k, v of the UPDATED image 0
                 if ((rc = qkv_proj(lw, 0, T0, WQ, QW))) return rc;

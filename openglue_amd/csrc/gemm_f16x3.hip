@@ -348,14 +348,49 @@ __device__ __forceinline__ void gemm_f16x3_epilogue_fast(const GemmHArgs& g, f32
     char* const out_h = reinterpret_cast<char*>(g.Ch);
     char* const out_l = reinterpret_cast<char*>(g.Cl);
     og_u32x4 raw[2][4];
-    if constexpr (HAS_RES) gemm_f16x3_load_residual<2, EM == OG_EM_RES_HL>(g, raw, tok0, oc0, lane);
+    // (hi, lo) residual, COALESCED: in the accumulator layout a lane owns one token and 4 channels per group, so fetching the residual
+    // directly means 8-byte pieces of 64 different 128-byte lines per load instruction -- 16 instructions per slice, ~1000 line
+    // accesses at the L1, ~30k cycles per 256 x 256 tile (fc.3 with the residual: 70 us against 54 without at C2).  Instead the
+    // slice's residual rows come in like the output rows go out: whole lines, 16 B per lane (8 rows x 128 B per instruction, one
+    // slice ahead, in registers), and are turned into the accumulator layout through the two slabs the output transposes use
+    // afterwards (LDS serves one wave's instructions in order: no extra synchronisation).
+    constexpr bool RES_SLAB = EM == OG_EM_RES_HL && HL;
+    og_u32x4 rrow[2][4];
+    const char* const res_b = reinterpret_cast<const char*>(g.res_hl);
+    const unsigned roff = (unsigned)((lane >> 3) * (int)g.ldrh * 2 + (lane & 7) * 16);
+    auto load_res_rows = [&](int t0s) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int64_t row = (int64_t)(t0s + it * 8) * g.ldrh;                     // scalar
+                rrow[i][it] = *reinterpret_cast<const og_u32x4*>(res_b + (row + og_hl_col(oc0 + i * 32)) * 2 + roff);
+            }
+    };
+    if constexpr (RES_SLAB) load_res_rows(tok0);
+    else if constexpr (HAS_RES) gemm_f16x3_load_residual<2, EM == OG_EM_RES_HL>(g, raw, tok0, oc0, lane);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         f32x16 a[2];
         a[0] = acc[0][j]; a[1] = acc[1][j];
+        if constexpr (RES_SLAB) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int it = 0; it < 4; ++it) *reinterpret_cast<og_u32x4*>(slab2 + i * EPI_SLAB + it * 8 * ROWB + rd_off) = rrow[i][it];
+            if (j + 1 < NJ) load_res_rows(tok0 + (j + 1) * 32);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const char* d = slab2 + i * EPI_SLAB + l31 * ROWB + (8 * q + 4 * hi) * 2;
+                    const uint2 h2 = *reinterpret_cast<const uint2*>(d), l2 = *reinterpret_cast<const uint2*>(d + 64);
+                    raw[i][q] = og_u32x4{h2.x, h2.y, l2.x, l2.y};
+                }
+        }
         if constexpr (EM == OG_EM_RUNTIME) gemm_f16x3_epilogue_finish<2, false>(g, a, raw, oc0, lane);
         else gemm_f16x3_epilogue_finish_spec<EM>(g, a, raw);
-        if constexpr (HAS_RES) { if (j + 1 < NJ) gemm_f16x3_load_residual<2, EM == OG_EM_RES_HL>(g, raw, tok0 + (j + 1) * 32, oc0, lane); }
+        if constexpr (HAS_RES && !RES_SLAB) { if (j + 1 < NJ) gemm_f16x3_load_residual<2, EM == OG_EM_RES_HL>(g, raw, tok0 + (j + 1) * 32, oc0, lane); }
         // registers -> slabs.  HL: slab i = [32 tok][hi 64 B | lo 64 B] of channel block i; planes: slab 0 = hi, slab 1 = lo of [32 tok][64 ch]
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -809,6 +844,8 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_big2_kernel(GemmHArgs g, in
     if (tm >= tiles_m) return;
     const int t0 = tm * BIG, n0 = tn * BIG;
     if (t0 >= g.M || n0 >= g.N) return;
+    if (t0 < g.split_row && n0 >= g.split_n) return;     // row-split launch: the first row range has fewer columns (exits at once: the
+                                                         // dispatcher back-fills the CU with the next block)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1051,8 +1088,20 @@ __global__ __launch_bounds__(256) void split_f16_hl_kernel(const float* __restri
 
 }  // namespace
 
+// A row-split launch (GemmHArgs::split_row) must end up on the second-generation 256-tile kernel: same conditions as the launcher's.
+bool og_gemm_f16x3_row_split_ok(const GemmHArgs& a) {
+    if (a.split_row <= 0 || a.split_row >= a.M || a.split_row % BIG || a.split_n <= 0 || a.split_n >= a.N || a.split_n % BIG) return false;
+    if (a.M % BIG || a.N % BIG || a.batch > 1 || a.rag || a.alpha || a.Ct || a.C32 || !a.Ch) return false;
+    static const int force = [] { const char* e = getenv("OG_GEMM_TILE"); return e ? atoi(e) : 0; }();
+    static const bool big2 = [] { const char* e = getenv("OG_GEMM_BIG2"); return !e || atoi(e) != 0; }();
+    static const bool on = [] { const char* e = getenv("OG_GEMM_ROW_SPLIT"); return !e || atoi(e) != 0; }();      // experiments: 0 = two launches
+    const int64_t blocks = (int64_t)(a.split_row / BIG) * (a.split_n / BIG) + (int64_t)((a.M - a.split_row) / BIG) * (a.N / BIG);
+    return on && big2 && force != 128 && blocks >= 192;
+}
+
 int og_launch_gemm_f16x3(const GemmHArgs& a, hipStream_t stream) {
     if (!a.A || !a.B || a.M <= 0 || a.N <= 0 || a.K <= 0) return OG_E_INVALID;
+    if (a.split_row && !og_gemm_f16x3_row_split_ok(a)) return OG_E_INVALID;
     if (!a.C32 && !a.Ch && !a.Ct) return OG_E_INVALID;
     if (a.Ch && !a.c_hl && !a.Cl) return OG_E_INVALID;
     if ((a.K % BKH) || (a.lda & 7) || (a.ldb & 7) || a.lda < 2 * (int64_t)a.K || a.ldb < 2 * (int64_t)a.K) return OG_E_ALIGN;

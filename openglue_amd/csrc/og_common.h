@@ -143,8 +143,12 @@ struct GemmHArgs {
     int64_t strideA, strideB, strideC32;      // elements (halves / floats) between consecutive problems
     const RaggedDesc* rag;                    // host pointer or null: batched problem z = pair z of a ragged batch
                                               // (A rows off0[z].., B rows T0 + off1[z].., M = m_z, N = n_z; C32 at z*strideC32)
+    int split_row, split_n;                   // split_row > 0: rows < split_row produce only columns < split_n (two row ranges with different
+                                              // column counts in ONE launch: the cross layer's q of image 0 + q | k | v of image 1).  Only the
+                                              // 256-tile kernel honours it: og_gemm_f16x3_row_split_ok() tells whether a launch qualifies.
 };
 int og_launch_gemm_f16x3(const GemmHArgs& a, hipStream_t stream);
+bool og_gemm_f16x3_row_split_ok(const GemmHArgs& a);
 int og_launch_split_f16(const float* x, int64_t n, void* hi, void* lo, hipStream_t stream);
 int og_launch_split_f16_hl(const float* x, int64_t rows, int cols, int64_t ldx, void* out, int64_t ldo, hipStream_t stream);
 
