@@ -32,7 +32,7 @@ constexpr int EPI_SLAB = 32 * 144;   // per-wave epilogue scratch: one 32-token 
 
 // Compile-time ablations of the LDS-DMA kernel (scripts/build_ablation.sh; results are wrong by construction):
 // 1 = no global stores, 2 = every block reads token tile 0 (operands L2-resident), 4 = no MFMA,
-// 8 = (256-tile kernel) no LDS-DMA after the first two stages, 16 = (256-tile kernel) no fragment reads after the first.
+// 8 = (256-tile kernels) no LDS-DMA after the first stages, 16 = (256-tile kernels) no fragment reads after the first.
 #ifndef OG_GEMM_ABL
 #define OG_GEMM_ABL 0
 #endif
@@ -861,7 +861,7 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_big2_kernel(GemmHArgs g, in
     // per-lane 32-bit byte offsets from the block's (scalar) tile bases: the DMA address of a stage is base + kt * 128 (SALU) + offset,
     // no vector arithmetic per stage
     unsigned soff[8];
-    const char* const baseA = reinterpret_cast<const char*>(g.A + (int64_t)t0 * g.lda);
+    const char* const baseA = reinterpret_cast<const char*>(g.A + (int64_t)((OG_GEMM_ABL & 2) ? 0 : t0) * g.lda);   // ablation 2: token tile 0 for all
     const char* const baseB = reinterpret_cast<const char*>(g.B + (int64_t)n0 * g.ldb);
     {
         const int rl = lane >> 3, pc = lane & 7;
@@ -972,8 +972,10 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_big2_kernel(GemmHArgs g, in
             const int ks = grp >> 2, j = grp & 3;
             if (grp < 7) {
                 const int ks1 = (grp + 1) >> 2, j1 = (grp + 1) & 3;
-                read_x(ks1, j1, (grp + 1) & 1);
-                if (j1 == 0) read_w(ks1, ks1 & 1);
+                if (!(OG_GEMM_ABL & 16)) {                  // ablation 16: no fragment reads after the first
+                    read_x(ks1, j1, (grp + 1) & 1);
+                    if (j1 == 0) read_w(ks1, ks1 & 1);
+                }
                 wait_frags(ks & 1, grp & 1, j1 == 0 ? 6 : 2);
             } else {
                 wait_frags(ks & 1, grp & 1, 0);                                // all my reads of stage kt are done
@@ -986,8 +988,10 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_big2_kernel(GemmHArgs g, in
                     __builtin_amdgcn_s_barrier();
                     OG_GT(10 + 3 * kt);
                     set_x(xbn); set_w(wbn);              // my reads of stage kt are complete: the address registers move on
-                    read_x(0, 0, 0);
-                    read_w(0, 0);
+                    if (!(OG_GEMM_ABL & 16)) {
+                        read_x(0, 0, 0);
+                        read_w(0, 0);
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -999,9 +1003,9 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_big2_kernel(GemmHArgs g, in
                 // the barrier that ended stage kt-1), then X(kt+2) in groups 2-3 (its slot held X(kt-1))
                 __builtin_amdgcn_sched_barrier(0);
                 if (grp < 2) {
-                    if (iw) { issue_w(kt + 1, 2 * grp); issue_w(kt + 1, 2 * grp + 1); }
+                    if (iw && !(OG_GEMM_ABL & 8)) { issue_w(kt + 1, 2 * grp); issue_w(kt + 1, 2 * grp + 1); }
                 } else {
-                    if (ix) { issue_x(kt + 2, 2 * (grp - 2)); issue_x(kt + 2, 2 * (grp - 2) + 1); }
+                    if (ix && !(OG_GEMM_ABL & 8)) { issue_x(kt + 2, 2 * (grp - 2)); issue_x(kt + 2, 2 * (grp - 2) + 1); }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
