@@ -673,7 +673,8 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(AttnArgs a, RD rd
                 for (int r = 0; r < 16; ++r) s[kb][r] -= delta;
         }
         f16x8 pf[2][2], pl[2][2];
-        float psum = 0.f;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 psum2 = {0.f, 0.f};                   // two partial row sums: one packed add per pair of exponentials
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -682,7 +683,8 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(AttnArgs a, RD rd
                 const float p1 = __builtin_amdgcn_exp2f(s[kb][r + 1]);
                 const float p2 = __builtin_amdgcn_exp2f(s[kb][r + 2]);
                 const float p3 = __builtin_amdgcn_exp2f(s[kb][r + 3]);
-                psum += (p0 + p1) + (p2 + p3);
+                psum2 += f32x2{p0, p1};
+                psum2 += f32x2{p2, p3};
                 unsigned ha, la, hb, lb;
                 og_split4(p0, p1, p2, p3, ha, la, hb, lb);      // og_common.h: 3 instructions per pair, hazard-safe
                 unsigned* pfw = reinterpret_cast<unsigned*>(&pf[kb][r >> 3]);
@@ -690,7 +692,7 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(AttnArgs a, RD rd
                 pfw[(r & 7) >> 1] = ha; pfw[((r & 7) >> 1) + 1] = hb;
                 plw[(r & 7) >> 1] = la; plw[((r & 7) >> 1) + 1] = lb;
             }
-        l_run += psum;
+        l_run += psum2[0] + psum2[1];
 
         OG_TP(3);
         // ---- O^T += V^T P^T of the same tile: group g = (key block kb, half t); A operand element e of lane (dv, hi) is
