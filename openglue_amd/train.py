@@ -12,8 +12,10 @@ Conv1d -> ReLU -> BatchNorm1d with batch statistics and running-statistics updat
 `feed_forward_train_autograd` adds the backward of that block (1x1 conv: dX, dW, db on the exact-fp32 GEMM; ReLU + train-mode
 BatchNorm: og_batchnorm_train_backward), so the keypoint-encoder MLP / a message MLP can be trained end to end on HIP kernels.
 
-Not yet built (stated in DESIGN.md): backward of attention and of the split-f16 GNN GEMMs; `SuperGlue.forward` therefore still
-refuses `train()` mode.
+`superglue_forward_train` (below) wires them -- plus `Conv1x1`, `SoftmaxAttention` (materialised attention matrix, batched exact-fp32
+GEMMs, row-softmax forward / backward kernels) and `MatchingScores` -- into the whole training-mode forward of the reference
+(superglue.py:29-72): `SuperGlue(config).train()(data)` returns tensors whose `loss.backward()` reaches every parameter.  Functional,
+not tuned (exact-fp32 MFMA, O(N^2) attention memory); not in training mode: Siren encoder, linear / FAVOR attention.
 """
 from __future__ import annotations
 

@@ -1,0 +1,100 @@
+"""Exploration (CPU, test infrastructure -- not collected by pytest, never on the product path): what would the parity budget look
+like if the two CORRECTION passes of the split-f16 products (Ah.Bl + Al.Bh) ran on the 8-bit matrix path (twice the f16 MFMA rate,
+DESIGN.md §9) instead of in f16?  Every GNN conv, Q K^T and P V of the oracle is replaced by
+
+    a.b  ~=  Ah.Bh  +  q8(Ah).q8(Bl) + q8(Al).q8(Bh),        x = hi + lo, hi = f16(x), lo = f16(x - hi)
+
+with q8 = identity (the kernels as built), MX-style fp8 e4m3 (one power-of-two scale per 32 elements along k), int8 with one scale
+per row, or "drop" (plain f16 operands), everything accumulated in float64, and the log-scores are compared with the float64 oracle on the golden cases.
+
+    python tests/emulate_cross_term_precision.py [case ...]
+"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import superglue_oracle as orc          # noqa: E402
+from tests.util import load_case                    # noqa: E402
+
+MODE = "exact"
+
+
+def split(x):
+    hi = x.to(torch.float16).to(torch.float64)
+    lo = (x - hi).to(torch.float16).to(torch.float64)
+    return hi, lo
+
+
+def q8(x):
+    """MX fp8 e4m3: blocks of 32 along the last axis share a power-of-two scale that brings the block maximum under 448."""
+    if MODE == "exact":
+        return x
+    if MODE == "drop":
+        return torch.zeros_like(x)
+    if MODE == "int8":      # v_mfma_i32_*_i8 has no block scales: ONE scale per row (the whole contraction), 7 bits + sign
+        scale = x.abs().amax(-1, keepdim=True).clamp_min(1e-300) / 127.0
+        return torch.round(x / scale) * scale
+    K = x.shape[-1]
+    pad = (-K) % 32
+    xp = torch.nn.functional.pad(x, (0, pad)) if pad else x
+    b = xp.reshape(*xp.shape[:-1], -1, 32)
+    amax = b.abs().amax(-1, keepdim=True).clamp_min(1e-300)
+    scale = torch.exp2(torch.ceil(torch.log2(amax / 448.0)))
+    q = (b / scale).to(torch.float32).to(torch.float8_e4m3fn).to(torch.float64) * scale
+    return q.reshape(xp.shape)[..., :K]
+
+
+def mm(a, b):          # a [..., M, K] @ b [..., N, K]^T with the operand handling under test
+    ah, al = split(a)
+    bh, bl = split(b)
+    out = ah @ bh.transpose(-1, -2)
+    if MODE != "drop":
+        out = out + q8(ah) @ q8(bl).transpose(-1, -2) + q8(al) @ q8(bh).transpose(-1, -2)
+    return out
+
+
+def conv1x1(x, sd, prefix):
+    W, b = orc._w(sd, prefix + ".weight", x.dtype), orc._w(sd, prefix + ".bias", x.dtype)
+    if not prefix.startswith("attention_gnn"):          # encoder / final projection: exact-fp32 MFMA or not under test here
+        return x @ W.T + b
+    return mm(x, W * 256.0) / 256.0 + b                 # weights are stored as hi/lo of 256 w (og_pack_weights)
+
+
+def softmax_attention(q, k, v, num_heads, operand_dtype=None):
+    B, nq, D = q.shape
+    d = D // num_heads
+    qh = q.view(B, nq, num_heads, d).transpose(1, 2) * d ** -0.5
+    kh = k.view(B, -1, num_heads, d).transpose(1, 2)
+    vh = v.view(B, -1, num_heads, d).transpose(1, 2)
+    logits = mm(qh, kh)
+    p = torch.exp(logits - logits.amax(-1, keepdim=True))
+    o = mm(p, vh.transpose(-1, -2)) / p.sum(-1, keepdim=True)
+    return o.transpose(1, 2).reshape(B, nq, D)
+
+
+def main():
+    global MODE
+    cases = sys.argv[1:] or ["c1", "flags", "mid"]
+    torch.set_num_threads(os.cpu_count() or 8)
+    for name in cases:
+        z, cfg, sd, data = load_case(name)
+        with torch.no_grad():
+            ref = orc.superglue_forward(sd, cfg, data, dtype=torch.float64)["scores"]
+            keep = orc.conv1x1, orc.softmax_attention
+            orc.conv1x1, orc.softmax_attention = conv1x1, softmax_attention
+            try:
+                for MODE in ("exact", "fp8", "int8", "drop"):
+                    got = orc.superglue_forward(sd, cfg, data, dtype=torch.float64)["scores"]
+                    err = (got - ref).abs().max().item()
+                    m_ref = orc.extract_matches(ref.float(), 0.2)["matches0"]
+                    m_got = orc.extract_matches(got.float(), 0.2)["matches0"]
+                    print(f"{name:6s} cross terms {MODE:5s}: max |scores - float64 oracle| = {err:.2e}; matches0 differ on {int((m_ref != m_got).sum())} rows")
+            finally:
+                orc.conv1x1, orc.softmax_attention = keep
+
+
+if __name__ == "__main__":
+    main()

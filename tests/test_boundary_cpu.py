@@ -193,3 +193,22 @@ def test_input_validation_before_any_launch():
         model.pack_ragged([p])
     with pytest.raises(ValueError):
         model.pack_ragged([])
+
+
+def test_openglue_matcher_contract_on_cpu():
+    """openglue_amd.matcher.OpenGlueMatcher keeps the reference constructor (local_feature, matcher, match_config) and its error
+    behaviour: unknown LAF method -> NameError (laf_converter.py:128); CPU tensors -> RuntimeError (no CPU path)."""
+    from openglue_amd.matcher import OpenGlueMatcher
+    cfg = syn.make_config(descriptor_dim=64, num_stages=1, num_heads=4, num_iters=3, side_info_size=2)
+    cfg["laf_to_sideinfo_method"] = "scale"
+    model = SuperGlue(cfg).eval()
+    mc = {"superglue": cfg, "inference": {"match_threshold": 0.2}}
+    pipe = OpenGlueMatcher(None, model, mc)
+    assert not pipe.training and pipe.no_match_output(torch.device("cpu"), torch.float32)["lafs0"].shape == (0, 0, 2, 3)
+    bad = dict(cfg); bad["laf_to_sideinfo_method"] = "nope"
+    with pytest.raises(NameError):
+        OpenGlueMatcher(None, model, {"superglue": bad, "inference": {"match_threshold": 0.2}})
+    data = {"lafs0": torch.randn(1, 8, 2, 3), "lafs1": torch.randn(1, 9, 2, 3), "responses0": torch.rand(1, 8), "responses1": torch.rand(1, 9),
+            "descriptors0": torch.randn(1, 8, 64), "descriptors1": torch.randn(1, 9, 64), "image0_size": [640, 480], "image1_size": [640, 480]}
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        pipe(data)

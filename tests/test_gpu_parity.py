@@ -479,6 +479,50 @@ def test_compact_matches(gpu_device):
     assert none["confidence"].numel() == 0
 
 
+def test_openglue_matcher_pipeline(gpu_device):
+    """openglue_amd.matcher.OpenGlueMatcher (inference.py:83-209 with pre-extracted features): LAFs / responses / descriptors of
+    two images -> compacted matches, against the same chain restated in the oracle (prepare_features_output -> SuperGlue.forward ->
+    mutual-NN extraction -> boolean-mask compaction).  SIFT-like config: `affine` side info (6 channels), log-transformed response."""
+    from openglue_amd.matcher import OpenGlueMatcher
+    B, m, n, D = 2, 180, 150, 128
+    cfg = syn.make_config(descriptor_dim=D, num_stages=2, num_heads=4, num_iters=12, side_info_size=6)
+    cfg["laf_to_sideinfo_method"] = "affine"; cfg["log_transform_response"] = True
+    sd = syn.make_state_dict(cfg, seed=4)
+    model = _build(cfg, sd, gpu_device)
+    base = syn.make_batch(B, m, n, D, 6, seed=21)                     # matched keypoints / descriptors; LAFs are built around the keypoints
+    g = torch.Generator().manual_seed(5)
+
+    def lafs_of(k):
+        A = 0.3 * torch.randn(*k.shape[:2], 2, 2, generator=g) + 3.0 * torch.eye(2)
+        return torch.cat([A, k[..., None]], dim=-1)
+    lafs0, lafs1 = lafs_of(base["keypoints0"]), lafs_of(base["keypoints1"])
+    resp0, resp1 = torch.rand(B, m, generator=g), torch.rand(B, n, generator=g)
+    data = {"lafs0": lafs0, "lafs1": lafs1, "responses0": resp0, "responses1": resp1,
+            "descriptors0": base["local_descriptors0"], "descriptors1": base["local_descriptors1"],
+            "image0": torch.empty(B, 1, 720, 960), "image1": torch.empty(B, 1, 600, 800)}
+    mc = {"superglue": cfg, "inference": {"match_threshold": MATCH_THRESHOLD}}
+    pipe = OpenGlueMatcher(None, model, mc)
+    got = pipe(to_device(data, gpu_device))
+    # the oracle chain (inference.py:141-209)
+    f0 = orc.prepare_features_output(lafs0, resp0, data["descriptors0"], "affine", log_response=True)
+    f1 = orc.prepare_features_output(lafs1, resp1, data["descriptors1"], "affine", log_response=True)
+    od = {"keypoints0": f0["keypoints"], "keypoints1": f1["keypoints"], "local_descriptors0": f0["local_descriptors"],
+          "local_descriptors1": f1["local_descriptors"], "side_info0": f0["side_info"], "side_info1": f1["side_info"],
+          "image0_size": [960, 720], "image1_size": [800, 600]}
+    with torch.no_grad():
+        ref = orc.match_pairs(sd, cfg, od, MATCH_THRESHOLD)
+    ndiff, unexplained, _ = _index_agreement(model.match(to_device(od, gpu_device), MATCH_THRESHOLD)["matches0"].cpu(), None, sd, cfg, od)
+    assert unexplained == 0
+    if ndiff == 0:
+        want = orc.compact_matches(ref["matches0"], ref["matching_scores0"], lafs0, lafs1)
+        assert set(got) == set(want) and want["confidence"].numel() > 20
+        for k in ("original_matching_idxs", "batch_indexes", "lafs0", "lafs1", "keypoints0", "keypoints1"):
+            assert torch.equal(got[k].cpu(), want[k]), k
+        assert (got["confidence"].cpu() - want["confidence"]).abs().max() < 1e-3
+    with pytest.raises(RuntimeError, match="no local feature extractor"):
+        pipe({"image0": data["image0"], "image1": data["image1"]})
+
+
 def test_hipgraph_replay_equals_eager(gpu_device):
     """The whole launch sequence captured into a hipGraph (launch-bound small shapes) gives identical results."""
     from openglue_amd.graph import GraphedMatcher
