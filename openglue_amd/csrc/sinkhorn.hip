@@ -353,18 +353,22 @@ __global__ __launch_bounds__(256) void sinkhorn_combine_kernel(int M, int N, con
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
-template <int CPL, int RG, int WPR, class RD>
+template <int CPL, int RG, int WPR, class RD, int ROWS = SK_ROWS, bool NT = false>
 __global__ __launch_bounds__(256) void sinkhorn_sweep_fast_kernel(const float* __restrict__ S, int64_t lds, int M, int N,
                                                                   const float* __restrict__ zdev, float zhost, float inv_reg,
                                                                   float la, const float* __restrict__ v_in, int ldv,
                                                                   float* __restrict__ u, int ldu, float* __restrict__ ps,
                                                                   int ldp, int RB, int64_t strideS, float in_scale,
                                                                   float out_scale, RD rd) {
+    // ROWS = rows per workgroup (a multiple of 32: fewer, larger workgroups mean fewer column partials to write and to merge, as long
+    // as the grid still fills the chip; sinkhorn_run); NT = stream the score rows with non-temporal loads (matrices that do not fit
+    // the 256 MB Infinity Cache: 4.6 -> 5.0-5.2 TB/s at 537 MB; with 64 / 128 rows per workgroup 5.6-5.8)
+    constexpr int rows = ROWS;
     // u, v in memory: base-2 units between two dual-stabilised iterations (no per-iteration unit conversion: at
     // convergence the increments vanish and the duals stop moving, instead of random-walking by an ulp per round trip);
     // in_scale = log2(e) when the previous iteration left natural units, out_scale = ln 2 on the last iteration.
     constexpr int NRS = 4 / WPR;                 // row streams
-    constexpr int RW = SK_ROWS / NRS;            // rows per stream
+    constexpr int RW = ROWS / NRS;               // rows per stream
     constexpr int NCW = 256 * CPL;               // columns per wave
     constexpr int NCB = NCW * WPR;               // columns per block
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -374,7 +378,7 @@ __global__ __launch_bounds__(256) void sinkhorn_sweep_fast_kernel(const float* _
     if (rd.B > 0) {
         M = rd.off0[b + 1] - rd.off0[b];
         N = rd.off1[b + 1] - rd.off1[b];
-        if (rb * SK_ROWS >= M) return;
+        if (rb * rows >= M) return;
         la = -__logf((float)(M + N));
     }
     S += (int64_t)b * strideS;
@@ -398,7 +402,7 @@ __global__ __launch_bounds__(256) void sinkhorn_sweep_fast_kernel(const float* _
         for (int e = 0; e < 4; ++e) { vv[k][e] = t[e] * in_scale; cs[k][e] = 0.f; }
     }
 
-    const int srow0 = rb * SK_ROWS + rs * RW;
+    const int srow0 = rb * rows + rs * RW;
     int parity = 0;
     f32x4 nx[RG][CPL];
     float nu[RG];                                // u of the next group's rows
@@ -411,7 +415,8 @@ __global__ __launch_bounds__(256) void sinkhorn_sweep_fast_kernel(const float* _
 #pragma unroll
             for (int k = 0; k < CPL; ++k) {
                 const int c0 = cbase + 256 * k;
-                if (row < M && c0 < N) nx[r][k] = *reinterpret_cast<const f32x4*>(sp + c0);
+                if (row < M && c0 < N) nx[r][k] = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sp + c0))
+                                                     : *reinterpret_cast<const f32x4*>(sp + c0);
                 else nx[r][k] = f32x4{OG_NEG_INF, OG_NEG_INF, OG_NEG_INF, OG_NEG_INF};
             }
         }
@@ -503,7 +508,7 @@ __global__ __launch_bounds__(256) void sinkhorn_combine_fast_kernel(int M, int N
                                                                     const float* __restrict__ v_in, float* __restrict__ v_out,
                                                                     int ldv, float* __restrict__ u, int ldu,
                                                                     const float* __restrict__ ps, int ldp, int RB, float in_scale,
-                                                                    float out_scale, RD rd) {
+                                                                    float out_scale, int rows, RD rd) {
     const int b = blockIdx.y, tid = threadIdx.x;
     const float u_scale = out_scale == 1.f ? 1.f : LOG2E;      // the sweep of this iteration stored u * out_scale
     int RBv = RB;
@@ -511,7 +516,7 @@ __global__ __launch_bounds__(256) void sinkhorn_combine_fast_kernel(int M, int N
         M = rd.off0[b + 1] - rd.off0[b];
         N = rd.off1[b + 1] - rd.off1[b];
         if ((int)blockIdx.x * 256 > N) return;
-        RBv = (M + SK_ROWS - 1) / SK_ROWS;
+        RBv = (M + rows - 1) / rows;
         const float norm = -__logf((float)(M + N));
         lb = norm; la_bin = norm + __logf((float)N); lb_bin = norm + __logf((float)M);
     }
@@ -635,13 +640,29 @@ void launch_sweep(const float* S, int64_t lds, int B, int m, int n, const float*
                        inv_reg, la, v_in, w.ldv, w.u, w.ldu, w.pm, w.ps, w.ldp, w.RB, (int64_t)m * lds, rd);
 }
 
-template <int CPL, int RG, int WPR, class RD>
-void launch_sweep_fast(const float* S, int64_t lds, int B, int m, int n, const float* zdev, float zhost, float inv_reg, float la,
-                       const float* v_in, const SinkhornWs& w, hipStream_t st, const RD& rd, float in_scale, float out_scale) {
+template <int CPL, int RG, int WPR, class RD, int ROWS, bool NT>
+void launch_sweep_fast_g(const float* S, int64_t lds, int B, int m, int n, const float* zdev, float zhost, float inv_reg, float la,
+                         const float* v_in, const SinkhornWs& w, hipStream_t st, const RD& rd, float in_scale, float out_scale) {
     constexpr int NRS = 4 / WPR;
     const size_t shmem = sizeof(float) * ((size_t)NRS * 256 * CPL * WPR + 2 * NRS * RG * WPR);
-    hipLaunchKernelGGL((sinkhorn_sweep_fast_kernel<CPL, RG, WPR, RD>), dim3(w.RB, B), dim3(256), shmem, st, S, lds, m, n, zdev, zhost,
-                       inv_reg, la, v_in, w.ldv, w.u, w.ldu, w.ps, w.ldp, w.RB, (int64_t)m * lds, in_scale, out_scale, rd);
+    const int RB = (m + ROWS - 1) / ROWS;        // <= w.RB (the workspace is laid out for 32 rows per workgroup)
+    hipLaunchKernelGGL((sinkhorn_sweep_fast_kernel<CPL, RG, WPR, RD, ROWS, NT>), dim3(RB, B), dim3(256), shmem, st, S, lds, m, n, zdev, zhost,
+                       inv_reg, la, v_in, w.ldv, w.u, w.ldu, w.ps, w.ldp, RB, (int64_t)m * lds, in_scale, out_scale, rd);
+}
+// rows per workgroup / streaming loads are compile-time forms of the wide geometries (n > 1024) of UNIFORM batches only; everything
+// else runs 32 rows per workgroup with plain loads
+template <int CPL, int RG, int WPR, class RD>
+void launch_sweep_fast(const float* S, int64_t lds, int B, int m, int n, const float* zdev, float zhost, float inv_reg, float la,
+                       const float* v_in, const SinkhornWs& w, hipStream_t st, const RD& rd, float in_scale, float out_scale, int rows,
+                       int nt) {
+#define OG_SKF(ROWS_, NT_) launch_sweep_fast_g<CPL, RG, WPR, RD, ROWS_, NT_>(S, lds, B, m, n, zdev, zhost, inv_reg, la, v_in, w, st, rd, in_scale, out_scale)
+    if constexpr (std::is_same<RD, RaggedNone>::value && WPR > 1) {
+        if (rows == 128) { if (nt) OG_SKF(128, true); else OG_SKF(128, false); return; }
+        if (rows == 64) { if (nt) OG_SKF(64, true); else OG_SKF(64, false); return; }
+        if (nt) { OG_SKF(SK_ROWS, true); return; }
+    }
+    OG_SKF(SK_ROWS, false);
+#undef OG_SKF
 }
 
 }  // namespace
@@ -687,6 +708,19 @@ int sinkhorn_run(const float* S, int64_t lds, const float* zdev, float dustbin, 
     const char* rm_env = getenv("OG_SINKHORN_RESIDENT");          // read per call: the parity tests switch it
     const int resident_mode = rm_env ? atoi(rm_env) : 1;
     const bool resident = std::is_same<RD, RaggedNone>::value && !robust_only && iters > 1 && og_sinkhorn_resident_wanted(B, m, n, resident_mode);
+    // Geometry of the dual-stabilised streaming sweeps (uniform batches): the largest 32 / 64 / 128 rows per workgroup that still gives
+    // >= 512 workgroups -- half the column partials to write and merge per doubling (2048 columns x 32 pairs: 11.6 -> 9.2 ms per 100
+    // iterations at 128 rows with streaming loads; 4096 x 8 pairs: 11.4 -> 9.5 at 64; below 512 workgroups the chip runs dry: 16.6 ms at
+    // 128 workgroups) -- and non-temporal loads when the score matrices exceed the 256 MB Infinity Cache (smaller ones get SLOWER with
+    // them: 3.9 -> 4.2 ms at 173 MB).  OG_SK_FAST_ROWS / OG_SK_FAST_NT override (experiments).
+    int fast_rows = SK_ROWS, fast_nt = 0;
+    if (std::is_same<RD, RaggedNone>::value) {
+        for (int r = 2 * SK_ROWS; r <= 4 * SK_ROWS; r *= 2)
+            if ((int64_t)((m + r - 1) / r) * B >= 512) fast_rows = r;
+        fast_nt = (int64_t)B * m * lds * (int64_t)sizeof(float) > ((int64_t)256 << 20);
+    }
+    { const char* e = getenv("OG_SK_FAST_ROWS"); if (e && (atoi(e) == 32 || atoi(e) == 64 || atoi(e) == 128)) fast_rows = atoi(e); }
+    { const char* e = getenv("OG_SK_FAST_NT"); if (e) fast_nt = atoi(e) != 0; }
     for (int it = 0; it < iters; ++it) {
         const float* vin = w.v[cur];
         if (it > 0 && resident) {         // iterations 2 .. iters in ONE launch, S read once (sinkhorn_resident.hip)
@@ -698,14 +732,15 @@ int sinkhorn_run(const float* S, int64_t lds, const float* zdev, float dustbin, 
         }
         if (it > 0 && !robust_only) {     // dual-stabilised form: valid once one max-subtracted iteration has been done
             const float is = it == 1 ? LOG2E : 1.f, os = it == iters - 1 ? LN2 : 1.f;     // duals stay in base 2 in between
-            if (g.CPL == 1) launch_sweep_fast<1, 4, 1>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd, is, os);
-            else if (g.CPL == 2) launch_sweep_fast<2, 4, 1>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd, is, os);
-            else if (g.CPL == 8) launch_sweep_fast<8, 1, 4>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd, is, os);
-            else if (g.WPR == 1) launch_sweep_fast<4, 2, 1>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd, is, os);
-            else if (g.WPR == 2) launch_sweep_fast<4, 2, 2>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd, is, os);
-            else launch_sweep_fast<4, 2, 4>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd, is, os);
+            const int rows = (std::is_same<RD, RaggedNone>::value && g.WPR > 1) ? fast_rows : SK_ROWS, RBf = (m + rows - 1) / rows;
+            if (g.CPL == 1) launch_sweep_fast<1, 4, 1>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd, is, os, rows, fast_nt);
+            else if (g.CPL == 2) launch_sweep_fast<2, 4, 1>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd, is, os, rows, fast_nt);
+            else if (g.CPL == 8) launch_sweep_fast<8, 1, 4>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd, is, os, rows, fast_nt);
+            else if (g.WPR == 1) launch_sweep_fast<4, 2, 1>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd, is, os, rows, fast_nt);
+            else if (g.WPR == 2) launch_sweep_fast<4, 2, 2>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd, is, os, rows, fast_nt);
+            else launch_sweep_fast<4, 2, 4>(S, lds, B, m, n, zdev, dustbin, inv_reg, la, vin, w, st, rd, is, os, rows, fast_nt);
             hipLaunchKernelGGL(sinkhorn_combine_fast_kernel<RD>, dim3((n + 1 + 255) / 256, B), dim3(256), 0, st, m, n, zdev, dustbin,
-                               inv_reg, la_bin, lb, lb_bin, w.v[cur], w.v[cur ^ 1], w.ldv, w.u, w.ldu, w.ps, w.ldp, w.RB, is, os, rd);
+                               inv_reg, la_bin, lb, lb_bin, w.v[cur], w.v[cur ^ 1], w.ldv, w.u, w.ldu, w.ps, w.ldp, RBf, is, os, rows, rd);
             cur ^= 1;
             continue;
         }
