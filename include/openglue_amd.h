@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define OG_ABI_VERSION 4
+#define OG_ABI_VERSION 5
 
 #define OG_E_INVALID   (-1)  /* NULL pointer / non-positive size                         */
 #define OG_E_SHAPE     (-2)  /* unsupported shape (see og_check_shape)                   */
@@ -159,6 +159,8 @@ typedef struct og_packed_layout_t {
     int64_t enc_w[OG_MAX_HIDDEN + 1], enc_b[OG_MAX_HIDDEN + 1];
     int64_t layer0, layer_stride, o_wqkv, o_bqkv, o_w0, o_b0, o_w3, o_b3;   /* o_w*: hl32 rows of 2K halves */
     int64_t wp, bp, alpha, dustbin, total;
+    int64_t o_wmlp;   /* ABI v5: per layer, the SAME folded w0 / w3 once more as the fragment-major stream og_mlp_block consumes
+                         (og_mlp_block_stream_bytes(D) bytes; -1 when D has no fused message-MLP kernel)                         */
 } og_packed_layout_t;
 int og_packed_layout(const og_shape* shape, og_packed_layout_t* layout);
 
@@ -233,6 +235,17 @@ int og_gemm_nt_f16x3(const void* A, int64_t lda, const void* B, int64_t ldb, int
 int og_gemm_nt_f16x3_reshl(const void* A, int64_t lda, const void* B, int64_t ldb, int32_t M, int32_t N, int32_t K,
                            float scale, const float* bias, int32_t relu, const void* res_hl, int64_t ldrh, float* C32, int64_t ldc,
                            void* Ch, void* Cl, int64_t ldch, int32_t c_hl, void* stream);
+
+/* The message MLP of one GNN layer (attention_gnn.py:53-55 with models/utils.py:48-58, BatchNorm and out_proj folded as
+ * og_pack_weights does) as ONE launch, in place on M token rows of hl32 rows [x | O] (4D halves used per row, row stride ld halves):
+ *     x <- x + W3 relu(W0 [x ; O] + b0) + b3,     W0 [2D][2D], W3 [D][2D] row-major fp32, b0 [2D], b3 [D] (device).
+ * The hidden activation lives in registers (csrc/mlp_fused.hip); the weights are consumed as a fragment-major stream of (hi, lo)
+ * halves of 256 w that og_mlp_block_pack writes on the host (og_mlp_block_stream_bytes(D) bytes, 0 = D not supported: D == 256).
+ * Same arithmetic as og_gemm_nt_f16x3 (relu) followed by og_gemm_nt_f16x3_reshl. */
+size_t og_mlp_block_stream_bytes(int32_t D);
+int og_mlp_block_pack(int32_t D, const float* W0, const float* W3, void* stream_host);
+int og_mlp_block(int32_t D, void* xo_rows, int64_t ld, int32_t M, const void* stream_dev, const float* b0, const float* b3,
+                 void* stream);
 
 /* softmax attention (attention.py:8-19) for `batch` independent problems and H heads, operands and
  * result as split-f16 planes: q [batch][nq][ldq] (columns h*dh.. of row i = head h, PRE-SCALED by

@@ -21,6 +21,7 @@ struct PackedLayout {
     int64_t layer0, layer_stride;               // per GNN layer block
     // offsets inside a layer block (float units); weights in the hl32 row format: [N][2K] halves = N*K floats
     int64_t o_wqkv, o_bqkv, o_w0, o_b0, o_w3, o_b3;
+    int64_t o_wmlp;                             // fragment-major stream of mlp_fused.hip (W0' then W3' per hidden half), -1: none
     int64_t wp, bp, alpha, dustbin;
     int64_t total;                              // floats
     int enc_maxw;                               // widest padded hidden activation
@@ -59,6 +60,8 @@ PackedLayout packed_layout(const og_shape& s) {
     L.o_b0 = lo; lo = al64(lo + 2 * D);
     L.o_w3 = lo; lo = al64(lo + 2 * D * D);
     L.o_b3 = lo; lo = al64(lo + D);
+    L.o_wmlp = -1;
+    if (og_mlp_fused_supported((int)D)) { L.o_wmlp = lo; lo = al64(lo + (int64_t)(og_mlp_stream_bytes((int)D) / 4)); }
     L.layer_stride = lo;
     L.layer0 = off; off += lo * 2 * s.num_stages;
     L.wp = off; off = al64(off + D * D);
@@ -86,7 +89,8 @@ WorkspaceLayout workspace_layout(const og_shape& s) {
     W.xo = off; off = al64(off + T * 2 * D);       // [T] hl32 rows of [x | O]: 4D halves each
     W.qkvh = off; off = al64(off + T * qkv_width(s) / 2); // [T][3D] halves (favor_relu: [T][5D])
     W.qkvl = off; off = al64(off + T * qkv_width(s) / 2);
-    W.h = off; off = al64(off + T * 2 * D);        // [T] hl32 rows of the 2D hidden activations
+    W.h = off;                                     // [T] hl32 rows of the 2D hidden activations -- only when fc.0 and fc.3 run as two
+    if (!og_mlp_fused_enabled((int)D)) off = al64(off + T * 2 * D);   // launches (mlp_fused.hip keeps the hidden activation in registers)
     W.g = off; off = al64(off + T * D);
     W.ei = off; off = al64(off + T * 32);
     W.ea = off; off = al64(off + T * ew);
@@ -164,7 +168,7 @@ extern "C" int og_packed_layout(const og_shape* shape, og_packed_layout_t* o) {
     o->layer0 = L.layer0; o->layer_stride = L.layer_stride;
     o->o_wqkv = L.o_wqkv; o->o_bqkv = L.o_bqkv;
     o->o_w0 = L.o_w0; o->o_b0 = L.o_b0;
-    o->o_w3 = L.o_w3; o->o_b3 = L.o_b3;
+    o->o_w3 = L.o_w3; o->o_b3 = L.o_b3; o->o_wmlp = L.o_wmlp;
     o->wp = L.wp; o->bp = L.bp; o->alpha = L.alpha; o->dustbin = L.dustbin; o->total = L.total;
     return 0;
 }
@@ -240,6 +244,8 @@ extern "C" int og_pack_weights(const og_shape* shape, const og_params* P, void* 
     const bool favor = s.flags & OG_FLAG_FAVOR_RELU;
     const int wq = qk_width(s);
     std::vector<double> Wm((size_t)D2 * D), prod((size_t)D2 * D), g, c;
+    std::vector<double> W0d, W3d;       // the folded fc.0 / fc.3 matrices once more, for the fragment-major stream of mlp_fused.hip
+    if (L.o_wmlp >= 0) { W0d.resize((size_t)D2 * D2); W3d.resize((size_t)D * D2); }
     bool ok = true;                     // every split-f16 weight fits binary16 after the 256x pre-scale
     for (int l = 0; l < 2 * s.num_stages; ++l) {
         if (!P->layers) return OG_E_INVALID;
@@ -288,6 +294,7 @@ extern "C" int og_pack_weights(const og_shape* shape, const og_params* P, void* 
             for (int k = 0; k < D; ++k) {
                 const double wa = lp.fc0.weight[(int64_t)o * D2 + k], wb = lp.fc0.weight[(int64_t)o * D2 + D + k];
                 ok &= put_split(W0, o, k, D2, wa);
+                if (L.o_wmlp >= 0) W0d[(size_t)o * D2 + k] = wa;
                 Wm[(size_t)o * D + k] = offset ? wb - wa : wb;
             }
         std::fill(prod.begin(), prod.end(), 0.0);
@@ -301,6 +308,7 @@ extern "C" int og_pack_weights(const og_shape* shape, const og_params* P, void* 
                 bb += w * (double)lp.out_proj.bias[k];
             }
             for (int j = 0; j < D; ++j) ok &= put_split(W0, o, D + j, D2, pr[j]);
+            if (L.o_wmlp >= 0) for (int j = 0; j < D; ++j) W0d[(size_t)o * D2 + D + j] = pr[j];
             b0[o] = (float)bb;
         }
         // fc.3 with BN(2D) folded in
@@ -313,10 +321,12 @@ extern "C" int og_pack_weights(const og_shape* shape, const og_params* P, void* 
             for (int k = 0; k < D2; ++k) {
                 const double w = lp.fc3.weight[(int64_t)o * D2 + k];
                 ok &= put_split(W3, o, k, D2, w * g[k]);
+                if (L.o_wmlp >= 0) W3d[(size_t)o * D2 + k] = w * g[k];
                 bb += w * c[k];
             }
             b3[o] = (float)bb;
         }
+        if (L.o_wmlp >= 0) ok &= og_pack_mlp_stream(D, W0d.data(), W3d.data(), base + L.o_wmlp);
     }
 
     // ---- tail ----
@@ -505,7 +515,15 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
     // message MLP on token rows [r0, r0+R):  h = relu([x;O] W0'^T + b0') ; x += h W3'^T + b3'  (x kept in fp32 AND as planes)
     // message MLP on token rows [r0, r0+R):  h = relu([x;O] W0'^T + b0') ; x += h W3'^T + b3'.  x lives as hl32 (hi, lo)
     // rows (the residual is read from them: 2^-22 relative per layer); no fp32 copy is kept.
+    const bool fused_mlp = og_mlp_fused_enabled(D) && L.o_wmlp >= 0;
     auto mlp = [&](const float* lw, int64_t r0, int64_t R) -> int {
+        if (fused_mlp) {          // one launch, the hidden activation never leaves the registers (mlp_fused.hip)
+            MlpFusedArgs a{};
+            a.XO = XO + r0 * D4; a.ld = D4; a.M = (int)R; a.wstream = (const char*)(lw + L.o_wmlp);
+            a.b0 = lw + L.o_b0; a.b3 = lw + L.o_b3; a.scale = (float)(1.0 / OG_W_SCALE);
+            Scope sc(prof, OG_STAGE_GEMM_F16X3);
+            return og_launch_mlp_fused(a, D, st);
+        }
         int e = gemmh(XO + r0 * D4, lw, L.o_w0, 0, R, D2, D2, lw + L.o_b0, 1, nullptr, nullptr, Hb + r0 * D4, nullptr, D4, 1);
         if (e) return e;
         return gemmh(Hb + r0 * D4, lw, L.o_w3, 0, R, D, D2, lw + L.o_b3, 0, XO + r0 * D4, nullptr, XO + r0 * D4, nullptr, D4, 1);

@@ -152,6 +152,21 @@ bool og_gemm_f16x3_row_split_ok(const GemmHArgs& a);
 int og_launch_split_f16(const float* x, int64_t n, void* hi, void* lo, hipStream_t stream);
 int og_launch_split_f16_hl(const float* x, int64_t rows, int cols, int64_t ldx, void* out, int64_t ldo, hipStream_t stream);
 
+// mlp_fused.hip: the message MLP of a GNN layer (fc.0 -> ReLU -> fc.3 + residual) in one launch, the hidden activation in registers
+struct MlpFusedArgs {
+    _Float16* XO; int64_t ld;     // [M] hl32 rows of [x | O] (4D halves used, row stride ld halves); x is updated in place
+    int M;
+    const char* wstream;          // og_pack_mlp_stream: fragment-major (hi, lo) halves of 256 W0', 256 W3'
+    const float* b0;              // [2D] folded fc.0 bias
+    const float* b3;              // [D] folded fc.3 bias
+    float scale;                  // 1 / OG_W_SCALE
+};
+bool og_mlp_fused_supported(int D);
+bool og_mlp_fused_enabled(int D);                    // supported and not switched off (OG_MLP_FUSED=0)
+size_t og_mlp_stream_bytes(int D);
+bool og_pack_mlp_stream(int D, const double* W0, const double* W3, void* out);   // false: a weight does not fit binary16
+int og_launch_mlp_fused(const MlpFusedArgs& a, int D, hipStream_t stream);
+
 struct AttnArgs {
     const _Float16* qh; const _Float16* ql; int64_t ldq;     // leading dimensions in halves
     const _Float16* kh; const _Float16* kl; int64_t ldk;

@@ -139,6 +139,28 @@ def gemm_nt_f16x3_split_only(a: torch.Tensor, b: torch.Tensor, bias: Optional[to
     return merge_f16(ch, cl) if planes else merge_f16_hl(ch)
 
 
+def mlp_block(x: torch.Tensor, o: torch.Tensor, w0: torch.Tensor, b0: torch.Tensor, w3: torch.Tensor, b3: torch.Tensor,
+              return_rows: bool = False):
+    """The message MLP of one GNN layer as ONE launch (og_mlp_block): x + w3 @ relu(w0 @ [x ; o] + b0) + b3 on token-major
+    fp32 x, o [M, D]; w0 [2D, 2D], w3 [D, 2D] (BatchNorm / out_proj already folded).  x and o are converted to the [x | O] hl32
+    rows of og_forward on the device, the weights to the kernel's fragment-major stream on the host."""
+    lib = _lib.load()
+    x, o = _req(x, "x"), _req(o, "o")
+    M, D = x.shape
+    nbytes = lib.og_mlp_block_stream_bytes(D)
+    if nbytes == 0:
+        raise RuntimeError(f"og_mlp_block: no fused message-MLP kernel for D = {D}")
+    w0h, w3h = w0.detach().float().cpu().contiguous(), w3.detach().float().cpu().contiguous()
+    stream_host = torch.empty(nbytes, dtype=torch.uint8)
+    _lib.check(lib.og_mlp_block_pack(D, w0h.data_ptr(), w3h.data_ptr(), stream_host.data_ptr()), "og_mlp_block_pack")
+    stream_dev = stream_host.to(x.device)
+    rows = split_f16_hl(torch.cat([x, o], dim=1).contiguous())          # [M][4D halves]: x | O
+    b0, b3 = _req(b0, "b0"), _req(b3, "b3")
+    _lib.check(lib.og_mlp_block(D, rows.data_ptr(), 4 * D, M, stream_dev.data_ptr(), b0.data_ptr(), b3.data_ptr(), _stream()), "og_mlp_block")
+    out = merge_f16_hl(rows)[:, :D].contiguous()
+    return (out, rows) if return_rows else out
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int) -> torch.Tensor:
     """Multi-head softmax attention on token-major fp32 tensors q [Z,nq,D], k,v [Z,nk,D]; head h owns
     channels h*d..(h+1)*d-1.  q must already carry the d^-1/2 scale (the log2(e) factor of the kernel's

@@ -106,6 +106,58 @@ def test_gemm_nt_f16x3_gnn_forms(gpu_device, M, N, K, form):
     assert torch.isfinite(out).all()
 
 
+@pytest.mark.parametrize("M", [128, 4096, 32768, 777, 1])
+def test_mlp_block_fused_vs_float64(gpu_device, M):
+    """og_mlp_block (csrc/mlp_fused.hip): x + W3 relu(W0 [x ; O] + b0) + b3 in ONE launch with the hidden activation in registers
+    (attention_gnn.py:53-55 + models/utils.py:48-58 after the folds of og_pack_weights) -- against float64 and against the two
+    split-f16 GEMM launches it replaces.  Asymmetric random operands: a wrong fragment permutation cannot pass.  M = 777 / 1: partial
+    tiles (clamped loads, predicated stores); rows past M must stay untouched."""
+    D = 256
+    g = torch.Generator().manual_seed(1000 + M)
+    x, o = _rand(g, M, D, scale=2.0), _rand(g, M, D, scale=1.5)
+    w0, w3 = _rand(g, 2 * D, 2 * D, scale=0.04), _rand(g, D, 2 * D, scale=0.05)
+    b0, b3 = _rand(g, 2 * D, scale=0.3), _rand(g, D, scale=0.3)
+    dev = lambda t: t.to(gpu_device)
+    out, rows = ops.mlp_block(dev(x), dev(o), dev(w0), dev(b0), dev(w3), dev(b3), return_rows=True)
+    out = out.cpu()
+    xo_in = ops.merge_f16_hl(ops.split_f16_hl(dev(torch.cat([x, o], 1).contiguous()))).cpu()       # what the kernel is given
+    sl = torch.cat([torch.arange(0, min(M, 400)), torch.arange(max(M - 300, 0), M)]).unique()
+    h = torch.relu(xo_in[sl].double() @ w0.double().T + b0.double())
+    ref = xo_in[sl, :D].double() + h @ w3.double().T + b3.double()
+    err = (out[sl].double() - ref).abs().max().item()
+    h32 = torch.relu(xo_in[sl] @ w0.T + b0)
+    fp32_err = ((xo_in[sl, :D] + h32 @ w3.T + b3).double() - ref).abs().max().item()
+    print(f"[mlp_block M={M}] err {err:.2e} (fp32 CPU err {fp32_err:.2e})")
+    assert torch.isfinite(out).all()
+    assert err < max(2.0 * fp32_err, 2e-6) + 2e-6 * ref.abs().max().item()
+    # the O half of the rows is read-only
+    assert torch.equal(ops.merge_f16_hl(rows)[:, D:].cpu(), xo_in[:, D:])
+    # the two-launch form (fc.0 with ReLU -> hl32 rows; fc.3 with the (hi, lo) residual): same operands, same hidden rounding
+    hid = ops.gemm_nt_f16x3_split_only(dev(xo_in), dev(w0), bias=dev(b0), relu=True)
+    two = ops.gemm_nt_f16x3_split_only(hid, dev(w3), bias=dev(b3), res=dev(xo_in[:, :D].contiguous())).cpu()
+    assert (two - out).abs().max().item() < 2e-5 + 1e-6 * ref.abs().max().item()
+
+
+def test_mlp_block_rows_past_m_untouched(gpu_device):
+    from openglue_amd import _lib
+    lib = _lib.load()
+    D, M, R = 256, 200, 384
+    g = torch.Generator().manual_seed(7)
+    xo = _rand(g, R, 2 * D).to(gpu_device)
+    w0, w3 = _rand(g, 2 * D, 2 * D, scale=0.04), _rand(g, D, 2 * D, scale=0.05)
+    b0, b3 = _rand(g, 2 * D).to(gpu_device), _rand(g, D).to(gpu_device)
+    st = torch.empty(lib.og_mlp_block_stream_bytes(D), dtype=torch.uint8)
+    _lib.check(lib.og_mlp_block_pack(D, w0.data_ptr(), w3.data_ptr(), st.data_ptr()), "pack")
+    st = st.to(gpu_device)
+    rows = ops.split_f16_hl(xo)
+    before = rows.clone()
+    _lib.check(lib.og_mlp_block(D, rows.data_ptr(), 4 * D, M, st.data_ptr(), b0.data_ptr(), b3.data_ptr(), torch.cuda.current_stream().cuda_stream), "og_mlp_block")
+    torch.cuda.synchronize()
+    assert torch.equal(rows[M:], before[M:])
+    assert not torch.equal(rows[:M, :2 * D], before[:M, :2 * D])
+    assert torch.equal(rows[:M, 2 * D:], before[:M, 2 * D:])
+
+
 def test_split_f16_roundtrip(gpu_device):
     g = torch.Generator().manual_seed(1)
     x = torch.cat([_rand(g, 1000, scale=s) for s in (1e-3, 1.0, 50.0, 3000.0)])

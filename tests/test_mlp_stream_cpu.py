@@ -1,0 +1,100 @@
+"""Host-side check of the fused message-MLP kernel's weight stream (csrc/mlp_fused.hip, og_mlp_block_pack) WITHOUT a GPU: a numpy
+emulation of the kernel's data flow -- the stage order, the MFMA operand / accumulator lane layouts the HIP kernels rely on
+(og_common.h: mfma32_row; cdna_hip_programming.md §3) and the re-use of fc.0's accumulator registers as fc.3's B fragments --
+consumes the packed stream exactly as the kernel does and must reproduce x + W3 relu(W0 [x ; O] + b0) + b3
+(reference attention_gnn.py:53-55 + models/utils.py:48-58 after the folds of og_pack_weights)."""
+import numpy as np
+import torch
+
+from openglue_amd import _lib
+
+
+def _mfma_32x32x16(a_frag, b_frag, acc):
+    """v_mfma_f32_32x32x16_f16 on lane-level fragments: a_frag, b_frag [64 lanes][8], acc [64 lanes][16] (float64 here).
+    A[row = l & 31][k = 8 (l >> 5) + e], B[k = 8 (l >> 5) + e][col = l & 31], D lane l reg r = D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31]."""
+    A = np.zeros((32, 16)); Bm = np.zeros((16, 32))
+    for l in range(64):
+        A[l & 31, 8 * (l >> 5):8 * (l >> 5) + 8] = a_frag[l]
+        Bm[8 * (l >> 5):8 * (l >> 5) + 8, l & 31] = b_frag[l]
+    Dm = A @ Bm
+    for l in range(64):
+        for r in range(16):
+            acc[l, r] += Dm[(r & 3) + 8 * (r >> 2) + 4 * (l >> 5), l & 31]
+
+
+def _split(v):
+    hi = v.astype(np.float16)
+    lo = (v - hi.astype(np.float64)).astype(np.float16)
+    return hi.astype(np.float64), lo.astype(np.float64)
+
+
+def test_mlp_stream_numpy_emulation_of_the_kernel():
+    lib = _lib.load()
+    D = 256
+    nbytes = lib.og_mlp_block_stream_bytes(D)
+    assert nbytes == 6 * D * D * 4
+    assert lib.og_mlp_block_stream_bytes(64) == 0 and lib.og_mlp_block_pack(64, None, None, None) != 0
+    g = torch.Generator().manual_seed(11)
+    w0 = (torch.randn(2 * D, 2 * D, generator=g) * 0.04).contiguous()
+    w3 = (torch.randn(D, 2 * D, generator=g) * 0.05).contiguous()
+    b0 = (torch.randn(2 * D, generator=g) * 0.3).double().numpy()
+    b3 = (torch.randn(D, generator=g) * 0.3).double().numpy()
+    st = torch.empty(nbytes, dtype=torch.uint8)
+    assert lib.og_mlp_block_pack(D, w0.data_ptr(), w3.data_ptr(), st.data_ptr()) == 0
+    halves = st.numpy().view(np.float16).astype(np.float64).reshape(48, 32, 64, 8)      # [stage][fragment][lane][element]
+
+    xo = (torch.randn(32, 2 * D, generator=g) * 1.5).double().numpy()                   # one wave: 32 tokens of [x | O]
+    xh, xl = _split(xo)
+    xo_rep = xh + xl
+    lanes = np.arange(64)
+    tok, hh = lanes & 31, lanes >> 5
+
+    acc3 = np.zeros((8, 64, 16))
+    for i in range(8):
+        for l in range(64):
+            for r in range(16):
+                acc3[i, l, r] = 256.0 * b3[32 * i + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)]
+    s = 0
+    for a in range(2):
+        acc0 = np.zeros((8, 64, 16))
+        for i in range(8):
+            for l in range(64):
+                for r in range(16):
+                    acc0[i, l, r] = 256.0 * b0[256 * a + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)]
+        for kg in range(16):                                 # fc.0 stages
+            for t in range(2):
+                cols = (32 * kg + 16 * t + 8 * hh)[:, None] + np.arange(8)[None, :]
+                bh, bl = xh[tok[:, None], cols], xl[tok[:, None], cols]
+                for i in range(8):
+                    wh, wl = halves[s, (t * 8 + i) * 2], halves[s, (t * 8 + i) * 2 + 1]
+                    _mfma_32x32x16(wl, bh, acc0[i]); _mfma_32x32x16(wh, bl, acc0[i]); _mfma_32x32x16(wh, bh, acc0[i])
+            s += 1
+        for j in range(8):                                   # fc.3 stages: hidden block j of this half from acc0[j]
+            v = np.maximum(acc0[j].astype(np.float32) * np.float32(1.0 / 256.0), 0).astype(np.float64)
+            vh, vl = _split(v)
+            for t in range(2):
+                bh, bl = vh[:, 8 * t:8 * t + 8], vl[:, 8 * t:8 * t + 8]          # element e of k-step t = accumulator register 8t + e
+                for i in range(8):
+                    wh, wl = halves[s, (t * 8 + i) * 2], halves[s, (t * 8 + i) * 2 + 1]
+                    _mfma_32x32x16(wl, bh, acc3[i]); _mfma_32x32x16(wh, bl, acc3[i]); _mfma_32x32x16(wh, bh, acc3[i])
+            s += 1
+    assert s == 48
+    out = np.zeros((32, D))
+    for i in range(8):
+        for l in range(64):
+            for r in range(16):
+                ch = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
+                out[l & 31, ch] = acc3[i, l, r] / 256.0 + xo_rep[l & 31, ch]
+    ref = xo_rep[:, :D] + np.maximum(xo_rep @ w0.double().numpy().T + b0, 0) @ w3.double().numpy().T + b3
+    err = np.abs(out - ref).max()
+    print(f"emulated kernel vs float64: {err:.2e}")
+    assert err < 2e-5          # fp32 rounding of the hidden activation + the dropped lo*lo terms
+
+
+def test_mlp_stream_range_error():
+    lib = _lib.load()
+    D = 256
+    w0 = torch.zeros(2 * D, 2 * D); w3 = torch.zeros(D, 2 * D)
+    w0[3, 5] = 300.0                                  # 256 * 300 > 65504
+    st = torch.empty(lib.og_mlp_block_stream_bytes(D), dtype=torch.uint8)
+    assert lib.og_mlp_block_pack(D, w0.data_ptr(), w3.data_ptr(), st.data_ptr()) == -5
