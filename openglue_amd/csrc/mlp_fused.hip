@@ -40,8 +40,30 @@ constexpr int XOFF = 3 * WSTAGE;
 constexpr int BOFF = XOFF + 3 * XSTAGE;       // biases * 256 (fp32): b0' [2D] then b3' [D]
 constexpr int EPI_SLAB = 32 * 144;            // epilogue scratch: one 32-token slice, rows of (128 B + 16 B pad)
 
+// Compile-time ablations (scripts/build_mlp_ablation.sh; results wrong by construction): 1 = no global stores, 4 = no MFMA,
+// 8 = no LDS-DMA after the prologue, 32 = no token LDS-DMA after the prologue.
 #ifndef OG_MLP_ABL
-#define OG_MLP_ABL 0                          // experiments: 1 = no stores, 4 = no MFMA (results wrong by construction)
+#define OG_MLP_ABL 0
+#endif
+// Experiment builds only (-DOG_MLP_TRACE=1): shader-cycle stamps of every wave at every stage hand-over (before the DMA wait, after
+// it, after the barrier), kept in the lanes of three VGPRs (stamp of stage s in lane s) and written out at the end
+// (og_debug_mlp_trace, scripts/trace_mlp.py).
+#ifndef OG_MLP_TRACE
+#define OG_MLP_TRACE 0
+#endif
+#if OG_MLP_TRACE
+constexpr int OG_MT_BLOCKS = 512;
+__device__ unsigned og_mlp_trace_buf[OG_MT_BLOCKS][4][4][64];
+#define OG_MT(k_, idx_)                                                                     \
+    do {                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        const unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime();                         \
+        mt_v[k_] = lane == (int)(idx_) ? (int)t_ : mt_v[k_];                                \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+    } while (0)
+#else
+#define OG_MT(k_, idx_) do {} while (0)
 #endif
 
 template <int D>
@@ -61,6 +83,10 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpFusedArgs g) {
     const int l31 = lane & 31, hi = lane >> 5;
     const int t0 = blockIdx.x * MT;
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+#if OG_MLP_TRACE
+    int mt_v[4] = {0, 0, 0, 0};
+    OG_MT(3, 0);
+#endif
 
     auto scalar_ptr = [](const char* p) {
         const uint64_t v = (uint64_t)(uintptr_t)p;
@@ -124,15 +150,8 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpFusedArgs g) {
     f32x16 acc0[8], acc3[8];
     f16x8 wh[2][2], wl[2][2], xh[2], xl[2];
     auto lds_read = [&](f16x8& dst, unsigned addr, int imm) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm)); };
-    // fragment (t, i, part) of the current weight stage: ((t * 8 + i) * 2 + part) KiB behind the stage base
+    // fragment (t, i, part) of the current weight stage: ((t * 8 + i) * 2 + part) KiB behind the stage base (part 0 = hi, 1 = lo)
     unsigned wa = 0;                                       // lds address of this lane's 16 bytes of fragment 0 of the stage being read
-    auto read_w = [&](int t, int ip, int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            lds_read(wh[buf][i], wa, ((t * 8 + 2 * ip + i) * 2) * 1024);
-            lds_read(wl[buf][i], wa, ((t * 8 + 2 * ip + i) * 2 + 1) * 1024);
-        }
-    };
     // token fragments: row 32w + l31 of the tile, logical chunk 2t + hi (hi part), + 4 (lo part), XOR-swizzled like the DMA source
     const int swz = (l31 >> 1) & 7;
     unsigned xk[2][2], xa[2][2];
@@ -148,12 +167,20 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpFusedArgs g) {
     };
     auto read_x = [&](int t) { lds_read(xh[t], xa[t][0], 0); lds_read(xl[t], xa[t][1], 0); };
     auto set_w = [&](int slot) { wa = lds0 + slot * WSTAGE + lane16; };
-    auto wait_w = [&](int b, int newer) {                 // frees fragment buffer b while `newer` younger LDS reads may stay in flight
-        if (newer == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wh[b][0]), "+v"(wl[b][0]), "+v"(wh[b][1]), "+v"(wl[b][1]));
-        else if (newer == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wh[b][0]), "+v"(wl[b][0]), "+v"(wh[b][1]), "+v"(wl[b][1]));
-        else asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(wh[b][0]), "+v"(wl[b][0]), "+v"(wh[b][1]), "+v"(wl[b][1]));
+    // One weight fragment of group grp (t = grp >> 2, channel blocks 2 (grp & 3) + {0, 1}) in the order the group's MFMAs first use
+    // them: k = 0: lo of block 0, 1: lo of block 1, 2: hi of block 0, 3: hi of block 1.
+    auto read_wk = [&](int grp, int k, int buf) {
+        const int f = ((grp >> 2) * 8 + 2 * (grp & 3) + (k & 1)) * 2 + (k < 2 ? 1 : 0);
+        lds_read(k < 2 ? wl[buf][k & 1] : wh[buf][k & 1], wa, f * 1024);
     };
-    auto tie_x = [&](int t) { asm volatile("" : "+v"(xh[t]), "+v"(xl[t])); };
+    // LDS returns in order: "all but the N newest reads have landed".  The "+v" operand ties the wait to the register it releases.
+    auto wait1 = [&](int newer, f16x8& r) {
+        if (newer == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r));
+        else if (newer == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(r));
+        else if (newer == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(r));
+        else asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(r));
+    };
+    auto tie2 = [&](f16x8& a, f16x8& b) { asm volatile("" : "+v"(a), "+v"(b)); };
 
     // accumulator initialisation: bias * 256 of 8 consecutive channel blocks from LDS (float offset `off`).  Register r of a 32x32
     // accumulator holds channel (r & 3) + 8 (r >> 2) + 4 hi of the block.  Inline-asm reads with their own full wait: LDS reads the
@@ -185,11 +212,69 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpFusedArgs g) {
     int xs = 0, xslot = 0;          // token stage being consumed (fc.0 stages only) and its ring slot
     auto next3 = [](int v) { return v == 2 ? 0 : v + 1; };
     auto prev3 = [](int v) { return v == 0 ? 2 : v - 1; };
+    const float sc = g.scale;
+
+    // ---- one stage = 8 groups of 6 MFMAs on ONE wave per SIMD.  With a single wave nothing else hides what sits between two MFMAs:
+    //      the first generation issued a group's four fragment reads, its wait and three LDS-DMA pieces in front of / inside the
+    //      group and ran at 2520 cycles per stage against 1536 of matrix-pipe time (profiles/r03_a_mlp_fused_trace.log: a wave issues
+    //      an MFMA only when the pipe is free, so everything between two MFMAs beyond the 32 cycles the previous one executes is
+    //      exposed).  Here every MFMA is followed by ONE small item that fits its shadow:
+    //        slots 0-3  the next group's fragment reads, one each, in first-use order (lo 0, lo 1, hi 0, hi 1), waited for one by one
+    //                   (lgkmcnt(3): a read has six MFMA slots = 192 cycles to land)
+    //        slots 0-3  of groups 0-5 also the LDS-DMA pieces, wave w in slots w and (w + 2) & 3 -- the four waves of a CU run in
+    //                   lock-step and the CU accepts one 1 KiB piece per >= 16 cycles: spread over different slots they do not queue
+    //                   behind each other
+    //        slots 4-5  fc.0: the token fragments of the second k-step; fc.3: the (hi, lo) conversion of the next hidden block, 12 small steps
+    //      The hand-over to the next stage (DMA wait + barrier) sits between MFMA 1 and 2 of the last group; the next stage's first
+    //      fragments are read in that group's remaining slots.
+    auto hand_over = [&](bool next_exists, bool next_is_fc0, int next_xslot, int issued) {
+        OG_MT(0, s);
+        // everything issued before this stage has landed (only this stage's own pieces may still fly)
+        if (issued == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (issued == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        OG_MT(1, s);
+        if (next_exists) {
+            __builtin_amdgcn_s_barrier();
+            OG_MT(2, s);
+            set_w(next3(wslot));
+            if (next_is_fc0) set_x(next_xslot);
+        }
+    };
+#define OG_MFMA(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, acc_, 0, 0, 0)
+#define OG_SB() __builtin_amdgcn_sched_barrier(0)
+    // the six MFMAs of group grp of a stage with their slots; ACC = accumulator array, BH / BL = the B fragments of k-step t
+#if OG_MLP_ABL & 4
+#define OG_MM(acc_, a_, b_) asm volatile("" ::"v"(a_), "v"(b_))
+#else
+#define OG_MM(acc_, a_, b_) OG_MFMA(acc_, a_, b_)
+#endif
+#define OG_GROUP(ACC, BH, BL, GRP, CNT, SLOT, HANDOVER, NEXT_EXISTS, NEXT_FC0)                                                  \
+    {                                                                                                                          \
+        constexpr int grp_ = GRP, ip_ = grp_ & 3, b_ = grp_ & 1, nb_ = b_ ^ 1;                                                  \
+        if constexpr (grp_ < 7) {                                                                                              \
+            wait1(CNT, wl[b_][0]); OG_SB(); OG_MM(ACC[2 * ip_], wl[b_][0], BH); OG_SB(); SLOT(grp_, 0); read_wk(grp_ + 1, 0, nb_); OG_SB();      \
+            wait1(CNT, wl[b_][1]); OG_SB(); OG_MM(ACC[2 * ip_ + 1], wl[b_][1], BH); OG_SB(); SLOT(grp_, 1); read_wk(grp_ + 1, 1, nb_); OG_SB();  \
+            wait1(CNT, wh[b_][0]); OG_SB(); OG_MM(ACC[2 * ip_], wh[b_][0], BL); OG_SB(); SLOT(grp_, 2); read_wk(grp_ + 1, 2, nb_); OG_SB();      \
+            wait1(CNT, wh[b_][1]); OG_SB(); OG_MM(ACC[2 * ip_ + 1], wh[b_][1], BL); OG_SB(); SLOT(grp_, 3); read_wk(grp_ + 1, 3, nb_); OG_SB();  \
+            OG_MM(ACC[2 * ip_], wh[b_][0], BH); OG_SB(); SLOT(grp_, 4); OG_SB();                                                \
+            OG_MM(ACC[2 * ip_ + 1], wh[b_][1], BH); OG_SB(); SLOT(grp_, 5); OG_SB();                                            \
+        } else {                                                                                                               \
+            wait1(3, wl[b_][0]); OG_SB(); OG_MM(ACC[2 * ip_], wl[b_][0], BH); OG_SB(); SLOT(grp_, 0); OG_SB();                   \
+            wait1(2, wl[b_][1]); OG_SB(); OG_MM(ACC[2 * ip_ + 1], wl[b_][1], BH); OG_SB(); SLOT(grp_, 1); OG_SB();               \
+            wait1(0, wh[b_][0]); tie2(wh[b_][0], wh[b_][1]); OG_SB();      /* all my LDS reads of this stage are done */         \
+            HANDOVER; OG_SB();                                                                                                 \
+            OG_MM(ACC[2 * ip_], wh[b_][0], BL); OG_SB(); if (NEXT_FC0) read_x(0); OG_SB();                                       \
+            OG_MM(ACC[2 * ip_ + 1], wh[b_][1], BL); OG_SB(); if (NEXT_EXISTS) read_wk(0, 0, 0); OG_SB();                         \
+            OG_MM(ACC[2 * ip_], wh[b_][0], BH); OG_SB(); if (NEXT_EXISTS) read_wk(0, 1, 0); OG_SB();                             \
+            OG_MM(ACC[2 * ip_ + 1], wh[b_][1], BH); OG_SB(); if (NEXT_EXISTS) { read_wk(0, 2, 0); read_wk(0, 3, 0); } OG_SB();   \
+        }                                                                                                                      \
+    }
+
     set_w(0); set_x(0);
     read_x(0);
-    read_w(0, 0, 0);
+    read_wk(0, 0, 0); read_wk(0, 1, 0); read_wk(0, 2, 0); read_wk(0, 3, 0);
 
-    const float sc = g.scale;
 #pragma unroll 1
     for (int pass = 0; pass < NPASS; ++pass) {
         init_acc8(acc0, pass * 256);
@@ -197,50 +282,32 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpFusedArgs g) {
         // ================= fc.0: acc0[i] += W0'[pass half, block i][k-group] · [x ; O][k-group], 16 stages =================
 #pragma unroll 1
         for (int kg = 0; kg < G0; ++kg) {
-            const bool iw = s + 2 < STAGES, ix = xs + 2 < XSTAGES;      // W(s+2) / X(xs+2) exist
-            const int wslot2 = prev3(wslot), xslot2 = prev3(xslot);     // their slots: (s + 2) % 3 = (s - 1) % 3
+            const bool ix = xs + 2 < XSTAGES;                           // X(xs+2) exists (W(s+2) always does during fc.0)
+            const int wslot2 = prev3(wslot), xslot2 = prev3(xslot);     // slots of W(s+2), X(xs+2): (s + 2) % 3 = (s - 1) % 3
             const bool next_x = kg + 1 < G0;                            // the next stage is an fc.0 stage (reads token fragments)
-#pragma unroll
-            for (int grp = 0; grp < 8; ++grp) {
-                const int t = grp >> 2, ip = grp & 3, b = grp & 1;
-                if (grp < 7) {
-                    if (grp == 0) read_x(1);
-                    read_w((grp + 1) >> 2, (grp + 1) & 3, (grp + 1) & 1);
-                    wait_w(b, grp == 0 ? 6 : 4);
-                    if (grp == 0) tie_x(0);
-                    if (grp == 1) tie_x(1);
-                } else {
-                    wait_w(b, 0);                                       // all my LDS reads of this stage are done
-                    // hand-over: everything issued before this stage has landed (only this stage's own pieces may still fly)
-                    if (iw && ix) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                    else if (iw) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    set_w(next3(wslot));
-                    if (next_x) { set_x(next3(xslot)); read_x(0); }
-                    read_w(0, 0, 0);
+            // piece p of this wave and stage: 0-7 weights, 8-11 tokens
+            auto piece = [&](int p) {
+                if (OG_MLP_ABL & 8) return;
+                if (p < 8) issue_w(s + 2, wslot2, p);
+                else if (ix && !(OG_MLP_ABL & 32)) issue_x(xs + 2, xslot2, p - 8);
+            };
+            auto slot = [&](int grp, int k) {
+                if (k < 4 && grp < 6) {
+                    if (wave == k) piece(2 * grp);
+                    else if (wave == ((k + 2) & 3)) piece(2 * grp + 1);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-#if !(OG_MLP_ABL & 4)
-                acc0[2 * ip] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[b][0], xh[t], acc0[2 * ip], 0, 0, 0);
-                acc0[2 * ip + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[b][1], xh[t], acc0[2 * ip + 1], 0, 0, 0);
-#endif
-                if (grp < 4) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (iw) { issue_w(s + 2, wslot2, 2 * grp); issue_w(s + 2, wslot2, 2 * grp + 1); }
-                    if (ix) issue_x(xs + 2, xslot2, grp);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#if !(OG_MLP_ABL & 4)
-                acc0[2 * ip] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[b][0], xl[t], acc0[2 * ip], 0, 0, 0);
-                acc0[2 * ip + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[b][1], xl[t], acc0[2 * ip + 1], 0, 0, 0);
-                acc0[2 * ip] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[b][0], xh[t], acc0[2 * ip], 0, 0, 0);
-                acc0[2 * ip + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[b][1], xh[t], acc0[2 * ip + 1], 0, 0, 0);
-#else
-                asm volatile("" ::"v"(wh[b][0]), "v"(wl[b][0]), "v"(wh[b][1]), "v"(wl[b][1]), "v"(xh[t]), "v"(xl[t]));
-#endif
-                __builtin_amdgcn_sched_barrier(0);
-            }
+                if (grp == 1 && k == 4) read_x(1);                      // the second k-step's token fragments (first used by group 4)
+            };
+            tie2(xh[0], xl[0]);
+            OG_GROUP(acc0, xh[0], xl[0], 0, 3, slot, , true, false)
+            OG_GROUP(acc0, xh[0], xl[0], 1, 3, slot, , true, false)
+            OG_GROUP(acc0, xh[0], xl[0], 2, 5, slot, , true, false)
+            OG_GROUP(acc0, xh[0], xl[0], 3, 3, slot, , true, false)
+            tie2(xh[1], xl[1]);
+            OG_GROUP(acc0, xh[1], xl[1], 4, 3, slot, , true, false)
+            OG_GROUP(acc0, xh[1], xl[1], 5, 3, slot, , true, false)
+            OG_GROUP(acc0, xh[1], xl[1], 6, 3, slot, , true, false)
+            OG_GROUP(acc0, xh[1], xl[1], 7, 3, slot, hand_over(true, next_x, next3(xslot), ix ? 12 : 8), true, next_x)
             ++s; wslot = next3(wslot);
             ++xs; xslot = next3(xslot);
         }
@@ -248,18 +315,25 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpFusedArgs g) {
         // ================= fc.3: acc3[i] += W3'[block i][hidden block j of this half] · relu(acc0[j] / 256), 8 stages =================
         // hidden block j as B fragments: element e of k-step t is accumulator register 8t + e (og_pack_mlp_stream permutes W3' to match)
         unsigned hh[2][2][4], hl[2][2][4];             // [buffer][t][dword]
-        auto convert_quarter = [&](const f32x16& a, int q, int buf) {
+        float cv[4];
+        // (hi, lo) conversion of quarter q (accumulator registers 4q .. 4q+3) of a hidden block in three small steps
+        auto convert_step = [&](const f32x16& a, int step, int buf) {
 #pragma clang fp contract(off)
-            float v0 = fmaxf(a[4 * q] * sc, 0.f), v1 = fmaxf(a[4 * q + 1] * sc, 0.f), v2 = fmaxf(a[4 * q + 2] * sc, 0.f), v3 = fmaxf(a[4 * q + 3] * sc, 0.f);
-            const int t = q >> 1, d = 2 * (q & 1);
-            og_split4(v0, v1, v2, v3, hh[buf][t][d], hl[buf][t][d], hh[buf][t][d + 1], hl[buf][t][d + 1]);
+            const int q = step / 3, k = step % 3;
+            if (k == 0) { cv[0] = a[4 * q] * sc; cv[1] = a[4 * q + 1] * sc; cv[2] = a[4 * q + 2] * sc; cv[3] = a[4 * q + 3] * sc; }
+            else if (k == 1) { cv[0] = fmaxf(cv[0], 0.f); cv[1] = fmaxf(cv[1], 0.f); cv[2] = fmaxf(cv[2], 0.f); cv[3] = fmaxf(cv[3], 0.f); }
+            else {
+                const int t = q >> 1, d = 2 * (q & 1);
+                og_split4(cv[0], cv[1], cv[2], cv[3], hh[buf][t][d], hl[buf][t][d], hh[buf][t][d + 1], hl[buf][t][d + 1]);
+            }
         };
 #pragma unroll
-        for (int q = 0; q < 4; ++q) convert_quarter(acc0[0], q, 0);
+        for (int st = 0; st < 12; ++st) convert_step(acc0[0], st, 0);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const bool iw = s + 2 < STAGES;
             const int wslot2 = prev3(wslot);
+            const bool next_exists = s + 1 < STAGES;
             const bool next_x = j + 1 == NJ && pass + 1 < NPASS;        // the next stage is the first fc.0 stage of the next pass
             const int hb = j & 1;
             f16x8 bh[2], bl[2];
@@ -268,51 +342,28 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpFusedArgs g) {
                 bh[t] = __builtin_bit_cast(f16x8, og_u32x4{hh[hb][t][0], hh[hb][t][1], hh[hb][t][2], hh[hb][t][3]});
                 bl[t] = __builtin_bit_cast(f16x8, og_u32x4{hl[hb][t][0], hl[hb][t][1], hl[hb][t][2], hl[hb][t][3]});
             }
-#pragma unroll
-            for (int grp = 0; grp < 8; ++grp) {
-                const int t = grp >> 2, ip = grp & 3, b = grp & 1;
-                if (grp < 7) {
-                    read_w((grp + 1) >> 2, (grp + 1) & 3, (grp + 1) & 1);
-                    wait_w(b, 4);
-                } else {
-                    wait_w(b, 0);
-                    if (iw) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (s + 1 < STAGES) {
-                        __builtin_amdgcn_s_barrier();
-                        set_w(next3(wslot));
-                        if (next_x) { set_x(xslot); read_x(0); }
-                        read_w(0, 0, 0);
-                    }
+            auto slot = [&](int grp, int k) {
+                if (k < 4 && grp < 4 && iw && !(OG_MLP_ABL & 8)) {
+                    if (wave == k) issue_w(s + 2, wslot2, 2 * grp);
+                    else if (wave == ((k + 2) & 3)) issue_w(s + 2, wslot2, 2 * grp + 1);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-#if !(OG_MLP_ABL & 4)
-                acc3[2 * ip] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[b][0], bh[t], acc3[2 * ip], 0, 0, 0);
-                acc3[2 * ip + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[b][1], bh[t], acc3[2 * ip + 1], 0, 0, 0);
-#endif
-                if (grp < 4) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (iw) { issue_w(s + 2, wslot2, 2 * grp); issue_w(s + 2, wslot2, 2 * grp + 1); }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (j + 1 < NJ && (grp & 1) == 0) {        // the next hidden block, a quarter at a time, between the MFMAs
-                    convert_quarter(acc0[j + 1 < NJ ? j + 1 : j], grp >> 1, hb ^ 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#if !(OG_MLP_ABL & 4)
-                acc3[2 * ip] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[b][0], bl[t], acc3[2 * ip], 0, 0, 0);
-                acc3[2 * ip + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[b][1], bl[t], acc3[2 * ip + 1], 0, 0, 0);
-                acc3[2 * ip] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[b][0], bh[t], acc3[2 * ip], 0, 0, 0);
-                acc3[2 * ip + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[b][1], bh[t], acc3[2 * ip + 1], 0, 0, 0);
-#else
-                asm volatile("" ::"v"(wh[b][0]), "v"(wl[b][0]), "v"(wh[b][1]), "v"(wl[b][1]), "v"(bh[t]), "v"(bl[t]));
-#endif
-                __builtin_amdgcn_sched_barrier(0);
-            }
+                if (k >= 4 && grp < 6 && j + 1 < NJ) convert_step(acc0[j + 1 < NJ ? j + 1 : j], 2 * grp + (k - 4), hb ^ 1);
+            };
+            OG_GROUP(acc3, bh[0], bl[0], 0, 3, slot, , true, false)
+            OG_GROUP(acc3, bh[0], bl[0], 1, 3, slot, , true, false)
+            OG_GROUP(acc3, bh[0], bl[0], 2, 3, slot, , true, false)
+            OG_GROUP(acc3, bh[0], bl[0], 3, 3, slot, , true, false)
+            OG_GROUP(acc3, bh[1], bl[1], 4, 3, slot, , true, false)
+            OG_GROUP(acc3, bh[1], bl[1], 5, 3, slot, , true, false)
+            OG_GROUP(acc3, bh[1], bl[1], 6, 3, slot, , true, false)
+            OG_GROUP(acc3, bh[1], bl[1], 7, 3, slot, hand_over(next_exists, next_x, xslot, iw ? 8 : 0), next_exists, next_x)
             ++s; wslot = next3(wslot);
         }
     }
+#undef OG_GROUP
+#undef OG_MM
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    OG_MT(3, 1);
     __builtin_amdgcn_s_barrier();          // every wave is past its last fragment reads, no DMA in flight: the rings are free
 
     // ================= epilogue: x <- acc3 / 256 + (x_hi + x_lo), written back as hl32 rows =================
@@ -405,6 +456,15 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpFusedArgs g) {
             }
         }
     }
+#if OG_MLP_TRACE
+    OG_MT(3, 2);                                   // all stores issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    OG_MT(3, 3);                                   // all stores acknowledged
+    mt_v[3] = lane == 4 ? (int)__builtin_amdgcn_s_getreg(0xF804) : mt_v[3];     // HW_ID
+    mt_v[3] = lane == 5 ? (int)__builtin_amdgcn_s_getreg(0xF814) : mt_v[3];     // XCC_ID
+    if (blockIdx.x < OG_MT_BLOCKS)
+        for (int k = 0; k < 4; ++k) og_mlp_trace_buf[blockIdx.x][wave][k][lane] = (unsigned)mt_v[k];
+#endif
 }
 
 }  // namespace
@@ -467,6 +527,13 @@ int og_launch_mlp_fused(const MlpFusedArgs& a, int D, hipStream_t stream) {
     hipLaunchKernelGGL(mlp_fused_kernel<256>, dim3(tiles), dim3(256), 0, stream, a);
     return og_launch_status();
 }
+
+#if OG_MLP_TRACE
+extern "C" int og_debug_mlp_trace(void* host_dst, size_t bytes) {
+    if (bytes > sizeof(og_mlp_trace_buf)) bytes = sizeof(og_mlp_trace_buf);
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(og_mlp_trace_buf), bytes);
+}
+#endif
 
 // Stage entry (include/openglue_amd.h): the message MLP of one GNN layer on M token rows of [x | O] hl32 rows, in place.
 extern "C" size_t og_mlp_block_stream_bytes(int32_t D) { return og_mlp_stream_bytes(D); }
