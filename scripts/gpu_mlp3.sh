@@ -8,7 +8,7 @@ mkdir -p $OUT
 timeout 600 python -m pytest tests -m gpu -q -x --timeout 300 -p no:cacheprovider -k "mlp_block" > $OUT/pytest_mlp.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_mlp.log
 grep -E "passed|failed|error|FAILED|ERROR|rc=|assert" $OUT/pytest_mlp.log | tail -12
 : > $OUT/mlp_ablations.log
-for tag in "" nodma nomfma; do
+for tag in "" nodma nomfma nostore; do
   lib=openglue_amd/lib/libopenglue_amd.so; [ -n "$tag" ] && lib=openglue_amd/lib/libog_$tag.so
   echo "--- ${tag:-as built}" >> $OUT/mlp_ablations.log
   OPENGLUE_AMD_LIB=$PWD/$lib timeout 200 python scripts/bench_mlp_fused.py 2>&1 | grep "M=\|err" >> $OUT/mlp_ablations.log

@@ -28,7 +28,7 @@ for M in (int(a) for a in (sys.argv[1:] or ["65536", "32768", "4096"])):
     for _ in range(10): run()
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 10 * 1e3
-    buf = np.zeros((512, 4, 4, 64), np.uint32)
+    buf = np.zeros((512, 8, 4, 64), np.uint32)
     assert lib.og_debug_mlp_trace(buf.ctypes.data, buf.nbytes) == 0
     nblk = min(512, M // 128)
     t = buf[:nblk].astype(np.int64)
@@ -38,7 +38,7 @@ for M in (int(a) for a in (sys.argv[1:] or ["65536", "32768", "4096"])):
     entry, loop_end, st_iss, st_ack = t[:, :, 3, 0], t[:, :, 3, 1], t[:, :, 3, 2], t[:, :, 3, 3]
     f = lambda x: f"{np.median(x):8.0f} (p10 {np.percentile(x, 10):7.0f} p90 {np.percentile(x, 90):7.0f})"
     print(f"\n=== M={M}: traced build {us:.1f} us per launch, {nblk} blocks traced")
-    print(f"  block life (cycles, per wave)   : {f(d(st_ack, entry))}   [pure MFMA issue: {S * 48 * 32}]")
+    print(f"  block life (cycles, per wave)   : {f(d(st_ack, entry))}   [pure MFMA issue, 2 waves per SIMD: {S * 48 * 32}]")
     print(f"  entry -> end of stage 0         : {f(d(bar[:, :, 0], entry))}")
     per = d(bar[:, :, 1:S - 1], bar[:, :, 0:S - 2])
     print(f"  stage period (all, steady)      : {f(per)}   [MFMA-bound: 1536]")

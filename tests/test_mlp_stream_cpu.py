@@ -49,36 +49,39 @@ def test_mlp_stream_numpy_emulation_of_the_kernel():
     lanes = np.arange(64)
     tok, hh = lanes & 31, lanes >> 5
 
-    acc3 = np.zeros((8, 64, 16))
-    for i in range(8):
+    # one token block = two waves: wave a owns hidden half a (two quarters of 4 blocks) and a PARTIAL fc.3 sum over all 8 output blocks
+    acc3 = np.zeros((2, 8, 64, 16))
+    for i in range(8):                                       # the bias enters once: in the wave that finishes the block (4a .. 4a+3)
         for l in range(64):
             for r in range(16):
-                acc3[i, l, r] = 256.0 * b3[32 * i + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)]
-    s = 0
+                acc3[i // 4, i, l, r] = 256.0 * b3[32 * i + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)]
     for a in range(2):
-        acc0 = np.zeros((8, 64, 16))
-        for i in range(8):
-            for l in range(64):
-                for r in range(16):
-                    acc0[i, l, r] = 256.0 * b0[256 * a + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)]
-        for kg in range(16):                                 # fc.0 stages
-            for t in range(2):
-                cols = (32 * kg + 16 * t + 8 * hh)[:, None] + np.arange(8)[None, :]
-                bh, bl = xh[tok[:, None], cols], xl[tok[:, None], cols]
-                for i in range(8):
-                    wh, wl = halves[s, (t * 8 + i) * 2], halves[s, (t * 8 + i) * 2 + 1]
-                    _mfma_32x32x16(wl, bh, acc0[i]); _mfma_32x32x16(wh, bl, acc0[i]); _mfma_32x32x16(wh, bh, acc0[i])
-            s += 1
-        for j in range(8):                                   # fc.3 stages: hidden block j of this half from acc0[j]
-            v = np.maximum(acc0[j].astype(np.float32) * np.float32(1.0 / 256.0), 0).astype(np.float64)
-            vh, vl = _split(v)
-            for t in range(2):
-                bh, bl = vh[:, 8 * t:8 * t + 8], vl[:, 8 * t:8 * t + 8]          # element e of k-step t = accumulator register 8t + e
-                for i in range(8):
-                    wh, wl = halves[s, (t * 8 + i) * 2], halves[s, (t * 8 + i) * 2 + 1]
-                    _mfma_32x32x16(wl, bh, acc3[i]); _mfma_32x32x16(wh, bl, acc3[i]); _mfma_32x32x16(wh, bh, acc3[i])
-            s += 1
-    assert s == 48
+        for q in range(2):
+            acc0 = np.zeros((4, 64, 16))
+            for i in range(4):
+                for l in range(64):
+                    for r in range(16):
+                        acc0[i, l, r] = 256.0 * b0[32 * (8 * a + 4 * q + i) + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)]
+            for kg in range(16):                             # fc.0 stages
+                s = 24 * q + kg
+                for t in range(2):
+                    cols = (32 * kg + 16 * t + 8 * hh)[:, None] + np.arange(8)[None, :]
+                    bh, bl = xh[tok[:, None], cols], xl[tok[:, None], cols]
+                    for i in range(4):
+                        f = ((a * 2 + t) * 4 + i) * 2
+                        wh, wl = halves[s, f], halves[s, f + 1]
+                        _mfma_32x32x16(wl, bh, acc0[i]); _mfma_32x32x16(wh, bl, acc0[i]); _mfma_32x32x16(wh, bh, acc0[i])
+            for j in range(4):                               # fc.3 stages (j, t): hidden block j of this quarter from acc0[j]
+                v = np.maximum(acc0[j].astype(np.float32) * np.float32(1.0 / 256.0), 0).astype(np.float64)
+                vh, vl = _split(v)
+                for t in range(2):
+                    s = 24 * q + 16 + 2 * j + t
+                    bh, bl = vh[:, 8 * t:8 * t + 8], vl[:, 8 * t:8 * t + 8]      # element e of k-step t = accumulator register 8t + e
+                    for i in range(8):
+                        f = (a * 8 + i) * 2
+                        wh, wl = halves[s, f], halves[s, f + 1]
+                        _mfma_32x32x16(wl, bh, acc3[a, i]); _mfma_32x32x16(wh, bl, acc3[a, i]); _mfma_32x32x16(wh, bh, acc3[a, i])
+    acc3 = acc3[0] + acc3[1]                                 # the exchange at the end of the kernel
     out = np.zeros((32, D))
     for i in range(8):
         for l in range(64):
