@@ -187,14 +187,16 @@ int og_forward_ragged(const og_shape* shape, const int32_t* lens0, const int32_t
 /* Profiling variant of og_forward (bench.py): same work, but every launch group is bracketed by HIP
  * events recorded on `stream`; the call SYNCHRONISES the stream and returns the summed elapsed
  * milliseconds and the number of bracketed launch groups per kernel class.  GEMM and attention are
- * bracketed per kernel launch, Sinkhorn / matches per stage (many small launches). */
+ * bracketed per kernel launch, Sinkhorn / matches per stage (many small launches: og_sinkhorn_schedule tells which). */
 #define OG_STAGE_ENCODER_INPUT 0
 #define OG_STAGE_GEMM          1
 #define OG_STAGE_ATTENTION     2
 #define OG_STAGE_SINKHORN      3
 #define OG_STAGE_MATCHES       4
-#define OG_STAGE_GEMM_F16X3    5   /* split-f16 GEMMs of the GNN; OG_STAGE_GEMM = the exact-fp32 ones */
-#define OG_NUM_STAGES          6
+#define OG_STAGE_GEMM_F16X3    5   /* split-f16 GEMMs (q/k/v projections, final projection, score matrix, last encoder conv; the message
+                                      MLP as two launches when it is not fused); OG_STAGE_GEMM = the exact-fp32 ones */
+#define OG_STAGE_MLP_FUSED     6   /* ABI v5: the fused message-MLP kernel (csrc/mlp_fused.hip), one launch per bracket */
+#define OG_NUM_STAGES          7
 int og_forward_profiled(const og_shape* shape, const og_inputs* in, const void* packed_dev,
                         void* workspace_dev, const og_outputs* out, void* stream,
                         float* stage_ms /*[OG_NUM_STAGES]*/, int32_t* stage_launches /*[OG_NUM_STAGES]*/);
@@ -263,15 +265,24 @@ int og_sinkhorn(const float* S, int64_t lds, float dustbin, int32_t batch, int32
                 int32_t iters, float reg, float* scores, void* workspace_dev, void* stream);
 
 /* Diagnostics (synchronises the device, copies 4 bytes): state of the last og_sinkhorn / og_forward Sinkhorn stage that ran on
- * this Sinkhorn workspace.  0 = completed (or the streaming kernels were used); 1 = a cross-workgroup wait of the
- * on-chip-resident iteration kernel timed out and the scores are invalid (cannot happen while batch * ceil(m/128)
- * workgroups are co-resident, which the launcher checks against the CU count); -1 = bad arguments.
+ * this Sinkhorn workspace (every call resets it).
+ *   0 = completed normally (streaming kernels, or the on-chip-resident kernel without incident);
+ *   2 = a cross-workgroup wait of the on-chip-resident iteration kernel timed out (its batch * ceil(m/128) workgroups must be
+ *       co-resident; the launcher checks that against the CU count, but another stream or process holding CUs can still break it)
+ *       and the safety-net kernel enqueued behind it solved the problem again, one workgroup per pair: the scores are VALID, the
+ *       call was slow (milliseconds);
+ *   1 = timed out and not recomputed (cannot happen with this build's launch sequence; scores invalid); -1 = bad arguments.
  * When the batch fits (batch * ceil(m/128) <= #CUs, n <= 1024, >= 16 MB of scores; OG_SINKHORN_RESIDENT=0 disables, =2 drops
- * the size threshold) iterations 2..iters run in ONE launch with the score matrices held in registers + LDS. */
+ * the size threshold) iterations 2..iters run in ONE launch with the score matrices held in registers + LDS.
+ * OG_SINKHORN_FORCE_TIMEOUT=1 (tests) makes that launch behave as if it had timed out. */
 int og_sinkhorn_status(const void* sinkhorn_workspace_dev, int32_t batch, int32_t m, int32_t n);
+/* Which schedule og_sinkhorn / og_forward take for a UNIFORM batch of this shape in this process (environment switches and the
+ * device's CU count included): 1 = first iteration streaming + ONE on-chip-resident launch for iterations 2..iters (+ the safety-net
+ * and scores kernels: 6 launches), 0 = streaming (2 launches per iteration + 1).  Ragged batches always stream.  bench.py uses it to
+ * name the kernels its Sinkhorn bracket timed. */
+int og_sinkhorn_schedule(int32_t batch, int32_t m, int32_t n, int32_t iters);
 /* The same check for the workspace of an og_forward / og_forward_ragged call with this shape (for ragged calls: the shape
- * that was passed, i.e. the maxima).  SYNCHRONISES the device.  0 = the last call's optimal-transport stage completed,
- * 1 = its resident kernel timed out waiting for a peer workgroup (scores invalid), -1 = bad arguments. */
+ * that was passed, i.e. the maxima).  SYNCHRONISES the device.  Return values as og_sinkhorn_status. */
 int og_forward_status(const og_shape* shape, const void* workspace_dev);
 
 /* ---- training slice of the optimal-transport layer (reference: autograd through superglue.py:88-111 +

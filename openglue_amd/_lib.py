@@ -16,7 +16,7 @@ OG_FLAG_RESIDUAL, OG_FLAG_USE_OFFSET, OG_FLAG_NO_DESCRIPTORS, OG_FLAG_SIREN_ENCO
 OG_FLAG_FAVOR_RELU = 32
 OG_MAX_HIDDEN = 8
 OG_MAX_RAGGED = 64
-OG_STAGES = ("encoder_input", "gemm_f32", "attention", "sinkhorn", "matches", "gemm_f16x3")
+OG_STAGES = ("encoder_input", "gemm_f32", "attention", "sinkhorn", "matches", "gemm_f16x3", "mlp_fused")
 
 _ERRORS = {-1: "OG_E_INVALID (null pointer / bad size)", -2: "OG_E_SHAPE (unsupported shape)",
            -3: "OG_E_ALIGN (pointer or leading dimension not 16-byte aligned)", -4: "OG_E_FLAG (unknown flag)",
@@ -103,6 +103,7 @@ SYMBOLS = {
                                _i32, _vp]),
     "og_sinkhorn_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "og_sinkhorn_status": (C.c_int, [_vp, _i32, _i32, _i32]),
+    "og_sinkhorn_schedule": (C.c_int, [_i32, _i32, _i32, _i32]),
     "og_forward_status": (C.c_int, [_vp, _vp]),
     "og_sinkhorn_train_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "og_sinkhorn_train_forward": (C.c_int, [_vp, _i64, _f, _i32, _i32, _i32, _i32, _f, _vp, _vp, _vp]),

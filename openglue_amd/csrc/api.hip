@@ -521,7 +521,7 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
             MlpFusedArgs a{};
             a.XO = XO + r0 * D4; a.ld = D4; a.M = (int)R; a.wstream = (const char*)(lw + L.o_wmlp);
             a.b0 = lw + L.o_b0; a.b3 = lw + L.o_b3; a.scale = (float)(1.0 / OG_W_SCALE);
-            Scope sc(prof, OG_STAGE_GEMM_F16X3);
+            Scope sc(prof, OG_STAGE_MLP_FUSED);
             return og_launch_mlp_fused(a, D, st);
         }
         int e = gemmh(XO + r0 * D4, lw, L.o_w0, 0, R, D2, D2, lw + L.o_b0, 1, nullptr, nullptr, Hb + r0 * D4, nullptr, D4, 1);

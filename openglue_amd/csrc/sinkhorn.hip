@@ -665,6 +665,87 @@ void launch_sweep_fast(const float* S, int64_t lds, int B, int m, int n, const f
 #undef OG_SKF
 }
 
+// Safety net of the on-chip-resident schedule (sinkhorn_resident.hip): its workgroups wait for each other with bounded spins and
+// give up with status = 1 when a peer never arrives (the co-residency of B * G workgroups is inferred from the CU count; another
+// stream or process holding CUs breaks it).  This kernel is enqueued right behind it; it returns at once while the status word is
+// 0 and otherwise solves the problem AGAIN from u = v = 0 -- ONE workgroup per pair, all `iters` max-subtracted iterations exactly
+// as optimal_transport.py:22-26 with the dustbin row / column in closed form -- leaving u, v where the scores kernel reads them
+// and status = 2 ("recomputed by the fallback, scores valid").  Slow (two sweeps of the pair's matrix per iteration from one CU:
+// milliseconds), never wrong.  n <= 1024 (resident shapes): one column per thread.
+__global__ __launch_bounds__(1024) void sinkhorn_fallback_kernel(const float* __restrict__ S, int64_t lds, int64_t strideS, int M, int N,
+                                                                 const float* __restrict__ zdev, float zhost, float inv_reg, float la,
+                                                                 float la_bin, float lb, float lb_bin, float* __restrict__ u, int ldu,
+                                                                 float* __restrict__ v, int ldv, int iters, unsigned* status) {
+    if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+    __shared__ float uL[8196];          // m + 1 duals when they fit (else they stay in global memory)
+    __shared__ float vL[1028];
+    __shared__ float red[2][16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* Sb = S + (int64_t)b * strideS;
+    float* ub = u + (int64_t)b * ldu;
+    float* vb = v + (int64_t)b * ldv;
+    float* uw = M + 1 <= 8196 ? uL : ub;
+    const float zr = (zdev ? zdev[0] : zhost) * inv_reg;
+    for (int j = tid; j <= N; j += 1024) vL[j] = 0.f;
+    __syncthreads();
+    auto block_lse = [&](float mx, float sm) -> float {      // (max, sum of exp(x - max)) per thread -> log-sum-exp over the block
+        float m2 = wave_max(mx);
+        sm = wave_sum(sm * (mx == OG_NEG_INF ? 0.f : expf(mx - m2)));
+        if (lane == 0) { red[0][wave] = m2; red[1][wave] = sm; }
+        __syncthreads();
+        float bm = OG_NEG_INF, bs = 0.f;
+        for (int w = 0; w < 16; ++w) bm = fmaxf(bm, red[0][w]);
+        for (int w = 0; w < 16; ++w) bs += red[1][w] * (red[0][w] == OG_NEG_INF ? 0.f : expf(red[0][w] - bm));
+        __syncthreads();
+        return bm + logf(bs);
+    };
+    for (int it = 0; it < iters; ++it) {
+        // rows: u_i = log a_i - LSE_j (S_ij / reg + v_j), the dustbin column (z + v_N) included; one wave per row
+        for (int i = wave; i < M; i += 16) {
+            const float* sp = Sb + (int64_t)i * lds;
+            float mx = OG_NEG_INF;
+            for (int j = lane; j < N; j += 64) mx = fmaxf(mx, sp[j] * inv_reg + vL[j]);
+            mx = wave_max(fmaxf(mx, zr + vL[N]));
+            float sm = 0.f;
+            for (int j = lane; j < N; j += 64) sm += expf(sp[j] * inv_reg + vL[j] - mx);
+            sm = wave_sum(sm) + expf(zr + vL[N] - mx);
+            if (lane == 0) uw[i] = la - (mx + logf(sm));
+        }
+        {   // the dustbin row: every entry is z
+            float mx = OG_NEG_INF, sm = 0.f;
+            for (int j = tid; j <= N; j += 1024) { const float x = zr + vL[j]; const float nm = fmaxf(mx, x); sm = sm * (mx == OG_NEG_INF ? 0.f : expf(mx - nm)) + expf(x - nm); mx = nm; }
+            const float l = block_lse(mx, sm);
+            if (tid == 0) uw[M] = la_bin - l;
+        }
+        __syncthreads();
+        if (uw != ub) __threadfence_block();
+        // columns: v_j = log b_j - LSE_i (S_ij / reg + u_i), the dustbin row (z + u_M) included; one column per thread, rows streamed
+        if (tid < N) {
+            float mx = zr + uw[M], sm = 1.f;
+            for (int i = 0; i < M; ++i) {
+                const float x = Sb[(int64_t)i * lds + tid] * inv_reg + uw[i];
+                const float nm = fmaxf(mx, x);
+                sm = sm * expf(mx - nm) + expf(x - nm);
+                mx = nm;
+            }
+            vb[tid] = lb - (mx + logf(sm));
+        }
+        float nv;
+        {   // the dustbin column
+            float mx = OG_NEG_INF, sm = 0.f;
+            for (int i = tid; i <= M; i += 1024) { const float x = zr + uw[i]; const float nm = fmaxf(mx, x); sm = sm * (mx == OG_NEG_INF ? 0.f : expf(mx - nm)) + expf(x - nm); mx = nm; }
+            nv = lb_bin - block_lse(mx, sm);
+        }
+        __syncthreads();
+        if (tid < N) vL[tid] = vb[tid];
+        if (tid == 0) { vL[N] = nv; vb[N] = nv; }
+        __syncthreads();
+    }
+    if (uw != ub) for (int i = tid; i <= M; i += 1024) ub[i] = uw[i];
+    __syncthreads();
+    if (tid == 0 && b == 0) { __threadfence(); __hip_atomic_store(status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+}
+
 }  // namespace
 
 extern "C" size_t og_sinkhorn_workspace_bytes(int32_t batch, int32_t m, int32_t n) {
@@ -721,13 +802,27 @@ int sinkhorn_run(const float* S, int64_t lds, const float* zdev, float dustbin, 
     }
     { const char* e = getenv("OG_SK_FAST_ROWS"); if (e && (atoi(e) == 32 || atoi(e) == 64 || atoi(e) == 128)) fast_rows = atoi(e); }
     { const char* e = getenv("OG_SK_FAST_NT"); if (e) fast_nt = atoi(e) != 0; }
+    // The status word of this workspace (og_sinkhorn_status) describes THIS call: the resident launcher zeroes it with its exchange
+    // area; every other schedule zeroes it here (it would otherwise hold whatever an earlier call or the allocator left there).
+    if (!resident && og_sinkhorn_resident_ws_bytes(B, m, n) > 0) {
+        e = hipMemsetAsync(sk_resident_ws(workspace, B, m, n), 0, sizeof(unsigned), st);
+        if (e != hipSuccess) return (int)e;
+    }
     for (int it = 0; it < iters; ++it) {
         const float* vin = w.v[cur];
         if (it > 0 && resident) {         // iterations 2 .. iters in ONE launch, S read once (sinkhorn_resident.hip)
-            if (int rc = og_launch_sinkhorn_resident(S, lds, zdev, dustbin, B, m, n, iters - 1, inv_reg, la, la_bin, lb, lb_bin, w.u, w.ldu,
-                                                     w.v[cur], w.v[cur ^ 1], w.ldv, sk_resident_ws(workspace, B, m, n), st))
+            unsigned* status = (unsigned*)sk_resident_ws(workspace, B, m, n);
+            const char* ft = getenv("OG_SINKHORN_FORCE_TIMEOUT");     // tests: behave as if a peer workgroup never arrived
+            if (ft && atoi(ft) != 0) {
+                e = hipMemsetAsync(status, 1, sizeof(unsigned), st);
+                if (e != hipSuccess) return (int)e;
+            } else if (int rc = og_launch_sinkhorn_resident(S, lds, zdev, dustbin, B, m, n, iters - 1, inv_reg, la, la_bin, lb, lb_bin, w.u, w.ldu,
+                                                            w.v[cur], w.v[cur ^ 1], w.ldv, status, st))
                 return rc;
             cur ^= 1;
+            // the safety net: a no-op while status == 0, else the whole solve again by one workgroup per pair (status -> 2)
+            hipLaunchKernelGGL(sinkhorn_fallback_kernel, dim3(B), dim3(1024), 0, st, S, lds, (int64_t)m * lds, m, n, zdev, dustbin, inv_reg, la,
+                               la_bin, lb, lb_bin, w.u, w.ldu, w.v[cur], w.ldv, iters, status);
             break;
         }
         if (it > 0 && !robust_only) {     // dual-stabilised form: valid once one max-subtracted iteration has been done
@@ -802,13 +897,20 @@ int og_launch_sinkhorn(const float* S, int64_t lds, const float* zdev, float dus
     return sinkhorn_run<RaggedNone>(S, lds, zdev, dustbin, B, m, n, iters, reg, scores, workspace, st, RaggedNone{}, row_best);
 }
 
+extern "C" int og_sinkhorn_schedule(int32_t batch, int32_t m, int32_t n, int32_t iters) {
+    static const bool robust_only = [] { const char* e = getenv("OG_SINKHORN_ROBUST"); return e && atoi(e) != 0; }();
+    const char* rm_env = getenv("OG_SINKHORN_RESIDENT");
+    const int resident_mode = rm_env ? atoi(rm_env) : 1;
+    return (!robust_only && iters > 1 && og_sinkhorn_resident_wanted(batch, m, n, resident_mode)) ? 1 : 0;
+}
+
 extern "C" int og_sinkhorn_status(const void* workspace_dev, int32_t batch, int32_t m, int32_t n) {
     if (!workspace_dev || batch <= 0 || m <= 0 || n <= 0 || n > 8192) return -1;
     if (og_sinkhorn_resident_ws_bytes(batch, m, n) == 0) return 0;
     unsigned st = 0;
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     if (hipMemcpy(&st, sk_resident_ws(const_cast<void*>(workspace_dev), batch, m, n), sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    return st == 0 ? 0 : 1;
+    return st == 0 ? 0 : st == 2 ? 2 : 1;
 }
 
 extern "C" int og_sinkhorn(const float* S, int64_t lds, float dustbin, int32_t batch, int32_t m, int32_t n,

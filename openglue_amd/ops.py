@@ -194,7 +194,7 @@ def sinkhorn(S: torch.Tensor, dustbin: float, iters: int, reg: float = 1.0, retu
     rc = lib.og_sinkhorn(S.data_ptr(), lds, float(dustbin), B, m, n, int(iters), float(reg), out.data_ptr(),
                          ws.data_ptr(), _stream())
     _lib.check(rc, "og_sinkhorn")
-    if return_status:        # 0 = ok / streaming kernels; 1 = a cross-workgroup wait of the on-chip-resident kernel timed out
+    if return_status:        # og_sinkhorn_status: 0 = ok; 2 = the resident kernel timed out and the fallback recomputed (valid); 1 = invalid
         return out, int(lib.og_sinkhorn_status(ws.data_ptr(), B, m, n))
     return out
 

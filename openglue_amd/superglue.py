@@ -185,17 +185,24 @@ class SuperGlue(nn.Module):
         # in-place updates (optimizer steps, copy_) bump _version; moves re-create the tensors (_apply above)
         return (str(device), ts[0].data_ptr()) + tuple(t._version for t in ts)
 
-    def check_status(self) -> None:
-        """Synchronise and verify that the optimal-transport stage of the LAST forward / match call completed: its on-chip-resident
-        kernel (large co-resident batches) waits for peer workgroups with bounded spins and flags a time-out instead of hanging
-        (og_forward_status).  Raises RuntimeError on a time-out; a no-op before the first call."""
+    def check_status(self) -> int:
+        """Synchronise and report how the optimal-transport stage of the LAST forward / match call went (og_forward_status): 0 = normal;
+        2 = its on-chip-resident kernel (large co-resident batches) timed out waiting for a peer workgroup and the safety-net kernel
+        behind it recomputed the solve (scores valid, call slow) -- a RuntimeWarning; anything else raises RuntimeError.  A no-op
+        (0) before the first call."""
         last = getattr(self, "_last_call", None)
         if last is None:
-            return
+            return 0
         shape, ws = last
-        rc = _lib.load().og_forward_status(C.byref(shape), ws.data_ptr())
-        if rc != 0:
+        with torch.cuda.device(ws.device):          # og_forward_status synchronises the CURRENT device
+            rc = _lib.load().og_forward_status(C.byref(shape), ws.data_ptr())
+        if rc == 2:
+            import warnings
+            warnings.warn("og_forward_status = 2: the resident Sinkhorn kernel timed out (CUs held by another stream / process?); "
+                          "the fallback kernel recomputed the scores", RuntimeWarning)
+        elif rc != 0:
             raise RuntimeError(f"og_forward_status = {rc}: the last call's Sinkhorn stage did not complete (scores invalid)")
+        return rc
 
     def _get_workspace(self, dev, key, nbytes: int) -> torch.Tensor:
         """One live workspace (shapes rarely change between calls); re-used while it is large enough."""

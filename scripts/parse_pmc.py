@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """gpurun_out/pmc/{sq1,sq2,sq3,grbm}/p_counter_collection.csv (scripts/gpu_pmc.sh: separate rocprofv3 --kernel-trace --pmc
-passes over scripts/traffic_driver.py = 2 hot-path steps at C2, B=32) -> profiles/r02_pmc_summary.json, the per-kernel-class SQ
+passes over scripts/traffic_driver.py = 2 hot-path steps at C2, B=32) -> profiles/r03_pmc_summary.json, the per-kernel-class SQ
 counter summary bench.py attaches to its roofline objects.
 
 Units (MI355X_MICROARCH.md, "Per-instruction cycle constants"): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles
@@ -12,9 +12,12 @@ issue capacity the kernel used while it ran."""
 import collections, csv, glob, json, os, sys
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
-out = sys.argv[2] if len(sys.argv) > 2 else "profiles/r02_pmc_summary.json"
-CLASSES = [("gemm_f16x3", "gemm_nt_f16x3"), ("attention", "attention"), ("sinkhorn", "sinkhorn_resident_kernel"), ("sinkhorn_sweep", "sinkhorn_sweep"),
-           ("gemm_f32", "gemm_nt_f32")]
+out = sys.argv[2] if len(sys.argv) > 2 else "profiles/r03_pmc_summary.json"
+# gemm_f16x3 = the whole split-f16 GEMM class (stand-alone GEMM launches AND the fused message-MLP kernel, like bench.py's class);
+# mlp_fused / gemm_f16x3_standalone = its two parts
+CLASSES = [("gemm_f16x3", ("gemm_nt_f16x3", "mlp_fused_kernel")), ("mlp_fused", ("mlp_fused_kernel",)), ("gemm_f16x3_standalone", ("gemm_nt_f16x3",)),
+           ("attention", ("attention",)), ("sinkhorn_resident", ("sinkhorn_resident_kernel",)), ("sinkhorn_sweep", ("sinkhorn_sweep",)),
+           ("gemm_f32", ("gemm_nt_f32",))]
 N_SIMD = 256 * 4
 
 acc = {c: collections.defaultdict(float) for c, _ in CLASSES}     # counter -> sum over launches
@@ -25,14 +28,15 @@ for path in sorted(glob.glob(os.path.join(root, "*", "*counter_collection.csv"))
     seen = set()
     for r in csv.DictReader(open(path)):
         for c, key in CLASSES:
-            if key in r["Kernel_Name"]:
+            if any(k_ in r["Kernel_Name"] for k_ in key):
                 acc[c][r["Counter_Name"]] += float(r["Counter_Value"])
                 did = (c, r["Dispatch_Id"])
                 if did not in seen:
                     seen.add(did)
                     dur[c][tag] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
                     cnt[c][tag] += 1
-res = {"_method": __doc__.strip().split("\n\n")[0].replace("\n", " "), "_units": "counter sums per launch (averaged over all launches of the class)"}
+res = {"_method": __doc__.strip().split("\n\n")[0].replace("\n", " "), "_units": "counter sums per launch (averaged over all launches of the class)",
+       "_commit": os.environ.get("OG_COMMIT")}
 for c, _ in CLASSES:
     if not cnt[c]:
         continue
@@ -57,6 +61,11 @@ for c, _ in CLASSES:
         for k, name in (("SQ_WAIT_ANY", "wave_parked_frac"), ("SQ_WAIT_INST_ANY", "wave_issue_stall_frac"), ("SQ_ACTIVE_INST_ANY", "wave_issuing_frac")):
             if g(k) is not None:
                 e[name] = round(g(k) / wc, 4)
+    if g("SQ_INSTS_VALU") is not None:
+        # vector-ALU issue utilisation: a wave64 VALU instruction occupies its SIMD's issue slot for 4 cycles (16 lanes per cycle)
+        t = next((d_ns[t] for t in tags if t.startswith("sq2")), None)
+        if t:
+            e["valu_issue_frac"] = round(g("SQ_INSTS_VALU") * 4.0 / (t * (clk or 2.4) * N_SIMD), 4)
     if g("SQ_LDS_IDX_ACTIVE"):
         e["lds_bank_conflict_frac"] = round((g("SQ_LDS_BANK_CONFLICT") or 0.0) / g("SQ_LDS_IDX_ACTIVE"), 4)
     if g("SQ_INSTS_MFMA"):

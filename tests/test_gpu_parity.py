@@ -705,3 +705,47 @@ def test_sinkhorn_resident_extreme_range_and_repeatability(gpu_device, monkeypat
     assert torch.equal(a, b2)                       # fixed summation orders everywhere: bit-identical from call to call
     tol = 1e-4 + 2e-6 * ref.abs().max().item()
     assert (a.cpu().double() - ref).abs().max().item() <= tol
+
+
+def test_sinkhorn_resident_timeout_is_survivable(gpu_device, monkeypatch):
+    """A time-out of the on-chip-resident kernel (peer workgroups not co-resident: another stream / process holds CUs) must not
+    hand back garbage: the safety-net kernel enqueued behind it recomputes the whole solve, one workgroup per pair
+    (optimal_transport.py:20-28 from u = v = 0), and the status says so.  OG_SINKHORN_FORCE_TIMEOUT=1 makes the resident launch
+    behave as if it had timed out."""
+    monkeypatch.setenv("OG_SINKHORN_RESIDENT", "2")
+    g = torch.Generator().manual_seed(77)
+    for (B, m, n, iters, reg) in [(3, 300, 257, 12, 1.0), (2, 129, 1000, 25, 0.7)]:
+        S = _rand(g, B, m, n, scale=2.0)
+        ref = _sinkhorn_ref(S, 0.7, iters, reg)
+        monkeypatch.setenv("OG_SINKHORN_FORCE_TIMEOUT", "1")
+        out, status = ops.sinkhorn(S.to(gpu_device), 0.7, iters, reg, return_status=True)
+        assert status == 2
+        assert (out.cpu().double() - ref).abs().max() < 1e-4
+        monkeypatch.delenv("OG_SINKHORN_FORCE_TIMEOUT")
+        out2, status2 = ops.sinkhorn(S.to(gpu_device), 0.7, iters, reg, return_status=True)
+        assert status2 == 0
+        assert (out2.cpu().double() - ref).abs().max() < 1e-4
+
+
+def test_forward_status_after_forced_timeout_and_on_dirty_workspace(gpu_device, monkeypatch):
+    """model.check_status(): 2 (+ RuntimeWarning) when the resident kernel of the last call timed out and the fallback recomputed --
+    the matches still equal the normal run's; 0 for a streaming-schedule call even when the workspace held a stale status word."""
+    cfg = syn.make_config(descriptor_dim=64, num_stages=1, num_heads=4, num_iters=8, side_info_size=1)
+    sd = syn.make_state_dict(cfg, seed=3)
+    model = _build(cfg, sd, gpu_device)
+    data = to_device(syn.make_batch(2, 200, 180, 64, 1, seed=9), gpu_device)
+    monkeypatch.setenv("OG_SINKHORN_RESIDENT", "2")
+    base = model.match(data, MATCH_THRESHOLD)
+    assert model.check_status() == 0
+    monkeypatch.setenv("OG_SINKHORN_FORCE_TIMEOUT", "1")
+    out = model.match(data, MATCH_THRESHOLD)
+    with pytest.warns(RuntimeWarning):
+        assert model.check_status() == 2
+    assert (out["scores"] - base["scores"]).abs().max().item() < 1e-4
+    assert (out["matches0"] != base["matches0"]).sum().item() <= 1
+    monkeypatch.delenv("OG_SINKHORN_FORCE_TIMEOUT")
+    # streaming schedule on the same (now dirty: status word = 2) workspace
+    monkeypatch.setenv("OG_SINKHORN_RESIDENT", "0")
+    out = model.match(data, MATCH_THRESHOLD)
+    assert model.check_status() == 0
+    assert (out["scores"] - base["scores"]).abs().max().item() < 1e-4
