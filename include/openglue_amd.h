@@ -171,6 +171,16 @@ int og_packed_layout(const og_shape* shape, og_packed_layout_t* layout);
 int og_forward(const og_shape* shape, const og_inputs* in, const void* packed_dev,
                void* workspace_dev, const og_outputs* out, void* stream);
 
+/* og_forward plus a copy of the RESIDUAL STREAM at one stage boundary, for per-stage parity tests (the reference's sub-modules:
+ * positional_encoding.py:16-19 + superglue.py:52-55 for tap 0; attention_gnn.py:57-77, one DescriptorsSelfAttention /
+ * DescriptorsCrossAttention = ResidualAttentionMessagePropagation on both images, for tap k >= 1):
+ *   tap = 0:        x = local_descriptors + keypoint_encoder(...) as it enters the GNN;
+ *   tap = k in 1..2L: x after GNN layer k - 1 (even layers self, odd layers cross);
+ * tap_x: [B*m + B*n][D] fp32, token-major, image-0 sets first (what the kernels hold as (hi, lo) f16 pairs, merged).
+ * Everything else as og_forward (the call runs the whole path). */
+int og_forward_tap(const og_shape* shape, const og_inputs* in, const void* packed_dev, void* workspace_dev,
+                   const og_outputs* out, void* stream, int32_t tap, float* tap_x);
+
 /* Ragged batch (BASELINE config 5): pair b has lens0[b] keypoints in image 0 and lens1[b] in image 1
  * (host arrays, batch <= OG_MAX_RAGGED; shape->m / shape->n are the maxima).  Every tensor is PACKED without
  * padding in pair order: keypoints0 [sum m_b][2], descriptors0 [sum m_b][D], ..., scores = the

@@ -81,6 +81,7 @@ SYMBOLS = {
     "og_packed_layout": (C.c_int, [C.POINTER(og_shape), C.POINTER(og_packed_layout_t)]),
     "og_pack_weights": (C.c_int, [C.POINTER(og_shape), C.POINTER(og_params), _vp]),
     "og_forward": (C.c_int, [C.POINTER(og_shape), C.POINTER(og_inputs), _vp, _vp, C.POINTER(og_outputs), _vp]),
+    "og_forward_tap": (C.c_int, [C.POINTER(og_shape), C.POINTER(og_inputs), _vp, _vp, C.POINTER(og_outputs), _vp, _i32, _vp]),
     "og_forward_ragged": (C.c_int, [C.POINTER(og_shape), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_float),
                                     C.POINTER(C.c_float), C.POINTER(og_inputs), _vp, _vp, C.POINTER(og_outputs), _vp]),
     "og_forward_profiled": (C.c_int, [C.POINTER(og_shape), C.POINTER(og_inputs), _vp, _vp, C.POINTER(og_outputs), _vp,

@@ -376,7 +376,7 @@ struct Scope {
 
 int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_dev, void* workspace_dev,
                  const og_outputs* outp, void* stream, Profiler* prof, const RaggedDesc* rag = nullptr,
-                 const EncoderRagged* er0 = nullptr, const EncoderRagged* er1 = nullptr) {
+                 const EncoderRagged* er0 = nullptr, const EncoderRagged* er1 = nullptr, int tap = -1, float* tap_x = nullptr) {
     if (!shape || !in || !packed_dev || !workspace_dev || !outp) return OG_E_INVALID;
     if (int e = check_shape(shape)) return e;
     og_clear_status();
@@ -480,6 +480,13 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
         }
     }
 
+    // og_forward_tap: the residual stream x (all T token rows, fp32 [T][D]) after the encoder (tap 0) or after GNN layer tap - 1
+    auto tap_here = [&](int idx) -> int {
+        if (tap != idx || !tap_x) return 0;
+        return og_launch_merge_f16_hl(XO, T, D, D4, tap_x, D, st);
+    };
+    if ((rc = tap_here(0))) return rc;
+
     // ---- 2. attentional GNN (attention_gnn.py:84-93) ----
     const int dh = D / s.num_heads;
     auto attention = [&](int nz, int split, int64_t qb0, int64_t qs0, int nq0, int64_t kb0, int64_t ks0, int nk0,
@@ -534,6 +541,7 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
         if ((rc = qkv_proj(lw, 0, T, 0, QW))) return rc;
         if ((rc = attention(2 * B, B, 0, m, m, 0, m, m, T0, n, n, T0, n, n, 1))) return rc;
         if ((rc = mlp(lw, 0, T))) return rc;
+        if ((rc = tap_here(2 * l + 1))) return rc;
         // cross layer 2l+1: image 0 first, then image 1 against the UPDATED image 0 (attention_gnn.py:74-77)
         lw = pk + L.layer0 + (int64_t)(2 * l + 1) * L.layer_stride;
         for (int side = 0; side < 2; ++side) {
@@ -563,6 +571,7 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
             if (rc) return rc;
             if ((rc = mlp(lw, qr0, qR))) return rc;
         }
+        if ((rc = tap_here(2 * l + 2))) return rc;
     }
 
     // ---- 3. final projection + residual mix (superglue.py:58-62): G as hl32 rows (operands of the score GEMM) and the
@@ -627,6 +636,13 @@ extern "C" int og_forward(const og_shape* shape, const og_inputs* in, const void
 extern "C" int og_forward_ragged(const og_shape* shape, const int32_t* lens0, const int32_t* lens1, const float* image0_wh,
                                  const float* image1_wh, const og_inputs* in, const void* packed_dev, void* workspace_dev,
                                  const og_outputs* outp, void* stream);
+
+// include/openglue_amd.h: og_forward plus a copy of the residual stream at one stage boundary (per-stage parity tests)
+extern "C" int og_forward_tap(const og_shape* shape, const og_inputs* in, const void* packed_dev, void* workspace_dev,
+                              const og_outputs* outp, void* stream, int32_t tap, float* tap_x) {
+    if (!shape || tap < 0 || tap > 2 * shape->num_stages || !tap_x || ((uintptr_t)tap_x & 15)) return OG_E_INVALID;
+    return forward_impl(shape, in, packed_dev, workspace_dev, outp, stream, nullptr, nullptr, nullptr, nullptr, tap, tap_x);
+}
 
 namespace {
 int build_ragged(const og_shape* shape, const int32_t* lens0, const int32_t* lens1, const float* image0_wh, const float* image1_wh,

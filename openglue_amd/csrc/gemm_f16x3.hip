@@ -1090,7 +1090,30 @@ __global__ __launch_bounds__(256) void split_f16_hl_kernel(const float* __restri
     *reinterpret_cast<f16x4*>(d + 32) = vl;
 }
 
+// hl32 rows -> fp32 [rows][cols] (inverse of split_f16_hl_kernel: hi + lo; the stage taps of og_forward_tap)
+__global__ __launch_bounds__(256) void merge_f16_hl_kernel(const _Float16* __restrict__ in, int64_t rows, int cols, int64_t ldi,
+                                                           float* __restrict__ out, int64_t ldo) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int c4 = cols / 4;
+    if (i >= rows * c4) return;
+    const int64_t r = i / c4; const int c = (int)(i % c4) * 4;
+    const _Float16* d = in + r * ldi + og_hl_col(c);
+    const f16x4 vh = *reinterpret_cast<const f16x4*>(d), vl = *reinterpret_cast<const f16x4*>(d + 32);
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (float)vh[e] + (float)vl[e];
+    *reinterpret_cast<f32x4*>(out + r * ldo + c) = v;
+}
+
 }  // namespace
+
+int og_launch_merge_f16_hl(const void* in, int64_t rows, int cols, int64_t ldi, float* out, int64_t ldo, hipStream_t stream) {
+    if (!in || !out || rows <= 0 || cols <= 0) return OG_E_INVALID;
+    if ((cols & 31) || (ldi & 3) || (ldo & 3) || ldi < 2 * (int64_t)cols || ((uintptr_t)in & 7) || ((uintptr_t)out & 15)) return OG_E_ALIGN;
+    const int64_t n4 = rows * (cols / 4);
+    hipLaunchKernelGGL(merge_f16_hl_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, (const _Float16*)in, rows, cols, ldi, out, ldo);
+    return og_launch_status();
+}
 
 // A row-split launch (GemmHArgs::split_row) must end up on the second-generation 256-tile kernel: same conditions as the launcher's.
 bool og_gemm_f16x3_row_split_ok(const GemmHArgs& a) {

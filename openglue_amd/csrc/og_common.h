@@ -151,6 +151,7 @@ int og_launch_gemm_f16x3(const GemmHArgs& a, hipStream_t stream);
 bool og_gemm_f16x3_row_split_ok(const GemmHArgs& a);
 int og_launch_split_f16(const float* x, int64_t n, void* hi, void* lo, hipStream_t stream);
 int og_launch_split_f16_hl(const float* x, int64_t rows, int cols, int64_t ldx, void* out, int64_t ldo, hipStream_t stream);
+int og_launch_merge_f16_hl(const void* in, int64_t rows, int cols, int64_t ldi, float* out, int64_t ldo, hipStream_t stream);
 
 // mlp_fused.hip: the message MLP of a GNN layer (fc.0 -> ReLU -> fc.3 + residual) in one launch, the hidden activation in registers
 struct MlpFusedArgs {

@@ -270,7 +270,7 @@ class SuperGlue(nn.Module):
         return blob
 
     # ------------------------------------------------------------------ the hot path
-    def _run(self, data: Mapping, want_matches: bool, match_threshold: float, both_sides: bool, _profile=None) -> Dict[str, torch.Tensor]:
+    def _run(self, data: Mapping, want_matches: bool, match_threshold: float, both_sides: bool, _profile=None, _tap=None) -> Dict[str, torch.Tensor]:
         if self.training:
             raise RuntimeError("openglue_amd.SuperGlue implements the eval()/inference path only "
                                "(train-mode BatchNorm + backward is the next scope row, SURVEY.md §8 f2); call .eval()")
@@ -322,13 +322,27 @@ class SuperGlue(nn.Module):
             o = _lib.og_outputs(ptr("scores"), ptr("context_descriptors0"), ptr("context_descriptors1"),
                                 ptr("matches0"), ptr("matching_scores0"), ptr("matches1"), ptr("matching_scores1"))
             st = torch.cuda.current_stream(dev).cuda_stream
-            if _profile is None:
+            if _tap is not None:     # per-stage parity tests: the residual stream at one stage boundary (og_forward_tap)
+                out["_tap_x"] = torch.empty(B * (m + n), D, device=dev, dtype=torch.float32)
+                rc = lib.og_forward_tap(C.byref(shape), C.byref(inp), packed.data_ptr(), ws.data_ptr(), C.byref(o), st, int(_tap),
+                                        out["_tap_x"].data_ptr())
+            elif _profile is None:
                 rc = lib.og_forward(C.byref(shape), C.byref(inp), packed.data_ptr(), ws.data_ptr(), C.byref(o), st)
             else:      # bench.py: per-kernel-class HIP-event times (synchronises the stream)
                 rc = lib.og_forward_profiled(C.byref(shape), C.byref(inp), packed.data_ptr(), ws.data_ptr(), C.byref(o), st,
                                              _profile[0], _profile[1])
             _lib.check(rc, "og_forward")
         return out
+
+    @torch.no_grad()
+    def forward_tap(self, data: Mapping, tap: int):
+        """The residual stream at one stage boundary (og_forward_tap): tap 0 = local_descriptors + keypoint encoder as it enters the GNN,
+        tap k = after GNN layer k - 1 (reference: attention_gnn.layers[k - 1](desc0, desc1)).  Returns (x0 [B, m, D], x1 [B, n, D])."""
+        out = self._run(data, want_matches=False, match_threshold=0.2, both_sides=False, _tap=tap)
+        B, _, m = out["context_descriptors0"].shape
+        n = out["context_descriptors1"].shape[2]
+        x = out["_tap_x"]
+        return x[:B * m].view(B, m, -1), x[B * m:].view(B, n, -1)
 
     # ------------------------------------------------------------------ ragged batches (BASELINE config 5)
     _RAGGED_KEYS = ("keypoints0", "keypoints1", "local_descriptors0", "local_descriptors1", "side_info0", "side_info1")

@@ -163,7 +163,7 @@ def message_passing(xq: torch.Tensor, xkv: torch.Tensor, sd, prefix: str, num_he
     return xq + feed_forward(y, sd, prefix + ".fc", 2)
 
 
-def attentional_gnn(x0: torch.Tensor, x1: torch.Tensor, sd, config, attn_operand_dtype=None):
+def attentional_gnn(x0: torch.Tensor, x1: torch.Tensor, sd, config, attn_operand_dtype=None, taps: Optional[list] = None):
     """GraphAttentionNet.forward, attention_gnn.py:84-93.  Layer 2l = self (both images through the
     SAME module, :63-66), layer 2l+1 = cross (:74-77): image 0 first, then image 1 attends to the
     UPDATED image-0 descriptors."""
@@ -176,8 +176,10 @@ def attentional_gnn(x0: torch.Tensor, x1: torch.Tensor, sd, config, attn_operand
         ps, pc = f"attention_gnn.layers.{2 * l}.module", f"attention_gnn.layers.{2 * l + 1}.module"
         x0 = message_passing(x0, x0, sd, ps, H, off, attn_operand_dtype, att)
         x1 = message_passing(x1, x1, sd, ps, H, off, attn_operand_dtype, att)
+        if taps is not None: taps.append((x0, x1))         # after attention_gnn.layers[2l] (self)
         x0 = message_passing(x0, x1, sd, pc, H, off, attn_operand_dtype, att)
         x1 = message_passing(x1, x0, sd, pc, H, off, attn_operand_dtype, att)
+        if taps is not None: taps.append((x0, x1))         # after attention_gnn.layers[2l + 1] (cross)
     return x0, x1
 
 
@@ -241,8 +243,10 @@ def superglue_forward(sd: Mapping[str, torch.Tensor], config: Mapping, data: Map
         x0, x1 = pe0, pe1
     else:                                                        # :52-55
         x0, x1 = d0 + pe0, d1 + pe1
-    inter = {"x0_in": x0, "x1_in": x1}
-    x0, x1 = attentional_gnn(x0, x1, sd, config, attn_operand_dtype)
+    inter = {"x0_in": x0, "x1_in": x1, "pe0": pe0, "pe1": pe1}
+    taps = [] if return_intermediates else None
+    x0, x1 = attentional_gnn(x0, x1, sd, config, attn_operand_dtype, taps)
+    if taps is not None: inter["layer_taps"] = taps
     inter.update(x0_gnn=x0, x1_gnn=x1)
     g0, g1 = conv1x1(x0, sd, "linear_proj"), conv1x1(x1, sd, "linear_proj")   # :58
     if config.get("residual", False):                            # :59-62, per-channel alpha

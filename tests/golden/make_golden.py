@@ -134,9 +134,56 @@ def stage_cases():
     print("stage fixtures written")
 
 
+LAYER_CASES = {
+    # name: (config kwargs, m, n, batch, data seed): the residual stream at every stage boundary of the GNN
+    "mid": (dict(descriptor_dim=128, num_stages=3, num_heads=4, num_iters=20, side_info_size=6), 300, 257, 2, 2),
+    "flags": (dict(descriptor_dim=64, num_stages=2, num_heads=2, num_iters=10, side_info_size=3,
+                   residual=False, use_offset=True, reg=0.5, dustbin_score_init=0.3), 96, 130, 2, 3),
+    "d256": (dict(descriptor_dim=256, num_stages=1, num_heads=4, num_iters=5, side_info_size=1), 130, 100, 2, 21),   # the fused message-MLP kernel
+}
+
+
+def layer_cases():
+    """Per-stage goldens: x = local_descriptors + positional_encoding(...) as it enters the GNN (superglue.py:41-55) and
+    the descriptors after every element of attention_gnn.layers (attention_gnn.py:57-77: DescriptorsSelfAttention /
+    DescriptorsCrossAttention = ResidualAttentionMessagePropagation on both images), from the reference's own modules.  Stored
+    token-major [B, n, D] (the reference holds them channel-first)."""
+    arrays = {}
+    for name, (kw, m, n, batch, seed) in LAYER_CASES.items():
+        cfg = syn.make_config(**kw)
+        sd = syn.make_state_dict(cfg, seed=0)
+        ref = RefSuperGlue(cfg)
+        ref.load_state_dict(sd, strict=True)
+        ref.eval()
+        data = syn.make_batch(batch, m, n, cfg["descriptor_dim"], cfg["positional_encoding"]["side_info_size"], seed=seed)
+        with torch.no_grad():
+            hw = (syn.IMAGE_WH[1], syn.IMAGE_WH[0])
+            pe0 = ref.positional_encoding(RefSuperGlue.normalize_keypoints(data["keypoints0"], hw), data["side_info0"])
+            pe1 = ref.positional_encoding(RefSuperGlue.normalize_keypoints(data["keypoints1"], hw), data["side_info1"])
+            d0 = data["local_descriptors0"].transpose(2, 1) + pe0
+            d1 = data["local_descriptors1"].transpose(2, 1) + pe1
+            arrays[f"{name}/x0_tap0"] = d0.transpose(1, 2).contiguous().numpy()
+            arrays[f"{name}/x1_tap0"] = d1.transpose(1, 2).contiguous().numpy()
+            nl = len(ref.attention_gnn.layers)
+            for i, layer in enumerate(ref.attention_gnn.layers):
+                d0, d1 = layer(d0, d1)
+                if i < 2 or i == nl - 1:          # the first self and cross layer and the last layer (file size)
+                    arrays[f"{name}/x0_tap{i + 1}"] = d0.transpose(1, 2).contiguous().numpy()
+                    arrays[f"{name}/x1_tap{i + 1}"] = d1.transpose(1, 2).contiguous().numpy()
+            # and the module alone with DIFFERENT query / key-value sets (the cross form), attention_gnn.py:43-55
+            arrays[f"{name}/ramp_q0_kv1"] = ref.attention_gnn.layers[1].module(
+                data["local_descriptors0"].transpose(2, 1), data["local_descriptors1"].transpose(2, 1)).transpose(1, 2).contiguous().numpy()
+        arrays[f"{name}/meta"] = np.array(repr(dict(kw=kw, m=m, n=n, batch=batch, seed=seed, taps=len(ref.attention_gnn.layers) + 1)))
+        print(f"layers {name}: {len(ref.attention_gnn.layers)} layers, |x| max {float(d0.abs().max()):.2f}")
+    np.savez_compressed(os.path.join(HERE, "stage_layers.npz"), **arrays)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if sys.argv[1:] == ["layers"]:
+        layer_cases()
+        sys.exit(0)
     only = sys.argv[1:]                      # e.g. `make_golden.py favor`: (re)generate the named cases only
     for name, (kw, m, n, batch, seed, store) in CASES.items():
         if not only or name in only:

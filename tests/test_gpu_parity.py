@@ -749,3 +749,51 @@ def test_forward_status_after_forced_timeout_and_on_dirty_workspace(gpu_device, 
     out = model.match(data, MATCH_THRESHOLD)
     assert model.check_status() == 0
     assert (out["scores"] - base["scores"]).abs().max().item() < 1e-4
+
+
+# ----------------------------------------------------------------------------- per-stage goldens, og_forward_tap
+@pytest.mark.parametrize("name", ["mid", "flags", "d256"])
+def test_stage_taps_against_reference_layers(gpu_device, name):
+    """The residual stream at every stored stage boundary against the reference's OWN sub-modules (tests/golden/make_golden.py layers):
+    tap 0 = local_descriptors + positional_encoding (superglue.py:41-55), tap k = attention_gnn.layers[k-1] (attention_gnn.py:57-77:
+    ResidualAttentionMessagePropagation on both images; cross layers use the UPDATED image-0 descriptors).  d256 runs the fused
+    message-MLP kernel, flags the use_offset form.  A stage-local failure shows up at its own tap, not only in the scores."""
+    import ast
+    z = np.load(os.path.join(GOLDEN, "stage_layers.npz"))
+    meta = ast.literal_eval(str(z[f"{name}/meta"]))
+    cfg = syn.make_config(**meta["kw"])
+    sd = syn.make_state_dict(cfg, seed=0)
+    model = _build(cfg, sd, gpu_device)
+    data = to_device(syn.make_batch(meta["batch"], meta["m"], meta["n"], cfg["descriptor_dim"], cfg["positional_encoding"]["side_info_size"],
+                                    seed=meta["seed"]), gpu_device)
+    checked = 0
+    for t in range(meta["taps"]):
+        if f"{name}/x0_tap{t}" not in z.files:
+            continue
+        x0, x1 = model.forward_tap(data, t)
+        ref0, ref1 = z[f"{name}/x0_tap{t}"], z[f"{name}/x1_tap{t}"]
+        e0 = np.abs(x0.cpu().numpy() - ref0).max(); e1 = np.abs(x1.cpu().numpy() - ref1).max()
+        scale = max(1.0, float(np.abs(ref0).max()))
+        print(f"[{name}] tap {t}: err {max(e0, e1):.2e} (|x| max {scale:.1f})")
+        assert max(e0, e1) < 1e-4 * scale, (name, t, e0, e1)
+        checked += 1
+    assert checked >= 3
+    # the taps do not disturb the call: same scores as the plain forward
+    plain = model(data)["scores"]
+    model.forward_tap(data, 1)
+    assert torch.equal(model(data)["scores"], plain)
+
+
+@pytest.mark.parametrize("name", ["c1", "mid", "flags", "nodesc", "siren"])
+def test_keypoint_encoder_against_stored_encoder0(gpu_device, name):
+    """The keypoint encoder alone (positional_encoding.py:16-19: the `encoder0` array of every whole-path fixture): tap 0 minus the
+    descriptors (no_descriptors: tap 0 itself)."""
+    z, cfg, sd, data = load_case(name)
+    model = _build(cfg, sd, gpu_device)
+    x0, _ = model.forward_tap(to_device(data, gpu_device), 0)
+    pe0 = x0.cpu() if cfg.get("no_descriptors", False) else x0.cpu() - data["local_descriptors0"]
+    ref = torch.from_numpy(z["encoder0"]).transpose(1, 2)              # stored channel-first [B, D, m]
+    scale = max(1.0, float(data["local_descriptors0"].abs().max()), float(ref.abs().max()))
+    err = (pe0 - ref).abs().max().item()
+    print(f"[{name}] encoder err {err:.2e} (scale {scale:.1f})")
+    assert err < 2e-5 * scale
