@@ -37,8 +37,8 @@ extern "C" {
 #define OG_E_SHAPE     (-2)  /* unsupported shape (see og_check_shape)                   */
 #define OG_E_ALIGN     (-3)  /* a device pointer is not 16-byte aligned                  */
 #define OG_E_FLAG      (-4)  /* unknown flag bits                                        */
-#define OG_E_RANGE     (-5)  /* og_pack_weights: a folded weight is not finite or |256 w| > 65504 (binary16 range of
-                                the split-f16 GEMM operands), e.g. BatchNorm over a dead channel with running_var ~ 0 */
+#define OG_E_RANGE     (-5)  /* og_pack_weights: a folded weight is not finite (or beyond 2^40).  Large finite weights -- e.g. a BatchNorm
+                                fold over a dead channel with running_var ~ 0 -- are packed with a smaller per-matrix pre-scale   */
 
 /* config flags (reference keys: superglue.py:18-19 `residual`, `no_descriptors`;
  * attention_gnn.py:51-52 `use_offset`) */
@@ -159,6 +159,10 @@ typedef struct og_packed_layout_t {
     int64_t enc_w[OG_MAX_HIDDEN + 1], enc_b[OG_MAX_HIDDEN + 1];
     int64_t layer0, layer_stride, o_wqkv, o_bqkv, o_w0, o_b0, o_w3, o_b3;   /* o_w*: hl32 rows of 2K halves */
     int64_t wp, bp, alpha, dustbin, total;
+    int64_t o_scale;  /* ABI v5: per layer, 4 floats {1 / S_qkv, 1 / S_0, 1 / S_3, 0}: every split-f16 matrix is stored as (hi, lo) halves of
+                         S * w with its own power-of-two S = 256 unless 256 * max|w| would leave binary16 (a BatchNorm fold over a dead
+                         channel, a huge gamma / sigma); the kernels multiply the accumulator by the stored 1 / S                    */
+    int64_t scales;   /* ABI v5: 2 floats {1 / S_wp, 1 / S of the last encoder conv}                                                 */
     int64_t o_wmlp;   /* ABI v5: per layer, the SAME folded w0 / w3 once more as the fragment-major stream og_mlp_block consumes
                          (og_mlp_block_stream_bytes(D) bytes; -1 when D has no fused message-MLP kernel)                         */
 } og_packed_layout_t;

@@ -20,7 +20,7 @@ OG_STAGES = ("encoder_input", "gemm_f32", "attention", "sinkhorn", "matches", "g
 
 _ERRORS = {-1: "OG_E_INVALID (null pointer / bad size)", -2: "OG_E_SHAPE (unsupported shape)",
            -3: "OG_E_ALIGN (pointer or leading dimension not 16-byte aligned)", -4: "OG_E_FLAG (unknown flag)",
-           -5: "OG_E_RANGE (a folded weight is not finite or exceeds the binary16 range of the split-f16 operands: |256 w| > 65504)"}
+           -5: "OG_E_RANGE (a folded weight is not finite)"}
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -68,7 +68,7 @@ class og_packed_layout_t(C.Structure):
     _fields_ = [("n_enc", C.c_int32), ("enc_k", C.c_int32 * (OG_MAX_HIDDEN + 1)), ("enc_out", C.c_int32 * (OG_MAX_HIDDEN + 1)),
                 ("enc_w", C.c_int64 * (OG_MAX_HIDDEN + 1)), ("enc_b", C.c_int64 * (OG_MAX_HIDDEN + 1))] + \
                [(k, C.c_int64) for k in ("layer0", "layer_stride", "o_wqkv", "o_bqkv", "o_w0", "o_b0", "o_w3", "o_b3",
-                                         "wp", "bp", "alpha", "dustbin", "total", "o_wmlp")]
+                                         "wp", "bp", "alpha", "dustbin", "total", "o_scale", "scales", "o_wmlp")]
 
 
 # every symbol include/openglue_amd.h declares: name -> (restype, argtypes)

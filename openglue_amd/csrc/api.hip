@@ -22,6 +22,8 @@ struct PackedLayout {
     // offsets inside a layer block (float units); weights in the hl32 row format: [N][2K] halves = N*K floats
     int64_t o_wqkv, o_bqkv, o_w0, o_b0, o_w3, o_b3;
     int64_t o_wmlp;                             // fragment-major stream of mlp_fused.hip (W0' then W3' per hidden half), -1: none
+    int64_t o_scale;                            // per layer: accumulator multipliers {1 / S_qkv, 1 / S_0, 1 / S_3, 0} of its three split-f16 matrices
+    int64_t scales;                             // {1 / S_wp, 1 / S_enc_whl}: final projection, last encoder conv
     int64_t wp, bp, alpha, dustbin;
     int64_t total;                              // floats
     int enc_maxw;                               // widest padded hidden activation
@@ -60,6 +62,7 @@ PackedLayout packed_layout(const og_shape& s) {
     L.o_b0 = lo; lo = al64(lo + 2 * D);
     L.o_w3 = lo; lo = al64(lo + 2 * D * D);
     L.o_b3 = lo; lo = al64(lo + D);
+    L.o_scale = lo; lo = al64(lo + 4);
     L.o_wmlp = -1;
     if (og_mlp_fused_supported((int)D)) { L.o_wmlp = lo; lo = al64(lo + (int64_t)(og_mlp_stream_bytes((int)D) / 4)); }
     L.layer_stride = lo;
@@ -68,6 +71,7 @@ PackedLayout packed_layout(const og_shape& s) {
     L.bp = off; off = al64(off + D);
     L.alpha = off; off = al64(off + D);
     L.dustbin = off; off = al64(off + 1);
+    L.scales = off; off = al64(off + 2);
     L.total = off;
     return L;
 }
@@ -122,17 +126,31 @@ int check_shape(const og_shape* s) {
     return 0;
 }
 
-// w -> (hi, lo) of w * OG_W_SCALE, element (row, col) of an hl32 weight matrix with K columns (og_common.h).
-// Returns false when the scaled weight does not fit binary16 (|w * 256| > 65504, e.g. a BatchNorm fold over a dead
-// channel with running_var ~ 0) or is not finite: og_pack_weights then fails with OG_E_RANGE instead of packing an inf.
-inline bool put_split(_Float16* W, int64_t row, int col, int K, double w) {
-    w *= OG_W_SCALE;
+// w -> (hi, lo) of w * S, element (row, col) of an hl32 weight matrix with K columns (og_common.h).  S is the matrix's power-of-two
+// pre-scale (og_weight_prescale of its largest |w|: 256 unless that would leave binary16, e.g. after a BatchNorm fold over a dead
+// channel with running_var ~ 0).  Returns false only when the weight is not finite (or beyond 2^40): og_pack_weights then fails
+// with OG_E_RANGE instead of packing an inf.
+inline bool put_split(_Float16* W, int64_t row, int col, int K, double w, double S) {
+    w *= S;
     if (!(fabs(w) <= 65504.0)) return false;
     const _Float16 hi = (_Float16)w;
     _Float16* d = W + row * 2 * K + og_hl_col(col);
     d[0] = hi;
     d[32] = (_Float16)(w - (double)hi);
     return true;
+}
+
+// a whole [rows][K] matrix (row-major doubles) as hl32 rows of S * w with S = og_weight_prescale(max |w|); *inv_scale = 1 / S
+inline bool put_matrix(_Float16* W, const double* M, int64_t rows, int K, float* inv_scale, double* S_out = nullptr) {
+    double mx = 0.0;
+    bool ok = true;
+    for (int64_t i = 0; i < rows * K; ++i) { const double a = fabs(M[i]); if (!(a <= 1e300)) ok = false; else if (a > mx) mx = a; }
+    const double S = og_weight_prescale(mx);
+    for (int64_t r = 0; r < rows; ++r)
+        for (int k = 0; k < K; ++k) ok &= put_split(W, r, k, K, M[r * K + k], S);
+    *inv_scale = (float)(1.0 / S);
+    if (S_out) *S_out = S;
+    return ok;
 }
 
 // BatchNorm (eval) as y*g + c
@@ -168,7 +186,7 @@ extern "C" int og_packed_layout(const og_shape* shape, og_packed_layout_t* o) {
     o->layer0 = L.layer0; o->layer_stride = L.layer_stride;
     o->o_wqkv = L.o_wqkv; o->o_bqkv = L.o_bqkv;
     o->o_w0 = L.o_w0; o->o_b0 = L.o_b0;
-    o->o_w3 = L.o_w3; o->o_b3 = L.o_b3; o->o_wmlp = L.o_wmlp;
+    o->o_w3 = L.o_w3; o->o_b3 = L.o_b3; o->o_wmlp = L.o_wmlp; o->o_scale = L.o_scale; o->scales = L.scales;
     o->wp = L.wp; o->bp = L.bp; o->alpha = L.alpha; o->dustbin = L.dustbin; o->total = L.total;
     return 0;
 }
@@ -218,9 +236,10 @@ extern "C" int og_pack_weights(const og_shape* shape, const og_params* P, void* 
             }
             if (i == L.n_enc - 1 && L.enc_whl >= 0) {        // the same folded weights as hl32 rows of 256*w
                 _Float16* Whl = (_Float16*)(out + L.enc_whl);
+                std::vector<double> Wd((size_t)out_real * L.enc_k[i], 0.0);
                 for (int o = 0; o < out_real; ++o)
-                    for (int k = 0; k < in_real; ++k)
-                        if (!put_split(Whl, o, k, L.enc_k[i], (double)W[(int64_t)o * L.enc_k[i] + k])) return OG_E_RANGE;
+                    for (int k = 0; k < in_real; ++k) Wd[(size_t)o * L.enc_k[i] + k] = (double)W[(int64_t)o * L.enc_k[i] + k];
+                if (!put_matrix(Whl, Wd.data(), out_real, L.enc_k[i], out + L.scales + 1)) return OG_E_RANGE;
             }
             if (i < s.num_hidden) {
                 if (s.flags & OG_FLAG_SIREN_ENCODER) {       // no BatchNorm between the layers: identity fold
@@ -244,9 +263,9 @@ extern "C" int og_pack_weights(const og_shape* shape, const og_params* P, void* 
     const bool favor = s.flags & OG_FLAG_FAVOR_RELU;
     const int wq = qk_width(s);
     std::vector<double> Wm((size_t)D2 * D), prod((size_t)D2 * D), g, c;
-    std::vector<double> W0d, W3d;       // the folded fc.0 / fc.3 matrices once more, for the fragment-major stream of mlp_fused.hip
-    if (L.o_wmlp >= 0) { W0d.resize((size_t)D2 * D2); W3d.resize((size_t)D * D2); }
-    bool ok = true;                     // every split-f16 weight fits binary16 after the 256x pre-scale
+    // every split-f16 matrix is assembled in double first: its power-of-two pre-scale depends on its largest |w| (put_matrix)
+    std::vector<double> Wqd((size_t)qkv_width(s) * D), W0d((size_t)D2 * D2), W3d((size_t)D * D2);
+    bool ok = true;                     // every split-f16 weight is finite
     for (int l = 0; l < 2 * s.num_stages; ++l) {
         if (!P->layers) return OG_E_INVALID;
         const og_layer_params& lp = P->layers[l];
@@ -274,16 +293,18 @@ extern "C" int og_pack_weights(const og_shape* shape, const og_params* P, void* 
                         for (int k = 0; k < D; ++k) row[k] += pw * (double)wr[k];
                         bb += pw * (double)proj[p]->bias[o];
                     }
-                    for (int k = 0; k < D; ++k) ok &= put_split(Wqkv, row0 + f, k, D, row[k]);
+                    for (int k = 0; k < D; ++k) Wqd[(size_t)(row0 + f) * D + k] = row[k];
                     bqkv[row0 + f] = (float)bb;
                 }
                 continue;
             }
             const double sc = (p == 0 && !favor) ? qscale : 1.0;
             for (int o = 0; o < D; ++o)
-                for (int k = 0; k < D; ++k) ok &= put_split(Wqkv, row0 + o, k, D, proj[p]->weight[(int64_t)o * D + k] * sc);
+                for (int k = 0; k < D; ++k) Wqd[(size_t)(row0 + o) * D + k] = proj[p]->weight[(int64_t)o * D + k] * sc;
             for (int i = 0; i < D; ++i) bqkv[row0 + i] = (float)(proj[p]->bias[i] * sc);
         }
+        float* scl = base + L.o_scale;      // {1 / S_qkv, 1 / S_0, 1 / S_3, 0}
+        ok &= put_matrix(Wqkv, Wqd.data(), qkv_width(s), D, scl + 0);
         // fc.0 on y = [x ; msg] (or [x - msg ; msg] with use_offset, attention_gnn.py:51-54), msg = Wo O + bo:
         //   W0 y = W0a x + Wm (Wo O + bo),  Wm = W0b (- W0a)   ->  [W0a | Wm Wo] [x ; O] + (b0 + Wm bo)
         if (!lp.fc0.weight || !lp.fc0.bias || !lp.out_proj.weight || !lp.out_proj.bias || !lp.fc3.weight || !lp.fc3.bias)
@@ -293,8 +314,7 @@ extern "C" int og_pack_weights(const og_shape* shape, const og_params* P, void* 
         for (int o = 0; o < D2; ++o)
             for (int k = 0; k < D; ++k) {
                 const double wa = lp.fc0.weight[(int64_t)o * D2 + k], wb = lp.fc0.weight[(int64_t)o * D2 + D + k];
-                ok &= put_split(W0, o, k, D2, wa);
-                if (L.o_wmlp >= 0) W0d[(size_t)o * D2 + k] = wa;
+                W0d[(size_t)o * D2 + k] = wa;
                 Wm[(size_t)o * D + k] = offset ? wb - wa : wb;
             }
         std::fill(prod.begin(), prod.end(), 0.0);
@@ -307,10 +327,11 @@ extern "C" int og_pack_weights(const og_shape* shape, const og_params* P, void* 
                 for (int j = 0; j < D; ++j) pr[j] += w * (double)wo[j];
                 bb += w * (double)lp.out_proj.bias[k];
             }
-            for (int j = 0; j < D; ++j) ok &= put_split(W0, o, D + j, D2, pr[j]);
-            if (L.o_wmlp >= 0) for (int j = 0; j < D; ++j) W0d[(size_t)o * D2 + D + j] = pr[j];
+            for (int j = 0; j < D; ++j) W0d[(size_t)o * D2 + D + j] = pr[j];
             b0[o] = (float)bb;
         }
+        double S0 = OG_W_SCALE, S3 = OG_W_SCALE;
+        ok &= put_matrix(W0, W0d.data(), D2, D2, scl + 1, &S0);
         // fc.3 with BN(2D) folded in
         if (!lp.fc_bn.weight || !lp.fc_bn.bias || !lp.fc_bn.running_mean || !lp.fc_bn.running_var) return OG_E_INVALID;
         bn_affine(lp.fc_bn, D2, g, c);
@@ -320,21 +341,22 @@ extern "C" int og_pack_weights(const og_shape* shape, const og_params* P, void* 
             double bb = lp.fc3.bias[o];
             for (int k = 0; k < D2; ++k) {
                 const double w = lp.fc3.weight[(int64_t)o * D2 + k];
-                ok &= put_split(W3, o, k, D2, w * g[k]);
-                if (L.o_wmlp >= 0) W3d[(size_t)o * D2 + k] = w * g[k];
+                W3d[(size_t)o * D2 + k] = w * g[k];
                 bb += w * c[k];
             }
             b3[o] = (float)bb;
         }
-        if (L.o_wmlp >= 0) ok &= og_pack_mlp_stream(D, W0d.data(), W3d.data(), base + L.o_wmlp);
+        ok &= put_matrix(W3, W3d.data(), D, D2, scl + 2, &S3);
+        if (L.o_wmlp >= 0) ok &= og_pack_mlp_stream(D, W0d.data(), W3d.data(), base + L.o_wmlp, S0, S3);
     }
 
     // ---- tail ----
     if (!P->linear_proj.weight || !P->linear_proj.bias) return OG_E_INVALID;
     {   // final projection: hl32 rows of 256*w like the GNN matrices (it runs on the split-f16 kernel, reading the x rows of XO)
         _Float16* Wp = (_Float16*)(out + L.wp);
-        for (int o = 0; o < D; ++o)
-            for (int k = 0; k < D; ++k) ok &= put_split(Wp, o, k, D, P->linear_proj.weight[(int64_t)o * D + k]);
+        std::vector<double> Wd((size_t)D * D);
+        for (int64_t i = 0; i < (int64_t)D * D; ++i) Wd[i] = P->linear_proj.weight[i];
+        ok &= put_matrix(Wp, Wd.data(), D, D, out + L.scales + 0);
     }
     memcpy(out + L.bp, P->linear_proj.bias, sizeof(float) * (size_t)D);
     if (s.flags & OG_FLAG_RESIDUAL) {
@@ -422,6 +444,7 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
                      const float* bias, int relu, const _Float16* res_hl, float* C32, _Float16* Ch, _Float16* Cl, int64_t ldch,
                      int c_hl) -> int {
         GemmHArgs g{};
+        g.scale_dev = wbase + L.o_scale + (o_w == L.o_wqkv ? 0 : o_w == L.o_w0 ? 1 : 2);      // the matrix's own 1 / pre-scale
         g.A = A; g.lda = D4;
         g.B = (const _Float16*)(wbase + o_w) + wrow0 * 2 * K; g.ldb = 2 * K;
         g.M = (int)M; g.N = N; g.K = K; g.scale = (float)(1.0 / OG_W_SCALE); g.bias = bias; g.relu = relu; g.res = nullptr; g.ldr = D; g.res_hl = res_hl; g.ldrh = D4;
@@ -466,7 +489,7 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
                         GemmHArgs g{};
                         g.A = Ehl + r0[side] * 2 * K; g.lda = 2 * K;
                         g.B = (const _Float16*)(pk + L.enc_whl); g.ldb = 2 * K;
-                        g.M = (int)R[side]; g.N = D; g.K = K; g.scale = (float)(1.0 / OG_W_SCALE); g.bias = bi; g.relu = 0;
+                        g.M = (int)R[side]; g.N = D; g.K = K; g.scale = (float)(1.0 / OG_W_SCALE); g.scale_dev = pk + L.scales + 1; g.bias = bi; g.relu = 0;
                         g.res = res[side]; g.ldr = D; g.res_hl = nullptr; g.ldrh = 0;
                         g.C32 = nullptr; g.ldc = D; g.Ch = XO + r0[side] * D4; g.Cl = g.Ch + 32; g.ldch = D4; g.c_hl = 1;
                         Scope sc(prof, OG_STAGE_GEMM_F16X3);
@@ -527,7 +550,7 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
         if (fused_mlp) {          // one launch, the hidden activation never leaves the registers (mlp_fused.hip)
             MlpFusedArgs a{};
             a.XO = XO + r0 * D4; a.ld = D4; a.M = (int)R; a.wstream = (const char*)(lw + L.o_wmlp);
-            a.b0 = lw + L.o_b0; a.b3 = lw + L.o_b3; a.scale = (float)(1.0 / OG_W_SCALE);
+            a.b0 = lw + L.o_b0; a.b3 = lw + L.o_b3; a.scale = (float)(1.0 / OG_W_SCALE); a.scales_dev = lw + L.o_scale + 1;
             Scope sc(prof, OG_STAGE_MLP_FUSED);
             return og_launch_mlp_fused(a, D, st);
         }
@@ -552,7 +575,7 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
                 // stop after the q columns.  [Two launches: 56 + 20 us at C2; one: the 512 tiles are exactly two rounds of the 256 CUs.]
                 GemmHArgs g{};
                 g.A = XO; g.lda = D4; g.B = (const _Float16*)(lw + L.o_wqkv); g.ldb = 2 * D;
-                g.M = (int)T; g.N = QW; g.K = D; g.scale = (float)(1.0 / OG_W_SCALE); g.bias = lw + L.o_bqkv;
+                g.M = (int)T; g.N = QW; g.K = D; g.scale = (float)(1.0 / OG_W_SCALE); g.scale_dev = lw + L.o_scale; g.bias = lw + L.o_bqkv;
                 g.Ch = QKVh; g.Cl = QKVl; g.ldch = QW; g.c_hl = 0; g.ldc = D; g.ldr = D; g.ldrh = D4;
                 g.split_row = (int)T0; g.split_n = WQ;
                 if (!favor && !rag && T < (int64_t)1 << 30 && og_gemm_f16x3_row_split_ok(g)) {
@@ -582,7 +605,7 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
         const bool resid = s.flags & OG_FLAG_RESIDUAL;
         GemmHArgs g{};
         g.A = XO + r0 * D4; g.lda = D4; g.B = (const _Float16*)(pk + L.wp); g.ldb = D2;
-        g.M = (int)R; g.N = D; g.K = D; g.scale = (float)(1.0 / OG_W_SCALE); g.bias = pk + L.bp; g.relu = 0;
+        g.M = (int)R; g.N = D; g.K = D; g.scale = (float)(1.0 / OG_W_SCALE); g.scale_dev = pk + L.scales; g.bias = pk + L.bp; g.relu = 0;
         g.res = resid ? (side ? in->descriptors1 : in->descriptors0) : nullptr; g.ldr = D;
         g.alpha = resid ? pk + L.alpha : nullptr;
         g.Ch = Gh + r0 * D2; g.Cl = g.Ch + 32; g.ldch = D2; g.c_hl = 1;

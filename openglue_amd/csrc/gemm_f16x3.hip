@@ -502,6 +502,7 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void gemm_nt_f16x3_kernel(G
     }
     const int t0 = tm * TOK, n0 = tn * OC;
     if (t0 >= g.M || n0 >= g.N) return;          // ragged batches: this problem is smaller than the grid
+    if (g.scale_dev) { const float s_ = *g.scale_dev; g.scale = s_; g.inv_scale = 1.f / s_; }      // per-matrix pre-scale chosen at pack time
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -657,6 +658,7 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_big_kernel(GemmHArgs g, int
     }
     const int t0 = tm * BIG, n0 = tn * BIG;
     if (t0 >= g.M || n0 >= g.N) return;          // ragged batches: this problem is smaller than the grid
+    if (g.scale_dev) { const float s_ = *g.scale_dev; g.scale = s_; g.inv_scale = 1.f / s_; }      // per-matrix pre-scale chosen at pack time
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -846,6 +848,7 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_big2_kernel(GemmHArgs g, in
     if (t0 >= g.M || n0 >= g.N) return;
     if (t0 < g.split_row && n0 >= g.split_n) return;     // row-split launch: the first row range has fewer columns (exits at once: the
                                                          // dispatcher back-fills the CU with the next block)
+    if (g.scale_dev) { const float s_ = *g.scale_dev; g.scale = s_; g.inv_scale = 1.f / s_; }      // per-matrix pre-scale chosen at pack time
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -155,15 +155,17 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpFusedArgs g) {
     }
     issue_w4(0, 0); issue_x2(0, 0);
     issue_w4(1, 1); issue_x2(1, 1);
+    // accumulator multipliers of the two matrices: 1 / (power-of-two pre-scale chosen at pack time)
+    const float sc0 = g.scales_dev ? g.scales_dev[0] : g.scale, sc3 = g.scales_dev ? g.scales_dev[1] : g.scale;
     {
-        const float is = 1.f / g.scale;
+        const float is0 = 1.f / sc0, is3 = 1.f / sc3;
         const unsigned ba0 = lds0 + BOFF + (unsigned)tid * 4u, ba3 = lds0 + BOFF + (unsigned)(2 * D + (tid & 255)) * 4u;
         asm volatile("s_waitcnt vmcnt(12)\n\t"          // the two bias loads are older than the 12 pieces
                      "v_mul_f32 %0, %0, %4\n\t"
-                     "v_mul_f32 %1, %1, %4\n\t"
+                     "v_mul_f32 %1, %1, %5\n\t"
                      "ds_write_b32 %2, %0\n\t"
                      "ds_write_b32 %3, %1"
-                     : "+v"(bv0), "+v"(bv3) : "v"(ba0), "v"(ba3), "s"(is) : "memory");
+                     : "+v"(bv0), "+v"(bv3) : "v"(ba0), "v"(ba3), "s"(is0), "s"(is3) : "memory");
     }
 
     f32x16 acc0[4], acc3[8];
@@ -227,7 +229,6 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpFusedArgs g) {
     int xs = 0, xslot = 0;          // token stage being consumed (fc.0 stages only) and its ring slot
     auto next3 = [](int v) { return v == 2 ? 0 : v + 1; };
     auto prev3 = [](int v) { return v == 0 ? 2 : v - 1; };
-    const float sc = g.scale;
 
     // ---- one stage = 4 groups of 6 MFMAs per wave (two channel blocks x three split-f16 passes).  The four fragment registers of a
     //      group (lo 0, lo 1, hi 0, hi 1) are re-used by the next group: each is re-loaded right after the LAST MFMA that reads it
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpFusedArgs g) {
 #pragma clang fp contract(off)
             const int h = step >> 1, r0 = 8 * t + 4 * h;
             if ((step & 1) == 0) {
-                cv[0] = fmaxf(a[r0] * sc, 0.f); cv[1] = fmaxf(a[r0 + 1] * sc, 0.f); cv[2] = fmaxf(a[r0 + 2] * sc, 0.f); cv[3] = fmaxf(a[r0 + 3] * sc, 0.f);
+                cv[0] = fmaxf(a[r0] * sc0, 0.f); cv[1] = fmaxf(a[r0 + 1] * sc0, 0.f); cv[2] = fmaxf(a[r0 + 2] * sc0, 0.f); cv[3] = fmaxf(a[r0 + 3] * sc0, 0.f);
             } else {
                 og_split4(cv[0], cv[1], cv[2], cv[3], hh[buf][2 * h], hl[buf][2 * h], hh[buf][2 * h + 1], hl[buf][2 * h + 1]);
             }
@@ -452,7 +453,7 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpFusedArgs g) {
                         "v_fma_mix_f32 %2, %8, 1.0, %2 op_sel_hi:[1,0,0]\n\t"
                         "v_fma_mix_f32 %3, %8, 1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3)
-                        : "s"(sc), "v"(raw[i][q][0]), "v"(raw[i][q][1]), "v"(raw[i][q][2]), "v"(raw[i][q][3]));
+                        : "s"(sc3), "v"(raw[i][q][0]), "v"(raw[i][q][1]), "v"(raw[i][q][2]), "v"(raw[i][q][3]));
                     a[i][4 * q] = x0; a[i][4 * q + 1] = x1; a[i][4 * q + 2] = x2; a[i][4 * q + 3] = x3;
                 }
             // registers -> slabs: slab i = [32 tok][hi 64 B | lo 64 B] of channel block cb0 + 2 ip + i
@@ -504,19 +505,19 @@ bool og_mlp_fused_enabled(int D) {
 }
 
 // Fragment-major weight stream of mlp_fused_kernel.  W0 [2D][2D], W3 [D][2D] row-major double (already folded), written as (hi, lo)
-// halves of 256 w.  48 stages of 32 fragments (1 KiB = 64 lanes x 8 halves; a lo fragment follows its hi fragment); quarter q:
+// halves of S0 w / S3 w (power-of-two pre-scales, 256 unless a weight would leave binary16).  48 stages of 32 fragments (1 KiB = 64 lanes x 8 halves; a lo fragment follows its hi fragment); quarter q:
 //   fc.0 stage 24 q + kg (k-group kg):   fragment ((a * 2 + t) * 4 + i) * 2 + part, lane l = (rho = l & 31, h = l >> 5), element e:
 //          W0[32 (8a + 4q + i) + rho][32 kg + 16 t + 8 h + e]                                   (a = hidden half, i = block of the quarter)
 //   fc.3 stage 24 q + 16 + 2 j + t:      fragment (a * 8 + i) * 2 + part (i = output block):
 //          W3[32 i + rho][32 (8a + 4q + j) + 16 t + 8 (e >> 2) + 4 h + (e & 3)]                   (the accumulator-register order, above)
 // Returns false when a scaled weight does not fit binary16.
-bool og_pack_mlp_stream(int D, const double* W0, const double* W3, void* out) {
+bool og_pack_mlp_stream(int D, const double* W0, const double* W3, void* out, double S0, double S3) {
     if (!og_mlp_fused_supported(D)) return false;
     const int D2 = 2 * D, G0 = D2 / 32;
     _Float16* o = (_Float16*)out;
     bool ok = true;
-    auto put = [&](int64_t stage, int f, int l, int e, double w) {
-        w *= OG_W_SCALE;
+    auto put = [&](int64_t stage, int f, int l, int e, double w, double S) {
+        w *= S;
         if (!(fabs(w) <= 65504.0)) { ok = false; w = 0.0; }
         const _Float16 hi = (_Float16)w;
         _Float16* base = o + stage * (32768 / 2) + (int64_t)f * 512 + l * 8 + e;     // fragment f: 1 KiB = 512 halves
@@ -531,7 +532,7 @@ bool og_pack_mlp_stream(int D, const double* W0, const double* W3, void* out) {
                         for (int l = 0; l < 64; ++l)
                             for (int e = 0; e < 8; ++e)
                                 put(24 * q + kg, ((a * 2 + t) * 4 + i) * 2, l, e,
-                                    W0[(int64_t)(32 * (8 * a + 4 * q + i) + (l & 31)) * D2 + 32 * kg + 16 * t + 8 * (l >> 5) + e]);
+                                    W0[(int64_t)(32 * (8 * a + 4 * q + i) + (l & 31)) * D2 + 32 * kg + 16 * t + 8 * (l >> 5) + e], S0);
         for (int j = 0; j < 4; ++j)
             for (int t = 0; t < 2; ++t)
                 for (int a = 0; a < 2; ++a)
@@ -539,7 +540,7 @@ bool og_pack_mlp_stream(int D, const double* W0, const double* W3, void* out) {
                         for (int l = 0; l < 64; ++l)
                             for (int e = 0; e < 8; ++e)
                                 put(24 * q + 16 + 2 * j + t, (a * 8 + i) * 2, l, e,
-                                    W3[(int64_t)(32 * i + (l & 31)) * D2 + 32 * (8 * a + 4 * q + j) + 16 * t + 8 * (e >> 2) + 4 * (l >> 5) + (e & 3)]);
+                                    W3[(int64_t)(32 * i + (l & 31)) * D2 + 32 * (8 * a + 4 * q + j) + 16 * t + 8 * (e >> 2) + 4 * (l >> 5) + (e & 3)], S3);
     }
     return ok;
 }

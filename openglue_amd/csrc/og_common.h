@@ -45,8 +45,16 @@ static inline int64_t og_round_up(int64_t x, int64_t a) { return (x + a - 1) / a
 // accumulator.  For |x| < 2^-3 lo is an f16 subnormal; v_mfma_f32_32x32x16_f16 honours subnormal inputs
 // (scripts/probes/mfma_denorm.hip, profiles/r01_probe_mfma_denorm.log), so the representation error is
 // <= max(2^-22 |x|, 2^-25).  Weights are additionally pre-scaled by OG_W_SCALE at pack time (exact) so that their
-// lo parts are normal numbers; the GEMM epilogue multiplies the accumulator by 1/OG_W_SCALE.
+// lo parts are normal numbers; the GEMM epilogue multiplies the accumulator by 1/OG_W_SCALE.  og_pack_weights lowers the pre-scale
+// per weight matrix (a power of two, og_weight_prescale) when 256 |w| would leave binary16 -- e.g. a BatchNorm fold over a dead
+// channel -- and stores 1 / S next to the matrix; the kernels read it from there (GemmHArgs::scale_dev).
 #define OG_W_SCALE 256.0
+// largest power of two S <= 256 with S * maxabs <= 32768 (half the binary16 range: room for rounding), at least 2^-40
+static inline double og_weight_prescale(double maxabs) {
+    double S = OG_W_SCALE;
+    while (S * maxabs > 32768.0 && S > 9.094947017729282e-13) S *= 0.5;
+    return S;
+}
 // CALLERS: if x is the result of a multiply, pin it first (`asm("" : "+v"(x))`, or compute it under `#pragma clang fp
 // contract(off)` and check the ISA for v_fma_mix).  The compiler may otherwise fuse that multiply into ONE of the two
 // conversions (v_fma_mixlo_f16: single rounding) while the other uses the separately rounded fp32 product
@@ -129,6 +137,8 @@ struct GemmHArgs {
     int M, N, K;
     float scale;                              // v = acc * scale + bias (undoes a power-of-two pre-scale of B)
     float inv_scale;                          // set by the launcher: 1 / scale (the bias enters the accumulators as bias / scale)
+    const float* scale_dev;                   // optional DEVICE scalar that overrides `scale` (read by the kernel): the per-matrix
+                                              // power-of-two pre-scale og_pack_weights chose for this weight matrix
     const float* bias; int relu;
     const float* res; int64_t ldr;            // fp32 residual [M][N] (may alias C32), or
     const _Float16* res_hl; int64_t ldrh;     //   split-f16 residual in hl32 rows (may alias Ch when c_hl): v += hi + lo
@@ -160,12 +170,13 @@ struct MlpFusedArgs {
     const char* wstream;          // og_pack_mlp_stream: fragment-major (hi, lo) halves of 256 W0', 256 W3'
     const float* b0;              // [2D] folded fc.0 bias
     const float* b3;              // [D] folded fc.3 bias
-    float scale;                  // 1 / OG_W_SCALE
+    float scale;                  // 1 / OG_W_SCALE: accumulator multiplier of both matrices, unless ...
+    const float* scales_dev;      // ... DEVICE [2] = {1 / S0, 1 / S3}: the per-matrix pre-scales og_pack_weights chose (null: `scale`)
 };
 bool og_mlp_fused_supported(int D);
 bool og_mlp_fused_enabled(int D);                    // supported and not switched off (OG_MLP_FUSED=0)
 size_t og_mlp_stream_bytes(int D);
-bool og_pack_mlp_stream(int D, const double* W0, const double* W3, void* out);   // false: a weight does not fit binary16
+bool og_pack_mlp_stream(int D, const double* W0, const double* W3, void* out, double S0 = OG_W_SCALE, double S3 = OG_W_SCALE);   // false: a weight does not fit binary16
 int og_launch_mlp_fused(const MlpFusedArgs& a, int D, hipStream_t stream);
 
 struct AttnArgs {

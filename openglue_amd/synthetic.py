@@ -159,6 +159,31 @@ def make_state_dict(config: dict, seed: int = 0) -> "OrderedDict[str, torch.Tens
     return out
 
 
+def make_trained_like_state_dict(config: dict, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
+    """make_state_dict with the statistics a TRAINED checkpoint shows and random initialisation never does:
+    in every message MLP a few BatchNorm channels are DEAD (post-ReLU output identically 0: running_mean = 0, running_var ~ 1e-12, so
+    the eval-mode fold multiplies the next conv's column by ~316 * gamma), a few have a large gamma / sigma ratio, the matching conv
+    columns carry ordinary weights, and a few projection weights are large.  Deterministic in (config, seed)."""
+    sd = make_state_dict(config, seed)
+    D = config["descriptor_dim"]
+    L = 2 * config["attention_gnn"]["num_stages"]
+    g = torch.Generator().manual_seed(977 + seed)
+    for l in range(L):
+        pre = f"attention_gnn.layers.{l}.module"
+        dead = torch.randperm(2 * D, generator=g)[:3]
+        sd[f"{pre}.fc.2.running_var"][dead] = 1e-12
+        sd[f"{pre}.fc.2.running_mean"][dead] = 0.0
+        sd[f"{pre}.fc.2.weight"][dead] = 8.0 + 4.0 * torch.rand(3, generator=g)
+        sd[f"{pre}.fc.3.weight"][:, dead, 0] = 0.3 * torch.randn(D, 3, generator=g)          # 0.3 * 10 / sqrt(1e-5) * 256 >> 65504
+        # a dead channel is dead because its conv row is strongly negative for every input: make it so (bias far below any response)
+        sd[f"{pre}.fc.0.bias"][dead] = -1e3
+        big = torch.randperm(2 * D, generator=g)[:4]
+        sd[f"{pre}.fc.2.running_var"][big] = 1e-4            # gamma / sigma ~ 100
+        if l % 3 == 0:
+            sd[f"{pre}.mha.in_proj_k.weight"][l % D, (7 * l + 3) % D, 0] = 150.0                # 256 * 150 > 32768
+    return sd
+
+
 def make_pair(m: int, n: int, descriptor_dim: int, side_info_size: int, seed: int,
               desc_scale: float = 32.0, inlier_frac: float = 0.6) -> Dict[str, torch.Tensor]:
     """One synthetic image pair (no batch dimension)."""

@@ -112,6 +112,29 @@ def full_case(name, kw, m, n, batch, seed, store):
     print(f"{name}: scores {tuple(scores.shape)} absmax {scores.abs().max():.3f} valid matches {nvalid}/{matches0.size}")
 
 
+def trained_case():
+    """`trained`: the reference on a TRAINED-LIKE checkpoint (syn.make_trained_like_state_dict: dead BatchNorm channels, large
+    gamma / sigma, a few large weights) and unit-norm descriptors (desc_scale = 1: the dustbin-dominated regime of real SuperPoint /
+    SIFT inputs) -- the statistics that make the eval-mode BatchNorm fold produce weights beyond 256 |w| < 65504."""
+    kw = dict(descriptor_dim=256, num_stages=2, num_heads=4, num_iters=20, side_info_size=1)
+    m, n, batch, seed = 140, 120, 2, 31
+    cfg = syn.make_config(**kw)
+    sd = syn.make_trained_like_state_dict(cfg, seed=0)
+    ref = RefSuperGlue(cfg)
+    ref.load_state_dict(sd, strict=True)
+    ref.eval()
+    arrays = {"config_kwargs": np.array(repr(kw)), "m": m, "n": n, "batch": batch, "seed": seed}
+    for tag, scale in (("unit", 1.0), ("x4", 4.0)):
+        data = syn.make_batch(batch, m, n, 256, 1, seed=seed, desc_scale=scale)
+        with torch.no_grad():
+            out = ref(data)
+        matches0, ms0 = brute_force_matches(out["scores"], MATCH_THRESHOLD)
+        arrays.update({f"{tag}_scores": out["scores"].numpy(), f"{tag}_matches0": matches0, f"{tag}_matching_scores0": ms0,
+                       f"{tag}_context_descriptors0": out["context_descriptors0"].numpy()})
+        print(f"trained/{tag}: scores absmax {out['scores'].abs().max():.3f} valid matches {int((matches0 >= 0).sum())}/{matches0.size}")
+    np.savez_compressed(os.path.join(HERE, "trained.npz"), **arrays)
+
+
 def stage_cases():
     g = torch.Generator().manual_seed(1234)
     # log_otp_solver alone (optimal_transport.py:4-28), non-square, reg != 1
@@ -183,6 +206,9 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     if sys.argv[1:] == ["layers"]:
         layer_cases()
+        sys.exit(0)
+    if sys.argv[1:] == ["trained"]:
+        trained_case()
         sys.exit(0)
     only = sys.argv[1:]                      # e.g. `make_golden.py favor`: (re)generate the named cases only
     for name, (kw, m, n, batch, seed, store) in CASES.items():

@@ -25,9 +25,9 @@ def forward_from_packed(model, data, dtype=torch.float64):
     blob = torch.from_numpy(raw).to(dtype)
     half = torch.from_numpy(raw.view("float16").copy()).to(dtype)       # same bytes viewed as f16 (2 per float slot)
 
-    def planes(off, r, c):     # hl32 rows (gemm_f16x3.hip): [r][c/32][hi 32 | lo 32] of 256 * w (OG_W_SCALE)
+    def planes(off, r, c, inv_off):     # hl32 rows (gemm_f16x3.hip): [r][c/32][hi 32 | lo 32] of S * w, 1 / S stored at inv_off
         g = half[2 * off:2 * off + 2 * r * c].view(r, c // 32, 2, 32)
-        return (g[:, :, 0] + g[:, :, 1]).reshape(r, c) / 256.0
+        return (g[:, :, 0] + g[:, :, 1]).reshape(r, c) * blob[inv_off]
 
     D, H, s = model.descriptor_dim, model.num_heads, model.side_info_size
     mat = lambda off, r, c: blob[off:off + r * c].view(r, c)
@@ -68,24 +68,24 @@ def forward_from_packed(model, data, dtype=torch.float64):
         if getattr(model, "favor_relu", False):
             # favor_relu (api.hip): rows [0, 2D) / [2D, 4D) = d^-1/4 P folded into in_proj_q / in_proj_k (ReLU in the GEMM epilogue,
             # + eps where the features are read), rows [4D, 5D) = in_proj_v; then linear attention over the 2D features
-            Wqkv, bqkv = planes(base + L.o_wqkv, 5 * D, D), vec(base + L.o_bqkv, 5 * D)
+            Wqkv, bqkv = planes(base + L.o_wqkv, 5 * D, D, base + L.o_scale), vec(base + L.o_bqkv, 5 * D)
             fq = torch.relu(xq @ Wqkv[:2 * D].T + bqkv[:2 * D]) + 1e-8
             fk = torch.relu(xkv @ Wqkv[2 * D:4 * D].T + bqkv[2 * D:4 * D]) + 1e-8
             v = xkv @ Wqkv[4 * D:].T + bqkv[4 * D:]
             o = (fq @ (fk.transpose(-1, -2) @ v)) / (fq @ fk.sum(1, keepdim=True).transpose(-1, -2))
         else:
-            Wqkv, bqkv = planes(base + L.o_wqkv, 3 * D, D), vec(base + L.o_bqkv, 3 * D)
+            Wqkv, bqkv = planes(base + L.o_wqkv, 3 * D, D, base + L.o_scale), vec(base + L.o_bqkv, 3 * D)
             q = xq @ Wqkv[:D].T + bqkv[:D]
             kv = xkv @ Wqkv[D:].T + bqkv[D:]
             o = attn(q, kv[..., :D], kv[..., D:])
-        h = torch.relu(torch.cat([xq, o], -1) @ planes(base + L.o_w0, 2 * D, 2 * D).T + vec(base + L.o_b0, 2 * D))
-        return xq + h @ planes(base + L.o_w3, D, 2 * D).T + vec(base + L.o_b3, D)
+        h = torch.relu(torch.cat([xq, o], -1) @ planes(base + L.o_w0, 2 * D, 2 * D, base + L.o_scale + 1).T + vec(base + L.o_b0, 2 * D))
+        return xq + h @ planes(base + L.o_w3, D, 2 * D, base + L.o_scale + 2).T + vec(base + L.o_b3, D)
 
     for l in range(model.num_stages):
         x0, x1 = prop(2 * l, x0, x0), prop(2 * l, x1, x1)
         x0 = prop(2 * l + 1, x0, x1)
         x1 = prop(2 * l + 1, x1, x0)
-    Wp, bp = planes(L.wp, D, D), vec(L.bp, D)
+    Wp, bp = planes(L.wp, D, D, L.scales), vec(L.bp, D)
     g0, g1 = x0 @ Wp.T + bp, x1 @ Wp.T + bp
     if model.residual:
         a = vec(L.alpha, D)

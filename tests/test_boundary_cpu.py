@@ -1,6 +1,7 @@
 """CPU: the drop-in boundary -- library exports, state-dict layout, weight packing, error behaviour.
 No kernel is launched here (no GPU in the build container)."""
 import ctypes as C
+import math
 import os
 import re
 import sys
@@ -145,22 +146,37 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         _lib.load()
 
 
-def test_pack_rejects_weights_outside_the_f16_operand_range():
-    """a BatchNorm fold over a dead channel (running_var ~ 0) multiplies a weight by ~316*gamma; 256*w then
-    leaves binary16 and used to be packed as inf (NaN scores).  og_pack_weights must refuse with OG_E_RANGE."""
+def test_pack_survives_trained_checkpoint_statistics():
+    """A BatchNorm fold over a dead post-ReLU channel (running_var ~ 0) multiplies a weight by ~316 * gamma; 256 * w then leaves
+    binary16 (round 1 packed an inf, round 2 refused with OG_E_RANGE).  Now the matrix gets a smaller power-of-two pre-scale, its
+    1 / S is stored next to it, and the packed model still reproduces the oracle (packing algebra on the CPU); only non-finite
+    weights are refused."""
+    from tests.packed_model import forward_from_packed, layout_of
     cfg = syn.make_config(descriptor_dim=64, num_stages=1, num_heads=4, num_iters=3)
     model = SuperGlue(cfg).eval()
     model.load_state_dict(syn.make_state_dict(cfg, seed=0), strict=True)
-    model.pack_host()                                           # fine as generated
+    L = layout_of(model)
+    blob = model.pack_host()                                    # as generated: every matrix at the default 256
+    base = L.layer0
+    assert list(blob[base + L.o_scale:base + L.o_scale + 3]) == [1 / 256.0] * 3 and float(blob[L.scales]) == 1 / 256.0
     bn = model.attention_gnn.layers[0].module.fc[2]
     with torch.no_grad():
         bn.running_var[5] = 0.0                                 # dead post-ReLU channel
+        bn.running_mean[5] = 0.0
         bn.weight[5] = 4.0
         model.attention_gnn.layers[0].module.fc[3].weight[:, 5, 0] = 0.9     # 0.9 * 4 / sqrt(1e-5) * 256 = 2.9e5 > 65504
-    with pytest.raises(RuntimeError, match="OG_E_RANGE"):
-        model.pack_host()
+        model.attention_gnn.layers[1].module.mha.in_proj_k.weight[7, 3, 0] = 700.0      # a plain large weight
+    blob = model.pack_host()
+    inv3 = float(blob[base + L.o_scale + 2])
+    assert inv3 > 1 / 256.0 and math.log2(inv3) == round(math.log2(inv3))               # fc.3 of layer 0: a smaller power of two
+    assert float(blob[base + L.o_scale + 1]) == 1 / 256.0                                 # its fc.0 is untouched
+    assert float(blob[base + L.layer_stride + L.o_scale]) > 1 / 256.0                     # q | k | v of layer 1
+    data = syn.make_batch(1, 40, 33, 64, 1, seed=5)
     with torch.no_grad():
-        bn.running_var[5] = 1.0
+        ref = orc.superglue_forward(model.state_dict(), cfg, data, dtype=torch.float64)
+        got = forward_from_packed(model, data)
+    assert (got["scores"] - ref["scores"]).abs().max() < 1e-6 * max(1.0, float(ref["scores"].abs().max()))
+    with torch.no_grad():
         model.linear_proj.weight[3, 3, 0] = float("nan")
     with pytest.raises(RuntimeError, match="OG_E_RANGE"):
         model.pack_host()

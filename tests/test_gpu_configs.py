@@ -44,6 +44,9 @@ def _unexplained(got_matches0, sd, cfg, one):
         j = int(want["_row_argmax"][0, i])
         if not (bool(amb_r[0, i]) or bool(near_thr[i]) or bool(amb_c[0, j])):
             bad += 1
+    # the exemptions are bounded: more than 0.1 % of a pair's rows differing fails even if every one is a near-tie
+    ceiling = max(2, int(math.ceil(1e-3 * diff.numel())))
+    assert int(diff.sum()) <= ceiling, f"{int(diff.sum())} of {diff.numel()} rows differ from the oracle (ceiling {ceiling})"
     return int(diff.sum()), bad, ref
 
 

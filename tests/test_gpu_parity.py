@@ -307,8 +307,13 @@ def _build(cfg, sd, device):
     return model.to(device)
 
 
+MAX_EXEMPT_FRAC = 1e-3      # ceiling on near-tie exemptions: at most 0.1 % of the rows (and never more than 2 on a tiny case)
+
+
 def _index_agreement(got_matches0, scores_gpu, sd, cfg, data):
-    """matches0 must equal the fp32 oracle's except on rows that are near-ties in float64."""
+    """matches0 must equal the fp32 oracle's except on rows that are near-ties in float64 -- and those exemptions are BOUNDED:
+    more than MAX_EXEMPT_FRAC of the rows differing fails even if every one of them is a near-tie.
+    -> (rows that differ = exemptions granted, rows not explained, float64 oracle output)"""
     with torch.no_grad():
         o64 = orc.superglue_forward(sd, cfg, data, dtype=torch.float64)
     want = orc.extract_matches(o64["scores"].float(), MATCH_THRESHOLD)
@@ -318,12 +323,15 @@ def _index_agreement(got_matches0, scores_gpu, sd, cfg, data):
     ms = want["matching_scores0"]
     near_thr = (ms - MATCH_THRESHOLD).abs() < 1e-3
     unexplained = diff & ~amb_r & ~near_thr
+    n_bad = 0
     for b, i in torch.nonzero(unexplained).tolist():
         j = int(want["_row_argmax"][b, i])
         if not amb_c[b, j]:
-            return int(diff.sum()), int(unexplained.sum()), o64
-        unexplained[b, i] = False
-    return int(diff.sum()), 0, o64
+            n_bad += 1
+    ndiff = int(diff.sum())
+    ceiling = max(2, int(math.ceil(MAX_EXEMPT_FRAC * diff.numel())))
+    assert ndiff <= ceiling, f"{ndiff} of {diff.numel()} rows differ from the oracle: over the exemption ceiling of {ceiling} even if all are near-ties"
+    return ndiff, n_bad, o64
 
 
 @pytest.mark.parametrize("name", ["c1", "mid", "flags", "nodesc", "siren", "linear", "favor"])
@@ -432,12 +440,18 @@ def test_full_size_c2_batch_properties(gpu_device):
     bi = torch.arange(B, device=s.device)[:, None].expand_as(m0)[valid]
     assert (m1[bi, m0[valid]] == torch.nonzero(valid)[:, 1]).all()
     assert int(valid.sum()) == int((m1 >= 0).sum())
-    # (5) oracle spot check on two pairs
-    for p in (0, 31):
-        onep = {k: (v[p:p + 1] if torch.is_tensor(v) else v) for k, v in data.items()}
-        with torch.no_grad():
-            ref = orc.superglue_forward(sd, cfg, onep)
-        assert (s[p].cpu() - ref["scores"][0]).abs().max() < TOL_SCORES
+    # (5) EVERY pair of the batch against the float64 oracle: scores within the bar, matches0 identical up to bounded near-ties.
+    #     (This is the call that takes the resident Sinkhorn schedule, the 256 x 256 GEMM tiles and the fused message MLP.)
+    s_cpu, m0_cpu = s.cpu(), out["matches0"].cpu()
+    worst, exempt = 0.0, 0
+    for p0 in range(0, B, 8):
+        chunk = {k: (v[p0:p0 + 8] if torch.is_tensor(v) else v) for k, v in data.items()}
+        ndiff, bad, o64 = _index_agreement(m0_cpu[p0:p0 + 8], s_cpu[p0:p0 + 8], sd, cfg, chunk)
+        assert bad == 0, f"pairs {p0}..{p0 + 7}: {ndiff} rows differ, {bad} not explained by float64 near-ties"
+        worst = max(worst, (s_cpu[p0:p0 + 8].double() - o64["scores"]).abs().max().item())
+        exempt += ndiff
+    print(f"[C2 B=32] all 32 pairs: scores err {worst:.2e}; {exempt} near-tie exemptions of {B * m} rows")
+    assert worst < TOL_SCORES
 
 
 def test_ragged_packed_wide_range(gpu_device):
@@ -511,6 +525,28 @@ def test_prepare_features_output(gpu_device, method):
         err_gpu = (got["side_info"].cpu().double() - truth).abs()
         err_cpu = (want["side_info"].double() - truth).abs()
         assert (err_gpu <= 4.0 * err_cpu + 2e-6 * truth.abs() + 1e-6).all()
+
+
+def test_prepare_features_against_reference_laf_fixture(gpu_device):
+    """og_prepare_features against tests/golden/laf.npz: the reference's prepare_features_output + LAF converters executed unchanged
+    (make_golden_laf.py; kornia's get_laf_scale is the one restated stub).  Thin frames make 1/scale ill-conditioned in fp32: the
+    bound is relative to the scale's own rounding (a few ulp of the determinant)."""
+    from openglue_amd import features
+    z = np.load(os.path.join(GOLDEN, "laf.npz"))
+    lafs, resp, desc = torch.from_numpy(z["lafs"]), torch.from_numpy(z["responses"]), torch.from_numpy(z["desc"])
+    A = lafs[..., :2].double()
+    det = (A[..., 0, 0] * A[..., 1, 1] - A[..., 1, 0] * A[..., 0, 1]).abs()
+    cond = ((A[..., 0, 0] * A[..., 1, 1]).abs() + (A[..., 1, 0] * A[..., 0, 1]).abs()) / det.clamp_min(1e-30)     # cancellation in the determinant
+    for method in ("none", "scale", "rotation", "scale_rotation", "affine"):
+        for lr in (0, 1):
+            got = features.prepare_features_output(lafs.to(gpu_device), resp.to(gpu_device), desc.to(gpu_device), method, log_response=bool(lr))
+            assert np.array_equal(got["keypoints"].cpu().numpy(), z[f"{method}_{lr}_keypoints"])
+            ref = torch.from_numpy(z[f"{method}_{lr}_side_info"]).double()
+            err = (got["side_info"].cpu().double() - ref).abs()
+            tol = (4e-7 * cond).unsqueeze(-1) * (ref.abs() + 1.0) + 2e-6
+            assert (err <= tol).all(), (method, lr, float((err / tol).max()))
+    with pytest.raises(NameError):
+        features.prepare_features_output(lafs.to(gpu_device), resp.to(gpu_device), desc.to(gpu_device), "bogus")
 
 
 def test_compact_matches(gpu_device):
@@ -797,3 +833,24 @@ def test_keypoint_encoder_against_stored_encoder0(gpu_device, name):
     err = (pe0 - ref).abs().max().item()
     print(f"[{name}] encoder err {err:.2e} (scale {scale:.1f})")
     assert err < 2e-5 * scale
+
+
+@pytest.mark.parametrize("tag,scale", [("unit", 1.0), ("x4", 4.0)])
+def test_forward_on_trained_like_checkpoint_fixture(gpu_device, tag, scale):
+    """A checkpoint with the statistics training produces and random initialisation never does (dead BatchNorm channels whose
+    eval-mode fold multiplies a conv column by ~3000, gamma / sigma ~ 100, weights of 150): og_pack_weights gives those matrices a
+    smaller power-of-two pre-scale (round 2 refused them with OG_E_RANGE) and the kernels read it from the packed blob.  Against
+    the REFERENCE's outputs (tests/golden/make_golden.py trained), unit-norm descriptors included."""
+    import ast
+    z = np.load(os.path.join(GOLDEN, "trained.npz"))
+    cfg = syn.make_config(**ast.literal_eval(str(z["config_kwargs"])))
+    sd = syn.make_trained_like_state_dict(cfg, seed=0)
+    model = _build(cfg, sd, gpu_device)
+    data = syn.make_batch(int(z["batch"]), int(z["m"]), int(z["n"]), 256, 1, seed=int(z["seed"]), desc_scale=scale)
+    out = {k: v.cpu() for k, v in model.match(to_device(data, gpu_device), MATCH_THRESHOLD).items()}
+    err = np.abs(out["scores"].numpy() - z[f"{tag}_scores"]).max()
+    print(f"[trained/{tag}] scores err {err:.2e} (|scores| max {np.abs(z[f'{tag}_scores']).max():.1f})")
+    assert err < TOL_SCORES
+    assert np.abs(out["context_descriptors0"].numpy() - z[f"{tag}_context_descriptors0"]).max() < TOL_SCORES
+    ndiff, unexplained, _ = _index_agreement(out["matches0"], out["scores"], sd, cfg, data)
+    assert unexplained == 0, (ndiff, unexplained)

@@ -144,3 +144,36 @@ def test_oracle_encoder_against_stored_encoder0():
             inter = orc.superglue_forward(sd, cfg, data, return_intermediates=True)["_intermediates"]
         pe0 = inter["pe0"].transpose(1, 2).numpy()            # the fixture is channel-first [B, D, m]
         assert np.abs(pe0 - z["encoder0"]).max() < 2e-5 * max(1.0, float(np.abs(z["encoder0"]).max())), name
+
+
+def test_oracle_prepare_features_against_reference_laf_fixture():
+    """models/features/utils.py:54-65 + models/laf_converter.py executed unchanged (tests/golden/make_golden_laf.py; only
+    kornia's get_laf_scale is a restated stub there): every method x log_transform_response."""
+    z = np.load(os.path.join(GOLDEN, "laf.npz"))
+    lafs, resp, desc = torch.from_numpy(z["lafs"]), torch.from_numpy(z["responses"]), torch.from_numpy(z["desc"])
+    for method in ("none", "scale", "rotation", "scale_rotation", "affine"):
+        for lr in (0, 1):
+            out = orc.prepare_features_output(lafs, resp, desc, method, log_response=bool(lr))
+            assert np.array_equal(out["keypoints"].numpy(), z[f"{method}_{lr}_keypoints"])
+            ref = z[f"{method}_{lr}_side_info"]
+            assert out["side_info"].shape == ref.shape
+            assert np.abs(out["side_info"].numpy() - ref).max() <= 1e-6 * max(1.0, float(np.abs(ref).max())), (method, lr)
+    with pytest.raises(NameError) as e:
+        orc.laf_side_info(lafs, "bogus")
+    assert str(e.value) == str(z["bogus_error"])
+
+
+def test_oracle_on_trained_like_checkpoint_fixture():
+    """tests/golden/trained.npz: the reference on a trained-LIKE checkpoint (dead BatchNorm channels, large gamma / sigma, large
+    weights: syn.make_trained_like_state_dict) with unit-norm and 4x descriptors."""
+    import ast
+    from openglue_amd import synthetic as syn
+    z = np.load(os.path.join(GOLDEN, "trained.npz"))
+    cfg = syn.make_config(**ast.literal_eval(str(z["config_kwargs"])))
+    sd = syn.make_trained_like_state_dict(cfg, seed=0)
+    for tag, scale in (("unit", 1.0), ("x4", 4.0)):
+        data = syn.make_batch(int(z["batch"]), int(z["m"]), int(z["n"]), 256, 1, seed=int(z["seed"]), desc_scale=scale)
+        with torch.no_grad():
+            out = orc.match_pairs(sd, cfg, data, MATCH_THRESHOLD)
+        assert np.abs(out["scores"].numpy() - z[f"{tag}_scores"]).max() < 2e-4
+        assert np.array_equal(out["matches0"].numpy(), z[f"{tag}_matches0"])
