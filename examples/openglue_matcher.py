@@ -17,7 +17,7 @@ from typing import Dict, Mapping, Optional
 import torch
 import torch.nn as nn
 
-from . import features
+from openglue_amd import features
 
 
 class OpenGlueMatcher(nn.Module):

@@ -16,12 +16,16 @@ import torch.distributed as dist
 
 
 def pair_cost(m: int, n: int, desc_dim: int = 256, num_stages: int = 9, iters: int = 100) -> float:
-    """Relative cost of one pair: algorithmic FLOPs + Sinkhorn bytes weighted by the
-    MI355X flop:byte ratio of the kernels that execute them (fp32 MFMA 157 TF vs ~5 TB/s)."""
+    """Estimated seconds of one pair on an MI355X: the algorithmic work of each kernel class over the rate that
+    class MEASURES on this path (round 3, BENCH / profiles/r03_*): split-f16 GEMMs incl. the fused message MLP ~330 algorithmic
+    TFLOP/s, flash attention ~305, streaming Sinkhorn (ragged batches never take the resident schedule) one read of the score
+    matrix per iteration at ~5.8 TB/s.  Only the RATIOS matter: the figure balances ragged pairs over the ranks (LPT)."""
     D, L = desc_dim, num_stages
-    flops = L * (40.0 * D * D * (m + n) + 4.0 * D * (m * m + n * n) + 8.0 * D * m * n) + 2.0 * D * D * (m + n) + 2.0 * m * n * D
-    bytes_ = 4.0 * ((m + 1) * (n + 1) * (2 * iters + 1) + 2 * m * n)
-    return flops / 157e12 + bytes_ / 5e12
+    gemm = L * 40.0 * D * D * (m + n) + 2.0 * D * D * (m + n) + 2.0 * m * n * D
+    attn = L * (4.0 * D * (m * m + n * n) + 8.0 * D * m * n)
+    rb = (m + 31) // 32
+    sink = 4.0 * (m * n * (iters + 1) + 2 * rb * n * iters + (m + 1) * (n + 1))
+    return gemm / 330e12 + attn / 305e12 + sink / 5.8e12
 
 
 def shard_pairs(num_pairs: int, world_size: int, costs: Optional[Sequence[float]] = None) -> List[List[int]]:

@@ -87,6 +87,21 @@ def _get_wh(data: Mapping, idx: int):
     return float(w), float(h)
 
 
+class _EvalFastPathOutputs(torch.autograd.Function):
+    """Marks the outputs of the fused eval-mode path as produced from the parameters WITHOUT a backward: asking for a gradient
+    through them raises instead of silently treating them as constants."""
+
+    @staticmethod
+    def forward(ctx, anchor, *outs):
+        return tuple(o.view_as(o) for o in outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        raise RuntimeError("openglue_amd.SuperGlue: the fused eval-mode path (og_forward) is not differentiable.  Set "
+                           "model.eval_autograd = True (eval-mode forward through the autograd kernels, BatchNorm on running "
+                           "statistics), call model.train(), or run inference under torch.no_grad().")
+
+
 class SuperGlue(nn.Module):
     def __init__(self, config: Mapping):
         super().__init__()
@@ -115,6 +130,9 @@ class SuperGlue(nn.Module):
             raise ValueError("attention 'favor_relu' runs with num_heads == 1 only (as in the reference) and descriptor_dim <= 256")
         self.residual = bool(config.get("residual", False))
         self.no_descriptors = bool(config.get("no_descriptors", False))
+        # eval() with autograd enabled and something requiring a gradient: False (default) = the fused inference kernels, outputs
+        # attached to a node that raises on backward; True = the differentiable eval-mode path (openglue_amd.train, frozen BatchNorm)
+        self.eval_autograd = False
 
         # ---- parameter tree with the reference's names ----
         self.siren = enc_name == "FeedForwardNetSiren"
@@ -182,8 +200,14 @@ class SuperGlue(nn.Module):
 
     def _param_key(self, device):
         ts = self._tensors()
-        # in-place updates (optimizer steps, copy_) bump _version; moves re-create the tensors (_apply above)
-        return (str(device), ts[0].data_ptr()) + tuple(t._version for t in ts)
+        # in-place updates (optimizer steps, copy_) bump _version; storage swaps (p.data = w, swap_tensors, set_) change data_ptr;
+        # moves re-create the tensors (_apply above).  Inference-mode tensors have no version counter.
+        def ver(t):
+            try:
+                return t._version
+            except RuntimeError:
+                return -1
+        return (str(device),) + tuple((t.data_ptr(), ver(t)) for t in ts)
 
     def check_status(self) -> int:
         """Synchronise and report how the optimal-transport stage of the LAST forward / match call went (og_forward_status): 0 = normal;
@@ -272,8 +296,8 @@ class SuperGlue(nn.Module):
     # ------------------------------------------------------------------ the hot path
     def _run(self, data: Mapping, want_matches: bool, match_threshold: float, both_sides: bool, _profile=None, _tap=None) -> Dict[str, torch.Tensor]:
         if self.training:
-            raise RuntimeError("openglue_amd.SuperGlue implements the eval()/inference path only "
-                               "(train-mode BatchNorm + backward is the next scope row, SURVEY.md §8 f2); call .eval()")
+            raise RuntimeError("match() / the fused og_forward path run in eval() mode only (BatchNorm on running statistics); the "
+                               "training-mode forward is SuperGlue.forward in train() (openglue_amd.train)")
         lib = _lib.load()
         names = ("keypoints0", "keypoints1", "local_descriptors0", "local_descriptors1", "side_info0", "side_info1")
         t = {}
@@ -477,8 +501,25 @@ class SuperGlue(nn.Module):
         if self.training:
             from . import train
             return train.superglue_forward_train(self, data)
+        wants_grad = torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters())
+                                                  or any(torch.is_tensor(v) and v.requires_grad for v in data.values()))
+        if wants_grad and self.eval_autograd:
+            # eval() under autograd (the reference's forward is differentiable in eval mode: fine-tuning on frozen BatchNorm
+            # statistics): the same Functions as the training path, BatchNorm on its running statistics
+            from . import train
+            return train.superglue_forward_train(self, data, frozen_bn=True)
         with torch.no_grad():
-            return self._run(data, want_matches=False, match_threshold=0.0, both_sides=False)
+            out = self._run(data, want_matches=False, match_threshold=0.0, both_sides=False)
+        if wants_grad:
+            # the fused inference kernels have no backward: the outputs stay attached to a node that RAISES when a gradient is
+            # asked of it -- never silently detached tensors (set model.eval_autograd = True for the differentiable eval path)
+            anchor = next((p for p in self.parameters() if p.requires_grad), None)
+            if anchor is None:
+                anchor = next(v for v in data.values() if torch.is_tensor(v) and v.requires_grad)
+            keys = list(out)
+            vals = _EvalFastPathOutputs.apply(anchor, *[out[k] for k in keys])
+            out = dict(zip(keys, vals))
+        return out
 
     @torch.no_grad()
     def match(self, data: Mapping, match_threshold: float = 0.2, both_sides: bool = True, _profile=None) -> Dict[str, torch.Tensor]:

@@ -384,15 +384,42 @@ def _mlp_train(x2d: torch.Tensor, seq: torch.nn.Module, momentum: float = 0.1, e
     return y
 
 
-def superglue_forward_train(model, data):
+def _mlp_frozen(x2d: torch.Tensor, seq: torch.nn.Module, siren: bool = False, eps: float = 1e-5) -> torch.Tensor:
+    """FeedForwardNet / FeedForwardNetSiren in EVAL mode under autograd (models/utils.py:23-58 with BatchNorm on its running
+    statistics): the 1x1 convs on the exact-fp32 GEMM Function, ReLU / sin(30 x) and the per-channel affine of eval-mode
+    BatchNorm as torch tensor algebra (differentiable w.r.t. the BatchNorm weight and bias too)."""
+    params, buffers = _seq_state(seq)
+    idx = sorted({int(k.split(".")[0]) for k in params if k.endswith(".weight") and params[k].dim() == 3})
+    y = x2d
+    for n_, i in enumerate(idx):
+        W = params[f"{i}.weight"]
+        W2 = W.reshape(W.shape[0], W.shape[1])
+        if n_ == 0:
+            y, W2 = _pad_k4(y, W2)
+        y = Conv1x1.apply(y.contiguous(), W2, params[f"{i}.bias"])
+        if n_ + 1 < len(idx):
+            if siren:
+                y = torch.sin(30.0 * y)
+            else:
+                y = torch.relu(y)
+                j = i + 2                                       # Conv, ReLU, BatchNorm1d
+                g = params[f"{j}.weight"] * torch.rsqrt(buffers[f"{j}.running_var"] + eps)
+                y = (y - buffers[f"{j}.running_mean"]) * g + params[f"{j}.bias"]
+    return y
+
+
+def superglue_forward_train(model, data, frozen_bn: bool = False):
     """`SuperGlue.forward` in training mode (reference superglue.py:29-72 with the modules in train()): batch-statistics BatchNorm
     (running statistics updated like torch's), every 1x1 conv / attention product / score matrix on the exact-fp32 MFMA GEMM,
     softmax + its backward, BatchNorm + ReLU backward and the optimal-transport layer on HIP kernels, all wired through
     torch.autograd.Functions -- loss.backward() reaches every parameter.  Glue that stays torch tensor algebra: keypoint
     normalisation, concatenations, residual adds, the sigmoid mix.  Supported: encoder FeedForwardNet, softmax attention,
     use_offset, residual, no_descriptors."""
-    if model.siren or model.linear_attention or getattr(model, 'favor_relu', False):
-        raise NotImplementedError("training mode: FeedForwardNet encoder and softmax attention only")
+    if model.linear_attention or getattr(model, 'favor_relu', False) or (model.siren and not frozen_bn):
+        raise NotImplementedError("autograd path: softmax attention only; the Siren encoder only with frozen statistics (eval mode)")
+    # frozen_bn: the module is in eval() and the caller wants gradients (fine-tuning on frozen BatchNorm statistics, saliency):
+    # the reference's eval-mode forward is differentiable (superglue.py:29-72 under autograd), so is this one
+    mlp = (lambda x_, seq_, siren_=False: _mlp_frozen(x_, seq_, siren_)) if frozen_bn else (lambda x_, seq_, siren_=False: _mlp_train(x_, seq_))
     D, H = model.descriptor_dim, model.num_heads
     k0, k1 = data["keypoints0"], data["keypoints1"]
     d0, d1 = data["local_descriptors0"], data["local_descriptors1"]                # [B, N, D] token-major as they arrive
@@ -407,7 +434,7 @@ def superglue_forward_train(model, data):
         wh1 = torch.tensor([wh[0] - 1.0, wh[1] - 1.0], device=k.device, dtype=torch.float32)
         kn = 2.0 * k.to(torch.float32) / wh1 - 1.0                                  # superglue.py:74-78
         inp = torch.cat([kn, s.to(torch.float32).reshape(k.shape[0], k.shape[1], -1)], dim=-1)
-        return _mlp_train(inp.reshape(-1, inp.shape[-1]), model.positional_encoding.encoder)
+        return mlp(inp.reshape(-1, inp.shape[-1]), model.positional_encoding.encoder, model.siren)
 
     pe0, pe1 = encode(k0, s0, _get_wh(data, 0)), encode(k1, s1, _get_wh(data, 1))
     d0f, d1f = d0.to(torch.float32).reshape(B * m, D), d1.to(torch.float32).reshape(B * n, D)
@@ -422,7 +449,7 @@ def superglue_forward_train(model, data):
         o = SoftmaxAttention.apply(q.reshape(B, nq, D), k.reshape(B, nk, D), v.reshape(B, nk, D), H)
         msg = conv(o.reshape(B * nq, D), mha.out_proj)
         y = torch.cat([xq - msg if model.use_offset else xq, msg], dim=-1)
-        return xq + _mlp_train(y, layer.module.fc)
+        return xq + mlp(y, layer.module.fc)
 
     for li, layer in enumerate(model.attention_gnn.layers):
         if li % 2 == 0:                                                            # self (attention_gnn.py:63-66)

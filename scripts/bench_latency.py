@@ -4,7 +4,7 @@ import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from openglue_amd import synthetic as syn
 from openglue_amd.superglue import SuperGlue
-from openglue_amd.graph import GraphedMatcher
+from examples.hipgraph_replay import GraphedMatcher
 dev = torch.device("cuda:0")
 kw = dict(syn.CONFIGS["C1"]); (m, n), B = kw.pop("kpts"), kw.pop("batch")
 cfg = syn.make_config(**kw); sd = syn.make_state_dict(cfg, 0)

@@ -159,5 +159,35 @@ def main_model():
     np.savez_compressed(os.path.join(HERE, "train_model.npz"), **out)
 
 
+def main_eval_grad():
+    """eval_grad: the reference SuperGlue in EVAL mode under autograd (its forward is differentiable with BatchNorm on running
+    statistics: fine-tuning on frozen statistics), L = criterion NLL: scores, loss, gradients w.r.t. every parameter and the
+    local descriptors."""
+    out = {}
+    for name, kw, B, m, n in MODEL_CASES:
+        cfg = syn.make_config(**kw)
+        sd = syn.make_state_dict(cfg, seed=len(name))
+        ref = RefSuperGlue(cfg)
+        ref.load_state_dict(sd)
+        ref.eval()
+        data = syn.make_batch(B, m, n, cfg["descriptor_dim"], 1, seed=3 + len(name))
+        data["local_descriptors0"].requires_grad_(True); data["local_descriptors1"].requires_grad_(True)
+        gt0, gt1 = gt_matches(B, m, n, torch.Generator().manual_seed(11))
+        y = ref(data)
+        loss = criterion({"gt_matches0": gt0, "gt_matches1": gt1}, y, margin=None)["loss"]
+        loss.backward()
+        out[f"{name}_scores"] = y["scores"].detach().numpy(); out[f"{name}_loss"] = np.float32(loss.item())
+        out[f"{name}_gt0"] = gt0.numpy(); out[f"{name}_gt1"] = gt1.numpy()
+        out[f"{name}_grad_desc0"] = data["local_descriptors0"].grad.numpy().copy()
+        out[f"{name}_grad_desc1"] = data["local_descriptors1"].grad.numpy().copy()
+        for k_, p_ in ref.named_parameters():
+            out[f"{name}_grad_{k_}"] = (p_.grad if p_.grad is not None else torch.zeros_like(p_)).numpy().copy()
+        print(name, "eval-mode model under autograd: loss", loss.item())
+    np.savez_compressed(os.path.join(HERE, "eval_grad.npz"), **out)
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["eval_grad"]:
+        main_eval_grad()
+    else:
+        main()

@@ -212,9 +212,9 @@ def test_input_validation_before_any_launch():
 
 
 def test_openglue_matcher_contract_on_cpu():
-    """openglue_amd.matcher.OpenGlueMatcher keeps the reference constructor (local_feature, matcher, match_config) and its error
+    """examples/openglue_matcher.py: OpenGlueMatcher keeps the reference constructor (local_feature, matcher, match_config) and its error
     behaviour: unknown LAF method -> NameError (laf_converter.py:128); CPU tensors -> RuntimeError (no CPU path)."""
-    from openglue_amd.matcher import OpenGlueMatcher
+    from examples.openglue_matcher import OpenGlueMatcher
     cfg = syn.make_config(descriptor_dim=64, num_stages=1, num_heads=4, num_iters=3, side_info_size=2)
     cfg["laf_to_sideinfo_method"] = "scale"
     model = SuperGlue(cfg).eval()

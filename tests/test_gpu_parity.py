@@ -478,7 +478,7 @@ def test_ragged_packed_wide_range(gpu_device):
 def test_ragged_pairs_equal_per_pair_oracle(gpu_device):
     """BASELINE configs[4] semantics at small scale: every pair has its own (m, n); the result must equal the
     per-pair (B=1) oracle, whatever the bucketing."""
-    from openglue_amd.ragged import bucket_by_shape, match_ragged
+    from tests.ragged_bucketing import bucket_by_shape, match_ragged
     cfg = syn.make_config(descriptor_dim=128, num_stages=2, num_heads=4, num_iters=10, side_info_size=1)
     sd = syn.make_state_dict(cfg, seed=0)
     model = _build(cfg, sd, gpu_device)
@@ -568,10 +568,10 @@ def test_compact_matches(gpu_device):
 
 
 def test_openglue_matcher_pipeline(gpu_device):
-    """openglue_amd.matcher.OpenGlueMatcher (inference.py:83-209 with pre-extracted features): LAFs / responses / descriptors of
+    """examples/openglue_matcher.py: OpenGlueMatcher (inference.py:83-209 with pre-extracted features): LAFs / responses / descriptors of
     two images -> compacted matches, against the same chain restated in the oracle (prepare_features_output -> SuperGlue.forward ->
     mutual-NN extraction -> boolean-mask compaction).  SIFT-like config: `affine` side info (6 channels), log-transformed response."""
-    from openglue_amd.matcher import OpenGlueMatcher
+    from examples.openglue_matcher import OpenGlueMatcher
     B, m, n, D = 2, 180, 150, 128
     cfg = syn.make_config(descriptor_dim=D, num_stages=2, num_heads=4, num_iters=12, side_info_size=6)
     cfg["laf_to_sideinfo_method"] = "affine"; cfg["log_transform_response"] = True
@@ -613,7 +613,7 @@ def test_openglue_matcher_pipeline(gpu_device):
 
 def test_hipgraph_replay_equals_eager(gpu_device):
     """The whole launch sequence captured into a hipGraph (launch-bound small shapes) gives identical results."""
-    from openglue_amd.graph import GraphedMatcher
+    from examples.hipgraph_replay import GraphedMatcher
     z, cfg, sd, data = load_case("c1")
     model = _build(cfg, sd, gpu_device)
     d0 = to_device(data, gpu_device)

@@ -152,3 +152,31 @@ def test_gather_validates_its_arguments():
         sharding.gather_matches({"matches0": m0, "matching_scores0": s0}, [0, 1], 3)
     with pytest.raises(ValueError, match="does not fit"):
         sharding.pad_ragged_matches([{"matches0": torch.zeros(9, dtype=torch.int64), "matching_scores0": torch.zeros(9)}], 8)
+
+
+def test_eight_rank_dry_run_of_the_bench_plumbing():
+    """`bench.py --gpus 8` end to end on gloo with the stub matcher (OG_BENCH_DRYRUN=1): self-spawn under torch.distributed.run on
+    127.0.0.1, eight ranks, the LPT-balanced ragged shards, ONE gather, ONE JSON line from rank 0 with n_gpus = 8."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OG_BENCH_DRYRUN"] = "1"
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["n_gpus"] == 8 and d["gather_ok"] is True
+
+
+def test_pair_cost_orders_pairs_like_the_measured_classes():
+    """pair_cost is seconds-like and monotone; a 2048-keypoint pair costs more than four 1024-keypoint pairs' worth of attention
+    would suggest less than 8x (the GEMM part is linear)."""
+    c1, c2 = sharding.pair_cost(1024, 1024), sharding.pair_cost(2048, 2048)
+    assert 2e-4 < c1 < 5e-4                      # the measured C2 step: 9.9 ms / 32 pairs = 0.31 ms per pair
+    assert 2.0 * c1 < c2 < 8.0 * c1
+    assert sharding.pair_cost(512, 2048) < sharding.pair_cost(2048, 2048)

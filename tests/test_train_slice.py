@@ -291,3 +291,89 @@ def test_training_step_against_reference_autograd(gpu_device, name):
     for k, b in model.named_buffers():
         if "running" in k:
             assert np.abs(b.cpu().numpy() - G[f"{name}_buf_{k}"]).max() < 1e-5, k
+
+
+# ----------------------------------------------------------------------------- eval mode under autograd
+GE = np.load(os.path.join(GOLDEN, "eval_grad.npz"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(MODEL_CASES))
+def test_eval_mode_autograd_against_reference(gpu_device, name):
+    """The reference's forward is differentiable in eval() (BatchNorm on running statistics: fine-tuning on frozen statistics).
+    With model.eval_autograd = True so is this one, through the same HIP forward / backward Functions as the training path:
+    scores, loss, gradients of every parameter and of the descriptors vs the reference (tests/golden/make_golden_train.py eval_grad);
+    the running statistics must not move."""
+    from openglue_amd.superglue import SuperGlue
+    cfg, sd, data, gt0, gt1 = _model_case(name)
+    model = SuperGlue(cfg)
+    model.load_state_dict(sd)
+    model = model.to(gpu_device).eval()
+    model.eval_autograd = True
+    before = {k: b.clone() for k, b in model.named_buffers()}
+    dd = {k: (v.to(gpu_device) if torch.is_tensor(v) else v) for k, v in data.items()}
+    dd["local_descriptors0"].requires_grad_(True); dd["local_descriptors1"].requires_grad_(True)
+    out = model(dd)
+    assert np.abs(out["scores"].detach().cpu().numpy() - GE[f"{name}_scores"]).max() < 1e-3
+    loss = orc.nll_criterion(out["scores"], gt0.to(gpu_device), gt1.to(gpu_device))
+    assert abs(loss.item() - float(GE[f"{name}_loss"])) < 1e-3 * abs(float(GE[f"{name}_loss"]))
+    loss.backward()
+    worst, worst_k = 0.0, ""
+    for key, got in (("desc0", dd["local_descriptors0"].grad), ("desc1", dd["local_descriptors1"].grad)):
+        want = GE[f"{name}_grad_{key}"]
+        e = np.abs(got.cpu().numpy() - want).max() / np.abs(want).max()
+        if e > worst: worst, worst_k = e, key
+    for k, p in model.named_parameters():
+        want = GE[f"{name}_grad_{k}"]
+        got = p.grad.cpu().numpy() if p.grad is not None else np.zeros_like(want)
+        e = np.abs(got - want).max() / max(np.abs(want).max(), 1e-8)
+        if np.abs(want).max() > 1e-7 and e > worst: worst, worst_k = e, k
+    print(f"[eval_grad {name}] loss {loss.item():.5f} vs {float(GE[f'{name}_loss']):.5f}; worst relative gradient error {worst:.2e} ({worst_k})")
+    assert worst < 1e-3
+    for k, b in model.named_buffers():
+        assert torch.equal(b, before[k]), k
+
+
+@pytest.mark.gpu
+def test_eval_mode_fast_path_is_never_silently_detached(gpu_device):
+    """Default eval(): the fused inference kernels.  With autograd enabled the outputs stay attached to a node that RAISES when a
+    gradient is asked of it; under torch.no_grad() they are plain tensors; both give the same numbers."""
+    from openglue_amd.superglue import SuperGlue
+    cfg, sd, data, gt0, gt1 = _model_case("base")
+    model = SuperGlue(cfg)
+    model.load_state_dict(sd)
+    model = model.to(gpu_device).eval()
+    dd = {k: (v.to(gpu_device) if torch.is_tensor(v) else v) for k, v in data.items()}
+    with torch.no_grad():
+        plain = model(dd)
+    assert not plain["scores"].requires_grad
+    out = model(dd)
+    assert out["scores"].requires_grad and torch.equal(out["scores"].detach(), plain["scores"])
+    with pytest.raises(RuntimeError, match="not differentiable"):
+        out["scores"].sum().backward()
+    for p in model.parameters():
+        p.requires_grad_(False)
+    assert not model(dd)["scores"].requires_grad          # nothing asks for a gradient: plain tensors
+
+
+@pytest.mark.parametrize("name", list(MODEL_CASES))
+def test_oracle_eval_mode_autograd_matches_the_reference(name):
+    """CPU: the oracle in eval mode under autograd vs the reference's eval-mode gradients (eval_grad.npz)."""
+    cfg, sd, data, gt0, gt1 = _model_case(name)
+    params = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in sd.items()}
+    data["local_descriptors0"].requires_grad_(True); data["local_descriptors1"].requires_grad_(True)
+    out = orc.superglue_forward(params, cfg, data)
+    assert np.abs(out["scores"].detach().numpy() - GE[f"{name}_scores"]).max() < 1e-4
+    loss = orc.nll_criterion(out["scores"], gt0, gt1)
+    loss.backward()
+    for key, got in (("desc0", data["local_descriptors0"].grad), ("desc1", data["local_descriptors1"].grad)):
+        want = GE[f"{name}_grad_{key}"]
+        assert np.abs(got.numpy() - want).max() < 1e-3 * np.abs(want).max() + 1e-7, key
+    checked = 0
+    for k, p in params.items():
+        if f"{name}_grad_{k}" in GE and p.requires_grad:
+            want = GE[f"{name}_grad_{k}"]
+            got = p.grad.numpy() if p.grad is not None else np.zeros_like(want)
+            assert np.abs(got - want).max() < 1e-3 * np.abs(want).max() + 1e-6, k
+            checked += 1
+    assert checked >= 40
