@@ -768,7 +768,7 @@ namespace {
 // RD = RaggedDesc (per-pair sizes by value in the kernarg segment) or RaggedNone (uniform batch: nothing; og_common.h)
 template <class RD>
 int sinkhorn_run(const float* S, int64_t lds, const float* zdev, float dustbin, int B, int m, int n, int iters, float reg,
-                 float* scores, void* workspace, hipStream_t st, const RD& rd, const RowBest* row_best) {
+                 float* scores, void* workspace, hipStream_t st, const RD& rd, const RowBest* row_best, bool trusted_padding) {
     if (!S || !scores || !workspace || B <= 0 || m <= 0 || n <= 0 || iters < 0 || !(reg > 0.f)) return OG_E_INVALID;
     if (n > 8192) return OG_E_SHAPE;
     if ((lds & 3) || ((uintptr_t)S & 15) || ((uintptr_t)workspace & 15)) return OG_E_ALIGN;
@@ -817,7 +817,7 @@ int sinkhorn_run(const float* S, int64_t lds, const float* zdev, float dustbin, 
                 e = hipMemsetAsync(status, 1, sizeof(unsigned), st);
                 if (e != hipSuccess) return (int)e;
             } else if (int rc = og_launch_sinkhorn_resident(S, lds, zdev, dustbin, B, m, n, iters - 1, inv_reg, la, la_bin, lb, lb_bin, w.u, w.ldu,
-                                                            w.v[cur], w.v[cur ^ 1], w.ldv, status, st))
+                                                            w.v[cur], w.v[cur ^ 1], w.ldv, status, st, trusted_padding))
                 return rc;
             cur ^= 1;
             // the safety net: a no-op while status == 0, else the whole solve again by one workgroup per pair (status -> 2)
@@ -889,12 +889,12 @@ int og_launch_sinkhorn_trajectory(const float* S, int64_t lds, float dustbin, in
 }
 
 int og_launch_sinkhorn(const float* S, int64_t lds, const float* zdev, float dustbin, int B, int m, int n, int iters, float reg,
-                       float* scores, void* workspace, hipStream_t st, const RaggedDesc* rag, const RowBest* row_best) {
+                       float* scores, void* workspace, hipStream_t st, const RaggedDesc* rag, const RowBest* row_best, bool trusted_padding) {
     if (rag) {
         if (rag->B != B) return OG_E_INVALID;
-        return sinkhorn_run<RaggedDesc>(S, lds, zdev, dustbin, B, m, n, iters, reg, scores, workspace, st, *rag, row_best);
+        return sinkhorn_run<RaggedDesc>(S, lds, zdev, dustbin, B, m, n, iters, reg, scores, workspace, st, *rag, row_best, trusted_padding);
     }
-    return sinkhorn_run<RaggedNone>(S, lds, zdev, dustbin, B, m, n, iters, reg, scores, workspace, st, RaggedNone{}, row_best);
+    return sinkhorn_run<RaggedNone>(S, lds, zdev, dustbin, B, m, n, iters, reg, scores, workspace, st, RaggedNone{}, row_best, trusted_padding);
 }
 
 extern "C" int og_sinkhorn_schedule(int32_t batch, int32_t m, int32_t n, int32_t iters) {
@@ -916,5 +916,6 @@ extern "C" int og_sinkhorn_status(const void* workspace_dev, int32_t batch, int3
 extern "C" int og_sinkhorn(const float* S, int64_t lds, float dustbin, int32_t batch, int32_t m, int32_t n,
                            int32_t iters, float reg, float* scores, void* workspace_dev, void* stream) {
     og_clear_status();
-    return og_launch_sinkhorn(S, lds, nullptr, dustbin, batch, m, n, iters, reg, scores, workspace_dev, (hipStream_t)stream, nullptr);
+    // the padding columns [n, lds) of a caller's S may hold anything (og_forward's own S buffer holds finite values there)
+    return og_launch_sinkhorn(S, lds, nullptr, dustbin, batch, m, n, iters, reg, scores, workspace_dev, (hipStream_t)stream, nullptr, nullptr, false);
 }

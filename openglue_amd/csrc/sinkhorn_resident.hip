@@ -110,6 +110,8 @@ struct SkResArgs {
     unsigned* status;                          // zeroed before the launch
     unsigned* xcc;                             // [B][8] XCC id + 1 of every workgroup, zeroed before the launch
     int force_agent_scope;                     // experiments / tests: never take the XCD-local path
+    int sanitize_pad;                          // n % 4 != 0 and the padding columns [n, lds) of S are the CALLER's (og_sinkhorn): they may
+                                               // hold NaN / Inf, which -inf duals do not neutralise -- zero them as the rows are loaded
     const float* zdev; float zhost;
     float inv_reg, la, la_bin, lb, lb_bin;     // natural units (see og_launch_sinkhorn)
     int m, n, mb, iters;                       // mb = rows per workgroup (<= 128), iters = dual-stabilised iterations to run (>= 1)
@@ -206,6 +208,13 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a) {
             unsigned o = ckb[k];
             asm volatile("" : "+v"(o));                    // re-launder per use: keeps the zero-extension next to the address add
             x[k] = *(const rs_gf32x4*)(rp + o);
+        }
+        if (a.sanitize_pad) {                              // wave-uniform; only the one chunk that straddles column N has anything to clear
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * lane + 256 * k + e >= N) x[k][e] = 0.f;
         }
     };
     auto load_row = [&](int row, f32x4 (&x)[4]) {          // -> s2 = S * c2 (waits for the data: resident rows only)
@@ -575,7 +584,7 @@ bool og_sinkhorn_resident_wanted(int B, int m, int n, int mode) {
 
 int og_launch_sinkhorn_resident(const float* S, int64_t lds, const float* zdev, float zhost, int B, int m, int n, int iters,
                                 float inv_reg, float la, float la_bin, float lb, float lb_bin, float* u, int ldu, const float* v_in,
-                                float* v_out, int ldv, void* xws, hipStream_t st) {
+                                float* v_out, int ldv, void* xws, hipStream_t st, bool trusted_padding) {
     if (!S || !u || !v_in || !v_out || !xws || iters < 1 || !og_sinkhorn_resident_shape_ok(B, m, n)) return OG_E_INVALID;
     const int G = rs_groups(m);
     const size_t bytes = og_sinkhorn_resident_ws_bytes(B, m, n);
@@ -589,6 +598,7 @@ int og_launch_sinkhorn_resident(const float* S, int64_t lds, const float* zdev, 
     { const char* e = getenv("OG_SINKHORN_AGENT_SCOPE"); a.force_agent_scope = e && atoi(e) != 0; }       // read per call: the tests switch it
     a.zdev = zdev; a.zhost = zhost; a.inv_reg = inv_reg; a.la = la; a.la_bin = la_bin; a.lb = lb; a.lb_bin = lb_bin;
     a.m = m; a.n = n; a.mb = (m + G - 1) / G; a.iters = iters;
+    a.sanitize_pad = (n & 3) && !trusted_padding;
     hipLaunchKernelGGL(sinkhorn_resident_kernel, dim3(B, G), dim3(512), 0, st, a);
     return og_launch_status();
 }

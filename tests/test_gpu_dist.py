@@ -61,6 +61,8 @@ def test_bench_with_the_collective_forced(gpu_device):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--batch", "8"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    line = json.loads(r.stdout.strip().splitlines()[-1])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads(lines[0])
     assert line["n_gpus"] == 1 and line["value"] > 0 and "roofline" in line
     print("forced-collective bench:", line["value"], line["unit"], line["ms_per_step"], "ms/step")

@@ -854,3 +854,24 @@ def test_forward_on_trained_like_checkpoint_fixture(gpu_device, tag, scale):
     assert np.abs(out["context_descriptors0"].numpy() - z[f"{tag}_context_descriptors0"]).max() < TOL_SCORES
     ndiff, unexplained, _ = _index_agreement(out["matches0"], out["scores"], sd, cfg, data)
     assert unexplained == 0, (ndiff, unexplained)
+
+
+def test_sinkhorn_resident_ignores_dirty_padding_columns(gpu_device, monkeypatch):
+    """og_sinkhorn on a caller's buffer whose padding columns [n, lds) hold NaN (n % 4 != 0): the resident schedule masks columns
+    >= n through -inf duals, which does not neutralise a NaN -- the straddling chunk is cleared as the rows are loaded."""
+    from openglue_amd import _lib
+    lib = _lib.load()
+    monkeypatch.setenv("OG_SINKHORN_RESIDENT", "2")
+    B, m, n, iters = 2, 260, 1023, 12
+    g = torch.Generator().manual_seed(5)
+    S = _rand(g, B, m, n, scale=2.0)
+    Sp = torch.full((B, m, 1024), float("nan"))
+    Sp[:, :, :n] = S
+    Sp = Sp.to(gpu_device)
+    ws = torch.empty(lib.og_sinkhorn_workspace_bytes(B, m, n), device=gpu_device, dtype=torch.uint8)
+    out = torch.empty(B, m + 1, n + 1, device=gpu_device)
+    assert lib.og_sinkhorn_schedule(B, m, n, iters) == 1
+    _lib.check(lib.og_sinkhorn(Sp.data_ptr(), 1024, 0.7, B, m, n, iters, 1.0, out.data_ptr(), ws.data_ptr(), torch.cuda.current_stream().cuda_stream), "og_sinkhorn")
+    assert lib.og_sinkhorn_status(ws.data_ptr(), B, m, n) == 0
+    assert torch.isfinite(out).all()
+    assert (out.cpu().double() - _sinkhorn_ref(S, 0.7, iters, 1.0)).abs().max() < 1e-4
