@@ -121,6 +121,45 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpFusedArgs g) {
     // carried ~10 SALU + a VGPR copy + its own M0 write; LDS-DMA issue is not hidden by the other wave of the SIMD: the kernel's
     // time was matrix-pipe time + ~90 cycles x pieces per SIMD (profiles/r03_c_*).]
     const char* const baseW = g.wstream + wave * 4 * 1024;
+#ifndef OG_MLP_BUF
+#define OG_MLP_BUF 0      // experiments: 1 = the LDS-DMA pieces as buffer_load ... lds (MUBUF) instead of global_load_lds
+#endif
+#if OG_MLP_BUF
+    typedef unsigned og_sgpr4 __attribute__((ext_vector_type(4)));
+    auto make_res = [&](const char* base, unsigned bytes) {
+        const uint64_t v = (uint64_t)(uintptr_t)base;
+        og_sgpr4 r;
+        r[0] = __builtin_amdgcn_readfirstlane((uint32_t)v);
+        r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32) & 0xFFFFu);       // stride 0
+        r[2] = __builtin_amdgcn_readfirstlane(bytes);
+        r[3] = 0x00020000u;
+        return r;
+    };
+    const og_sgpr4 resW = make_res(g.wstream, (unsigned)(STAGES * WSTAGE));
+    const og_sgpr4 resX = make_res(baseX, 0x7FFFFFFFu);
+    auto issue_w4 = [&](int s, int slot) {
+        const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(s * WSTAGE + wave * 4096));
+        const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + slot * WSTAGE + wave * 4096);
+        asm volatile("s_mov_b32 m0, %3\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_dwordx4 %0, %1, %2 offen lds\n\t"
+                     "buffer_load_dwordx4 %0, %1, %2 offen offset:1024 lds\n\t"
+                     "buffer_load_dwordx4 %0, %1, %2 offen offset:2048 lds\n\t"
+                     "buffer_load_dwordx4 %0, %1, %2 offen offset:3072 lds"
+                     :: "v"(lane16), "s"(resW), "s"(so), "s"(m0v) : "memory");
+    };
+    auto issue_x2 = [&](int xs, int slot) {
+        const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)((xs % G0) * 128));
+        const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + XOFF + slot * XSTAGE + wave * 2048);
+        asm volatile("s_mov_b32 m0, %4\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_dwordx4 %0, %2, %3 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_dwordx4 %1, %2, %3 offen lds"
+                     :: "v"(xoff[0]), "v"(xoff[1]), "s"(resX), "s"(so), "s"(m0v) : "memory");
+    };
+#else
     auto issue_w4 = [&](int s, int slot) {               // the 4 pieces of this wave of weight stage s into ring slot `slot`
         const char* src = scalar_ptr(baseW + (int64_t)s * WSTAGE);
         const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + slot * WSTAGE + wave * 4096);
@@ -143,6 +182,8 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpFusedArgs g) {
                      "global_load_lds_dwordx4 %1, %2"
                      :: "v"(xoff[0]), "v"(xoff[1]), "s"(src), "s"(m0v) : "memory");
     };
+
+#endif
 
     // ---- prologue: the bias loads first (inline asm: the compiler must not drain the DMA pieces issued behind them), then W(0), X(0),
     //      W(1), X(1); the biases * 256 go to LDS in their shadow ----

@@ -1,52 +1,35 @@
 #!/bin/bash
-# Round-2, second session: all GPU tests, bench line, A/B of the compile-time GEMM epilogues, GEMM microbench, other configs, kernel trace.
-# usage: gpu_round3.sh [tests|notests] [configs|noconfigs]
+# round-3 reference measurement: smoke, the whole GPU suite, the bench line (with the CPU baseline), C1/C3/C4/C5 lines, the fused-MLP
+# microbench, rocprofv3 kernel stats of the bench command, optionally ("pmc") the SQ counter and traffic passes.
+# usage: OG_COMMIT=<hash> gpu_round3.sh <tag> [pmc]
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 OUT=gpurun_out
+TAG="${1:-r03x}"
 mkdir -p $OUT
-{ nproc; lscpu | grep -E "Model name|Socket|Thread|Core"; free -g | head -2; } > $OUT/host.txt 2>&1
-if [ "${1:-tests}" = "tests" ]; then
-  echo "== pytest"
-  timeout 1500 python -m pytest tests -m gpu -q -rA --timeout 600 -p no:cacheprovider --durations=12 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
-  grep -E "passed|failed|error|FAILED|ERROR|^\[|rc=|s call" $OUT/pytest_gpu.log | tail -70
+timeout 300 python __graft_entry__.py smoke > $OUT/${TAG}_smoke.log 2>&1; tail -2 $OUT/${TAG}_smoke.log
+timeout 2400 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider > $OUT/${TAG}_pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/${TAG}_pytest_gpu.log
+tail -4 $OUT/${TAG}_pytest_gpu.log
+timeout 900 python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/${TAG}_bench.json
+python - <<PY
+import json
+d = json.loads(open("gpurun_out/${TAG}_bench.json").read()); print("BENCH", d["value"], d["ms_per_step"], d["stages_ms"], "cpu", d["cpu_baseline"]["value"])
+PY
+: > $OUT/${TAG}_bench_configs.jsonl
+for c in C1 C3 C4 C5; do timeout 600 python bench.py --config $c --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 >> $OUT/${TAG}_bench_configs.jsonl; done
+python - <<PY
+import json
+for l in open("gpurun_out/${TAG}_bench_configs.jsonl"):
+    d = json.loads(l); print(d["metric"], d["value"], d["ms_per_step"], d["stages_ms"])
+PY
+timeout 300 python scripts/bench_mlp_fused.py > $OUT/${TAG}_mlp_micro.log 2>&1; grep "M=" $OUT/${TAG}_mlp_micro.log
+timeout 300 python scripts/bench_gemm.py > $OUT/${TAG}_gemm_micro.log 2>&1; tail -9 $OUT/${TAG}_gemm_micro.log
+( cd /tmp && rm -rf /tmp/prof_$TAG && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o run -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > /tmp/prof_$TAG.log 2>&1 )
+f=$(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1)
+if [ -n "$f" ]; then cp $f $OUT/${TAG}_kernel_stats.csv; head -16 $OUT/${TAG}_kernel_stats.csv | cut -c1-160; else tail -5 /tmp/prof_$TAG.log; find /tmp/prof_$TAG | head; fi
+if [ "${2:-}" = "pmc" ]; then
+  bash scripts/gpu_pmc.sh > $OUT/${TAG}_pmc.log 2>&1; tail -3 $OUT/${TAG}_pmc.log
+  bash scripts/gpu_traffic.sh > $OUT/${TAG}_traffic.log 2>&1
+  python scripts/parse_traffic.py gpurun_out/traffic gpurun_out/traffic_c2.json > /dev/null 2>&1; ls -la gpurun_out/traffic_c2.json gpurun_out/pmc_summary.json
 fi
-echo "== bench"
-timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench.log 2>&1; echo "bench rc=$?" >> $OUT/bench.log
-tail -2 $OUT/bench.log | cut -c1-600
-python - <<'PY'
-import json
-for f in ("gpurun_out/bench.log",):
-    for l in open(f):
-        if l.startswith("{"):
-            d = json.loads(l); print("BENCH", d["value"], d["ms_per_step"], d["stages_ms"], "frac", d["roofline"]["frac"])
-PY
-echo "== bench with the run-time epilogues (OG_GEMM_SPEC_EPI=0)"
-OG_GEMM_SPEC_EPI=0 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_spec0.json
-python - <<'PY'
-import json
-d = json.loads(open("gpurun_out/bench_spec0.json").read()); print("SPEC0", d["value"], d["ms_per_step"], d["stages_ms"])
-PY
-echo "== gemm microbench (spec epilogues, then run-time epilogues)"
-timeout 300 python scripts/bench_gemm.py > $OUT/gemm_micro.log 2>&1; tail -9 $OUT/gemm_micro.log
-OG_GEMM_SPEC_EPI=0 timeout 300 python scripts/bench_gemm.py > $OUT/gemm_micro_spec0.log 2>&1; tail -9 $OUT/gemm_micro_spec0.log
-if [ "${2:-configs}" = "configs" ]; then
-  echo "== configs"
-  rm -f $OUT/bench_configs.jsonl
-  for c in C1 C3 C4 C5; do timeout 600 python bench.py --config $c --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 >> $OUT/bench_configs.jsonl; done
-  python - <<'PY'
-import json
-for l in open("gpurun_out/bench_configs.jsonl"):
-    try:
-        d = json.loads(l); print(d["metric"], d["value"], d["ms_per_step"], d["stages_ms"])
-    except Exception as e:
-        print("bad line", e, l[:200])
-PY
-fi
-echo "== rocprof"
-rm -rf $OUT/prof; mkdir -p $OUT/prof
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/rocprof.log 2>&1; echo "rocprof rc=$?" >> $OUT/rocprof.log
-for f in $(find $OUT/prof -name "*kernel_stats.csv"); do cp $f $OUT/kernel_stats.csv; done
-find $OUT/prof -name "*kernel_trace.csv" -size +20M -delete
-head -20 $OUT/kernel_stats.csv | cut -c1-200
