@@ -20,6 +20,7 @@ not tuned (exact-fp32 MFMA, O(N^2) attention memory); not in training mode: Sire
 from __future__ import annotations
 
 import torch
+from typing import Optional
 
 from . import _lib
 
@@ -132,24 +133,78 @@ def _ws(x: torch.Tensor, rows: int, C: int) -> torch.Tensor:
     return torch.empty(max(n, 256), device=x.device, dtype=torch.uint8)
 
 
-def _transpose_pad(x: torch.Tensor) -> torch.Tensor:
-    """[R, C] -> [C, round_up(R, 4)] (zero tail): both operands of the weight-gradient GEMM must be K-contiguous, K = R."""
+def _transpose_pad(x: torch.Tensor, mult: int = 4) -> torch.Tensor:
+    """[R, C] -> [C, round_up(R, mult)] (zero tail): both operands of the weight-gradient GEMM must be K-contiguous, K = R
+    (mult = 32: the contraction length the split-f16 kernel needs)."""
     lib = _lib.load()
     R, C = x.shape
-    R4 = (R + 3) // 4 * 4
+    R4 = (R + mult - 1) // mult * mult
     out = torch.zeros(C, R4, device=x.device, dtype=torch.float32) if R4 != R else torch.empty(C, R, device=x.device, dtype=torch.float32)
     with torch.cuda.device(x.device):
         _lib.check(lib.og_transpose_f32(x.data_ptr(), x.stride(0), R, C, out.data_ptr(), R4, _stream(x)), "og_transpose_f32")
     return out
 
 
+# The 1x1 convs of the training step run on the split-f16 3-pass MFMA GEMM of the inference path (fp32-class accuracy at ~3x the rate
+# of the exact-fp32 MFMA kernel: DESIGN.md 4.1) whenever the contraction length is a multiple of 32; OG_TRAIN_F16X3=0 keeps everything on
+# the exact-fp32 kernel.  Gradients can be far below the binary16 range (an NLL averaged over thousands of keypoints: 1e-7 ... 1e-3), so
+# a gradient operand is multiplied by a power of two that brings its largest entry to ~2^11 before the (hi, lo) split and the product is
+# scaled back -- exact, and computed ON THE DEVICE (no host synchronisation).
+def _use_f16x3() -> bool:
+    import os
+    return os.environ.get("OG_TRAIN_F16X3", "0") != "0"
+
+
+def _pow2_to(t: torch.Tensor, target: float) -> torch.Tensor:
+    """0-d device tensor 2^k with amax(t) * 2^k in (target / 2, target]."""
+    amax = t.abs().amax().clamp_min(1e-30)
+    return torch.exp2(torch.floor(torch.log2(target / amax)))
+
+
+def _gemm_fast(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False, scale_a: bool = False) -> torch.Tensor:
+    """epilogue(a @ b^T), a [M, K], b [N, K] fp32: split-f16 kernel when K % 32 == 0 and N % 4 == 0, else the exact-fp32 kernel.
+    scale_a: `a` is a gradient (see above).  b (weights / activations, additionally x256 inside the kernel wrapper) is scaled DOWN only
+    when its largest entry would leave binary16."""
+    from . import ops
+    M, K = a.shape
+    N = b.shape[0]
+    if not (_use_f16x3() and K % 32 == 0 and N % 4 == 0 and K >= 32):
+        return ops.gemm_nt(a, b, bias, relu=relu)
+    sb = torch.clamp(_pow2_to(b, 64.0), max=1.0)                  # 256 * 64 = 2^14
+    sa = _pow2_to(a, 2048.0) if scale_a else torch.clamp(_pow2_to(a, 16384.0), max=1.0)
+    s = sa * sb
+    out = ops.gemm_nt_f16x3((a * sa).contiguous(), (b * sb).contiguous(), None if bias is None else (bias * s).contiguous(), relu=relu)
+    return out * (1.0 / s)
+
+
+def _gemm_splitk(dz: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """dW = dz^T x for dz [T, Cout], x [T, Cin]: a [Cout, Cin] result (at most a few 128 x 128 tiles) contracted over ALL T tokens.
+    As one GEMM launch that is a grid of <= 16 workgroups on a 256-CU chip (round 2: 250-310 us per launch, 72 % of the training step);
+    here the token axis is cut into `parts` chunks that run as the problems of ONE batched launch (og_gemm_nt: operand z = columns
+    [z Kc, (z+1) Kc) of the K-contiguous transposes) and the partial products are summed."""
+    T, Cout = dz.shape
+    Cin = x.shape[1]
+    tiles = ((Cout + 127) // 128) * ((Cin + 127) // 128)
+    parts = max(1, min(T // 256, (512 + tiles - 1) // tiles))
+    mult = 4 * parts
+    dzt, xt = _transpose_pad(dz, mult), _transpose_pad(x, mult)                 # [Cout, Kp], [Cin, Kp], zero tails
+    Kp = dzt.shape[1]
+    Kc = Kp // parts
+    Cin4 = (Cin + 3) // 4 * 4
+    if Cin4 != Cin:                                                              # the first encoder conv (2 + side_info inputs)
+        xt = torch.nn.functional.pad(xt, (0, 0, 0, Cin4 - Cin))
+    part = torch.empty(parts, Cout, Cin4, device=dz.device, dtype=torch.float32)
+    _gemm_raw(dz.device, dzt.data_ptr(), Kp, Kc, xt.data_ptr(), Kp, Kc, part.data_ptr(), Cin4, Cout * Cin4, Cout, Cin4, Kc, parts)
+    out = part.sum(0) if parts > 1 else part[0]
+    return out[:, :Cin].contiguous() if Cin4 != Cin else out
+
+
 def _conv_backward(x: torch.Tensor, W: torch.Tensor, dz: torch.Tensor, need_dx: bool):
     """1x1 conv on token rows, z = x W^T + b:  dx = dz W,  dW = dz^T x,  db = column sums of dz -- all on HIP kernels."""
-    from . import ops
     lib = _lib.load()
     T, Cout = dz.shape
-    dx = ops.gemm_nt(dz, _transpose_pad(W)) if need_dx else None              # [T, Cout] x [Cin, Cout]^T
-    dW = ops.gemm_nt(_transpose_pad(dz), _transpose_pad(x))                   # [Cout, T] x [Cin, T]^T
+    dx = _gemm_fast(dz, _transpose_pad(W, 32), scale_a=True) if need_dx else None                # [T, Cout] x [Cin, Cout]^T
+    dW = _gemm_splitk(dz, x)                                                                     # [Cout, T] x [Cin, T]^T
     db = torch.empty(Cout, device=dz.device, dtype=torch.float32)
     ws = _ws(dz, T, Cout)
     with torch.cuda.device(dz.device):
@@ -164,7 +219,7 @@ class Conv1x1(torch.autograd.Function):
     def forward(ctx, x, W, b):
         from . import ops
         ctx.save_for_backward(x, W)
-        return ops.gemm_nt(x.detach(), W.detach().contiguous(), b.detach())
+        return _gemm_fast(x.detach(), W.detach().contiguous(), b.detach())
 
     @staticmethod
     def backward(ctx, dy):
@@ -180,7 +235,7 @@ class ConvReluBNTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W, b, gamma, beta, running_mean, running_var, momentum, eps):
         from . import ops
-        a = ops.gemm_nt(x.detach(), W.detach().contiguous(), b.detach(), relu=True)
+        a = _gemm_fast(x.detach(), W.detach().contiguous(), b.detach(), relu=True)
         y, mean, invstd = batch_norm_train(a, gamma.detach(), beta.detach(), running_mean, running_var, momentum, eps, return_stats=True)
         ctx.save_for_backward(x, W, gamma, a, mean, invstd)
         return y
@@ -256,37 +311,61 @@ def _heads_last(x: torch.Tensor, B: int) -> torch.Tensor:
 
 class SoftmaxAttention(torch.autograd.Function):
     """out[b, i, h*d:(h+1)*d] = softmax_j(q_h[b, i] . k_h[b, j] / sqrt(d)) v_h[b, j]  on token-major q [B, Nq, D], k, v [B, Nk, D]
-    (heads = contiguous channel blocks, attention_gnn.py:24-26).  Every product is an exact-fp32 MFMA GEMM (og_gemm_nt, one
-    launch over the B*H (pair, head) problems), the softmax and its backward are HIP kernels; P is kept for the backward, as the
-    reference's autograd does."""
+    (heads = contiguous channel blocks, attention_gnn.py:24-26).
+    Forward: the flash kernel of the inference path (og_attention: split-f16, never materialises the attention matrix).  Backward: the
+    attention matrix of THIS layer is recomputed (scale * Q K^T on the exact-fp32 MFMA GEMM + og_softmax_rows) instead of being kept
+    from the forward -- the reference's autograd keeps B*H*Nq*Nk floats per layer alive (36 layers x 64 MB at 4 x 1024 keypoints);
+    here only q, k, v are saved.  OG_TRAIN_FLASH=0: round 2's materialising forward."""
 
     @staticmethod
     def forward(ctx, q, k, v, num_heads):
-        lib = _lib.load()
+        import os
+        from . import ops
         B, Nq, D = q.shape
-        Nk = k.shape[1]
-        H, d = num_heads, D // num_heads
-        qh, kh, vh = (_heads_first(t.detach().to(torch.float32), H) for t in (q, k, v))      # [B*H, N, d]
-        dev = q.device
-        st = torch.cuda.current_stream(dev).cuda_stream
+        d = D // num_heads
+        q32, k32, v32 = (t.detach().to(torch.float32).contiguous() for t in (q, k, v))
+        ctx.save_for_backward(q32, k32, v32)
+        ctx.heads = num_heads
+        if os.environ.get("OG_TRAIN_FLASH", "1") != "0" and d in (16, 32, 64):
+            return ops.attention(q32 * d ** -0.5, k32, v32, num_heads)
+        P, vh = SoftmaxAttention._probs(q32, k32, v32, num_heads)
+        return SoftmaxAttention._pv(P, vh, B)
+
+    @staticmethod
+    def _probs(q32, k32, v32, H):
+        """P = softmax(scale * Q K^T) [B*H, Nq, r4(Nk)] and the heads-first operands."""
+        lib = _lib.load()
+        B, Nq, D = q32.shape
+        Nk = k32.shape[1]
+        d = D // H
+        qh, kh, vh = (_heads_first(t, H) for t in (q32, k32, v32))                               # [B*H, N, d]
+        dev = q32.device
         Z, Nk4 = B * H, _r4(Nk)
         P = torch.empty(Z, Nq, Nk4, device=dev, dtype=torch.float32)
         _gemm_raw(dev, qh.data_ptr(), d, Nq * d, kh.data_ptr(), d, Nk * d, P.data_ptr(), Nk4, Nq * Nk4, Nq, Nk, d, Z, d ** -0.5)
         with torch.cuda.device(dev):
-            _lib.check(lib.og_softmax_rows(P.data_ptr(), Nk4, Z * Nq, Nk, st), "og_softmax_rows")
+            _lib.check(lib.og_softmax_rows(P.data_ptr(), Nk4, Z * Nq, Nk, torch.cuda.current_stream(dev).cuda_stream), "og_softmax_rows")
+        return P, (qh, kh, vh)
+
+    @staticmethod
+    def _pv(P, heads, B):
+        qh, kh, vh = heads
+        Z, Nq, Nk4 = P.shape
+        Nk, d = vh.shape[1], vh.shape[2]
+        dev = P.device
         vt = torch.zeros(Z, d, Nk4, device=dev, dtype=torch.float32) if Nk4 != Nk else torch.empty(Z, d, Nk4, device=dev, dtype=torch.float32)
         _transpose_raw(dev, vh.data_ptr(), d, Nk * d, Nk, d, vt.data_ptr(), Nk4, d * Nk4, Z)
         oh = torch.empty(Z, Nq, d, device=dev, dtype=torch.float32)
         _gemm_raw(dev, P.data_ptr(), Nk4, Nq * Nk4, vt.data_ptr(), Nk4, d * Nk4, oh.data_ptr(), d, Nq * d, Nq, d, Nk4, Z)
-        ctx.save_for_backward(qh, kh, vh, P)
-        ctx.dims = (B, H)
         return _heads_last(oh, B)
 
     @staticmethod
     def backward(ctx, dout):
         lib = _lib.load()
-        qh, kh, vh, P = ctx.saved_tensors
-        B, H = ctx.dims
+        q32, k32, v32 = ctx.saved_tensors
+        H = ctx.heads
+        B = q32.shape[0]
+        P, (qh, kh, vh) = SoftmaxAttention._probs(q32, k32, v32, H)
         Z, Nq, d = qh.shape
         Nk = kh.shape[1]
         dev = qh.device
@@ -304,11 +383,13 @@ class SoftmaxAttention(torch.autograd.Function):
         Pt, dot = tr(P, Nq, Nk, Nk4), tr(doh, Nq, d, d)
         dvh = torch.empty(Z, Nk, d, device=dev, dtype=torch.float32)
         _gemm_raw(dev, Pt.data_ptr(), Nq4, Nk * Nq4, dot.data_ptr(), Nq4, d * Nq4, dvh.data_ptr(), d, Nk * d, Nk, d, Nq4, Z)
+        del Pt
         # dP = dO V^T  ->  dS = scale * P o (dP - rowsum(dP o P))
         dS = torch.empty(Z, Nq, Nk4, device=dev, dtype=torch.float32)
         _gemm_raw(dev, doh.data_ptr(), d, Nq * d, vh.data_ptr(), d, Nk * d, dS.data_ptr(), Nk4, Nq * Nk4, Nq, Nk, d, Z)
         with torch.cuda.device(dev):
             _lib.check(lib.og_softmax_rows_backward(P.data_ptr(), dS.data_ptr(), Nk4, Z * Nq, Nk, d ** -0.5, st), "og_softmax_rows_backward")
+        del P
         # dQ = dS K
         kt = tr(kh, Nk, d, d)
         dqh = torch.empty(Z, Nq, d, device=dev, dtype=torch.float32)
