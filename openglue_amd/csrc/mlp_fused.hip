@@ -399,6 +399,24 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpFusedArgs g) {
 #undef OG_RD
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     OG_MT(3, 1);
+    // the residual rows of this wave's four output blocks (whole 128-byte lines, 8 rows per instruction) are requested NOW: their
+    // HBM / L2 round trip runs under the two block barriers and the LDS traffic of the exchange below
+    const int tok0 = t0 + tb * 32;
+    char* const rows = reinterpret_cast<char*>(g.XO);
+    int64_t rowb[4];                                          // byte offset of this lane's row per store / load instruction
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        int r = tok0 + it * 8 + (lane >> 3);
+        if (r > g.M - 1) r = g.M - 1;
+        rowb[it] = (int64_t)r * g.ld * 2 + (lane & 7) * 16 + 4 * ha * 128;
+    }
+    og_u32x4 rres[2][2][4];                                   // [pair][block of the pair][8-row group]
+#pragma unroll
+    for (int ip = 0; ip < 2; ++ip)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) rres[ip][i][it] = *reinterpret_cast<const og_u32x4*>(rows + rowb[it] + (2 * ip + i) * 128);
     __syncthreads();          // every wave is past its last fragment reads, no DMA in flight: the rings are free
 
     // ================= the two waves of a token block exchange half of their partial sums =================
@@ -434,32 +452,14 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpFusedArgs g) {
     // ================= epilogue: x <- acc / 256 + (x_hi + x_lo), written back as hl32 rows =================
     // A lane owns ONE token and 4 consecutive channels per register group.  Residual rows come in and result rows go out as whole
     // 128-byte lines (one channel block of one token: 64 B hi | 64 B lo), 8 rows per instruction, and change layout through two
-    // per-wave LDS slabs (as gemm_f16x3_epilogue_fast).  Channel blocks are handled in pairs; the next pair's residual is in flight
-    // while the current one is finished.
+    // per-wave LDS slabs (as gemm_f16x3_epilogue_fast).  Channel blocks are handled in pairs; their residual rows were requested before
+    // the exchange.
     {
 #pragma clang fp contract(off)
         constexpr int ROWB = 128 + 16;
         char* const slab2 = smem + (wave ^ 1) * 16384;
-        const int tok0 = t0 + tb * 32;
-        const int cb0 = 4 * ha;                               // first of this wave's four channel blocks
-        char* const rows = reinterpret_cast<char*>(g.XO);
         const unsigned rd_off = (unsigned)((lane >> 3) * ROWB + (lane & 7) * 16);
         const bool full = t0 + MT <= g.M;                    // block-uniform
-        int64_t rowb[4];                                      // byte offset of this lane's row per store / load instruction
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            int r = tok0 + it * 8 + (lane >> 3);
-            if (r > g.M - 1) r = g.M - 1;
-            rowb[it] = (int64_t)r * g.ld * 2 + (lane & 7) * 16 + cb0 * 128;
-        }
-        og_u32x4 rrow[2][4];
-        auto load_res = [&](int ip) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int it = 0; it < 4; ++it) rrow[i][it] = *reinterpret_cast<const og_u32x4*>(rows + rowb[it] + (2 * ip + i) * 128);
-        };
-        load_res(0);
 #pragma unroll
         for (int ip = 0; ip < 2; ++ip) {
             f32x16 a[2];
@@ -467,8 +467,7 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpFusedArgs g) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int it = 0; it < 4; ++it) *reinterpret_cast<og_u32x4*>(slab2 + i * EPI_SLAB + it * 8 * ROWB + rd_off) = rrow[i][it];
-            if (ip + 1 < 2) load_res(ip + 1);
+                for (int it = 0; it < 4; ++it) *reinterpret_cast<og_u32x4*>(slab2 + i * EPI_SLAB + it * 8 * ROWB + rd_off) = rres[ip][i][it];
             og_u32x4 raw[2][4];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
