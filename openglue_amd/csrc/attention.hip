@@ -486,6 +486,7 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(AttnArgs a, RD rd
     //      chunks): K chunk ^ ((r >> 2) & 3), V none (a [4 keys][32 dv] transposing pass already covers all banks) ----
     const int rl = lane / LPR, pc = lane % LPR;
     const int ldkb = (int)a.ldk * 2, ldvb = (int)a.ldv * 2;          // row strides in bytes
+    const unsigned lds0_dma = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     unsigned ksw[2], vsw;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -497,10 +498,48 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(AttnArgs a, RD rd
     // one tile = 8 DMA instructions per wave, issued in pairs (plane pair pp: 0 = K hi/lo, 1 = V hi/lo of piece i) so that
     // the main loop can spread them under its MFMA bursts: the vector-memory path takes 64 B/clk per CU, a burst of 8 per
     // wave right after the barrier stalls every wave of the workgroup for ~700 cycles (scripts/trace_attention.py)
+#ifndef OG_ATTN_ASMDMA
+#define OG_ATTN_ASMDMA 0      // 1 (experiment, round 3): scalar plane base + 32-bit lane offset in one asm block per (hi, lo) pair -- measured no gain (252 vs 249 us)
+#endif
+    // (scalar plane base + 32-bit lane offset) addressing, one asm block per (hi, lo) pair: the lane part is loop invariant except in
+    // the last tile (row clamp); as builtin calls every piece carried 64-bit per-lane address arithmetic on the vector ALU -- which
+    // shares its issue with the matrix pipe.
+    unsigned koffs[NPI], voffs[NPI];
+#pragma unroll
+    for (int i = 0; i < NPI; ++i) {
+        const int r = wave * 16 + i * RPI + rl;
+        koffs[i] = (unsigned)(r * ldkb) + ksw[i];
+        voffs[i] = (unsigned)(r * ldvb) + vsw;
+        asm volatile("" : "+v"(koffs[i]), "+v"(voffs[i]));
+    }
+    auto sptr = [](const char* p) {
+        const uint64_t v = (uint64_t)(uintptr_t)p;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi32 = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        return reinterpret_cast<const char*>((uintptr_t)(((uint64_t)hi32 << 32) | lo));
+    };
     auto issue_pair = [&](int kt, auto BUF, auto I, auto PP) {
         constexpr int b = decltype(BUF)::value, i = decltype(I)::value, pp = decltype(PP)::value;
         const int key0 = kt * KV_TILE;
         const int last = nk - 1 - key0;                  // rows past the last key are clamped (masked in the softmax)
+#if OG_ATTN_ASMDMA
+        unsigned off = pp == 0 ? koffs[i] : voffs[i];
+        if (last < KV_TILE - 1) {                        // block-uniform: only the last tile of a problem
+            int r = wave * 16 + i * RPI + rl;
+            r = r < last ? r : last;
+            off = pp == 0 ? (unsigned)(r * ldkb) + ksw[i] : (unsigned)(r * ldvb) + vsw;
+        }
+        const int64_t o = pp == 0 ? k_tile0 + (int64_t)key0 * ldkb : v_tile0 + (int64_t)key0 * ldvb;       // uniform
+        const char* bh = sptr(reinterpret_cast<const char*>(pp == 0 ? a.kh : a.vh) + o);
+        const char* bl = sptr(reinterpret_cast<const char*>(pp == 0 ? a.kl : a.vl) + o);
+        const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0_dma + b * BUFB + (wave * 16 + i * RPI) * ROWB + pp * 2 * PLANE);
+        asm volatile("s_mov_b32 m0, %3\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dwordx4 %0, %1\n\t"
+                     "s_add_u32 m0, m0, %4\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dwordx4 %0, %2"
+                     :: "v"(off), "s"(bh), "s"(bl), "s"(m0v), "n"(PLANE) : "memory");
+#else
         int r = wave * 16 + i * RPI + rl;
         r = r < last ? r : last;
         char* dst = smem + b * BUFB + (wave * 16 + i * RPI) * ROWB + pp * 2 * PLANE;
@@ -513,6 +552,7 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(AttnArgs a, RD rd
             __builtin_amdgcn_global_load_lds((og_glb_void*)(reinterpret_cast<const char*>(a.vh) + o), (og_lds_void*)(dst), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((og_glb_void*)(reinterpret_cast<const char*>(a.vl) + o), (og_lds_void*)(dst + PLANE), 16, 0, 0);
         }
+#endif
     };
     auto issue_tile = [&](int kt, auto BUF) {
         static_for<2 * NPI>([&](auto J) {
