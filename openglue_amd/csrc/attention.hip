@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(AttnArgs a, RD rd
     //      chunks): K chunk ^ ((r >> 2) & 3), V none (a [4 keys][32 dv] transposing pass already covers all banks) ----
     const int rl = lane / LPR, pc = lane % LPR;
     const int ldkb = (int)a.ldk * 2, ldvb = (int)a.ldv * 2;          // row strides in bytes
-    const unsigned lds0_dma = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    [[maybe_unused]] const unsigned lds0_dma = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     unsigned ksw[2], vsw;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(AttnArgs a, RD rd
         voffs[i] = (unsigned)(r * ldvb) + vsw;
         asm volatile("" : "+v"(koffs[i]), "+v"(voffs[i]));
     }
-    auto sptr = [](const char* p) {
+    [[maybe_unused]] auto sptr = [](const char* p) {
         const uint64_t v = (uint64_t)(uintptr_t)p;
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi32 = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
         return reinterpret_cast<const char*>((uintptr_t)(((uint64_t)hi32 << 32) | lo));
