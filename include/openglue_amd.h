@@ -285,6 +285,8 @@ int og_sinkhorn(const float* S, int64_t lds, float dustbin, int32_t batch, int32
  *       co-resident; the launcher checks that against the CU count, but another stream or process holding CUs can still break it)
  *       and the safety-net kernel enqueued behind it solved the problem again, one workgroup per pair: the scores are VALID, the
  *       call was slow (milliseconds);
+ *   3 = a NON-FINITE value was written to the scores: something upstream overflowed or was NaN -- an activation beyond the binary16
+ *       range of the split-f16 operands (|x| >= 65504), non-finite inputs.  The scores are invalid;
  *   1 = timed out and not recomputed (cannot happen with this build's launch sequence; scores invalid); -1 = bad arguments.
  * When the batch fits (batch * ceil(m/128) <= #CUs, n <= 1024, >= 16 MB of scores; OG_SINKHORN_RESIDENT=0 disables, =2 drops
  * the size threshold) iterations 2..iters run in ONE launch with the score matrices held in registers + LDS.

@@ -39,6 +39,7 @@ inline SinkhornGeom sk_geom(int n) {
 struct SinkhornWs {
     float* u;       // [B][ldu]
     float* v[2];    // [B][ldv] ping-pong
+    unsigned* flags; // [4] zeroed with u, v on every call: [0] != 0 = a non-finite value reached the scores (og_sinkhorn_status 3)
     float* pm;      // [B][RB][ldp] partial column max
     float* ps;      // [B][RB][ldp] partial column sum-exp
     int ldu, ldv, ldp, RB;
@@ -54,6 +55,7 @@ static SinkhornWs sk_layout(void* ws, int B, int m, int n) {
     w.u = p; p += (int64_t)B * w.ldu;
     w.v[0] = p; p += (int64_t)B * w.ldv;
     w.v[1] = p; p += (int64_t)B * w.ldv;
+    w.flags = (unsigned*)p; p += 4;
     w.pm = p; p += (int64_t)B * w.RB * w.ldp;
     w.ps = p;
     return w;
@@ -588,7 +590,8 @@ __global__ __launch_bounds__(256) void sinkhorn_scores_kernel(const float* __res
                                                               float inv_reg, float norm,
                                                               const float* __restrict__ u, int ldu,
                                                               const float* __restrict__ v, int ldv,
-                                                              float* __restrict__ scores, int64_t strideS, RD rd, RowBest rb) {
+                                                              float* __restrict__ scores, int64_t strideS, RD rd, RowBest rb,
+                                                              unsigned* __restrict__ nonfinite) {
     const int b = blockIdx.y;
     int64_t so = (int64_t)b * (M + 1) * (N + 1);
     if (rd.B > 0) {
@@ -605,6 +608,7 @@ __global__ __launch_bounds__(256) void sinkhorn_scores_kernel(const float* __res
     const float ui = u[(int64_t)b * ldu + row];
     const float* vb = v + (int64_t)b * ldv;
     float* out = scores + so + (int64_t)row * (N + 1);
+    float chk = 0.f;            // stays 0 while every value written is finite (inf * 0 = NaN): one FMA per element of a memory-bound kernel
     if (row < M) {
         const float* sp = S + (int64_t)row * lds;
         if (rb.idx) {        // + row max / argmax over j < N on the values just written ("first maximal index wins", matches.hip)
@@ -613,6 +617,7 @@ __global__ __launch_bounds__(256) void sinkhorn_scores_kernel(const float* __res
             for (int j = lane; j < N; j += 64) {
                 const float val = ((sp[j] * inv_reg + ui) + vb[j]) - norm;
                 out[j] = val;
+                chk = fmaf(val, 0.f, chk);
                 if (val > best || bi == 0x7FFFFFFF) { best = val; bi = j; }
             }
 #pragma unroll
@@ -623,12 +628,15 @@ __global__ __launch_bounds__(256) void sinkhorn_scores_kernel(const float* __res
             }
             if (lane == 0) { rb.idx[(int64_t)b * rb.stride + row] = bi; rb.val[(int64_t)b * rb.stride + row] = best; }
         } else {
-            for (int j = lane; j < N; j += 64) out[j] = ((sp[j] * inv_reg + ui) + vb[j]) - norm;
+            for (int j = lane; j < N; j += 64) { const float val = ((sp[j] * inv_reg + ui) + vb[j]) - norm; out[j] = val; chk = fmaf(val, 0.f, chk); }
         }
     } else {
-        for (int j = lane; j < N; j += 64) out[j] = ((zr + ui) + vb[j]) - norm;
+        for (int j = lane; j < N; j += 64) { const float val = ((zr + ui) + vb[j]) - norm; out[j] = val; chk = fmaf(val, 0.f, chk); }
     }
-    if (lane == 0) out[N] = ((zr + ui) + vb[N]) - norm;
+    if (lane == 0) { const float val = ((zr + ui) + vb[N]) - norm; out[N] = val; chk = fmaf(val, 0.f, chk); }
+    // a non-finite value anywhere upstream (an activation beyond the binary16 range of the (hi, lo) operands, NaN inputs or weights)
+    // ends up here: report it through the status word instead of handing back NaN scores silently
+    if (nonfinite && __any(chk != chk) && lane == 0) atomicOr(nonfinite, 1u);
 }
 
 template <int CPL, int RG, int WPR, class RD>
@@ -779,7 +787,7 @@ int sinkhorn_run(const float* S, int64_t lds, const float* zdev, float dustbin, 
     const float la_bin = (float)norm + (float)log((double)n);   // log_a[-1] += log(n) in fp32 (superglue.py:100)
     const float lb_bin = (float)norm + (float)log((double)m);
     // u = v = 0 (optimal_transport.py:22)
-    hipError_t e = hipMemsetAsync(w.u, 0, sizeof(float) * (size_t)B * (w.ldu + 2 * (size_t)w.ldv), st);
+    hipError_t e = hipMemsetAsync(w.u, 0, sizeof(float) * ((size_t)B * (w.ldu + 2 * (size_t)w.ldv) + 4), st);      // ... and the flags behind them
     if (e != hipSuccess) return (int)e;
     const SinkhornGeom g = sk_geom(n);
     int cur = 0;
@@ -850,7 +858,7 @@ int sinkhorn_run(const float* S, int64_t lds, const float* zdev, float dustbin, 
         cur ^= 1;
     }
     hipLaunchKernelGGL(sinkhorn_scores_kernel<RD>, dim3((m + 1 + 3) / 4, B), dim3(256), 0, st, S, lds, m, n, zdev, dustbin, inv_reg,
-                       (float)norm, w.u, w.ldu, w.v[cur], w.ldv, scores, (int64_t)m * lds, rd, row_best ? *row_best : RowBest{nullptr, nullptr, 0});
+                       (float)norm, w.u, w.ldu, w.v[cur], w.ldv, scores, (int64_t)m * lds, rd, row_best ? *row_best : RowBest{nullptr, nullptr, 0}, w.flags);
     return og_launch_status();
 }
 }  // namespace
@@ -884,7 +892,7 @@ int og_launch_sinkhorn_trajectory(const float* S, int64_t lds, float dustbin, in
     }
     hipLaunchKernelGGL(sinkhorn_scores_kernel<RaggedNone>, dim3((m + 1 + 3) / 4, B), dim3(256), 0, st, S, lds, m, n, (const float*)nullptr, dustbin,
                        inv_reg, (float)norm, U + (size_t)(iters - 1) * B * w.ldu, w.ldu, V + (size_t)iters * B * w.ldv, w.ldv, scores,
-                       (int64_t)m * lds, rd, RowBest{nullptr, nullptr, 0});
+                       (int64_t)m * lds, rd, RowBest{nullptr, nullptr, 0}, (unsigned*)nullptr);
     return og_launch_status();
 }
 
@@ -906,9 +914,13 @@ extern "C" int og_sinkhorn_schedule(int32_t batch, int32_t m, int32_t n, int32_t
 
 extern "C" int og_sinkhorn_status(const void* workspace_dev, int32_t batch, int32_t m, int32_t n) {
     if (!workspace_dev || batch <= 0 || m <= 0 || n <= 0 || n > 8192) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    unsigned bad = 0;
+    const SinkhornWs w = sk_layout(const_cast<void*>(workspace_dev), batch, m, n);
+    if (hipMemcpy(&bad, w.flags, sizeof(bad), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (bad) return 3;                                  // non-finite scores were written
     if (og_sinkhorn_resident_ws_bytes(batch, m, n) == 0) return 0;
     unsigned st = 0;
-    if (hipDeviceSynchronize() != hipSuccess) return -1;
     if (hipMemcpy(&st, sk_resident_ws(const_cast<void*>(workspace_dev), batch, m, n), sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return st == 0 ? 0 : st == 2 ? 2 : 1;
 }

@@ -224,6 +224,9 @@ class SuperGlue(nn.Module):
             import warnings
             warnings.warn("og_forward_status = 2: the resident Sinkhorn kernel timed out (CUs held by another stream / process?); "
                           "the fallback kernel recomputed the scores", RuntimeWarning)
+        elif rc == 3:
+            raise RuntimeError("og_forward_status = 3: non-finite scores -- an activation left the binary16 range of the split-f16 "
+                               "operands (|x| >= 65504) or the inputs / weights hold NaN or Inf")
         elif rc != 0:
             raise RuntimeError(f"og_forward_status = {rc}: the last call's Sinkhorn stage did not complete (scores invalid)")
         return rc

@@ -875,3 +875,22 @@ def test_sinkhorn_resident_ignores_dirty_padding_columns(gpu_device, monkeypatch
     assert lib.og_sinkhorn_status(ws.data_ptr(), B, m, n) == 0
     assert torch.isfinite(out).all()
     assert (out.cpu().double() - _sinkhorn_ref(S, 0.7, iters, 1.0)).abs().max() < 1e-4
+
+
+def test_activation_overflow_is_reported_not_silent(gpu_device):
+    """Activations beyond the binary16 range of the (hi, lo) operands (|x| >= 65504) turn into inf inside the GNN; the non-finite
+    values reach the scores and og_forward_status / model.check_status() report it (status 3) instead of NaN scores going unnoticed."""
+    cfg = syn.make_config(descriptor_dim=64, num_stages=1, num_heads=4, num_iters=5, side_info_size=1)
+    sd = syn.make_state_dict(cfg, seed=0)
+    model = _build(cfg, sd, gpu_device)
+    data = to_device(syn.make_batch(2, 80, 70, 64, 1, seed=3), gpu_device)
+    model.match(data, MATCH_THRESHOLD)
+    assert model.check_status() == 0
+    big = dict(data)
+    big["local_descriptors0"] = data["local_descriptors0"] * 1e5          # ~3e6: far outside binary16
+    out = model.match(big, MATCH_THRESHOLD)
+    assert not torch.isfinite(out["scores"]).all()
+    with pytest.raises(RuntimeError, match="non-finite"):
+        model.check_status()
+    model.match(data, MATCH_THRESHOLD)                                     # the flag describes the LAST call only
+    assert model.check_status() == 0
