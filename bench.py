@@ -42,6 +42,7 @@ SUSTAINED_F16_MFMA_TFLOPS = 1670.0
 # line carries its source file and the commit it was collected on.
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
 TRAFFIC_SUMMARY = os.path.join(ROOT, "profiles", "r03_traffic_c2.json")
+TRAFFIC_BY_CONFIG = {"C3": os.path.join(ROOT, "profiles", "r03_traffic_c3.json"), "C4": os.path.join(ROOT, "profiles", "r03_traffic_c4.json")}
 
 
 def algorithmic_counts(cfg_kw, m, n):
@@ -80,14 +81,15 @@ def _load_json(path):
         return {}
 
 
-def roofline_block(counts_per_step, stages, launches, num_iters, measured_on_this_workload, sinkhorn_resident):
+def roofline_block(counts_per_step, stages, launches, num_iters, measured_on_this_workload, sinkhorn_resident, traffic_path=None):
     """Per-kernel-class roofline objects.  achieved = algorithmic work per step / class time (HIP events on the launch
     stream, median of 3 profiled steps) = algorithmic work per launch / average launch duration.
     sinkhorn_resident: the schedule the library took for this shape (og_sinkhorn_schedule), not a guess from bracket counts."""
     pmc = _load_json(PMC_SUMMARY) if measured_on_this_workload else {}
-    tj = _load_json(TRAFFIC_SUMMARY) if measured_on_this_workload else {}
+    tpath = TRAFFIC_SUMMARY if measured_on_this_workload else traffic_path      # counter summaries exist for C2 (PMC + traffic) and C3 / C4 (traffic)
+    tj = _load_json(tpath) if tpath else {}
     src_pmc = {"source": os.path.relpath(PMC_SUMMARY, ROOT), "collected_at_commit": pmc.get("_commit"), "measured_in_this_run": False}
-    src_tr = {"source": os.path.relpath(TRAFFIC_SUMMARY, ROOT), "collected_at_commit": tj.get("_commit"), "measured_in_this_run": False}
+    src_tr = {"source": os.path.relpath(tpath, ROOT) if tpath else None, "collected_at_commit": tj.get("_commit"), "measured_in_this_run": False}
     # the split-f16 GEMM class = the stand-alone GEMM launches + the fused message-MLP launches (same arithmetic, same pipe)
     gemm_ms = stages["gemm_f16x3"] + stages.get("mlp_fused", 0.0)
     gemm_launches = launches["gemm_f16x3"] + launches.get("mlp_fused", 0)
@@ -477,7 +479,9 @@ def main():
             return _stage_dict(ms, cnt)
         stages, launches = _median_stages(run_profiled)
         resident = bool(_lib.load().og_sinkhorn_schedule(B, m, n, kw["num_iters"]))
-        roof, roof2 = roofline_block(counts, stages, launches, kw["num_iters"], args.config == "C2" and B == 32, resident)
+        std_batch = B == syn.CONFIGS[args.config]["batch"]
+        roof, roof2 = roofline_block(counts, stages, launches, kw["num_iters"], args.config == "C2" and std_batch, resident,
+                                     TRAFFIC_BY_CONFIG.get(args.config) if std_batch else None)
         line = {
             "metric": "image-pairs/sec (1024 kpts, 256-dim, 9 GNN layers)" if args.config == "C2" else f"image-pairs/sec ({args.config})",
             "value": round(value, 2), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
