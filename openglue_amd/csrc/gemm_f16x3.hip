@@ -483,13 +483,18 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void gemm_nt_f16x3_kernel(G
     constexpr int PPW = 4 + WPC;               // DMA instructions per wave per stage
     __shared__ __attribute__((aligned(16))) char smem[NS * STAGE > 4 * EPI_SLAB ? NS * STAGE : 4 * EPI_SLAB];
 
+    // Workgroups are dealt to the 8 XCDs round-robin by linear id.  Token tiles are numbered over ALL problems of a batched launch
+    // (virtual tile vt = z * tiles_m + tm) and tile vt runs on XCD vt % 8 with all its channel tiles.  [Round 2 numbered them per
+    // problem (grid.y = problem): with 4 token tiles per problem -- the score matrices of 1024-keypoint pairs -- XCDs 4-7 only ever
+    // received the padding blocks that exit at once, and the batched score GEMM ran on half the chip: 130 us at C2.]
     const int id = blockIdx.x;
     const int xcd = id & 7, local = id >> 3;
-    const int tm = (local / tiles_n) * 8 + xcd;       // all channel tiles of a token tile on one XCD
+    const int nzk = (rd.B > 0 && !g.ct_rag) ? rd.B : (g.batch > 1 ? g.batch : 1);
+    const int vt = (local / tiles_n) * 8 + xcd;
     const int tn = local % tiles_n;
-    if (tm >= tiles_m) return;
-    if (g.batch > 1 || (rd.B > 0 && !g.ct_rag)) {   // batched problems (the per-pair score matrices): z = blockIdx.y
-        const int z = blockIdx.y;
+    if (vt >= tiles_m * nzk) return;
+    const int z = vt / tiles_m, tm = vt - z * tiles_m;
+    if (g.batch > 1 || (rd.B > 0 && !g.ct_rag)) {   // batched problems (the per-pair score matrices)
         if (rd.B > 0 && !g.ct_rag) {           // ragged: problem z = pair z, operands are row ranges of the packed token matrix
             g.M = rd.off0[z + 1] - rd.off0[z];
             g.N = rd.off1[z + 1] - rd.off1[z];
@@ -639,13 +644,18 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_big_kernel(GemmHArgs g, int
     __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
     static_assert(NS * STAGE >= 8 * EPI_SLAB, "epilogue slabs must fit in the ring");
 
+    // Workgroups are dealt to the 8 XCDs round-robin by linear id.  Token tiles are numbered over ALL problems of a batched launch
+    // (virtual tile vt = z * tiles_m + tm) and tile vt runs on XCD vt % 8 with all its channel tiles.  [Round 2 numbered them per
+    // problem (grid.y = problem): with 4 token tiles per problem -- the score matrices of 1024-keypoint pairs -- XCDs 4-7 only ever
+    // received the padding blocks that exit at once, and the batched score GEMM ran on half the chip: 130 us at C2.]
     const int id = blockIdx.x;
     const int xcd = id & 7, local = id >> 3;
-    const int tm = (local / tiles_n) * 8 + xcd;       // all channel tiles of a token tile on one XCD
+    const int nzk = (rd.B > 0 && !g.ct_rag) ? rd.B : (g.batch > 1 ? g.batch : 1);
+    const int vt = (local / tiles_n) * 8 + xcd;
     const int tn = local % tiles_n;
-    if (tm >= tiles_m) return;
-    if (g.batch > 1 || (rd.B > 0 && !g.ct_rag)) {   // batched problems (the per-pair score matrices): z = blockIdx.y
-        const int z = blockIdx.y;
+    if (vt >= tiles_m * nzk) return;
+    const int z = vt / tiles_m, tm = vt - z * tiles_m;
+    if (g.batch > 1 || (rd.B > 0 && !g.ct_rag)) {   // batched problems (the per-pair score matrices)
         if (rd.B > 0 && !g.ct_rag) {           // ragged: problem z = pair z, operands are row ranges of the packed token matrix
             g.M = rd.off0[z + 1] - rd.off0[z];
             g.N = rd.off1[z + 1] - rd.off1[z];
@@ -1190,7 +1200,7 @@ int og_launch_gemm_f16x3(const GemmHArgs& a, hipStream_t stream) {
 #undef OG_BIG2
                     return og_launch_status();
                 }
-                hipLaunchKernelGGL(gemm_nt_f16x3_big_kernel<RD>, dim3(tiles_m8 * tiles_n, nz), dim3(512), 0, stream, g, tiles_m, tiles_n, rd);
+                hipLaunchKernelGGL(gemm_nt_f16x3_big_kernel<RD>, dim3((tiles_m * nz + 7) / 8 * 8 * tiles_n), dim3(512), 0, stream, g, tiles_m, tiles_n, rd);
                 return og_launch_status();
             }
         }
@@ -1211,9 +1221,9 @@ int og_launch_gemm_f16x3(const GemmHArgs& a, hipStream_t stream) {
 #undef OG_T128
                 }
             }
-            hipLaunchKernelGGL((gemm_nt_f16x3_kernel<128, 2, RD>), dim3(tiles_m8 * tiles_n, nz), dim3(256), 0, stream, g, tiles_m, tiles_n, rd);
+            hipLaunchKernelGGL((gemm_nt_f16x3_kernel<128, 2, RD>), dim3((tiles_m * nz + 7) / 8 * 8 * tiles_n), dim3(256), 0, stream, g, tiles_m, tiles_n, rd);
         } else {
-            hipLaunchKernelGGL((gemm_nt_f16x3_kernel<64, 2, RD>), dim3(tiles_m8, nz), dim3(256), 0, stream, g, tiles_m, 1, rd);
+            hipLaunchKernelGGL((gemm_nt_f16x3_kernel<64, 2, RD>), dim3((tiles_m * nz + 7) / 8 * 8), dim3(256), 0, stream, g, tiles_m, 1, rd);
         }
         return og_launch_status();
     };
