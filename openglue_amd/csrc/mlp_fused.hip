@@ -29,6 +29,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <cmath>
+#include <type_traits>
 
 #include "og_common.h"
 
@@ -324,6 +325,29 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpFusedArgs g) {
         OG_MM(A1, wh[1], BH); OG_SB(); if (NEXT_EXISTS) OG_RD(0, 3); OG_SB();                                 \
     }
 
+    // ---- the residual enters through the matrix pipe: x_new = x + W3' h  =>  acc3[i] += (S3 I) · x[channel block i], and the (hi, lo)
+    //      B fragments of x are exactly the token fragments the fc.0 stages of k-groups 0..7 (the x half of [x ; O]) hold in registers
+    //      anyway.  In the LAST quarter's stages kg = 0..7 every wave adds HALF of the residual of output block kg to its own partial
+    //      sum (the partial sums of the two waves of a token block are added in the exchange anyway): wave (tb, a) the channels of
+    //      k-step t = a, 2 MFMAs with a constant "S3 x identity" A fragment (k-step t covers channels 16t .. 16t+15 of the block) --
+    //      the same extra work for all eight waves, so nobody arrives late at the stage barrier.  [Round 3, first version: residual rows fetched in the epilogue, turned into the accumulator layout through the LDS
+    //      slabs and added with mixed-precision FMAs -- 8 global loads, 48 LDS operations and 32 VALU per wave of an epilogue that is
+    //      bound by its LDS operations.]
+    const _Float16 s3h = (_Float16)(1.f / sc3);               // power of two >= 2^-14 (og_weight_prescale): exact in binary16
+    auto ident = [&](int t) {                                 // built where it is used (4 stages per tile): no registers held across the loop
+        int row = l31 - 8 * hi;
+        asm volatile("" : "+v"(row));                         // opaque: re-computed at every use, not hoisted out of the loop and spilled
+        f16x8 f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = (row == 16 * t + e) ? s3h : (_Float16)0.f;
+        return f;
+    };
+// RB_ >= 0 (compile time): this stage is k-group RB_ of the last quarter -- the wave that finishes output block RB_ adds its residual
+#define OG_RESID(RB_, T_, XF_)                                                                               \
+    if constexpr ((RB_) >= 0) {                                                                              \
+        if (ha == (T_)) { const f16x8 idt_ = ident(T_); OG_MM(acc3[(RB_) < 0 ? 0 : (RB_)], idt_, XF_); OG_SB(); }   \
+    }
+
     set_w(0); set_x(0);
     read_x(0);
     OG_RD(0, 0); OG_RD(0, 1); OG_RD(0, 2); OG_RD(0, 3);
@@ -334,8 +358,8 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpFusedArgs g) {
         init_acc2(acc0[2], acc0[3], (8 * ha + 4 * pass + 2) * 32);
 
         // ================= fc.0: acc0[i] += W0'[hidden block 8 ha + 4 pass + i][k-group] · [x ; O][k-group], 16 stages =================
-#pragma unroll 1
-        for (int kg = 0; kg < G0; ++kg) {
+        auto fc0_stage = [&](int kg, auto RB) {
+            constexpr int rb = decltype(RB)::value;                     // >= 0: the residual of output block rb rides in this stage
             const bool ix = xs + 2 < XSTAGES;                           // X(xs+2) exists (W(s+2) always does during fc.0)
             const int wslot2 = prev3(wslot), xslot2 = prev3(xslot);     // slots of W(s+2), X(xs+2): (s + 2) % 3 = (s - 1) % 3
             const bool next_x = kg + 1 < G0;                            // the next stage is an fc.0 stage (reads token fragments)
@@ -345,13 +369,28 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpFusedArgs g) {
 #define OG_SLOT_NONE(k) {}
             tie2(xh[0], xl[0]);
             OG_GROUP(acc0[0], acc0[1], xh[0], xl[0], 0, 3, 3, 3, 2, OG_SLOT_G0)
+            OG_RESID(rb, 0, xh[0])
             OG_GROUP(acc0[2], acc0[3], xh[0], xl[0], 1, 5, 5, 3, 2, OG_SLOT_G1)
+            OG_RESID(rb, 0, xl[0])
             tie2(xh[1], xl[1]);
             OG_GROUP(acc0[0], acc0[1], xh[1], xl[1], 2, 3, 3, 3, 2, OG_SLOT_G2)
+            OG_RESID(rb, 1, xh[1])
+            OG_RESID(rb, 1, xl[1])
             OG_GROUP_LAST(acc0[2], acc0[3], xh[1], xl[1], OG_SLOT_NONE, hand_over(true, next_x, next3(xslot), ix ? 6 : 4), true, next_x)
             ++s; wslot = next3(wslot);
             ++xs; xslot = next3(xslot);
+        };
+        using NoRes = std::integral_constant<int, -1>;
+        int kg0 = 0;
+        if (pass == NPASS - 1) {        // the x half of [x ; O] (k-groups 0..7) in the last quarter: unrolled, every stage knows its output block
+            fc0_stage(0, std::integral_constant<int, 0>{}); fc0_stage(1, std::integral_constant<int, 1>{});
+            fc0_stage(2, std::integral_constant<int, 2>{}); fc0_stage(3, std::integral_constant<int, 3>{});
+            fc0_stage(4, std::integral_constant<int, 4>{}); fc0_stage(5, std::integral_constant<int, 5>{});
+            fc0_stage(6, std::integral_constant<int, 6>{}); fc0_stage(7, std::integral_constant<int, 7>{});
+            kg0 = 8;
         }
+#pragma unroll 1
+        for (int kg = kg0; kg < G0; ++kg) fc0_stage(kg, NoRes{});
 
         // ================= fc.3: acc3[i] += W3'[block i][hidden block 8 ha + 4 pass + j] · relu(acc0[j] / 256), 8 stages (j, t) =================
         // hidden block j as B fragments: element e of k-step t is accumulator register 8t + e (og_pack_mlp_stream permutes W3' to match)
@@ -395,28 +434,21 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpFusedArgs g) {
     }
 #undef OG_GROUP
 #undef OG_GROUP_LAST
+#undef OG_RESID
+#undef OG_RES1
 #undef OG_MM
 #undef OG_RD
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     OG_MT(3, 1);
-    // the residual rows of this wave's four output blocks (whole 128-byte lines, 8 rows per instruction) are requested NOW: their
-    // HBM / L2 round trip runs under the two block barriers and the LDS traffic of the exchange below
     const int tok0 = t0 + tb * 32;
     char* const rows = reinterpret_cast<char*>(g.XO);
-    int64_t rowb[4];                                          // byte offset of this lane's row per store / load instruction
+    int64_t rowb[4];                                          // byte offset of this lane's row per store instruction
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         int r = tok0 + it * 8 + (lane >> 3);
         if (r > g.M - 1) r = g.M - 1;
         rowb[it] = (int64_t)r * g.ld * 2 + (lane & 7) * 16 + 4 * ha * 128;
     }
-    og_u32x4 rres[2][2][4];                                   // [pair][block of the pair][8-row group]
-#pragma unroll
-    for (int ip = 0; ip < 2; ++ip)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int it = 0; it < 4; ++it) rres[ip][i][it] = *reinterpret_cast<const og_u32x4*>(rows + rowb[it] + (2 * ip + i) * 128);
     __syncthreads();          // every wave is past its last fragment reads, no DMA in flight: the rings are free
 
     // ================= the two waves of a token block exchange half of their partial sums =================
@@ -449,11 +481,10 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpFusedArgs g) {
         }
     }
 
-    // ================= epilogue: x <- acc / 256 + (x_hi + x_lo), written back as hl32 rows =================
-    // A lane owns ONE token and 4 consecutive channels per register group.  Residual rows come in and result rows go out as whole
-    // 128-byte lines (one channel block of one token: 64 B hi | 64 B lo), 8 rows per instruction, and change layout through two
-    // per-wave LDS slabs (as gemm_f16x3_epilogue_fast).  Channel blocks are handled in pairs; their residual rows were requested before
-    // the exchange.
+    // ================= epilogue: x <- acc / S3 (bias and residual inside), written back as hl32 rows =================
+    // A lane owns ONE token and 4 consecutive channels per register group.  Result rows go out as whole 128-byte lines (one channel
+    // block of one token: 64 B hi | 64 B lo), 8 rows per instruction, through two per-wave LDS slabs (as gemm_f16x3_epilogue_fast),
+    // channel blocks in pairs.
     {
 #pragma clang fp contract(off)
         constexpr int ROWB = 128 + 16;
@@ -464,38 +495,13 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpFusedArgs g) {
         for (int ip = 0; ip < 2; ++ip) {
             f32x16 a[2];
             a[0] = accf[2 * ip]; a[1] = accf[2 * ip + 1];
+            // v = acc / S3 (bias and residual are inside the accumulator); pinned: og_split4 must see ONE rounded product
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i) {
+                a[i] = a[i] * sc3;
 #pragma unroll
-                for (int it = 0; it < 4; ++it) *reinterpret_cast<og_u32x4*>(slab2 + i * EPI_SLAB + it * 8 * ROWB + rd_off) = rres[ip][i][it];
-            og_u32x4 raw[2][4];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const char* d = slab2 + i * EPI_SLAB + l31 * ROWB + (8 * q + 4 * hi) * 2;
-                    const uint2 h2 = *reinterpret_cast<const uint2*>(d), l2 = *reinterpret_cast<const uint2*>(d + 64);
-                    raw[i][q] = og_u32x4{h2.x, h2.y, l2.x, l2.y};
-                }
-            // v = acc * scale + hi + lo: two mixed-precision FMAs per element (gemm_f16x3_epilogue_finish_spec<OG_EM_RES_HL>)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float x0 = a[i][4 * q], x1 = a[i][4 * q + 1], x2 = a[i][4 * q + 2], x3 = a[i][4 * q + 3];
-                    asm("s_nop 1\n\t"
-                        "v_fma_mix_f32 %0, %0, %4, %5 op_sel_hi:[0,0,1]\n\t"
-                        "v_fma_mix_f32 %1, %1, %4, %5 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-                        "v_fma_mix_f32 %2, %2, %4, %6 op_sel_hi:[0,0,1]\n\t"
-                        "v_fma_mix_f32 %3, %3, %4, %6 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-                        "v_fma_mix_f32 %0, %7, 1.0, %0 op_sel_hi:[1,0,0]\n\t"
-                        "v_fma_mix_f32 %1, %7, 1.0, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-                        "v_fma_mix_f32 %2, %8, 1.0, %2 op_sel_hi:[1,0,0]\n\t"
-                        "v_fma_mix_f32 %3, %8, 1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-                        : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3)
-                        : "s"(sc3), "v"(raw[i][q][0]), "v"(raw[i][q][1]), "v"(raw[i][q][2]), "v"(raw[i][q][3]));
-                    a[i][4 * q] = x0; a[i][4 * q + 1] = x1; a[i][4 * q + 2] = x2; a[i][4 * q + 3] = x3;
-                }
+                for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(a[i][r]));
+            }
             // registers -> slabs: slab i = [32 tok][hi 64 B | lo 64 B] of channel block cb0 + 2 ip + i
 #pragma unroll
             for (int i = 0; i < 2; ++i)

@@ -49,10 +49,11 @@ static inline int64_t og_round_up(int64_t x, int64_t a) { return (x + a - 1) / a
 // per weight matrix (a power of two, og_weight_prescale) when 256 |w| would leave binary16 -- e.g. a BatchNorm fold over a dead
 // channel -- and stores 1 / S next to the matrix; the kernels read it from there (GemmHArgs::scale_dev).
 #define OG_W_SCALE 256.0
-// largest power of two S <= 256 with S * maxabs <= 32768 (half the binary16 range: room for rounding), at least 2^-40
+// largest power of two S <= 256 with S * maxabs <= 32768 (half the binary16 range: room for rounding), at least 2^-14 (S itself is
+// used as a binary16 constant by mlp_fused.hip: weights up to 5e8; beyond that og_pack_weights fails with OG_E_RANGE)
 static inline double og_weight_prescale(double maxabs) {
     double S = OG_W_SCALE;
-    while (S * maxabs > 32768.0 && S > 9.094947017729282e-13) S *= 0.5;
+    while (S * maxabs > 32768.0 && S > 6.103515625e-05) S *= 0.5;
     return S;
 }
 // CALLERS: if x is the result of a multiply, pin it first (`asm("" : "+v"(x))`, or compute it under `#pragma clang fp
