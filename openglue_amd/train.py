@@ -14,8 +14,9 @@ BatchNorm: og_batchnorm_train_backward), so the keypoint-encoder MLP / a message
 
 `superglue_forward_train` (below) wires them -- plus `Conv1x1`, `SoftmaxAttention` (materialised attention matrix, batched exact-fp32
 GEMMs, row-softmax forward / backward kernels) and `MatchingScores` -- into the whole training-mode forward of the reference
-(superglue.py:29-72): `SuperGlue(config).train()(data)` returns tensors whose `loss.backward()` reaches every parameter.  Functional,
-not tuned (exact-fp32 MFMA, O(N^2) attention memory); not in training mode: Siren encoder, linear / FAVOR attention.
+(superglue.py:29-72): `SuperGlue(config).train()(data)` returns tensors whose `loss.backward()` reaches every parameter.  `LinearAttentionCore`
+(+ `linear_attention_elu_train`, `favor_relu_attention_train`) is the O(N) attention of attention.py:22-40 / :86-95 under autograd, the
+Siren encoder (models/utils.py:32-45) runs through `Conv1x1` + sin(30 x).
 """
 from __future__ import annotations
 
@@ -199,11 +200,14 @@ def _gemm_splitk(dz: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     return out[:, :Cin].contiguous() if Cin4 != Cin else out
 
 
-def _conv_backward(x: torch.Tensor, W: torch.Tensor, dz: torch.Tensor, need_dx: bool):
-    """1x1 conv on token rows, z = x W^T + b:  dx = dz W,  dW = dz^T x,  db = column sums of dz -- all on HIP kernels."""
+def _conv_backward(x: torch.Tensor, W: torch.Tensor, dz: torch.Tensor, need_dx: bool, need_dw: bool = True):
+    """1x1 conv on token rows, z = x W^T + b:  dx = dz W,  dW = dz^T x,  db = column sums of dz -- all on HIP kernels.
+    need_dw False (W is a buffer: the FAVOR projection): only dx."""
     lib = _lib.load()
     T, Cout = dz.shape
     dx = _gemm_fast(dz, _transpose_pad(W, 32), scale_a=True) if need_dx else None                # [T, Cout] x [Cin, Cout]^T
+    if not need_dw:
+        return dx, None, None
     dW = _gemm_splitk(dz, x)                                                                     # [Cout, T] x [Cin, T]^T
     db = torch.empty(Cout, device=dz.device, dtype=torch.float32)
     ws = _ws(dz, T, Cout)
@@ -224,7 +228,8 @@ class Conv1x1(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, W = ctx.saved_tensors
-        dx, dW, db = _conv_backward(x.detach(), W.detach().contiguous(), dy.detach().contiguous(), ctx.needs_input_grad[0])
+        dx, dW, db = _conv_backward(x.detach(), W.detach().contiguous(), dy.detach().contiguous(), ctx.needs_input_grad[0],
+                                    ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
         return dx, dW, db
 
 
@@ -401,6 +406,85 @@ class SoftmaxAttention(torch.autograd.Function):
         return _heads_last(dqh, B), _heads_last(dkh, B), _heads_last(dvh, B), None
 
 
+def _bmm_nt(A: torch.Tensor, Bm: torch.Tensor) -> torch.Tensor:
+    """C[z] = A[z] Bm[z]^T for contiguous fp32 A [Z, M, K], Bm [Z, N, K], K % 4 == 0: one batched launch of the exact-fp32 MFMA GEMM."""
+    Z, M, K = A.shape
+    N = Bm.shape[1]
+    C = torch.empty(Z, M, N, device=A.device, dtype=torch.float32)
+    _gemm_raw(A.device, A.data_ptr(), K, M * K, Bm.data_ptr(), K, N * K, C.data_ptr(), N, M * N, M, N, K, Z)
+    return C
+
+
+def _bt(x: torch.Tensor) -> torch.Tensor:
+    """[Z, R, C] contiguous -> [Z, C, r4(R)] with a zero tail (the K-contiguous operand of a contraction over R)."""
+    Z, R, C = x.shape
+    R4 = _r4(R)
+    out = torch.zeros(Z, C, R4, device=x.device, dtype=torch.float32) if R4 != R else torch.empty(Z, C, R4, device=x.device, dtype=torch.float32)
+    _transpose_raw(x.device, x.data_ptr(), C, R * C, R, C, out.data_ptr(), R4, C * R4, Z)
+    return out
+
+
+class LinearAttentionCore(torch.autograd.Function):
+    """out[z] = (Q' (K'^T V)) / (Q' . sum_j K'_j)  -- the reference's `linear_attention` (attention.py:29-40) on positive feature maps
+    Q' [Z, Nq, F], K' [Z, Nk, F] and values V [Z, Nk, d] (Z = batch x heads, F % 4 == 0, d % 4 == 0).  O(N F d): no N x N matrix exists
+    in either direction.  Every contraction is a batched launch of the exact-fp32 MFMA GEMM (og_gemm_nt); the division and the two
+    rank-one terms are tensor algebra.  Backward, with num = Q' kv, den = Q' z:
+        dnum = dO / den,  dden = -sum_c(dO o out) / den,
+        dQ' = dnum kv^T + dden z^T,   dkv = Q'^T dnum,   dz = Q'^T dden,
+        dK' = V dkv^T + 1 dz^T,       dV = K' dkv."""
+
+    @staticmethod
+    def forward(ctx, fq, fk, v):
+        fq, fk, v = (t.detach().to(torch.float32).contiguous() for t in (fq, fk, v))
+        if fq.shape[2] % 4 or v.shape[2] % 4:
+            raise ValueError("LinearAttentionCore: feature and value widths must be multiples of 4")
+        fkt, vt = _bt(fk), _bt(v)                                   # [Z, F, Nk4], [Z, d, Nk4]
+        kvT = _bmm_nt(vt, fkt)                                      # [Z, d, F]:  kvT[c][f] = sum_j v[j][c] k'[j][f]
+        z = fk.sum(1)                                               # [Z, F]
+        num = _bmm_nt(fq, kvT)                                      # [Z, Nq, d]
+        den = (fq * z[:, None, :]).sum(-1, keepdim=True)            # [Z, Nq, 1]
+        out = num / den
+        ctx.save_for_backward(fq, fk, v, fkt, vt, z, den, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        fq, fk, v, fkt, vt, z, den, out = ctx.saved_tensors
+        dout = dout.detach().to(torch.float32).contiguous()
+        dnum = (dout / den).contiguous()
+        dden = -(dout * out).sum(-1, keepdim=True) / den            # [Z, Nq, 1]
+        kv = _bmm_nt(fkt, vt)                                       # [Z, F, d]
+        dfq = _bmm_nt(dnum, kv) + dden * z[:, None, :]
+        fqt, dnt = _bt(fq), _bt(dnum)                               # [Z, F, Nq4], [Z, d, Nq4]
+        dkv, dkvT = _bmm_nt(fqt, dnt), _bmm_nt(dnt, fqt)            # [Z, F, d], [Z, d, F]
+        dz = (fq * dden).sum(1)                                     # [Z, F]
+        dfk = _bmm_nt(v, dkv) + dz[:, None, :]
+        dv = _bmm_nt(fk, dkvT)
+        return dfq, dfk, dv
+
+
+def linear_attention_elu_train(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int) -> torch.Tensor:
+    """attention = 'linear' under autograd (attention.py:22-40): phi(x) = elu(x) + 1 + 1e-6 per head, then LinearAttentionCore.
+    q [B, Nq, D], k, v [B, Nk, D] token-major -> [B, Nq, D]."""
+    B = q.shape[0]
+    fq = torch.nn.functional.elu(_heads_first(q, num_heads)) + (1.0 + 1e-6)
+    fk = torch.nn.functional.elu(_heads_first(k, num_heads)) + (1.0 + 1e-6)
+    return _heads_last(LinearAttentionCore.apply(fq, fk, _heads_first(v, num_heads)), B)
+
+
+def favor_relu_attention_train(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, projection: torch.Tensor, eps: float = 1e-8) -> torch.Tensor:
+    """attention = 'favor_relu' under autograd (GeneralizedFavorAttention.randomized_kernel, attention.py:91-95, with the ReLU kernel
+    and eps of __init__.py:19-25; one head, as the reference requires): phi(x) = relu(P (x d^-1/4)) + eps with the [2D, D] buffer P
+    (the projection is a 1x1 conv without bias or weight gradient), then LinearAttentionCore."""
+    B, Nq, D = q.shape
+    Nk = k.shape[1]
+    P = projection.detach().to(torch.float32).contiguous()
+    zero = torch.zeros(P.shape[0], device=q.device, dtype=torch.float32)
+    fq = torch.relu(Conv1x1.apply((q * D ** -0.25).reshape(B * Nq, D).contiguous(), P, zero)).reshape(B, Nq, -1) + eps
+    fk = torch.relu(Conv1x1.apply((k * D ** -0.25).reshape(B * Nk, D).contiguous(), P, zero)).reshape(B, Nk, -1) + eps
+    return LinearAttentionCore.apply(fq, fk, v)
+
+
 class MatchingScores(torch.autograd.Function):
     """S[b] = g0[b] g1[b]^T * scale on token-major g0 [B, m, D], g1 [B, n, D] (superglue.py:81-86 with its D^-1/2 factor)."""
 
@@ -494,13 +578,12 @@ def superglue_forward_train(model, data, frozen_bn: bool = False):
     (running statistics updated like torch's), every 1x1 conv / attention product / score matrix on the exact-fp32 MFMA GEMM,
     softmax + its backward, BatchNorm + ReLU backward and the optimal-transport layer on HIP kernels, all wired through
     torch.autograd.Functions -- loss.backward() reaches every parameter.  Glue that stays torch tensor algebra: keypoint
-    normalisation, concatenations, residual adds, the sigmoid mix.  Supported: encoder FeedForwardNet, softmax attention,
-    use_offset, residual, no_descriptors."""
-    if model.linear_attention or getattr(model, 'favor_relu', False) or (model.siren and not frozen_bn):
-        raise NotImplementedError("autograd path: softmax attention only; the Siren encoder only with frozen statistics (eval mode)")
+    normalisation, concatenations, residual adds, the sigmoid mix, the elementwise feature maps of the linear attentions and sin(30 x).
+    Supported: everything the inference path runs -- both encoders (FeedForwardNet, FeedForwardNetSiren), attention 'softmax' / 'linear' /
+    'favor_relu', use_offset, residual, no_descriptors."""
     # frozen_bn: the module is in eval() and the caller wants gradients (fine-tuning on frozen BatchNorm statistics, saliency):
     # the reference's eval-mode forward is differentiable (superglue.py:29-72 under autograd), so is this one
-    mlp = (lambda x_, seq_, siren_=False: _mlp_frozen(x_, seq_, siren_)) if frozen_bn else (lambda x_, seq_, siren_=False: _mlp_train(x_, seq_))
+    mlp = (lambda x_, seq_: _mlp_frozen(x_, seq_)) if frozen_bn else (lambda x_, seq_: _mlp_train(x_, seq_))
     D, H = model.descriptor_dim, model.num_heads
     k0, k1 = data["keypoints0"], data["keypoints1"]
     d0, d1 = data["local_descriptors0"], data["local_descriptors1"]                # [B, N, D] token-major as they arrive
@@ -515,7 +598,10 @@ def superglue_forward_train(model, data, frozen_bn: bool = False):
         wh1 = torch.tensor([wh[0] - 1.0, wh[1] - 1.0], device=k.device, dtype=torch.float32)
         kn = 2.0 * k.to(torch.float32) / wh1 - 1.0                                  # superglue.py:74-78
         inp = torch.cat([kn, s.to(torch.float32).reshape(k.shape[0], k.shape[1], -1)], dim=-1)
-        return mlp(inp.reshape(-1, inp.shape[-1]), model.positional_encoding.encoder, model.siren)
+        enc = model.positional_encoding.encoder
+        if model.siren:                                   # FeedForwardNetSiren has no BatchNorm (models/utils.py:32-45): one form in both modes
+            return _mlp_frozen(inp.reshape(-1, inp.shape[-1]), enc, True)
+        return mlp(inp.reshape(-1, inp.shape[-1]), enc)
 
     pe0, pe1 = encode(k0, s0, _get_wh(data, 0)), encode(k1, s1, _get_wh(data, 1))
     d0f, d1f = d0.to(torch.float32).reshape(B * m, D), d1.to(torch.float32).reshape(B * n, D)
@@ -527,7 +613,13 @@ def superglue_forward_train(model, data, frozen_bn: bool = False):
     def propagate(layer, xq, nq, xkv, nk):                                         # attention_gnn.py:45-55
         mha = layer.module.mha
         q, k, v = conv(xq, mha.in_proj_q), conv(xkv, mha.in_proj_k), conv(xkv, mha.in_proj_v)
-        o = SoftmaxAttention.apply(q.reshape(B, nq, D), k.reshape(B, nk, D), v.reshape(B, nk, D), H)
+        q3, k3, v3 = q.reshape(B, nq, D), k.reshape(B, nk, D), v.reshape(B, nk, D)
+        if model.linear_attention:
+            o = linear_attention_elu_train(q3, k3, v3, H)
+        elif model.favor_relu:
+            o = favor_relu_attention_train(q3, k3, v3, mha.attention_func.projection_matrix)
+        else:
+            o = SoftmaxAttention.apply(q3, k3, v3, H)
         msg = conv(o.reshape(B * nq, D), mha.out_proj)
         y = torch.cat([xq - msg if model.use_offset else xq, msg], dim=-1)
         return xq + mlp(y, layer.module.fc)
