@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Training fixtures FROM THE REFERENCE under torch autograd (build container only: needs /root/reference).
 
-    python tests/golden/make_golden_train.py        # writes tests/golden/train_ot.npz
+    python tests/golden/make_golden_train.py             # writes tests/golden/train_ot.npz, train_mlp.npz, train_model.npz
+    python tests/golden/make_golden_train.py eval_grad   # eval_grad.npz
+    python tests/golden/make_golden_train.py variants    # train_variants.npz (linear / FAVOR attention, Siren encoder in train mode)
 
 train_ot: the optimal-transport layer of the reference (SuperGlue.get_matching_probs, superglue.py:88-111, calling
 log_otp_solver, optimal_transport.py:20-28) on seeded score matrices, differentiated by autograd through two losses:
@@ -186,8 +188,48 @@ def main_eval_grad():
     np.savez_compressed(os.path.join(HERE, "eval_grad.npz"), **out)
 
 
+VARIANT_CASES = [  # name, config overrides, B, m, n  (train-mode linear attention and Siren)
+    ("linear", dict(descriptor_dim=64, num_stages=2, num_heads=4, num_iters=6, attention="linear"), 2, 45, 38),
+    ("favor", dict(descriptor_dim=64, num_stages=1, num_heads=1, num_iters=6, attention="favor_relu"), 2, 33, 47),
+    ("siren", dict(descriptor_dim=64, num_stages=1, num_heads=4, num_iters=6, encoder_name="FeedForwardNetSiren", use_offset=True), 2, 40, 36),
+]
+
+
+def main_variants():
+    """train_variants: like train_model for the other attention mechanisms (attention.py:22-40 linear_attention_elu, :86-95 the ReLU
+    FAVOR kernel) and the Siren keypoint encoder (models/utils.py:32-45), reference in train() mode."""
+    out = {}
+    for name, kw, B, m, n in VARIANT_CASES:
+        cfg = syn.make_config(**kw)
+        sd = syn.make_state_dict(cfg, seed=len(name) + 20)
+        ref = RefSuperGlue(cfg)
+        ref.load_state_dict(sd)
+        ref.train()
+        data = syn.make_batch(B, m, n, cfg["descriptor_dim"], 1, seed=5 + len(name))
+        data["local_descriptors0"].requires_grad_(True); data["local_descriptors1"].requires_grad_(True)
+        gt0, gt1 = gt_matches(B, m, n, torch.Generator().manual_seed(13))
+        y = ref(data)
+        loss = criterion({"gt_matches0": gt0, "gt_matches1": gt1}, y, margin=None)["loss"]
+        loss.backward()
+        out[f"{name}_scores"] = y["scores"].detach().numpy(); out[f"{name}_loss"] = np.float32(loss.item())
+        out[f"{name}_ctx0"] = y["context_descriptors0"].detach().numpy()
+        out[f"{name}_gt0"] = gt0.numpy(); out[f"{name}_gt1"] = gt1.numpy()
+        out[f"{name}_grad_desc0"] = data["local_descriptors0"].grad.numpy().copy()
+        out[f"{name}_grad_desc1"] = data["local_descriptors1"].grad.numpy().copy()
+        for k_, p_ in ref.named_parameters():
+            out[f"{name}_grad_{k_}"] = (p_.grad if p_.grad is not None else torch.zeros_like(p_)).numpy().copy()
+        for k_, b_ in ref.named_buffers():
+            if "running" in k_:
+                out[f"{name}_buf_{k_}"] = b_.numpy().copy()
+        out[f"{name}_meta"] = np.array([B, m, n], np.int64)
+        print(name, "train-mode model: loss", loss.item(), "|scores| max", float(y["scores"].abs().max()))
+    np.savez_compressed(os.path.join(HERE, "train_variants.npz"), **out)
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["eval_grad"]:
         main_eval_grad()
+    elif sys.argv[1:] == ["variants"]:
+        main_variants()
     else:
         main()

@@ -293,6 +293,90 @@ def test_training_step_against_reference_autograd(gpu_device, name):
             assert np.abs(b.cpu().numpy() - G[f"{name}_buf_{k}"]).max() < 1e-5, k
 
 
+# ----------------------------------------------------------------------------- the other attentions / encoder in training mode
+GV = dict(np.load(os.path.join(GOLDEN, "train_variants.npz")))
+VARIANT_CASES = {"linear": dict(descriptor_dim=64, num_stages=2, num_heads=4, num_iters=6, attention="linear"),
+                 "favor": dict(descriptor_dim=64, num_stages=1, num_heads=1, num_iters=6, attention="favor_relu"),
+                 "siren": dict(descriptor_dim=64, num_stages=1, num_heads=4, num_iters=6, encoder_name="FeedForwardNetSiren", use_offset=True)}
+
+
+def _variant_case(name):
+    from openglue_amd import synthetic as syn
+    cfg = syn.make_config(**VARIANT_CASES[name])
+    sd = syn.make_state_dict(cfg, seed=len(name) + 20)
+    B, m, n = (int(v) for v in GV[f"{name}_meta"])
+    data = syn.make_batch(B, m, n, cfg["descriptor_dim"], 1, seed=5 + len(name))
+    return cfg, sd, data, torch.from_numpy(GV[f"{name}_gt0"]), torch.from_numpy(GV[f"{name}_gt1"])
+
+
+@pytest.mark.parametrize("name", list(VARIANT_CASES))
+def test_oracle_training_step_variants_match_the_reference(name):
+    """CPU: the oracle in training mode with attention 'linear' / 'favor_relu' and with the Siren encoder vs the reference's training
+    step (tests/golden/make_golden_train.py variants): scores, loss, gradients."""
+    cfg, sd, data, gt0, gt1 = _variant_case(name)
+    params = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k and "projection" not in k else v.clone())
+              for k, v in sd.items()}
+    data["local_descriptors0"].requires_grad_(True); data["local_descriptors1"].requires_grad_(True)
+    stats = {}
+    out = orc.superglue_forward(params, cfg, data, train_stats=stats)
+    # the bar of the path (1e-3): sin(30 x) amplifies fp32 rounding of the first conv (F.linear here, Conv1d there) to 3e-4 on |scores| ~ 80
+    assert np.abs(out["scores"].detach().numpy() - GV[f"{name}_scores"]).max() < 1e-3
+    loss = orc.nll_criterion(out["scores"], gt0, gt1)
+    assert abs(loss.item() - float(GV[f"{name}_loss"])) < 1e-3
+    loss.backward()
+    for key, got in (("desc0", data["local_descriptors0"].grad), ("desc1", data["local_descriptors1"].grad)):
+        want = GV[f"{name}_grad_{key}"]
+        assert np.abs(got.numpy() - want).max() < 1e-3 * np.abs(want).max() + 1e-7, key
+    checked = 0
+    for k, p in params.items():
+        if f"{name}_grad_{k}" in GV and p.requires_grad:
+            want = GV[f"{name}_grad_{k}"]
+            got = p.grad.numpy() if p.grad is not None else np.zeros_like(want)
+            assert np.abs(got - want).max() < 1e-3 * np.abs(want).max() + 1e-6, k
+            checked += 1
+    assert checked >= 20
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(VARIANT_CASES))
+def test_training_step_variants_against_reference_autograd(gpu_device, name):
+    """HIP: SuperGlue(config).train() with attention 'linear' (elu + 1 feature map), 'favor_relu' (ReLU random features) -- both through
+    train.LinearAttentionCore, O(N), no N x N matrix -- and with the Siren keypoint encoder: scores, loss, gradients of every parameter
+    and of the descriptors, running statistics after the step, vs the reference's training step."""
+    from openglue_amd.superglue import SuperGlue
+    cfg, sd, data, gt0, gt1 = _variant_case(name)
+    model = SuperGlue(cfg)
+    model.load_state_dict(sd)
+    model = model.to(gpu_device).train()
+    dd = {k: (v.to(gpu_device) if torch.is_tensor(v) else v) for k, v in data.items()}
+    dd["local_descriptors0"].requires_grad_(True); dd["local_descriptors1"].requires_grad_(True)
+    out = model(dd)
+    err_s = np.abs(out["scores"].detach().cpu().numpy() - GV[f"{name}_scores"]).max()
+    assert err_s < 1e-3
+    assert np.abs(out["context_descriptors0"].detach().cpu().numpy() - GV[f"{name}_ctx0"]).max() < 1e-4
+    loss = orc.nll_criterion(out["scores"], gt0.to(gpu_device), gt1.to(gpu_device))
+    assert abs(loss.item() - float(GV[f"{name}_loss"])) < 1e-3 * abs(float(GV[f"{name}_loss"]))
+    loss.backward()
+    worst, worst_k = 0.0, ""
+    for key, got in (("desc0", dd["local_descriptors0"].grad), ("desc1", dd["local_descriptors1"].grad)):
+        want = GV[f"{name}_grad_{key}"]
+        e = np.abs(got.cpu().numpy() - want).max() / np.abs(want).max()
+        if e > worst: worst, worst_k = e, key
+    n_checked = 0
+    for k, p in model.named_parameters():
+        want = GV[f"{name}_grad_{k}"]
+        got = p.grad.cpu().numpy() if p.grad is not None else np.zeros_like(want)
+        e = np.abs(got - want).max() / max(np.abs(want).max(), 1e-8)
+        if np.abs(want).max() > 1e-7 and e > worst: worst, worst_k = e, k
+        n_checked += 1
+    print(f"[train_variants {name}] scores err {err_s:.2e}; loss {loss.item():.5f} vs {float(GV[f'{name}_loss']):.5f}; "
+          f"{n_checked} parameter gradients, worst relative error {worst:.2e} ({worst_k})")
+    assert worst < 1e-3
+    for k, b in model.named_buffers():
+        if "running" in k:
+            assert np.abs(b.cpu().numpy() - GV[f"{name}_buf_{k}"]).max() < 1e-5, k
+
+
 # ----------------------------------------------------------------------------- eval mode under autograd (VERDICT r2 item 8)
 GE = np.load(os.path.join(GOLDEN, "eval_grad.npz"))
 
