@@ -17,6 +17,7 @@
 // Block ids are remapped so that all N-tiles of one M-tile run on the same XCD (block b is
 // dispatched to XCD b % 8): the A panel is then fetched into one L2 instead of up to eight.
 #include "og_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -24,19 +25,33 @@ constexpr int BM = 128;
 constexpr int BK = 32;
 constexpr int LDSW = BK + 4;   // padded LDS row, floats
 
-template <int BN, class RD>
+// TA / TB: the operand is stored K-MAJOR (A[k][m] with row stride lda, B[k][n]) -- the layouts the backward products of a 1x1 conv
+// and of attention come in (dW = dZ^T X: both operands [tokens][channels]; dX = dZ W: W [out][in]) -- so no transposed copy of a
+// token-sized tensor is ever made.  Staged into LDS k-major ([32][tile + 4], float4 along the tile), fragments by four ds_read_b32.
+template <int BN, bool TA, bool TB, class RD>
 __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g, int tiles_m, int tiles_n, RD rd) {
     constexpr int TN = BN / 64;            // MFMA tiles per wave along N
     constexpr int BROWS = BN / 32;         // staging passes for B
-    __shared__ __attribute__((aligned(16))) float As[BM * LDSW];
-    __shared__ __attribute__((aligned(16))) float Bs[BN * LDSW];
+    constexpr int LDTA = BM + 4, LDTB = BN + 4;     // k-major LDS rows
+    constexpr int AS = TA ? (BK * LDTA > BM * LDSW ? BK * LDTA : BM * LDSW) : BM * LDSW;
+    constexpr int BS = TB ? (BK * LDTB > BN * LDSW ? BK * LDTB : BN * LDSW) : BN * LDSW;
+    __shared__ __attribute__((aligned(16))) float As[AS];
+    __shared__ __attribute__((aligned(16))) float Bs[BS];
 
     const int id = blockIdx.x;
     const int xcd = id & 7, local = id >> 3;
-    const int tm = (local / tiles_n) * 8 + xcd;
+    int tm = (local / tiles_n) * 8 + xcd;
     const int tn = local % tiles_n;
-    if (tm >= tiles_m) return;
-    const int z = blockIdx.y;
+    int z = blockIdx.y;
+    if constexpr (std::is_same<RD, RaggedNone>::value) {
+        // uniform batch: ONE 1-D grid over the batch * tiles_m "virtual" M-tiles, dealt round-robin to the XCDs (workgroup b runs on
+        // XCD b % 8; with a (tiles, batch) grid and tiles_m < 8 -- a split-K weight gradient has 2-4 -- only tiles_m of the 8 XCDs worked)
+        z = tm / tiles_m;
+        tm -= z * tiles_m;
+        if (z >= g.batch) return;
+    } else {
+        if (tm >= tiles_m) return;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
 
     const float* __restrict__ A = g.A + (int64_t)z * g.strideA;
@@ -49,34 +64,69 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g, int tiles_
         B = g.B + (int64_t)(rd.off0[rd.B] + rd.off1[z]) * g.ldb;
     }
 
+    if (g.ktot > 0) {        // split-K: problem z contracts rows [z K, min((z+1) K, ktot)) of the k-major operands
+        const int left = g.ktot - z * g.K;
+        g.K = left < g.K ? (left > 0 ? left : 0) : g.K;
+    }
+
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int lrow = tid >> 3;          // 0..31: staging row within a 32-row pass
     const int lc4 = (tid & 7) * 4;      // staging column (floats)
+    // k-major staging: a k-row of the tile is BX / 4 float4; 256 threads cover 1024 / BX k-rows per pass, BX / 32 passes
+    const int ta_k = tid >> 5, ta_c4 = (tid & 31) * 4;                                  // A tile: 128 wide
+    const int tb_k = tid / (BN / 4), tb_c4 = (tid % (BN / 4)) * 4;                      // B tile: BN wide
+    constexpr int TB_KROWS = 1024 / BN;
+
+    auto load_kmajor = [&](const float* __restrict__ P, int64_t ld, int krow, int col, int ncols) -> f32x4 {
+        f32x4 v{0.f, 0.f, 0.f, 0.f};
+        if (krow < g.K && col < ncols) {
+            const float* src = P + (int64_t)krow * ld + col;
+            if (col + 3 < ncols) v = *reinterpret_cast<const f32x4*>(src);
+            else
+                for (int e = 0; e < 4; ++e)
+                    if (col + e < ncols) v[e] = src[e];
+        }
+        return v;
+    };
 
     f32x4 ra[4], rb[BROWS];
     auto load_tiles = [&](int k0) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            const int row = m0 + lrow + 32 * p;
-            const int kk = k0 + lc4;
-            if (row < g.M && kk < g.K) ra[p] = *reinterpret_cast<const f32x4*>(A + (int64_t)row * g.lda + kk);
-            else ra[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (TA) {
+                ra[p] = load_kmajor(A, g.lda, k0 + ta_k + 8 * p, m0 + ta_c4, g.M);
+            } else {
+                const int row = m0 + lrow + 32 * p;
+                const int kk = k0 + lc4;
+                if (row < g.M && kk < g.K) ra[p] = *reinterpret_cast<const f32x4*>(A + (int64_t)row * g.lda + kk);
+                else ra[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
 #pragma unroll
         for (int p = 0; p < BROWS; ++p) {
-            const int row = n0 + lrow + 32 * p;
-            const int kk = k0 + lc4;
-            if (row < g.N && kk < g.K) rb[p] = *reinterpret_cast<const f32x4*>(B + (int64_t)row * g.ldb + kk);
-            else rb[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (TB) {
+                rb[p] = load_kmajor(B, g.ldb, k0 + tb_k + TB_KROWS * p, n0 + tb_c4, g.N);
+            } else {
+                const int row = n0 + lrow + 32 * p;
+                const int kk = k0 + lc4;
+                if (row < g.N && kk < g.K) rb[p] = *reinterpret_cast<const f32x4*>(B + (int64_t)row * g.ldb + kk);
+                else rb[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
     };
     auto store_tiles = [&]() {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(&As[(lrow + 32 * p) * LDSW + lc4]) = ra[p];
+        for (int p = 0; p < 4; ++p) {
+            if constexpr (TA) *reinterpret_cast<f32x4*>(&As[(ta_k + 8 * p) * LDTA + ta_c4]) = ra[p];
+            else *reinterpret_cast<f32x4*>(&As[(lrow + 32 * p) * LDSW + lc4]) = ra[p];
+        }
 #pragma unroll
-        for (int p = 0; p < BROWS; ++p) *reinterpret_cast<f32x4*>(&Bs[(lrow + 32 * p) * LDSW + lc4]) = rb[p];
+        for (int p = 0; p < BROWS; ++p) {
+            if constexpr (TB) *reinterpret_cast<f32x4*>(&Bs[(tb_k + TB_KROWS * p) * LDTB + tb_c4]) = rb[p];
+            else *reinterpret_cast<f32x4*>(&Bs[(lrow + 32 * p) * LDSW + lc4]) = rb[p];
+        }
     };
 
     f32x16 acc[2][TN];
@@ -87,8 +137,8 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g, int tiles_
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int a_off = (wm * 64 + (lane & 31)) * LDSW + (lane >> 5) * 4;
-    const int b_off = (wn * (BN / 2) + (lane & 31)) * LDSW + (lane >> 5) * 4;
+    const int a_off = TA ? (lane >> 5) * 4 * LDTA + wm * 64 + (lane & 31) : (wm * 64 + (lane & 31)) * LDSW + (lane >> 5) * 4;
+    const int b_off = TB ? (lane >> 5) * 4 * LDTB + wn * (BN / 2) + (lane & 31) : (wn * (BN / 2) + (lane & 31)) * LDSW + (lane >> 5) * 4;
 
     const int nk = (g.K + BK - 1) / BK;
     load_tiles(0);
@@ -100,9 +150,23 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g, int tiles_
         for (int kk = 0; kk < BK / 8; ++kk) {
             f32x4 a[2], b[TN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f32x4*>(&As[a_off + i * 32 * LDSW + kk * 8]);
+            for (int i = 0; i < 2; ++i) {
+                if constexpr (TA) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(&Bs[b_off + j * 32 * LDSW + kk * 8]);
+                    for (int e = 0; e < 4; ++e) a[i][e] = As[a_off + (kk * 8 + e) * LDTA + i * 32];
+                } else {
+                    a[i] = *reinterpret_cast<const f32x4*>(&As[a_off + i * 32 * LDSW + kk * 8]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (TB) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b[j][e] = Bs[b_off + (kk * 8 + e) * LDTB + j * 32];
+                } else {
+                    b[j] = *reinterpret_cast<const f32x4*>(&Bs[b_off + j * 32 * LDSW + kk * 8]);
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -156,24 +220,38 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g, int tiles_
 
 int og_launch_gemm(const GemmArgs& a, hipStream_t stream) {
     if (!a.A || !a.B || !(a.C || a.Ch) || a.M <= 0 || a.N <= 0 || a.K <= 0 || a.batch <= 0) return OG_E_INVALID;
-    if ((a.lda & 3) || (a.ldb & 3) || (a.K & 3)) return OG_E_ALIGN;
+    if ((a.lda & 3) || (a.ldb & 3)) return OG_E_ALIGN;
+    if ((!a.ta || !a.tb) && (a.K & 3)) return OG_E_ALIGN;          // a K-contiguous operand is read in float4 along K
     if (((uintptr_t)a.A & 15) || ((uintptr_t)a.B & 15)) return OG_E_ALIGN;
     if ((a.strideA & 3) || (a.strideB & 3)) return OG_E_ALIGN;
+    if (a.ta && !a.tb) return OG_E_SHAPE;                    // forms: NT (default), A normal x B k-major, both k-major
+    if ((a.ta || a.tb) && (a.rag || a.Ch || a.Ct)) return OG_E_SHAPE;
+    if (a.ktot > 0 && !(a.ta && a.tb)) return OG_E_SHAPE;
     const int tiles_m = (a.M + BM - 1) / BM;
     const int tiles_m8 = (tiles_m + 7) / 8 * 8;
+    const int64_t vtiles8 = ((int64_t)tiles_m * a.batch + 7) / 8 * 8;      // uniform batches: see the kernel
+    if (vtiles8 * ((a.N + 127) / 128) > 0x7fffffffLL) return OG_E_SHAPE;
     GemmArgs k = a;
     k.rag = nullptr;
     auto launch = [&](auto rd) -> int {       // the per-pair descriptor is a kernel argument only for ragged launches (og_common.h)
         using RD = decltype(rd);
-        if (a.N > 64) {
-            const int tiles_n = (a.N + 127) / 128;
-            hipLaunchKernelGGL((gemm_nt_f32_kernel<128, RD>), dim3(tiles_m8 * tiles_n, a.batch), dim3(256), 0, stream,
-                               k, tiles_m, tiles_n, rd);
-        } else {
-            hipLaunchKernelGGL((gemm_nt_f32_kernel<64, RD>), dim3(tiles_m8, a.batch), dim3(256), 0, stream, k, tiles_m, 1, rd);
-        }
+        constexpr bool uniform = std::is_same<RD, RaggedNone>::value;
+        const int tiles_n = a.N > 64 ? (a.N + 127) / 128 : 1;
+        const dim3 grid = uniform ? dim3((unsigned)(vtiles8 * tiles_n)) : dim3(tiles_m8 * tiles_n, a.batch);
+        if (a.N > 64) hipLaunchKernelGGL((gemm_nt_f32_kernel<128, false, false, RD>), grid, dim3(256), 0, stream, k, tiles_m, tiles_n, rd);
+        else hipLaunchKernelGGL((gemm_nt_f32_kernel<64, false, false, RD>), grid, dim3(256), 0, stream, k, tiles_m, 1, rd);
         return og_launch_status();
     };
+    auto launch_t = [&](auto ta, auto tb) -> int {
+        constexpr bool TA_ = decltype(ta)::value, TB_ = decltype(tb)::value;
+        const int tiles_n = a.N > 64 ? (a.N + 127) / 128 : 1;
+        const dim3 grid((unsigned)(vtiles8 * tiles_n));
+        if (a.N > 64) hipLaunchKernelGGL((gemm_nt_f32_kernel<128, TA_, TB_, RaggedNone>), grid, dim3(256), 0, stream, k, tiles_m, tiles_n, RaggedNone{});
+        else hipLaunchKernelGGL((gemm_nt_f32_kernel<64, TA_, TB_, RaggedNone>), grid, dim3(256), 0, stream, k, tiles_m, 1, RaggedNone{});
+        return og_launch_status();
+    };
+    if (a.ta) return launch_t(std::true_type{}, std::true_type{});
+    if (a.tb) return launch_t(std::false_type{}, std::true_type{});
     return a.rag ? launch(*a.rag) : launch(RaggedNone{});
 }
 
@@ -192,5 +270,19 @@ extern "C" int og_gemm_nt(const float* A, int64_t lda, int64_t strideA, const fl
     g.alpha = alpha; g.scale = scale;
     g.Ct = nullptr; g.ldct = 0; g.strideCt = 0; g.ct_rows = 1;
     g.Ch = nullptr; g.Cl = nullptr; g.ldch = 0; g.c_hl = 0; g.rag = nullptr;
+    return og_launch_gemm(g, (hipStream_t)stream);
+}
+
+extern "C" int og_gemm_kmajor(const float* A, int64_t lda, int64_t strideA, int32_t a_kmajor, const float* B, int64_t ldb, int64_t strideB,
+                              float* C, int64_t ldc, int64_t strideC, int32_t M, int32_t N, int32_t K, int32_t batch, int32_t k_total,
+                              float scale, void* stream) {
+    og_clear_status();
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.strideA = strideA;
+    g.B = B; g.ldb = ldb; g.strideB = strideB;
+    g.C = C; g.ldc = ldc; g.strideC = strideC;
+    g.M = M; g.N = N; g.K = K; g.batch = batch;
+    g.scale = scale; g.ct_rows = 1;
+    g.ta = a_kmajor ? 1 : 0; g.tb = 1; g.ktot = k_total;
     return og_launch_gemm(g, (hipStream_t)stream);
 }

@@ -181,23 +181,19 @@ def _gemm_fast(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = 
 def _gemm_splitk(dz: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     """dW = dz^T x for dz [T, Cout], x [T, Cin]: a [Cout, Cin] result (at most a few 128 x 128 tiles) contracted over ALL T tokens.
     As one GEMM launch that is a grid of <= 16 workgroups on a 256-CU chip (round 2: 250-310 us per launch, 72 % of the training step);
-    here the token axis is cut into `parts` chunks that run as the problems of ONE batched launch (og_gemm_nt: operand z = columns
-    [z Kc, (z+1) Kc) of the K-contiguous transposes) and the partial products are summed."""
+    here the token axis is cut into `parts` chunks that run as the problems of ONE batched launch and the partial products are summed.
+    Both operands are token-major = K-MAJOR for this product: og_gemm_kmajor reads them as they lie (no transposed copies)."""
     T, Cout = dz.shape
     Cin = x.shape[1]
+    if Cout % 4 or Cin % 4 or dz.stride(0) % 4 or x.stride(0) % 4:
+        raise ValueError("_gemm_splitk: channel counts / row strides must be multiples of 4")
     tiles = ((Cout + 127) // 128) * ((Cin + 127) // 128)
-    parts = max(1, min(T // 256, (512 + tiles - 1) // tiles))
-    mult = 4 * parts
-    dzt, xt = _transpose_pad(dz, mult), _transpose_pad(x, mult)                 # [Cout, Kp], [Cin, Kp], zero tails
-    Kp = dzt.shape[1]
-    Kc = Kp // parts
-    Cin4 = (Cin + 3) // 4 * 4
-    if Cin4 != Cin:                                                              # the first encoder conv (2 + side_info inputs)
-        xt = torch.nn.functional.pad(xt, (0, 0, 0, Cin4 - Cin))
-    part = torch.empty(parts, Cout, Cin4, device=dz.device, dtype=torch.float32)
-    _gemm_raw(dz.device, dzt.data_ptr(), Kp, Kc, xt.data_ptr(), Kp, Kc, part.data_ptr(), Cin4, Cout * Cin4, Cout, Cin4, Kc, parts)
-    out = part.sum(0) if parts > 1 else part[0]
-    return out[:, :Cin].contiguous() if Cin4 != Cin else out
+    parts = max(1, min(T // 64, (512 + tiles - 1) // tiles))              # ~512 workgroups, at least two 32-row k-steps each
+    Kc = (T + parts - 1) // parts
+    part = torch.empty(parts, Cout, Cin, device=dz.device, dtype=torch.float32)
+    _gemm_km(dz.device, dz.data_ptr(), dz.stride(0), Kc * dz.stride(0), 1, x.data_ptr(), x.stride(0), Kc * x.stride(0),
+             part.data_ptr(), Cin, Cout * Cin, Cout, Cin, Kc, parts, k_total=T)
+    return part.sum(0) if parts > 1 else part[0]
 
 
 def _conv_backward(x: torch.Tensor, W: torch.Tensor, dz: torch.Tensor, need_dx: bool, need_dw: bool = True):
@@ -205,7 +201,13 @@ def _conv_backward(x: torch.Tensor, W: torch.Tensor, dz: torch.Tensor, need_dx: 
     need_dw False (W is a buffer: the FAVOR projection): only dx."""
     lib = _lib.load()
     T, Cout = dz.shape
-    dx = _gemm_fast(dz, _transpose_pad(W, 32), scale_a=True) if need_dx else None                # [T, Cout] x [Cin, Cout]^T
+    dx = None
+    if need_dx and _use_f16x3():
+        dx = _gemm_fast(dz, _transpose_pad(W, 32), scale_a=True)                                 # [T, Cout] x [Cin, Cout]^T
+    elif need_dx:                                                                                # dz [T, Cout] x W [Cout][Cin] as it lies (k-major B)
+        Cin = W.shape[1]
+        dx = torch.empty(T, Cin, device=dz.device, dtype=torch.float32)
+        _gemm_km(dz.device, dz.data_ptr(), dz.stride(0), 0, 0, W.data_ptr(), W.stride(0), 0, dx.data_ptr(), Cin, 0, T, Cin, Cout, 1)
     if not need_dw:
         return dx, None, None
     dW = _gemm_splitk(dz, x)                                                                     # [Cout, T] x [Cin, T]^T
@@ -290,6 +292,15 @@ def _gemm_raw(dev, A, lda, sA, Bp, ldb, sB, Cp, ldc, sC, M, N, K, batch, scale=1
                                   torch.cuda.current_stream(dev).cuda_stream), "og_gemm_nt")
 
 
+def _gemm_km(dev, A, lda, sA, a_kmajor, Bp, ldb, sB, Cp, ldc, sC, M, N, K, batch, k_total=0, scale=1.0):
+    """og_gemm_kmajor: C[z] = op(A[z]) B[z] with B stored [K][N] and, with a_kmajor, A stored [K][M] (the layouts of the backward products:
+    no transposed copies)."""
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        _lib.check(lib.og_gemm_kmajor(A, lda, sA, int(a_kmajor), Bp, ldb, sB, Cp, ldc, sC, M, N, K, batch, int(k_total), float(scale),
+                                      torch.cuda.current_stream(dev).cuda_stream), "og_gemm_kmajor")
+
+
 def _transpose_raw(dev, src, ld_src, s_src, rows, cols, dst, ld_dst, s_dst, batch):
     lib = _lib.load()
     with torch.cuda.device(dev):
@@ -358,10 +369,9 @@ class SoftmaxAttention(torch.autograd.Function):
         Z, Nq, Nk4 = P.shape
         Nk, d = vh.shape[1], vh.shape[2]
         dev = P.device
-        vt = torch.zeros(Z, d, Nk4, device=dev, dtype=torch.float32) if Nk4 != Nk else torch.empty(Z, d, Nk4, device=dev, dtype=torch.float32)
-        _transpose_raw(dev, vh.data_ptr(), d, Nk * d, Nk, d, vt.data_ptr(), Nk4, d * Nk4, Z)
+        vp = _pad_rows(vh, Nk4)
         oh = torch.empty(Z, Nq, d, device=dev, dtype=torch.float32)
-        _gemm_raw(dev, P.data_ptr(), Nk4, Nq * Nk4, vt.data_ptr(), Nk4, d * Nk4, oh.data_ptr(), d, Nq * d, Nq, d, Nk4, Z)
+        _gemm_km(dev, P.data_ptr(), Nk4, Nq * Nk4, 0, vp.data_ptr(), d, Nk4 * d, oh.data_ptr(), d, Nq * d, Nq, d, Nk4, Z)      # P V
         return _heads_last(oh, B)
 
     @staticmethod
@@ -375,35 +385,31 @@ class SoftmaxAttention(torch.autograd.Function):
         Nk = kh.shape[1]
         dev = qh.device
         st = torch.cuda.current_stream(dev).cuda_stream
-        Nk4, Nq4 = _r4(Nk), _r4(Nq)
+        Nk4 = _r4(Nk)
         doh = _heads_first(dout.detach().to(torch.float32), H)                                  # [Z, Nq, d]
-
-        def tr(x, rows, cols, ld):      # [Z, rows, cols] (row stride ld) -> [Z, cols, r4(rows)], zero tail
-            r4 = _r4(rows)
-            out = torch.zeros(Z, cols, r4, device=dev, dtype=torch.float32) if r4 != rows else torch.empty(Z, cols, r4, device=dev, dtype=torch.float32)
-            _transpose_raw(dev, x.data_ptr(), ld, rows * ld, rows, cols, out.data_ptr(), r4, cols * r4, Z)
-            return out
-
+        # every product below reads its operands as they lie (og_gemm_kmajor): no transposed copy of P, dS, dO, Q or K
         # dV = P^T dO
-        Pt, dot = tr(P, Nq, Nk, Nk4), tr(doh, Nq, d, d)
         dvh = torch.empty(Z, Nk, d, device=dev, dtype=torch.float32)
-        _gemm_raw(dev, Pt.data_ptr(), Nq4, Nk * Nq4, dot.data_ptr(), Nq4, d * Nq4, dvh.data_ptr(), d, Nk * d, Nk, d, Nq4, Z)
-        del Pt
+        _gemm_km(dev, P.data_ptr(), Nk4, Nq * Nk4, 1, doh.data_ptr(), d, Nq * d, dvh.data_ptr(), d, Nk * d, Nk, d, Nq, Z)
         # dP = dO V^T  ->  dS = scale * P o (dP - rowsum(dP o P))
         dS = torch.empty(Z, Nq, Nk4, device=dev, dtype=torch.float32)
         _gemm_raw(dev, doh.data_ptr(), d, Nq * d, vh.data_ptr(), d, Nk * d, dS.data_ptr(), Nk4, Nq * Nk4, Nq, Nk, d, Z)
         with torch.cuda.device(dev):
             _lib.check(lib.og_softmax_rows_backward(P.data_ptr(), dS.data_ptr(), Nk4, Z * Nq, Nk, d ** -0.5, st), "og_softmax_rows_backward")
         del P
-        # dQ = dS K
-        kt = tr(kh, Nk, d, d)
+        # dQ = dS K   (columns [Nk, Nk4) of dS are zero; K gets zero rows up to Nk4)
+        kp = _pad_rows(kh, Nk4)
         dqh = torch.empty(Z, Nq, d, device=dev, dtype=torch.float32)
-        _gemm_raw(dev, dS.data_ptr(), Nk4, Nq * Nk4, kt.data_ptr(), Nk4, d * Nk4, dqh.data_ptr(), d, Nq * d, Nq, d, Nk4, Z)
+        _gemm_km(dev, dS.data_ptr(), Nk4, Nq * Nk4, 0, kp.data_ptr(), d, Nk4 * d, dqh.data_ptr(), d, Nq * d, Nq, d, Nk4, Z)
         # dK = dS^T Q
-        dSt, qt = tr(dS, Nq, Nk, Nk4), tr(qh, Nq, d, d)
         dkh = torch.empty(Z, Nk, d, device=dev, dtype=torch.float32)
-        _gemm_raw(dev, dSt.data_ptr(), Nq4, Nk * Nq4, qt.data_ptr(), Nq4, d * Nq4, dkh.data_ptr(), d, Nk * d, Nk, d, Nq4, Z)
+        _gemm_km(dev, dS.data_ptr(), Nk4, Nq * Nk4, 1, qh.data_ptr(), d, Nq * d, dkh.data_ptr(), d, Nk * d, Nk, d, Nq, Z)
         return _heads_last(dqh, B), _heads_last(dkh, B), _heads_last(dvh, B), None
+
+
+def _pad_rows(x: torch.Tensor, rows: int) -> torch.Tensor:
+    """[Z, R, C] -> [Z, rows, C] with zero rows (only when R is not a multiple of 4: the K-contiguous operand's K)."""
+    return x if x.shape[1] == rows else torch.nn.functional.pad(x, (0, 0, 0, rows - x.shape[1]))
 
 
 def _bmm_nt(A: torch.Tensor, Bm: torch.Tensor) -> torch.Tensor:
@@ -415,20 +421,29 @@ def _bmm_nt(A: torch.Tensor, Bm: torch.Tensor) -> torch.Tensor:
     return C
 
 
-def _bt(x: torch.Tensor) -> torch.Tensor:
-    """[Z, R, C] contiguous -> [Z, C, r4(R)] with a zero tail (the K-contiguous operand of a contraction over R)."""
-    Z, R, C = x.shape
-    R4 = _r4(R)
-    out = torch.zeros(Z, C, R4, device=x.device, dtype=torch.float32) if R4 != R else torch.empty(Z, C, R4, device=x.device, dtype=torch.float32)
-    _transpose_raw(x.device, x.data_ptr(), C, R * C, R, C, out.data_ptr(), R4, C * R4, Z)
-    return out
+def _bmm_nn(A: torch.Tensor, Bm: torch.Tensor) -> torch.Tensor:
+    """C[z] = A[z] Bm[z] for contiguous A [Z, M, K] (K % 4 == 0), Bm [Z, K, N]."""
+    Z, M, K = A.shape
+    N = Bm.shape[2]
+    C = torch.empty(Z, M, N, device=A.device, dtype=torch.float32)
+    _gemm_km(A.device, A.data_ptr(), K, M * K, 0, Bm.data_ptr(), N, K * N, C.data_ptr(), N, M * N, M, N, K, Z)
+    return C
+
+
+def _bmm_tn(A: torch.Tensor, Bm: torch.Tensor) -> torch.Tensor:
+    """C[z] = A[z]^T Bm[z] for contiguous A [Z, K, M], Bm [Z, K, N] (M, N multiples of 4; any K)."""
+    Z, K, M = A.shape
+    N = Bm.shape[2]
+    C = torch.empty(Z, M, N, device=A.device, dtype=torch.float32)
+    _gemm_km(A.device, A.data_ptr(), M, K * M, 1, Bm.data_ptr(), N, K * N, C.data_ptr(), N, M * N, M, N, K, Z)
+    return C
 
 
 class LinearAttentionCore(torch.autograd.Function):
     """out[z] = (Q' (K'^T V)) / (Q' . sum_j K'_j)  -- the reference's `linear_attention` (attention.py:29-40) on positive feature maps
     Q' [Z, Nq, F], K' [Z, Nk, F] and values V [Z, Nk, d] (Z = batch x heads, F % 4 == 0, d % 4 == 0).  O(N F d): no N x N matrix exists
-    in either direction.  Every contraction is a batched launch of the exact-fp32 MFMA GEMM (og_gemm_nt); the division and the two
-    rank-one terms are tensor algebra.  Backward, with num = Q' kv, den = Q' z:
+    in either direction.  Every contraction is a batched launch of the exact-fp32 MFMA GEMM on the operands as they lie (og_gemm_nt /
+    og_gemm_kmajor); the division and the two rank-one terms are tensor algebra.  Backward, with num = Q' kv, den = Q' z:
         dnum = dO / den,  dden = -sum_c(dO o out) / den,
         dQ' = dnum kv^T + dden z^T,   dkv = Q'^T dnum,   dz = Q'^T dden,
         dK' = V dkv^T + 1 dz^T,       dV = K' dkv."""
@@ -438,28 +453,25 @@ class LinearAttentionCore(torch.autograd.Function):
         fq, fk, v = (t.detach().to(torch.float32).contiguous() for t in (fq, fk, v))
         if fq.shape[2] % 4 or v.shape[2] % 4:
             raise ValueError("LinearAttentionCore: feature and value widths must be multiples of 4")
-        fkt, vt = _bt(fk), _bt(v)                                   # [Z, F, Nk4], [Z, d, Nk4]
-        kvT = _bmm_nt(vt, fkt)                                      # [Z, d, F]:  kvT[c][f] = sum_j v[j][c] k'[j][f]
+        kv = _bmm_tn(fk, v)                                         # [Z, F, d]:  kv[f][c] = sum_j k'[j][f] v[j][c]
         z = fk.sum(1)                                               # [Z, F]
-        num = _bmm_nt(fq, kvT)                                      # [Z, Nq, d]
+        num = _bmm_nn(fq, kv)                                       # [Z, Nq, d]
         den = (fq * z[:, None, :]).sum(-1, keepdim=True)            # [Z, Nq, 1]
         out = num / den
-        ctx.save_for_backward(fq, fk, v, fkt, vt, z, den, out)
+        ctx.save_for_backward(fq, fk, v, kv, z, den, out)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        fq, fk, v, fkt, vt, z, den, out = ctx.saved_tensors
+        fq, fk, v, kv, z, den, out = ctx.saved_tensors
         dout = dout.detach().to(torch.float32).contiguous()
         dnum = (dout / den).contiguous()
         dden = -(dout * out).sum(-1, keepdim=True) / den            # [Z, Nq, 1]
-        kv = _bmm_nt(fkt, vt)                                       # [Z, F, d]
         dfq = _bmm_nt(dnum, kv) + dden * z[:, None, :]
-        fqt, dnt = _bt(fq), _bt(dnum)                               # [Z, F, Nq4], [Z, d, Nq4]
-        dkv, dkvT = _bmm_nt(fqt, dnt), _bmm_nt(dnt, fqt)            # [Z, F, d], [Z, d, F]
+        dkv = _bmm_tn(fq, dnum)                                     # [Z, F, d]
         dz = (fq * dden).sum(1)                                     # [Z, F]
         dfk = _bmm_nt(v, dkv) + dz[:, None, :]
-        dv = _bmm_nt(fk, dkvT)
+        dv = _bmm_nn(fk, dkv)
         return dfq, dfk, dv
 
 
@@ -505,19 +517,17 @@ class MatchingScores(torch.autograd.Function):
         B, m, D = g0.shape
         n = g1.shape[1]
         dev = g0.device
-        n4, m4 = _r4(n), _r4(m)
-        dSp = torch.zeros(B, m, n4, device=dev, dtype=torch.float32)
-        dSp[:, :, :n] = dS.detach()
-        g1t = torch.zeros(B, D, n4, device=dev, dtype=torch.float32)
-        _transpose_raw(dev, g1.data_ptr(), D, n * D, n, D, g1t.data_ptr(), n4, D * n4, B)
-        dg0 = torch.empty_like(g0)
-        _gemm_raw(dev, dSp.data_ptr(), n4, m * n4, g1t.data_ptr(), n4, D * n4, dg0.data_ptr(), D, m * D, m, D, n4, B, ctx.scale)
-        dSt = torch.zeros(B, n, m4, device=dev, dtype=torch.float32)
-        _transpose_raw(dev, dSp.data_ptr(), n4, m * n4, m, n, dSt.data_ptr(), m4, n * m4, B)
-        g0t = torch.zeros(B, D, m4, device=dev, dtype=torch.float32)
-        _transpose_raw(dev, g0.data_ptr(), D, m * D, m, D, g0t.data_ptr(), m4, D * m4, B)
-        dg1 = torch.empty_like(g1)
-        _gemm_raw(dev, dSt.data_ptr(), m4, n * m4, g0t.data_ptr(), m4, D * m4, dg1.data_ptr(), D, n * D, n, D, m4, B, ctx.scale)
+        n4 = _r4(n)
+        dSp = dS.detach().to(torch.float32)
+        if n4 != n or not dSp.is_contiguous():
+            buf = torch.zeros(B, m, n4, device=dev, dtype=torch.float32)
+            buf[:, :, :n] = dSp
+            dSp = buf
+        g1p = _pad_rows(g1, n4)
+        dg0 = torch.empty_like(g0)                                                   # dS g1
+        _gemm_km(dev, dSp.data_ptr(), n4, m * n4, 0, g1p.data_ptr(), D, n4 * D, dg0.data_ptr(), D, m * D, m, D, n4, B, scale=ctx.scale)
+        dg1 = torch.empty_like(g1)                                                   # dS^T g0
+        _gemm_km(dev, dSp.data_ptr(), n4, m * n4, 1, g0.data_ptr(), D, m * D, dg1.data_ptr(), D, n * D, n, D, m, B, scale=ctx.scale)
         return dg0, dg1, None
 
 
@@ -610,28 +620,51 @@ def superglue_forward_train(model, data, frozen_bn: bool = False):
     def conv(x2d, c):
         return Conv1x1.apply(x2d.contiguous(), c.weight.reshape(c.weight.shape[0], c.weight.shape[1]), c.bias)
 
-    def propagate(layer, xq, nq, xkv, nk):                                         # attention_gnn.py:45-55
-        mha = layer.module.mha
-        q, k, v = conv(xq, mha.in_proj_q), conv(xkv, mha.in_proj_k), conv(xkv, mha.in_proj_v)
-        q3, k3, v3 = q.reshape(B, nq, D), k.reshape(B, nk, D), v.reshape(B, nk, D)
+    def conv_many(x2d, *cs):
+        """Several 1x1 convs of the SAME input as one GEMM (weights stacked along the output channels; autograd splits the gradient):
+        at 4096 tokens a [T, 256] x [256, 256] launch is 64 workgroups on 256 CUs -- merged launches fill the chip."""
+        W = torch.cat([c.weight.reshape(c.weight.shape[0], c.weight.shape[1]) for c in cs])
+        b = torch.cat([c.bias for c in cs])
+        return Conv1x1.apply(x2d.contiguous(), W, b).split([c.weight.shape[0] for c in cs], dim=1)
+
+    def attend(mha, q3, k3, v3):
         if model.linear_attention:
-            o = linear_attention_elu_train(q3, k3, v3, H)
-        elif model.favor_relu:
-            o = favor_relu_attention_train(q3, k3, v3, mha.attention_func.projection_matrix)
-        else:
-            o = SoftmaxAttention.apply(q3, k3, v3, H)
-        msg = conv(o.reshape(B * nq, D), mha.out_proj)
+            return linear_attention_elu_train(q3, k3, v3, H)
+        if model.favor_relu:
+            return favor_relu_attention_train(q3, k3, v3, mha.attention_func.projection_matrix)
+        return SoftmaxAttention.apply(q3, k3, v3, H)
+
+    def finish(layer, xq, msg):                                                    # attention_gnn.py:51-55 (BatchNorm statistics per call)
         y = torch.cat([xq - msg if model.use_offset else xq, msg], dim=-1)
         return xq + mlp(y, layer.module.fc)
 
+    T0 = B * m
     for li, layer in enumerate(model.attention_gnn.layers):
-        if li % 2 == 0:                                                            # self (attention_gnn.py:63-66)
-            x0 = propagate(layer, x0, m, x0, m)
-            x1 = propagate(layer, x1, n, x1, n)
+        mha = layer.module.mha
+        if li % 2 == 0:                                                            # self (attention_gnn.py:63-66): the two images are independent
+            if m == n:                                                             # one token matrix: projections and attention in one launch each
+                q, k, v = conv_many(torch.cat([x0, x1]), mha.in_proj_q, mha.in_proj_k, mha.in_proj_v)
+                o = attend(mha, q.reshape(2 * B, m, D), k.reshape(2 * B, m, D), v.reshape(2 * B, m, D))
+                msg = conv(o.reshape(2 * T0, D), mha.out_proj)
+                msg0, msg1 = msg[:T0], msg[T0:]
+            else:
+                msgs = []
+                for x, nx in ((x0, m), (x1, n)):
+                    q, k, v = conv_many(x, mha.in_proj_q, mha.in_proj_k, mha.in_proj_v)
+                    o = attend(mha, q.reshape(B, nx, D), k.reshape(B, nx, D), v.reshape(B, nx, D))
+                    msgs.append(conv(o.reshape(B * nx, D), mha.out_proj))
+                msg0, msg1 = msgs
+            x0, x1 = finish(layer, x0, msg0), finish(layer, x1, msg1)
         else:                                                                      # cross: image 1 sees the UPDATED image 0 (:74-77)
-            x0 = propagate(layer, x0, m, x1, n)
-            x1 = propagate(layer, x1, n, x0, m)
-    g0, g1 = conv(x0, model.linear_proj), conv(x1, model.linear_proj)
+            q1, k1, v1 = conv_many(x1, mha.in_proj_q, mha.in_proj_k, mha.in_proj_v)   # x1 is unchanged until the second propagate
+            q0 = conv(x0, mha.in_proj_q)
+            o0 = attend(mha, q0.reshape(B, m, D), k1.reshape(B, n, D), v1.reshape(B, n, D))
+            x0 = finish(layer, x0, conv(o0.reshape(T0, D), mha.out_proj))
+            k0, v0 = conv_many(x0, mha.in_proj_k, mha.in_proj_v)
+            o1 = attend(mha, q1.reshape(B, n, D), k0.reshape(B, m, D), v0.reshape(B, m, D))
+            x1 = finish(layer, x1, conv(o1.reshape(B * n, D), mha.out_proj))
+    g01 = conv(torch.cat([x0, x1]), model.linear_proj)                             # superglue.py:58, both images in one launch
+    g0, g1 = g01[:T0], g01[T0:]
     if model.residual:
         alpha = torch.sigmoid(model.mix_coefs).reshape(1, D)
         g0 = alpha * g0 + (1.0 - alpha) * d0f

@@ -293,6 +293,38 @@ def test_training_step_against_reference_autograd(gpu_device, name):
             assert np.abs(b.cpu().numpy() - G[f"{name}_buf_{k}"]).max() < 1e-5, k
 
 
+# ----------------------------------------------------------------------------- og_gemm_kmajor: the backward products on the operands as they lie
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3, 100, 52, 64, False), (2, 132, 256, 37, True), (1, 64, 12, 301, True), (5, 260, 68, 1024, True),
+                                   (2, 33, 260, 128, False)])
+def test_gemm_kmajor_against_float64(gpu_device, shape):
+    """C[z] = A[z] B[z] (B stored [K][N]) and C[z] = A[z]^T B[z] (A stored [K][M] too): ragged tile edges (row strides stay multiples of 4: the contract), K not a multiple of 4 in
+    the doubly k-major form, batched; vs float64 (exact-fp32 MFMA: 1e-6 relative)."""
+    from openglue_amd import train
+    Z, M, N, K, a_km = shape
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn((Z, K, M) if a_km else (Z, M, K), generator=g).to(gpu_device)
+    Bm = torch.randn(Z, K, N, generator=g).to(gpu_device)
+    got = (train._bmm_tn(A, Bm) if a_km else train._bmm_nn(A, Bm)).cpu().double()
+    want = (A.cpu().double().transpose(1, 2) if a_km else A.cpu().double()) @ Bm.cpu().double()
+    assert (got - want).abs().max() < 2e-6 * want.abs().max() * max(1.0, K ** 0.5 / 8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,Cout,Cin", [(4096, 256, 256), (8192, 512, 512), (1000, 64, 4), (301, 128, 36), (77, 32, 8)])
+def test_split_k_weight_gradient(gpu_device, T, Cout, Cin):
+    """dW = dz^T x contracted over all T tokens as ONE batched split-K launch on the token-major operands (the last chunk is ragged:
+    k_total); vs float64."""
+    from openglue_amd import train
+    g = torch.Generator().manual_seed(T + Cout)
+    dz = torch.randn(T, Cout, generator=g).to(gpu_device)
+    x = torch.randn(T, Cin, generator=g).to(gpu_device)
+    got = train._gemm_splitk(dz, x).cpu().double()
+    want = dz.cpu().double().T @ x.cpu().double()
+    assert got.shape == want.shape
+    assert (got - want).abs().max() < 2e-6 * want.abs().max() * max(1.0, T ** 0.5 / 8)
+
+
 # ----------------------------------------------------------------------------- the other attentions / encoder in training mode (VERDICT r2 item 6)
 GV = dict(np.load(os.path.join(GOLDEN, "train_variants.npz")))
 VARIANT_CASES = {"linear": dict(descriptor_dim=64, num_stages=2, num_heads=4, num_iters=6, attention="linear"),
