@@ -231,11 +231,12 @@ int og_gemm_nt(const float* A, int64_t lda, int64_t strideA, const float* B, int
  * a_kmajor, A[z] is stored [K][M] -- the layouts the backward products of a 1x1 conv and of attention come in (dX = dZ W with
  * W [out][in]; dW = dZ^T X with both operands [tokens][channels]), so that no transposed copy of a token-sized tensor is made.
  * k_total > 0 (a_kmajor only) = split-K: problem z contracts k-rows [z K, min((z+1) K, k_total)) -- strideA = K*lda, strideB = K*ldb
- * cut one long contraction into `batch` partial products C[z] the caller sums.  lda, ldb multiples of 4; K % 4 == 0 only when A is
- * K-contiguous (a_kmajor == 0). */
+ * cut one long contraction into `batch` partial products C[z] the caller sums.  a_colsum (a_kmajor only, ldc > N): column N of C[z]
+ * receives sum_k A[k][m] -- the bias gradient of the conv comes out of the weight-gradient launch.  lda, ldb multiples of 4;
+ * K % 4 == 0 only when A is K-contiguous (a_kmajor == 0). */
 int og_gemm_kmajor(const float* A, int64_t lda, int64_t strideA, int32_t a_kmajor, const float* B, int64_t ldb, int64_t strideB,
                    float* C, int64_t ldc, int64_t strideC, int32_t M, int32_t N, int32_t K, int32_t batch, int32_t k_total,
-                   float scale, void* stream);
+                   int32_t a_colsum, float scale, void* stream);
 
 /* Split-f16 representation used inside the GNN: x = hi + lo with hi = f16(x), lo = f16(x - hi), both IEEE
  * binary16 (|x| < 65504; lo may be subnormal, the matrix cores honour it), stored either as two planes or in the "hl32" row format the GEMM consumes: one row of

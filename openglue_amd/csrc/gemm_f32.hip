@@ -141,11 +141,18 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g, int tiles_
     const int b_off = TB ? (lane >> 5) * 4 * LDTB + wn * (BN / 2) + (lane & 31) : (wn * (BN / 2) + (lane & 31)) * LDSW + (lane >> 5) * 4;
 
     const int nk = (g.K + BK - 1) / BK;
+    float asum = 0.f;                   // g.a_colsum: thread t < 128 sums column m0 + t of the k-major A tile over this problem's k range
     load_tiles(0);
     for (int kt = 0; kt < nk; ++kt) {
         store_tiles();
         __syncthreads();
         if (kt + 1 < nk) load_tiles((kt + 1) * BK);
+        if constexpr (TA) {
+            if (g.a_colsum && tn == 0 && tid < BM) {
+#pragma unroll
+                for (int r = 0; r < BK; ++r) asum += As[r * LDTA + tid];
+            }
+        }
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
             f32x4 a[2], b[TN];
@@ -180,6 +187,9 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g, int tiles_
 
     // ---- epilogue ----
     float* C = g.C + (int64_t)z * g.strideC;      // may alias R (in-place residual): no __restrict__
+    if constexpr (TA) {
+        if (g.a_colsum && tn == 0 && tid < BM && m0 + tid < g.M) C[(int64_t)(m0 + tid) * g.ldc + g.N] = asum * g.scale;
+    }
     const float* R = g.res ? g.res + (int64_t)z * g.strideR : nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -227,6 +237,7 @@ int og_launch_gemm(const GemmArgs& a, hipStream_t stream) {
     if (a.ta && !a.tb) return OG_E_SHAPE;                    // forms: NT (default), A normal x B k-major, both k-major
     if ((a.ta || a.tb) && (a.rag || a.Ch || a.Ct)) return OG_E_SHAPE;
     if (a.ktot > 0 && !(a.ta && a.tb)) return OG_E_SHAPE;
+    if (a.a_colsum && (!a.ta || a.ldc <= a.N)) return OG_E_SHAPE;
     const int tiles_m = (a.M + BM - 1) / BM;
     const int tiles_m8 = (tiles_m + 7) / 8 * 8;
     const int64_t vtiles8 = ((int64_t)tiles_m * a.batch + 7) / 8 * 8;      // uniform batches: see the kernel
@@ -275,7 +286,7 @@ extern "C" int og_gemm_nt(const float* A, int64_t lda, int64_t strideA, const fl
 
 extern "C" int og_gemm_kmajor(const float* A, int64_t lda, int64_t strideA, int32_t a_kmajor, const float* B, int64_t ldb, int64_t strideB,
                               float* C, int64_t ldc, int64_t strideC, int32_t M, int32_t N, int32_t K, int32_t batch, int32_t k_total,
-                              float scale, void* stream) {
+                              int32_t a_colsum, float scale, void* stream) {
     og_clear_status();
     GemmArgs g{};
     g.A = A; g.lda = lda; g.strideA = strideA;
@@ -283,6 +294,6 @@ extern "C" int og_gemm_kmajor(const float* A, int64_t lda, int64_t strideA, int3
     g.C = C; g.ldc = ldc; g.strideC = strideC;
     g.M = M; g.N = N; g.K = K; g.batch = batch;
     g.scale = scale; g.ct_rows = 1;
-    g.ta = a_kmajor ? 1 : 0; g.tb = 1; g.ktot = k_total;
+    g.ta = a_kmajor ? 1 : 0; g.tb = 1; g.ktot = k_total; g.a_colsum = a_colsum ? 1 : 0;
     return og_launch_gemm(g, (hipStream_t)stream);
 }

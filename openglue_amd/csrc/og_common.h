@@ -129,6 +129,7 @@ struct GemmArgs {
     const RaggedDesc* rag;                            // host pointer or null: batched problem z = pair z of a ragged batch
                                                       // (A rows off0[z].., B rows T0 + off1[z].., M = m_z, N = n_z)
     int ta, tb;                                       // operand stored K-MAJOR: A[k][m] (row stride lda) / B[k][n]; forms: 00, 01, 11
+    int a_colsum;                                     // ta: column N of C (ldc > N) receives sum_k A[k][m] * scale (the bias gradient of a conv)
     int ktot;                                         // ta && tb, split-K: problem z contracts k-rows [z K, min((z+1) K, ktot)); 0 = off
 };
 int og_launch_gemm(const GemmArgs& a, hipStream_t stream);

@@ -178,11 +178,12 @@ def _gemm_fast(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = 
     return out * (1.0 / s)
 
 
-def _gemm_splitk(dz: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+def _gemm_splitk(dz: torch.Tensor, x: torch.Tensor, with_colsum: bool = False):
     """dW = dz^T x for dz [T, Cout], x [T, Cin]: a [Cout, Cin] result (at most a few 128 x 128 tiles) contracted over ALL T tokens.
     As one GEMM launch that is a grid of <= 16 workgroups on a 256-CU chip (round 2: 250-310 us per launch, 72 % of the training step);
     here the token axis is cut into `parts` chunks that run as the problems of ONE batched launch and the partial products are summed.
-    Both operands are token-major = K-MAJOR for this product: og_gemm_kmajor reads them as they lie (no transposed copies)."""
+    Both operands are token-major = K-MAJOR for this product: og_gemm_kmajor reads them as they lie (no transposed copies).
+    with_colsum: also db = column sums of dz, out of the same launch (an extra output column) -> (dW, db)."""
     T, Cout = dz.shape
     Cin = x.shape[1]
     if Cout % 4 or Cin % 4 or dz.stride(0) % 4 or x.stride(0) % 4:
@@ -190,10 +191,14 @@ def _gemm_splitk(dz: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     tiles = ((Cout + 127) // 128) * ((Cin + 127) // 128)
     parts = max(1, min(T // 64, (512 + tiles - 1) // tiles))              # ~512 workgroups, at least two 32-row k-steps each
     Kc = (T + parts - 1) // parts
-    part = torch.empty(parts, Cout, Cin, device=dz.device, dtype=torch.float32)
+    ldc = Cin + 4 if with_colsum else Cin
+    part = torch.empty(parts, Cout, ldc, device=dz.device, dtype=torch.float32)
     _gemm_km(dz.device, dz.data_ptr(), dz.stride(0), Kc * dz.stride(0), 1, x.data_ptr(), x.stride(0), Kc * x.stride(0),
-             part.data_ptr(), Cin, Cout * Cin, Cout, Cin, Kc, parts, k_total=T)
-    return part.sum(0) if parts > 1 else part[0]
+             part.data_ptr(), ldc, Cout * ldc, Cout, Cin, Kc, parts, k_total=T, a_colsum=with_colsum)
+    if not with_colsum:
+        return part.sum(0) if parts > 1 else part[0]
+    full = part[:, :, :Cin + 1].sum(0) if parts > 1 else part[0, :, :Cin + 1]
+    return full[:, :Cin].contiguous(), full[:, Cin].contiguous()
 
 
 def _conv_backward(x: torch.Tensor, W: torch.Tensor, dz: torch.Tensor, need_dx: bool, need_dw: bool = True):
@@ -210,11 +215,7 @@ def _conv_backward(x: torch.Tensor, W: torch.Tensor, dz: torch.Tensor, need_dx: 
         _gemm_km(dz.device, dz.data_ptr(), dz.stride(0), 0, 0, W.data_ptr(), W.stride(0), 0, dx.data_ptr(), Cin, 0, T, Cin, Cout, 1)
     if not need_dw:
         return dx, None, None
-    dW = _gemm_splitk(dz, x)                                                                     # [Cout, T] x [Cin, T]^T
-    db = torch.empty(Cout, device=dz.device, dtype=torch.float32)
-    ws = _ws(dz, T, Cout)
-    with torch.cuda.device(dz.device):
-        _lib.check(lib.og_colsum_f32(dz.data_ptr(), dz.stride(0), T, Cout, db.data_ptr(), ws.data_ptr(), _stream(dz)), "og_colsum_f32")
+    dW, db = _gemm_splitk(dz, x, with_colsum=True)                                               # dz^T [x | 1]: one launch
     return dx, dW, db
 
 
@@ -292,12 +293,12 @@ def _gemm_raw(dev, A, lda, sA, Bp, ldb, sB, Cp, ldc, sC, M, N, K, batch, scale=1
                                   torch.cuda.current_stream(dev).cuda_stream), "og_gemm_nt")
 
 
-def _gemm_km(dev, A, lda, sA, a_kmajor, Bp, ldb, sB, Cp, ldc, sC, M, N, K, batch, k_total=0, scale=1.0):
+def _gemm_km(dev, A, lda, sA, a_kmajor, Bp, ldb, sB, Cp, ldc, sC, M, N, K, batch, k_total=0, scale=1.0, a_colsum=False):
     """og_gemm_kmajor: C[z] = op(A[z]) B[z] with B stored [K][N] and, with a_kmajor, A stored [K][M] (the layouts of the backward products:
     no transposed copies)."""
     lib = _lib.load()
     with torch.cuda.device(dev):
-        _lib.check(lib.og_gemm_kmajor(A, lda, sA, int(a_kmajor), Bp, ldb, sB, Cp, ldc, sC, M, N, K, batch, int(k_total), float(scale),
+        _lib.check(lib.og_gemm_kmajor(A, lda, sA, int(a_kmajor), Bp, ldb, sB, Cp, ldc, sC, M, N, K, batch, int(k_total), int(a_colsum), float(scale),
                                       torch.cuda.current_stream(dev).cuda_stream), "og_gemm_kmajor")
 
 

@@ -323,6 +323,10 @@ def test_split_k_weight_gradient(gpu_device, T, Cout, Cin):
     want = dz.cpu().double().T @ x.cpu().double()
     assert got.shape == want.shape
     assert (got - want).abs().max() < 2e-6 * want.abs().max() * max(1.0, T ** 0.5 / 8)
+    dW, db = train._gemm_splitk(dz, x, with_colsum=True)            # the bias gradient (column sums of dz) out of the same launch
+    assert (dW.cpu().double() - want).abs().max() < 2e-6 * want.abs().max() * max(1.0, T ** 0.5 / 8)
+    wb = dz.cpu().double().sum(0)
+    assert db.shape == (Cout,) and (db.cpu().double() - wb).abs().max() < 2e-6 * max(wb.abs().max(), T ** 0.5)
 
 
 # ----------------------------------------------------------------------------- the other attentions / encoder in training mode
