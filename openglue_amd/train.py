@@ -81,7 +81,7 @@ def matching_log_probs(S: torch.Tensor, dustbin_score: torch.Tensor, num_iters: 
 
 
 def batch_norm_train(x: torch.Tensor, weight, bias, running_mean, running_var, momentum: float = 0.1, eps: float = 1e-5,
-                     return_stats: bool = False):
+                     return_stats: bool = False, out: Optional[torch.Tensor] = None):
     """nn.BatchNorm1d in training mode on TOKEN-MAJOR activations x [T, C] (T = B*N rows of the reference's [B, C, N] tensor):
     batch statistics per channel, `running_mean` / `running_var` updated IN PLACE like torch.  Returns y [T, C] (and the saved
     mean / inverse std when `return_stats`).  Forward only."""
@@ -98,7 +98,7 @@ def batch_norm_train(x: torch.Tensor, weight, bias, running_mean, running_var, m
         if t is not None and (t.device != x.device or t.dtype != torch.float32 or t.numel() != C or not t.is_contiguous()):
             raise ValueError(f"{name} must be a contiguous float32 [C] tensor on the device of x")
     ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
-    y = torch.empty(T, C, device=x.device, dtype=torch.float32)
+    y = torch.empty(T, C, device=x.device, dtype=torch.float32) if out is None else out          # out: a [T, C] row slice of a larger buffer
     mean = torch.empty(C, device=x.device, dtype=torch.float32) if return_stats else None
     invstd = torch.empty(C, device=x.device, dtype=torch.float32) if return_stats else None
     p = lambda t: None if t is None else t.data_ptr()       # noqa: E731
@@ -238,35 +238,57 @@ class Conv1x1(torch.autograd.Function):
 
 class ConvReluBNTrain(torch.autograd.Function):
     """The hidden block of FeedForwardNet in training mode (models/utils.py:52-56): y = BatchNorm_train(relu(x W^T + b)); running
-    statistics are updated in place in forward."""
+    statistics are updated in place in forward.
+    splits = (T0, T1, ...): x holds the token rows of SEVERAL calls of the reference (the two images of a self layer,
+    attention_gnn.py:63-66) stacked: the conv and its backward run once over all rows, BatchNorm keeps its per-call semantics
+    (batch statistics and one running-statistics update per row range, in order)."""
 
     @staticmethod
-    def forward(ctx, x, W, b, gamma, beta, running_mean, running_var, momentum, eps):
-        from . import ops
+    def forward(ctx, x, W, b, gamma, beta, running_mean, running_var, momentum, eps, splits=None):
         a = _gemm_fast(x.detach(), W.detach().contiguous(), b.detach(), relu=True)
-        y, mean, invstd = batch_norm_train(a, gamma.detach(), beta.detach(), running_mean, running_var, momentum, eps, return_stats=True)
-        ctx.save_for_backward(x, W, gamma, a, mean, invstd)
+        splits = tuple(splits) if splits else (a.shape[0],)
+        if sum(splits) != a.shape[0]:
+            raise ValueError("ConvReluBNTrain: splits must add up to the rows of x")
+        y = torch.empty_like(a)
+        stats, r0 = [], 0
+        for rows in splits:
+            _, mean, invstd = batch_norm_train(a[r0:r0 + rows], gamma.detach(), beta.detach(), running_mean, running_var, momentum, eps,
+                                               return_stats=True, out=y[r0:r0 + rows])
+            stats += [mean, invstd]
+            r0 += rows
+        ctx.save_for_backward(x, W, gamma, a, *stats)
+        ctx.splits = splits
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
-        x, W, gamma, a, mean, invstd = ctx.saved_tensors
+        x, W, gamma, a, *stats = ctx.saved_tensors
         T, C = a.shape
         dy = dy.detach().contiguous()
         dz = torch.empty_like(a)
-        dgamma = torch.empty(C, device=a.device, dtype=torch.float32)
-        dbeta = torch.empty(C, device=a.device, dtype=torch.float32)
-        ws = _ws(a, T, C)
-        with torch.cuda.device(a.device):
-            _lib.check(lib.og_batchnorm_train_backward(a.data_ptr(), a.stride(0), dy.data_ptr(), dy.stride(0), T, C, gamma.detach().data_ptr(),
-                                                       mean.data_ptr(), invstd.data_ptr(), 1, dz.data_ptr(), dz.stride(0), dgamma.data_ptr(),
-                                                       dbeta.data_ptr(), ws.data_ptr(), _stream(a)), "og_batchnorm_train_backward")
+        dgamma = dbeta = None
+        r0 = 0
+        for i, rows in enumerate(ctx.splits):
+            mean, invstd = stats[2 * i], stats[2 * i + 1]
+            dg = torch.empty(C, device=a.device, dtype=torch.float32)
+            dbt = torch.empty(C, device=a.device, dtype=torch.float32)
+            a_s, dy_s, dz_s = a[r0:r0 + rows], dy[r0:r0 + rows], dz[r0:r0 + rows]
+            ws = _ws(a, rows, C)
+            with torch.cuda.device(a.device):
+                _lib.check(lib.og_batchnorm_train_backward(a_s.data_ptr(), a_s.stride(0), dy_s.data_ptr(), dy_s.stride(0), rows, C,
+                                                           gamma.detach().data_ptr(), mean.data_ptr(), invstd.data_ptr(), 1, dz_s.data_ptr(),
+                                                           dz_s.stride(0), dg.data_ptr(), dbt.data_ptr(), ws.data_ptr(), _stream(a)),
+                           "og_batchnorm_train_backward")
+            dgamma = dg if dgamma is None else dgamma + dg
+            dbeta = dbt if dbeta is None else dbeta + dbt
+            r0 += rows
         dx, dW, db = _conv_backward(x.detach(), W.detach().contiguous(), dz, ctx.needs_input_grad[0])
-        return dx, dW, db, dgamma, dbeta, None, None, None, None
+        return dx, dW, db, dgamma, dbeta, None, None, None, None, None
 
 
-def feed_forward_train_autograd(x: torch.Tensor, net_params, buffers, prefix: str = "", momentum: float = 0.1, eps: float = 1e-5) -> torch.Tensor:
+def feed_forward_train_autograd(x: torch.Tensor, net_params, buffers, prefix: str = "", momentum: float = 0.1, eps: float = 1e-5,
+                                splits=None) -> torch.Tensor:
     """FeedForwardNet (models/utils.py:48-58) in TRAINING mode with gradients: `net_params` maps the nn.Sequential parameter names
     (`{prefix}{3i}.weight|bias`, `{prefix}{3i+2}.weight|bias`) to tensors (requires_grad as wanted; conv weights [out, in, 1] or
     [out, in]), `buffers` the BatchNorm running statistics (updated in place).  x: token-major [T, C_in]."""
@@ -278,7 +300,7 @@ def feed_forward_train_autograd(x: torch.Tensor, net_params, buffers, prefix: st
         if i + 1 < n_conv:
             bn = f"{prefix}{3 * i + 2}"
             x = ConvReluBNTrain.apply(x, W, b, net_params[bn + ".weight"], net_params[bn + ".bias"], buffers[bn + ".running_mean"],
-                                      buffers[bn + ".running_var"], momentum, eps)
+                                      buffers[bn + ".running_var"], momentum, eps, splits)
         else:
             x = Conv1x1.apply(x, W, b)
     return x
@@ -547,16 +569,16 @@ def _seq_state(seq: torch.nn.Module):
     return dict(seq.named_parameters()), dict(seq.named_buffers())
 
 
-def _mlp_train(x2d: torch.Tensor, seq: torch.nn.Module, momentum: float = 0.1, eps: float = 1e-5) -> torch.Tensor:
+def _mlp_train(x2d: torch.Tensor, seq: torch.nn.Module, momentum: float = 0.1, eps: float = 1e-5, splits=None) -> torch.Tensor:
     params, buffers = _seq_state(seq)
     W0 = params["0.weight"]
     x2d, W0p = _pad_k4(x2d, W0.reshape(W0.shape[0], W0.shape[1]))
     params = dict(params)
     params["0.weight"] = W0p
-    y = feed_forward_train_autograd(x2d.contiguous(), params, buffers, "", momentum, eps)
+    y = feed_forward_train_autograd(x2d.contiguous(), params, buffers, "", momentum, eps, splits)
     for k, b in buffers.items():                      # nn.BatchNorm1d bookkeeping (unused by the arithmetic: momentum is fixed)
         if k.endswith("num_batches_tracked"):
-            b.add_(1)
+            b.add_(len(splits) if splits else 1)
     return y
 
 
@@ -594,7 +616,8 @@ def superglue_forward_train(model, data, frozen_bn: bool = False):
     'favor_relu', use_offset, residual, no_descriptors."""
     # frozen_bn: the module is in eval() and the caller wants gradients (fine-tuning on frozen BatchNorm statistics, saliency):
     # the reference's eval-mode forward is differentiable (superglue.py:29-72 under autograd), so is this one
-    mlp = (lambda x_, seq_: _mlp_frozen(x_, seq_)) if frozen_bn else (lambda x_, seq_: _mlp_train(x_, seq_))
+    mlp = ((lambda x_, seq_, splits_=None: _mlp_frozen(x_, seq_)) if frozen_bn
+           else (lambda x_, seq_, splits_=None: _mlp_train(x_, seq_, splits=splits_)))
     D, H = model.descriptor_dim, model.num_heads
     k0, k1 = data["keypoints0"], data["keypoints1"]
     d0, d1 = data["local_descriptors0"], data["local_descriptors1"]                # [B, N, D] token-major as they arrive
@@ -605,18 +628,22 @@ def superglue_forward_train(model, data, frozen_bn: bool = False):
     B, m, n = k0.shape[0], k0.shape[1], k1.shape[1]
     from .superglue import _get_wh
 
-    def encode(k, s, wh):
+    T0, T1 = B * m, B * n
+
+    def encoder_input(k, s, wh):
         wh1 = torch.tensor([wh[0] - 1.0, wh[1] - 1.0], device=k.device, dtype=torch.float32)
         kn = 2.0 * k.to(torch.float32) / wh1 - 1.0                                  # superglue.py:74-78
         inp = torch.cat([kn, s.to(torch.float32).reshape(k.shape[0], k.shape[1], -1)], dim=-1)
-        enc = model.positional_encoding.encoder
-        if model.siren:                                   # FeedForwardNetSiren has no BatchNorm (models/utils.py:32-45): one form in both modes
-            return _mlp_frozen(inp.reshape(-1, inp.shape[-1]), enc, True)
-        return mlp(inp.reshape(-1, inp.shape[-1]), enc)
+        return inp.reshape(-1, inp.shape[-1])
 
-    pe0, pe1 = encode(k0, s0, _get_wh(data, 0)), encode(k1, s1, _get_wh(data, 1))
-    d0f, d1f = d0.to(torch.float32).reshape(B * m, D), d1.to(torch.float32).reshape(B * n, D)
-    x0, x1 = (pe0, pe1) if model.no_descriptors else (d0f + pe0, d1f + pe1)
+    # both images through the keypoint encoder as ONE token matrix (the reference calls it twice: BatchNorm on the two row ranges)
+    inp01 = torch.cat([encoder_input(k0, s0, _get_wh(data, 0)), encoder_input(k1, s1, _get_wh(data, 1))])
+    enc = model.positional_encoding.encoder
+    pe01 = _mlp_frozen(inp01, enc, True) if model.siren else mlp(inp01, enc, (T0, T1))   # FeedForwardNetSiren has no BatchNorm (models/utils.py:32-45)
+    d01 = torch.cat([d0.to(torch.float32).reshape(T0, D), d1.to(torch.float32).reshape(T1, D)])
+    d0f, d1f = d01[:T0], d01[T0:]
+    xs = pe01 if model.no_descriptors else d01 + pe01
+    x0, x1 = xs[:T0], xs[T0:]
 
     def conv(x2d, c):
         return Conv1x1.apply(x2d.contiguous(), c.weight.reshape(c.weight.shape[0], c.weight.shape[1]), c.bias)
@@ -635,27 +662,22 @@ def superglue_forward_train(model, data, frozen_bn: bool = False):
             return favor_relu_attention_train(q3, k3, v3, mha.attention_func.projection_matrix)
         return SoftmaxAttention.apply(q3, k3, v3, H)
 
-    def finish(layer, xq, msg):                                                    # attention_gnn.py:51-55 (BatchNorm statistics per call)
+    def finish(layer, xq, msg, splits=None):                                       # attention_gnn.py:51-55 (BatchNorm statistics per call)
         y = torch.cat([xq - msg if model.use_offset else xq, msg], dim=-1)
-        return xq + mlp(y, layer.module.fc)
+        return xq + mlp(y, layer.module.fc, splits)
 
-    T0 = B * m
     for li, layer in enumerate(model.attention_gnn.layers):
         mha = layer.module.mha
-        if li % 2 == 0:                                                            # self (attention_gnn.py:63-66): the two images are independent
-            if m == n:                                                             # one token matrix: projections and attention in one launch each
-                q, k, v = conv_many(torch.cat([x0, x1]), mha.in_proj_q, mha.in_proj_k, mha.in_proj_v)
-                o = attend(mha, q.reshape(2 * B, m, D), k.reshape(2 * B, m, D), v.reshape(2 * B, m, D))
-                msg = conv(o.reshape(2 * T0, D), mha.out_proj)
-                msg0, msg1 = msg[:T0], msg[T0:]
+        if li % 2 == 0:                                                            # self (attention_gnn.py:63-66): the two images are independent:
+            xs = torch.cat([x0, x1])                                               # one token matrix, every conv in one launch, BatchNorm on the
+            q, k, v = conv_many(xs, mha.in_proj_q, mha.in_proj_k, mha.in_proj_v)   # two row ranges like the reference's two calls
+            if m == n:
+                o = attend(mha, q.reshape(2 * B, m, D), k.reshape(2 * B, m, D), v.reshape(2 * B, m, D)).reshape(T0 + T1, D)
             else:
-                msgs = []
-                for x, nx in ((x0, m), (x1, n)):
-                    q, k, v = conv_many(x, mha.in_proj_q, mha.in_proj_k, mha.in_proj_v)
-                    o = attend(mha, q.reshape(B, nx, D), k.reshape(B, nx, D), v.reshape(B, nx, D))
-                    msgs.append(conv(o.reshape(B * nx, D), mha.out_proj))
-                msg0, msg1 = msgs
-            x0, x1 = finish(layer, x0, msg0), finish(layer, x1, msg1)
+                o = torch.cat([attend(mha, q[r0:r1].reshape(B, nx, D), k[r0:r1].reshape(B, nx, D), v[r0:r1].reshape(B, nx, D)).reshape(r1 - r0, D)
+                               for r0, r1, nx in ((0, T0, m), (T0, T0 + T1, n))])
+            xs = finish(layer, xs, conv(o, mha.out_proj), (T0, T1))
+            x0, x1 = xs[:T0], xs[T0:]
         else:                                                                      # cross: image 1 sees the UPDATED image 0 (:74-77)
             q1, k1, v1 = conv_many(x1, mha.in_proj_q, mha.in_proj_k, mha.in_proj_v)   # x1 is unchanged until the second propagate
             q0 = conv(x0, mha.in_proj_q)
@@ -663,7 +685,7 @@ def superglue_forward_train(model, data, frozen_bn: bool = False):
             x0 = finish(layer, x0, conv(o0.reshape(T0, D), mha.out_proj))
             k0, v0 = conv_many(x0, mha.in_proj_k, mha.in_proj_v)
             o1 = attend(mha, q1.reshape(B, n, D), k0.reshape(B, m, D), v0.reshape(B, m, D))
-            x1 = finish(layer, x1, conv(o1.reshape(B * n, D), mha.out_proj))
+            x1 = finish(layer, x1, conv(o1.reshape(T1, D), mha.out_proj))
     g01 = conv(torch.cat([x0, x1]), model.linear_proj)                             # superglue.py:58, both images in one launch
     g0, g1 = g01[:T0], g01[T0:]
     if model.residual:

@@ -192,6 +192,8 @@ VARIANT_CASES = [  # name, config overrides, B, m, n  (train-
     ("linear", dict(descriptor_dim=64, num_stages=2, num_heads=4, num_iters=6, attention="linear"), 2, 45, 38),
     ("favor", dict(descriptor_dim=64, num_stages=1, num_heads=1, num_iters=6, attention="favor_relu"), 2, 33, 47),
     ("siren", dict(descriptor_dim=64, num_stages=1, num_heads=4, num_iters=6, encoder_name="FeedForwardNetSiren", use_offset=True), 2, 40, 36),
+    # m == n: the self layers run both images as ONE token matrix (merged launches, BatchNorm per row range) -- the bench shape
+    ("square", dict(descriptor_dim=64, num_stages=2, num_heads=4, num_iters=6, use_offset=True), 3, 44, 44),
 ]
 
 

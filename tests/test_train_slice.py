@@ -333,7 +333,8 @@ def test_split_k_weight_gradient(gpu_device, T, Cout, Cin):
 GV = dict(np.load(os.path.join(GOLDEN, "train_variants.npz")))
 VARIANT_CASES = {"linear": dict(descriptor_dim=64, num_stages=2, num_heads=4, num_iters=6, attention="linear"),
                  "favor": dict(descriptor_dim=64, num_stages=1, num_heads=1, num_iters=6, attention="favor_relu"),
-                 "siren": dict(descriptor_dim=64, num_stages=1, num_heads=4, num_iters=6, encoder_name="FeedForwardNetSiren", use_offset=True)}
+                 "siren": dict(descriptor_dim=64, num_stages=1, num_heads=4, num_iters=6, encoder_name="FeedForwardNetSiren", use_offset=True),
+                 "square": dict(descriptor_dim=64, num_stages=2, num_heads=4, num_iters=6, use_offset=True)}   # m == n: merged self layers
 
 
 def _variant_case(name):
