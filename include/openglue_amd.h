@@ -359,6 +359,19 @@ int og_transpose_f32_batched(const float* src, int64_t ld_src, int64_t stride_sr
 int og_softmax_rows(float* S, int64_t ld, int64_t rows, int32_t cols, void* stream);
 int og_softmax_rows_backward(const float* P, float* dP, int64_t ld, int64_t rows, int32_t cols, float scale, void* stream);
 
+/* Backward of multi-head softmax attention without the attention matrix (flash style, exact fp32 MFMA; csrc/attention_train.hip):
+ * q, dout [batch][nq][D], k, v [batch][nk][D] token-major fp32, D = num_heads * dh, head h = columns [h dh, (h+1) dh), dh in {16, 32, 64}.
+ * og_attention_train_lse: lse[batch][num_heads][nq] = log sum_j exp(scale q_i . k_j).
+ * og_attention_backward: delta[batch][nq][num_heads] = sum_c dout o out over the head's columns (caller); writes dk, dv [batch][nk][D] and
+ * og_attention_backward_parts(nk) partial dq tensors dq_part[part][batch][nq][D] (one per 64-key block; dq = their sum: deterministic,
+ * no atomics). */
+int og_attention_train_lse(const float* q, const float* k, int32_t batch, int32_t nq, int32_t nk, int32_t num_heads, int32_t dh,
+                           float scale, float* lse, void* stream);
+int32_t og_attention_backward_parts(int32_t nk);
+int og_attention_backward(const float* q, const float* k, const float* v, const float* dout, const float* lse, const float* delta,
+                          int32_t batch, int32_t nq, int32_t nk, int32_t num_heads, int32_t dh, float scale, float* dq_part, float* dk,
+                          float* dv, void* stream);
+
 /* mutual-NN match extraction from a scores tensor [B][m+1][n+1] (matching_module.py:174-187;
  * matches1/matching_scores1 as inference.py:183-188, may be NULL).  First maximal index wins.
  * workspace: og_matches_workspace_bytes. */

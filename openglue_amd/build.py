@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libopenglue_amd.so")
-SOURCES = ["gemm_f32.hip", "gemm_f16x3.hip", "mlp_fused.hip", "attention.hip", "linear_attention.hip", "sinkhorn.hip", "sinkhorn_resident.hip", "sinkhorn_train.hip", "batchnorm_train.hip", "matches.hip", "features.hip", "api.hip"]
+SOURCES = ["gemm_f32.hip", "gemm_f16x3.hip", "mlp_fused.hip", "attention.hip", "attention_train.hip", "linear_attention.hip", "sinkhorn.hip", "sinkhorn_resident.hip", "sinkhorn_train.hip", "batchnorm_train.hip", "matches.hip", "features.hip", "api.hip"]
 ARCH = "gfx950"
 
 

@@ -351,10 +351,12 @@ def _heads_last(x: torch.Tensor, B: int) -> torch.Tensor:
 class SoftmaxAttention(torch.autograd.Function):
     """out[b, i, h*d:(h+1)*d] = softmax_j(q_h[b, i] . k_h[b, j] / sqrt(d)) v_h[b, j]  on token-major q [B, Nq, D], k, v [B, Nk, D]
     (heads = contiguous channel blocks, attention_gnn.py:24-26).
-    Forward: the flash kernel of the inference path (og_attention: split-f16, never materialises the attention matrix).  Backward: the
-    attention matrix of THIS layer is recomputed (scale * Q K^T on the exact-fp32 MFMA GEMM + og_softmax_rows) instead of being kept
-    from the forward -- the reference's autograd keeps B*H*Nq*Nk floats per layer alive (36 layers x 64 MB at 4 x 1024 keypoints);
-    here only q, k, v are saved.  OG_TRAIN_FLASH=0: round 2's materialising forward."""
+    Forward: the flash kernel of the inference path (og_attention: split-f16, never materialises the attention matrix).  Backward:
+    flash too (og_attention_train_lse + og_attention_backward, exact fp32): the attention matrix is recomputed tile by tile in
+    registers -- the reference's autograd keeps B*H*Nq*Nk floats per layer alive (36 layers x 64 MB at 4 x 1024 keypoints); here only
+    q, k, v and the output are saved and nothing of that size is ever written.  OG_TRAIN_FLASH_BWD=0: the attention matrix of the
+    layer is recomputed as a whole (batched GEMM + og_softmax_rows) and the five products run as GEMM launches (other head sizes
+    than 16 / 32 / 64 always do); OG_TRAIN_FLASH=0: round 2's materialising forward."""
 
     @staticmethod
     def forward(ctx, q, k, v, num_heads):
@@ -363,12 +365,14 @@ class SoftmaxAttention(torch.autograd.Function):
         B, Nq, D = q.shape
         d = D // num_heads
         q32, k32, v32 = (t.detach().to(torch.float32).contiguous() for t in (q, k, v))
-        ctx.save_for_backward(q32, k32, v32)
         ctx.heads = num_heads
         if os.environ.get("OG_TRAIN_FLASH", "1") != "0" and d in (16, 32, 64):
-            return ops.attention(q32 * d ** -0.5, k32, v32, num_heads)
-        P, vh = SoftmaxAttention._probs(q32, k32, v32, num_heads)
-        return SoftmaxAttention._pv(P, vh, B)
+            out = ops.attention(q32 * d ** -0.5, k32, v32, num_heads)
+        else:
+            P, vh = SoftmaxAttention._probs(q32, k32, v32, num_heads)
+            out = SoftmaxAttention._pv(P, vh, B)
+        ctx.save_for_backward(q32, k32, v32, out)               # `out` is also the saved input of the out-projection conv: no extra memory
+        return out
 
     @staticmethod
     def _probs(q32, k32, v32, H):
@@ -399,10 +403,32 @@ class SoftmaxAttention(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        import os
         lib = _lib.load()
-        q32, k32, v32 = ctx.saved_tensors
+        q32, k32, v32, out = ctx.saved_tensors
         H = ctx.heads
-        B = q32.shape[0]
+        B, Nq, D = q32.shape
+        Nk = k32.shape[1]
+        dh = D // H
+        if os.environ.get("OG_TRAIN_FLASH_BWD", "1") != "0" and dh in (16, 32, 64):
+            # flash backward (csrc/attention_train.hip): P is recomputed tile by tile in registers from q, k and the row
+            # log-sum-exp; nothing of size Nq x Nk is ever written.  Token-major tensors in and out: no head-major copies either.
+            dev = q32.device
+            st = torch.cuda.current_stream(dev).cuda_stream
+            do = dout.detach().to(torch.float32).contiguous()
+            scale = dh ** -0.5
+            lse = torch.empty(B, H, Nq, device=dev, dtype=torch.float32)
+            delta = (do * out).reshape(B, Nq, H, dh).sum(-1)                                     # [B, Nq, H]
+            parts = lib.og_attention_backward_parts(Nk)
+            dq_part = torch.empty(parts, B, Nq, D, device=dev, dtype=torch.float32)
+            dk, dv = torch.empty_like(k32), torch.empty_like(v32)
+            with torch.cuda.device(dev):
+                _lib.check(lib.og_attention_train_lse(q32.data_ptr(), k32.data_ptr(), B, Nq, Nk, H, dh, scale, lse.data_ptr(), st),
+                           "og_attention_train_lse")
+                _lib.check(lib.og_attention_backward(q32.data_ptr(), k32.data_ptr(), v32.data_ptr(), do.data_ptr(), lse.data_ptr(),
+                                                     delta.data_ptr(), B, Nq, Nk, H, dh, scale, dq_part.data_ptr(), dk.data_ptr(),
+                                                     dv.data_ptr(), st), "og_attention_backward")
+            return (dq_part.sum(0) if parts > 1 else dq_part[0]), dk, dv, None
         P, (qh, kh, vh) = SoftmaxAttention._probs(q32, k32, v32, H)
         Z, Nq, d = qh.shape
         Nk = kh.shape[1]

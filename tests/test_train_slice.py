@@ -329,6 +329,34 @@ def test_split_k_weight_gradient(gpu_device, T, Cout, Cin):
     assert db.shape == (Cout,) and (db.cpu().double() - wb).abs().max() < 2e-6 * max(wb.abs().max(), T ** 0.5)
 
 
+# ----------------------------------------------------------------------------- flash attention backward (no Nq x Nk tensor)
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 37, 53, 4, 16), (1, 64, 64, 2, 32), (2, 130, 97, 2, 64), (1, 200, 333, 4, 64), (3, 5, 3, 1, 16)])
+@pytest.mark.parametrize("flash_bwd", ["1", "0"])
+def test_softmax_attention_backward_against_float64(gpu_device, shape, flash_bwd, monkeypatch):
+    """train.SoftmaxAttention (forward: the split-f16 flash kernel; backward: og_attention_train_lse + og_attention_backward, P
+    recomputed in registers -- or with OG_TRAIN_FLASH_BWD=0 the GEMM-by-GEMM path) vs torch autograd in float64 of
+    softmax(q k^T / sqrt(d)) v per head (attention.py:8-19): ragged tile edges in queries and keys, all head sizes."""
+    from openglue_amd import train
+    monkeypatch.setenv("OG_TRAIN_FLASH_BWD", flash_bwd)
+    B, Nq, Nk, H, d = shape
+    D = H * d
+    g = torch.Generator().manual_seed(Nq * 3 + Nk)
+    q, k, v = (torch.randn(B, n_, D, generator=g) for n_ in (Nq, Nk, Nk))
+    R = torch.randn(B, Nq, D, generator=g)
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    qh, kh, vh = (t.reshape(B, -1, H, d).transpose(1, 2) for t in (qd, kd, vd))
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * d ** -0.5, -1) @ vh).transpose(1, 2).reshape(B, Nq, D)
+    (ref * R.double()).sum().backward()
+    qg, kg, vg = (t.to(gpu_device).requires_grad_(True) for t in (q, k, v))
+    out = train.SoftmaxAttention.apply(qg, kg, vg, H)
+    (out * R.to(gpu_device)).sum().backward()
+    assert (out.detach().cpu().double() - ref.detach()).abs().max() < 2e-5
+    for name, got, want in (("dq", qg.grad, qd.grad), ("dk", kg.grad, kd.grad), ("dv", vg.grad, vd.grad)):
+        err = (got.cpu().double() - want).abs().max() / want.abs().max()
+        assert err < 2e-5, (name, float(err))
+
+
 # ----------------------------------------------------------------------------- the other attentions / encoder in training mode (VERDICT r2 item 6)
 GV = dict(np.load(os.path.join(GOLDEN, "train_variants.npz")))
 VARIANT_CASES = {"linear": dict(descriptor_dim=64, num_stages=2, num_heads=4, num_iters=6, attention="linear"),
