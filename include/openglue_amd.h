@@ -367,7 +367,7 @@ int og_softmax_rows_backward(const float* P, float* dP, int64_t ld, int64_t rows
  * no atomics). */
 int og_attention_train_lse(const float* q, const float* k, int32_t batch, int32_t nq, int32_t nk, int32_t num_heads, int32_t dh,
                            float scale, float* lse, void* stream);
-int32_t og_attention_backward_parts(int32_t nk);
+int og_attention_backward_parts(int32_t nk);
 int og_attention_backward(const float* q, const float* k, const float* v, const float* dout, const float* lse, const float* delta,
                           int32_t batch, int32_t nq, int32_t nk, int32_t num_heads, int32_t dh, float scale, float* dq_part, float* dk,
                           float* dv, void* stream);

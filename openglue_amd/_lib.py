@@ -93,7 +93,7 @@ SYMBOLS = {
                              _vp, _i64, _vp, _f, _vp]),
     "og_gemm_kmajor": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _f, _vp]),
     "og_attention_train_lse": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f, _vp, _vp]),
-    "og_attention_backward_parts": (C.c_int32, [_i32]),
+    "og_attention_backward_parts": (C.c_int, [_i32]),
     "og_attention_backward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f, _vp, _vp, _vp, _vp]),
     "og_split_f16": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
     "og_split_f16_hl": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i64, _vp]),

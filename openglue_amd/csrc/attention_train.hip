@@ -340,7 +340,7 @@ extern "C" int og_attention_train_lse(const float* q, const float* k, int32_t ba
     return og_launch_status();
 }
 
-extern "C" int32_t og_attention_backward_parts(int32_t nk) { return nk > 0 ? (nk + BC - 1) / BC : 0; }
+extern "C" int og_attention_backward_parts(int32_t nk) { return nk > 0 ? (nk + BC - 1) / BC : 0; }
 
 extern "C" int og_attention_backward(const float* q, const float* k, const float* v, const float* dout, const float* lse,
                                      const float* delta, int32_t batch, int32_t nq, int32_t nk, int32_t num_heads, int32_t dh,

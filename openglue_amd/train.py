@@ -287,12 +287,79 @@ class ConvReluBNTrain(torch.autograd.Function):
         return dx, dW, db, dgamma, dbeta, None, None, None, None, None
 
 
+class MLPBlockTrain(torch.autograd.Function):
+    """The two-conv FeedForwardNet of a GNN layer in training mode (attention_gnn.py:41-44, models/utils.py:48-58) as ONE node:
+    z = (BatchNorm_train(relu(x W0^T + b0))) W3^T + b3.  Same kernels as ConvReluBNTrain followed by Conv1x1, but the BatchNorm output
+    (the widest activation of the layer, 2D channels) is NOT kept for the backward: it is one fused multiply-add of the saved
+    pre-normalisation activation and is recomputed there.  splits: see ConvReluBNTrain."""
+
+    @staticmethod
+    def forward(ctx, x, W0, b0, gamma, beta, running_mean, running_var, momentum, eps, splits, W3, b3):
+        a = _gemm_fast(x.detach(), W0.detach().contiguous(), b0.detach(), relu=True)
+        splits = tuple(splits) if splits else (a.shape[0],)
+        if sum(splits) != a.shape[0]:
+            raise ValueError("MLPBlockTrain: splits must add up to the rows of x")
+        y = torch.empty_like(a)
+        stats, r0 = [], 0
+        for rows in splits:
+            _, mean, invstd = batch_norm_train(a[r0:r0 + rows], gamma.detach(), beta.detach(), running_mean, running_var, momentum, eps,
+                                               return_stats=True, out=y[r0:r0 + rows])
+            stats += [mean, invstd]
+            r0 += rows
+        z = _gemm_fast(y, W3.detach().contiguous(), b3.detach())
+        ctx.save_for_backward(x, W0, gamma, beta, a, W3, *stats)
+        ctx.splits = splits
+        return z
+
+    @staticmethod
+    def backward(ctx, dzo):
+        lib = _lib.load()
+        x, W0, gamma, beta, a, W3, *stats = ctx.saved_tensors
+        T, C = a.shape
+        dzo = dzo.detach().contiguous()
+        g, bt = gamma.detach(), beta.detach()
+        y = torch.empty_like(a)
+        r0 = 0
+        for i, rows in enumerate(ctx.splits):                      # y = (a - mean) invstd gamma + beta, recomputed
+            sc = stats[2 * i + 1] * g
+            torch.addcmul(bt - stats[2 * i] * sc, a[r0:r0 + rows], sc, out=y[r0:r0 + rows])
+            r0 += rows
+        dy, dW3, db3 = _conv_backward(y, W3.detach().contiguous(), dzo, True)
+        del y
+        dz = torch.empty_like(a)
+        dgamma = dbeta = None
+        r0 = 0
+        for i, rows in enumerate(ctx.splits):
+            mean, invstd = stats[2 * i], stats[2 * i + 1]
+            dg = torch.empty(C, device=a.device, dtype=torch.float32)
+            dbt = torch.empty(C, device=a.device, dtype=torch.float32)
+            a_s, dy_s, dz_s = a[r0:r0 + rows], dy[r0:r0 + rows], dz[r0:r0 + rows]
+            ws = _ws(a, rows, C)
+            with torch.cuda.device(a.device):
+                _lib.check(lib.og_batchnorm_train_backward(a_s.data_ptr(), a_s.stride(0), dy_s.data_ptr(), dy_s.stride(0), rows, C,
+                                                           g.data_ptr(), mean.data_ptr(), invstd.data_ptr(), 1, dz_s.data_ptr(),
+                                                           dz_s.stride(0), dg.data_ptr(), dbt.data_ptr(), ws.data_ptr(), _stream(a)),
+                           "og_batchnorm_train_backward")
+            dgamma = dg if dgamma is None else dgamma + dg
+            dbeta = dbt if dbeta is None else dbeta + dbt
+            r0 += rows
+        del dy
+        dx, dW0, db0 = _conv_backward(x.detach(), W0.detach().contiguous(), dz, ctx.needs_input_grad[0])
+        return dx, dW0, db0, dgamma, dbeta, None, None, None, None, None, dW3, db3
+
+
 def feed_forward_train_autograd(x: torch.Tensor, net_params, buffers, prefix: str = "", momentum: float = 0.1, eps: float = 1e-5,
                                 splits=None) -> torch.Tensor:
     """FeedForwardNet (models/utils.py:48-58) in TRAINING mode with gradients: `net_params` maps the nn.Sequential parameter names
     (`{prefix}{3i}.weight|bias`, `{prefix}{3i+2}.weight|bias`) to tensors (requires_grad as wanted; conv weights [out, in, 1] or
     [out, in]), `buffers` the BatchNorm running statistics (updated in place).  x: token-major [T, C_in]."""
     n_conv = len({k for k in net_params if k.startswith(prefix) and k.endswith(".weight") and net_params[k].dim() >= 2})
+    if n_conv == 2:                                               # the message MLP of a GNN layer: one node, BatchNorm output not kept
+        W0, W3 = (net_params[f"{prefix}{j}.weight"] for j in (0, 3))
+        bn = f"{prefix}2"
+        return MLPBlockTrain.apply(x, W0.reshape(W0.shape[0], W0.shape[1]), net_params[f"{prefix}0.bias"], net_params[bn + ".weight"],
+                                   net_params[bn + ".bias"], buffers[bn + ".running_mean"], buffers[bn + ".running_var"], momentum, eps,
+                                   splits, W3.reshape(W3.shape[0], W3.shape[1]), net_params[f"{prefix}3.bias"])
     for i in range(n_conv):
         W = net_params[f"{prefix}{3 * i}.weight"]
         W = W.reshape(W.shape[0], W.shape[1])
@@ -346,6 +413,36 @@ def _heads_last(x: torch.Tensor, B: int) -> torch.Tensor:
     BH, N, d = x.shape
     H = BH // B
     return x.reshape(B, H, N, d).permute(0, 2, 1, 3).reshape(B, N, H * d).contiguous()
+
+
+def _flash_backward_enabled(dh: int) -> bool:
+    import os
+    return os.environ.get("OG_TRAIN_FLASH_BWD", "1") != "0" and dh in (16, 32, 64)
+
+
+def _flash_attention_backward(q32, k32, v32, out, dout, H):
+    """Flash backward (csrc/attention_train.hip): P is recomputed tile by tile in registers from q, k and the row log-sum-exp; nothing
+    of size Nq x Nk is ever written.  Token-major tensors in and out ([B, N, D]): no head-major copies either.  -> dq, dk, dv."""
+    lib = _lib.load()
+    B, Nq, D = q32.shape
+    Nk = k32.shape[1]
+    dh = D // H
+    dev = q32.device
+    st = torch.cuda.current_stream(dev).cuda_stream
+    do = dout.detach().to(torch.float32).contiguous()
+    scale = dh ** -0.5
+    lse = torch.empty(B, H, Nq, device=dev, dtype=torch.float32)
+    delta = (do * out).reshape(B, Nq, H, dh).sum(-1)                                     # [B, Nq, H]
+    parts = lib.og_attention_backward_parts(Nk)
+    dq_part = torch.empty(parts, B, Nq, D, device=dev, dtype=torch.float32)
+    dk, dv = torch.empty_like(k32), torch.empty_like(v32)
+    with torch.cuda.device(dev):
+        _lib.check(lib.og_attention_train_lse(q32.data_ptr(), k32.data_ptr(), B, Nq, Nk, H, dh, scale, lse.data_ptr(), st),
+                   "og_attention_train_lse")
+        _lib.check(lib.og_attention_backward(q32.data_ptr(), k32.data_ptr(), v32.data_ptr(), do.data_ptr(), lse.data_ptr(),
+                                             delta.data_ptr(), B, Nq, Nk, H, dh, scale, dq_part.data_ptr(), dk.data_ptr(),
+                                             dv.data_ptr(), st), "og_attention_backward")
+    return (dq_part.sum(0) if parts > 1 else dq_part[0]), dk, dv
 
 
 class SoftmaxAttention(torch.autograd.Function):
@@ -410,25 +507,8 @@ class SoftmaxAttention(torch.autograd.Function):
         B, Nq, D = q32.shape
         Nk = k32.shape[1]
         dh = D // H
-        if os.environ.get("OG_TRAIN_FLASH_BWD", "1") != "0" and dh in (16, 32, 64):
-            # flash backward (csrc/attention_train.hip): P is recomputed tile by tile in registers from q, k and the row
-            # log-sum-exp; nothing of size Nq x Nk is ever written.  Token-major tensors in and out: no head-major copies either.
-            dev = q32.device
-            st = torch.cuda.current_stream(dev).cuda_stream
-            do = dout.detach().to(torch.float32).contiguous()
-            scale = dh ** -0.5
-            lse = torch.empty(B, H, Nq, device=dev, dtype=torch.float32)
-            delta = (do * out).reshape(B, Nq, H, dh).sum(-1)                                     # [B, Nq, H]
-            parts = lib.og_attention_backward_parts(Nk)
-            dq_part = torch.empty(parts, B, Nq, D, device=dev, dtype=torch.float32)
-            dk, dv = torch.empty_like(k32), torch.empty_like(v32)
-            with torch.cuda.device(dev):
-                _lib.check(lib.og_attention_train_lse(q32.data_ptr(), k32.data_ptr(), B, Nq, Nk, H, dh, scale, lse.data_ptr(), st),
-                           "og_attention_train_lse")
-                _lib.check(lib.og_attention_backward(q32.data_ptr(), k32.data_ptr(), v32.data_ptr(), do.data_ptr(), lse.data_ptr(),
-                                                     delta.data_ptr(), B, Nq, Nk, H, dh, scale, dq_part.data_ptr(), dk.data_ptr(),
-                                                     dv.data_ptr(), st), "og_attention_backward")
-            return (dq_part.sum(0) if parts > 1 else dq_part[0]), dk, dv, None
+        if _flash_backward_enabled(dh):
+            return (*_flash_attention_backward(q32, k32, v32, out, dout, H), None)
         P, (qh, kh, vh) = SoftmaxAttention._probs(q32, k32, v32, H)
         Z, Nq, d = qh.shape
         Nk = kh.shape[1]
@@ -454,6 +534,56 @@ class SoftmaxAttention(torch.autograd.Function):
         dkh = torch.empty(Z, Nk, d, device=dev, dtype=torch.float32)
         _gemm_km(dev, dS.data_ptr(), Nk4, Nq * Nk4, 1, qh.data_ptr(), d, Nq * d, dkh.data_ptr(), d, Nk * d, Nk, d, Nq, Z)
         return _heads_last(dqh, B), _heads_last(dkh, B), _heads_last(dvh, B), None
+
+
+class ProjectedAttention(torch.autograd.Function):
+    """The q / k / v projections and the multi-head softmax attention of a GNN layer (attention_gnn.py:16-33) as ONE node:
+    out = attention(xq Wq^T + bq, xkv Wk^T + bk, xkv Wv^T + bv).  Only the layer inputs and the attention output are saved (both are
+    kept by their neighbours anyway); q, k, v -- three activations per layer in the reference's graph -- are RECOMPUTED in the backward
+    by the same GEMM launch, then the flash backward and the conv backward run.  xkv None = self attention (one [T, 3D] projection
+    launch).  xq [Bz * nq, D], xkv [Bz * nk, D] token-major; returns [Bz * nq, D]."""
+
+    @staticmethod
+    def _project(xq, xkv, Wq, bq, Wk, bk, Wv, bv):
+        D = Wq.shape[0]
+        if xkv is None:
+            qkv = _gemm_fast(xq, torch.cat([Wq, Wk, Wv]), torch.cat([bq, bk, bv]))
+            return tuple(qkv[:, i * D:(i + 1) * D].contiguous() for i in range(3))
+        q = _gemm_fast(xq, Wq.contiguous(), bq)
+        kv = _gemm_fast(xkv, torch.cat([Wk, Wv]), torch.cat([bk, bv]))
+        return q, kv[:, :D].contiguous(), kv[:, D:].contiguous()
+
+    @staticmethod
+    def forward(ctx, xq, xkv, Wq, bq, Wk, bk, Wv, bv, Bz, nq, nk, H):
+        from . import ops
+        xq = xq.detach().contiguous()
+        xkv = None if xkv is None else xkv.detach().contiguous()
+        params = tuple(t.detach() for t in (Wq, bq, Wk, bk, Wv, bv))
+        D = Wq.shape[0]
+        q, k, v = ProjectedAttention._project(xq, xkv, *params)
+        out = ops.attention(q.reshape(Bz, nq, D) * (D // H) ** -0.5, k.reshape(Bz, nk, D), v.reshape(Bz, nk, D), H)
+        ctx.geom = (Bz, nq, nk, H, xkv is None)
+        ctx.save_for_backward(xq, *params, out, *(() if xkv is None else (xkv,)))
+        return out.reshape(Bz * nq, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        Bz, nq, nk, H, is_self = ctx.geom
+        xq, Wq, bq, Wk, bk, Wv, bv, out, *rest = ctx.saved_tensors
+        xkv = None if is_self else rest[0]
+        D = Wq.shape[0]
+        q, k, v = ProjectedAttention._project(xq, xkv, Wq, bq, Wk, bk, Wv, bv)
+        dq, dk, dv = _flash_attention_backward(q.reshape(Bz, nq, D), k.reshape(Bz, nk, D), v.reshape(Bz, nk, D), out,
+                                               dout.reshape(Bz, nq, D), H)
+        del q, k, v
+        if is_self:
+            dqkv = torch.cat([dq.reshape(-1, D), dk.reshape(-1, D), dv.reshape(-1, D)], dim=1)
+            dx, dW, db = _conv_backward(xq, torch.cat([Wq, Wk, Wv]), dqkv, ctx.needs_input_grad[0])
+            return (dx, None, dW[:D], db[:D], dW[D:2 * D], db[D:2 * D], dW[2 * D:], db[2 * D:], None, None, None, None)
+        dxq, dWq, dbq = _conv_backward(xq, Wq.contiguous(), dq.reshape(-1, D), ctx.needs_input_grad[0])
+        dkv = torch.cat([dk.reshape(-1, D), dv.reshape(-1, D)], dim=1)
+        dxkv, dWkv, dbkv = _conv_backward(xkv, torch.cat([Wk, Wv]), dkv, ctx.needs_input_grad[1])
+        return (dxq, dxkv, dWq, dbq, dWkv[:D], dbkv[:D], dWkv[D:], dbkv[D:], None, None, None, None)
 
 
 def _pad_rows(x: torch.Tensor, rows: int) -> torch.Tensor:
@@ -692,19 +822,38 @@ def superglue_forward_train(model, data, frozen_bn: bool = False):
         y = torch.cat([xq - msg if model.use_offset else xq, msg], dim=-1)
         return xq + mlp(y, layer.module.fc, splits)
 
+    import os
+    fused_attn = (not model.linear_attention and not model.favor_relu and _flash_backward_enabled(D // H)
+                  and os.environ.get("OG_TRAIN_FLASH", "1") != "0")
+
+    def w2(c):
+        return c.weight.reshape(c.weight.shape[0], c.weight.shape[1])
+
+    def proj_attend(mha, xq, xkv, Bz, nq, nk):                                     # projections + attention, q / k / v not kept
+        return ProjectedAttention.apply(xq, xkv, w2(mha.in_proj_q), mha.in_proj_q.bias, w2(mha.in_proj_k), mha.in_proj_k.bias,
+                                        w2(mha.in_proj_v), mha.in_proj_v.bias, Bz, nq, nk, H)
+
     for li, layer in enumerate(model.attention_gnn.layers):
         mha = layer.module.mha
         if li % 2 == 0:                                                            # self (attention_gnn.py:63-66): the two images are independent:
             xs = torch.cat([x0, x1])                                               # one token matrix, every conv in one launch, BatchNorm on the
-            q, k, v = conv_many(xs, mha.in_proj_q, mha.in_proj_k, mha.in_proj_v)   # two row ranges like the reference's two calls
-            if m == n:
-                o = attend(mha, q.reshape(2 * B, m, D), k.reshape(2 * B, m, D), v.reshape(2 * B, m, D)).reshape(T0 + T1, D)
+            if fused_attn and m == n:                                              # two row ranges like the reference's two calls
+                o = proj_attend(mha, xs, None, 2 * B, m, m)
+            elif fused_attn:
+                o = torch.cat([proj_attend(mha, xs[:T0], None, B, m, m), proj_attend(mha, xs[T0:], None, B, n, n)])
             else:
-                o = torch.cat([attend(mha, q[r0:r1].reshape(B, nx, D), k[r0:r1].reshape(B, nx, D), v[r0:r1].reshape(B, nx, D)).reshape(r1 - r0, D)
-                               for r0, r1, nx in ((0, T0, m), (T0, T0 + T1, n))])
+                q, k, v = conv_many(xs, mha.in_proj_q, mha.in_proj_k, mha.in_proj_v)
+                if m == n:
+                    o = attend(mha, q.reshape(2 * B, m, D), k.reshape(2 * B, m, D), v.reshape(2 * B, m, D)).reshape(T0 + T1, D)
+                else:
+                    o = torch.cat([attend(mha, q[r0:r1].reshape(B, nx, D), k[r0:r1].reshape(B, nx, D), v[r0:r1].reshape(B, nx, D)).reshape(r1 - r0, D)
+                                   for r0, r1, nx in ((0, T0, m), (T0, T0 + T1, n))])
             xs = finish(layer, xs, conv(o, mha.out_proj), (T0, T1))
             x0, x1 = xs[:T0], xs[T0:]
-        else:                                                                      # cross: image 1 sees the UPDATED image 0 (:74-77)
+        elif fused_attn:                                                           # cross: image 1 sees the UPDATED image 0 (:74-77)
+            x0 = finish(layer, x0, conv(proj_attend(mha, x0, x1, B, m, n), mha.out_proj))
+            x1 = finish(layer, x1, conv(proj_attend(mha, x1, x0, B, n, m), mha.out_proj))
+        else:
             q1, k1, v1 = conv_many(x1, mha.in_proj_q, mha.in_proj_k, mha.in_proj_v)   # x1 is unchanged until the second propagate
             q0 = conv(x0, mha.in_proj_q)
             o0 = attend(mha, q0.reshape(B, m, D), k1.reshape(B, n, D), v1.reshape(B, n, D))
