@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define OG_ABI_VERSION 5
+#define OG_ABI_VERSION 6
 
 #define OG_E_INVALID   (-1)  /* NULL pointer / non-positive size                         */
 #define OG_E_SHAPE     (-2)  /* unsupported shape (see og_check_shape)                   */
@@ -318,11 +318,12 @@ int og_forward_status(const og_shape* shape, const void* workspace_dev);
  * the training workspace; og_sinkhorn_backward: given grad_scores = dL/dscores [B][m+1][n+1] it back-propagates through the
  * `iters` unrolled iterations and writes dS [B][m][ldds] (gradient w.r.t. the raw score matrix) and *d_dustbin (device
  * scalar, may be NULL; gradient w.r.t. dustbin_score).  n <= 4159, iters >= 1.  fp32 atomics: gradients reproducible to
- * rounding, not bit for bit.  The same workspace must be passed to both calls. */
+ * rounding, not bit for bit.  The same workspace must be passed to both calls.  ABI v6: dustbin_dev (device scalar, or NULL =
+ * use the host value `dustbin`) -- the learnable dustbin_score is read ON the device, the training step never waits for the GPU. */
 size_t og_sinkhorn_train_workspace_bytes(int32_t batch, int32_t m, int32_t n, int32_t iters);
-int og_sinkhorn_train_forward(const float* S, int64_t lds, float dustbin, int32_t batch, int32_t m, int32_t n, int32_t iters,
-                              float reg, float* scores, void* train_workspace_dev, void* stream);
-int og_sinkhorn_backward(const float* S, int64_t lds, float dustbin, int32_t batch, int32_t m, int32_t n, int32_t iters,
+int og_sinkhorn_train_forward(const float* S, int64_t lds, float dustbin, const float* dustbin_dev, int32_t batch, int32_t m, int32_t n,
+                              int32_t iters, float reg, float* scores, void* train_workspace_dev, void* stream);
+int og_sinkhorn_backward(const float* S, int64_t lds, float dustbin, const float* dustbin_dev, int32_t batch, int32_t m, int32_t n, int32_t iters,
                          float reg, const float* grad_scores, void* train_workspace_dev, float* dS, int64_t ldds,
                          float* d_dustbin, void* stream);
 

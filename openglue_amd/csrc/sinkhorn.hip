@@ -865,7 +865,7 @@ int sinkhorn_run(const float* S, int64_t lds, const float* zdev, float dustbin, 
 
 // Training forward (sinkhorn_train.hip): max-subtracted iterations only, u_t / v_t of every iteration kept:
 // U [iters][B][ldu], V [iters + 1][B][ldv] with V[0] = 0; ldu / ldv as sk_layout.
-int og_launch_sinkhorn_trajectory(const float* S, int64_t lds, float dustbin, int B, int m, int n, int iters, float reg, float* scores,
+int og_launch_sinkhorn_trajectory(const float* S, int64_t lds, const float* dustbin_dev, float dustbin, int B, int m, int n, int iters, float reg, float* scores,
                                   void* workspace, float* U, float* V, hipStream_t st) {
     if (n > 8192) return OG_E_SHAPE;
     SinkhornWs w = sk_layout(workspace, B, m, n);
@@ -881,16 +881,16 @@ int og_launch_sinkhorn_trajectory(const float* S, int64_t lds, float dustbin, in
         const float* vin = V + (size_t)it * B * w.ldv;
         float* vout = V + (size_t)(it + 1) * B * w.ldv;
         w.u = U + (size_t)it * B * w.ldu;                      // the sweep writes u_t of every row, the combine u_t of the dustbin row
-        if (g.CPL == 1) launch_sweep<1, 4, 1>(S, lds, B, m, n, nullptr, dustbin, inv_reg, la, vin, w, st, rd);
-        else if (g.CPL == 2) launch_sweep<2, 4, 1>(S, lds, B, m, n, nullptr, dustbin, inv_reg, la, vin, w, st, rd);
-        else if (g.CPL == 8) launch_sweep<8, 1, 4>(S, lds, B, m, n, nullptr, dustbin, inv_reg, la, vin, w, st, rd);
-        else if (g.WPR == 1) launch_sweep<4, 2, 1>(S, lds, B, m, n, nullptr, dustbin, inv_reg, la, vin, w, st, rd);
-        else if (g.WPR == 2) launch_sweep<4, 2, 2>(S, lds, B, m, n, nullptr, dustbin, inv_reg, la, vin, w, st, rd);
-        else launch_sweep<4, 2, 4>(S, lds, B, m, n, nullptr, dustbin, inv_reg, la, vin, w, st, rd);
-        hipLaunchKernelGGL(sinkhorn_combine_kernel<RaggedNone>, dim3((n + 1 + 255) / 256, B), dim3(256), 0, st, m, n, (const float*)nullptr, dustbin,
+        if (g.CPL == 1) launch_sweep<1, 4, 1>(S, lds, B, m, n, dustbin_dev, dustbin, inv_reg, la, vin, w, st, rd);
+        else if (g.CPL == 2) launch_sweep<2, 4, 1>(S, lds, B, m, n, dustbin_dev, dustbin, inv_reg, la, vin, w, st, rd);
+        else if (g.CPL == 8) launch_sweep<8, 1, 4>(S, lds, B, m, n, dustbin_dev, dustbin, inv_reg, la, vin, w, st, rd);
+        else if (g.WPR == 1) launch_sweep<4, 2, 1>(S, lds, B, m, n, dustbin_dev, dustbin, inv_reg, la, vin, w, st, rd);
+        else if (g.WPR == 2) launch_sweep<4, 2, 2>(S, lds, B, m, n, dustbin_dev, dustbin, inv_reg, la, vin, w, st, rd);
+        else launch_sweep<4, 2, 4>(S, lds, B, m, n, dustbin_dev, dustbin, inv_reg, la, vin, w, st, rd);
+        hipLaunchKernelGGL(sinkhorn_combine_kernel<RaggedNone>, dim3((n + 1 + 255) / 256, B), dim3(256), 0, st, m, n, dustbin_dev, dustbin,
                            inv_reg, la_bin, lb, lb_bin, vin, vout, w.ldv, w.u, w.ldu, w.pm, w.ps, w.ldp, w.RB, rd);
     }
-    hipLaunchKernelGGL(sinkhorn_scores_kernel<RaggedNone>, dim3((m + 1 + 3) / 4, B), dim3(256), 0, st, S, lds, m, n, (const float*)nullptr, dustbin,
+    hipLaunchKernelGGL(sinkhorn_scores_kernel<RaggedNone>, dim3((m + 1 + 3) / 4, B), dim3(256), 0, st, S, lds, m, n, dustbin_dev, dustbin,
                        inv_reg, (float)norm, U + (size_t)(iters - 1) * B * w.ldu, w.ldu, V + (size_t)iters * B * w.ldv, w.ldv, scores,
                        (int64_t)m * lds, rd, RowBest{nullptr, nullptr, 0}, (unsigned*)nullptr);
     return og_launch_status();

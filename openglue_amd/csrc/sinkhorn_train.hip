@@ -23,7 +23,7 @@
 #include "og_common.h"
 
 // sinkhorn.hip
-int og_launch_sinkhorn_trajectory(const float* S, int64_t lds, float dustbin, int B, int m, int n, int iters, float reg, float* scores,
+int og_launch_sinkhorn_trajectory(const float* S, int64_t lds, const float* dustbin_dev, float dustbin, int B, int m, int n, int iters, float reg, float* scores,
                                   void* workspace, float* U, float* V, hipStream_t st);
 
 namespace {
@@ -58,11 +58,13 @@ TrainWs tw_layout(void* ws, int B, int m, int n, int T) {
 }
 
 // Za = [[S, z], [z, z]] / reg ; dZ = G ; du = rowsum(G) ; dv += colsum(G) (dv zeroed before).  One wave per row.
-__global__ __launch_bounds__(256) void sk_bwd_init_kernel(const float* __restrict__ S, int64_t lds, float z, float inv_reg, int M, int N,
+__global__ __launch_bounds__(256) void sk_bwd_init_kernel(const float* __restrict__ S, int64_t lds, const float* __restrict__ z_dev, float z,
+                                                          float inv_reg, int M, int N,
                                                           const float* __restrict__ G, float* __restrict__ Za, float* __restrict__ dZ,
                                                           int lda, float* __restrict__ du, int ldu, float* __restrict__ dv, int ldv) {
     const int b = blockIdx.y, row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row > M) return;
+    if (z_dev) z = *z_dev;
     const float* g = G + ((int64_t)b * (M + 1) + row) * (N + 1);
     float* za = Za + ((int64_t)b * (M + 1) + row) * lda;
     float* dz = dZ + ((int64_t)b * (M + 1) + row) * lda;
@@ -154,16 +156,16 @@ extern "C" size_t og_sinkhorn_train_workspace_bytes(int32_t batch, int32_t m, in
     return tw_layout(nullptr, batch, m, n, iters).total;
 }
 
-extern "C" int og_sinkhorn_train_forward(const float* S, int64_t lds, float dustbin, int32_t batch, int32_t m, int32_t n, int32_t iters,
+extern "C" int og_sinkhorn_train_forward(const float* S, int64_t lds, float dustbin, const float* dustbin_dev, int32_t batch, int32_t m, int32_t n, int32_t iters,
                                          float reg, float* scores, void* train_workspace_dev, void* stream) {
     og_clear_status();
     if (!S || !scores || !train_workspace_dev || batch <= 0 || m <= 0 || n <= 0 || n > 4159 || iters < 1 || !(reg > 0.f)) return OG_E_INVALID;
     if ((lds & 3) || ((uintptr_t)S & 15) || ((uintptr_t)train_workspace_dev & 255)) return OG_E_ALIGN;
     const TrainWs w = tw_layout(train_workspace_dev, batch, m, n, iters);
-    return og_launch_sinkhorn_trajectory(S, lds, dustbin, batch, m, n, iters, reg, scores, w.fwd, w.U, w.V, (hipStream_t)stream);
+    return og_launch_sinkhorn_trajectory(S, lds, dustbin_dev, dustbin, batch, m, n, iters, reg, scores, w.fwd, w.U, w.V, (hipStream_t)stream);
 }
 
-extern "C" int og_sinkhorn_backward(const float* S, int64_t lds, float dustbin, int32_t batch, int32_t m, int32_t n, int32_t iters,
+extern "C" int og_sinkhorn_backward(const float* S, int64_t lds, float dustbin, const float* dustbin_dev, int32_t batch, int32_t m, int32_t n, int32_t iters,
                                     float reg, const float* grad_scores, void* train_workspace_dev, float* dS, int64_t ldds,
                                     float* d_dustbin, void* stream) {
     og_clear_status();
@@ -179,7 +181,7 @@ extern "C" int og_sinkhorn_backward(const float* S, int64_t lds, float dustbin, 
     hipError_t e = hipMemsetAsync(w.dv[0], 0, sizeof(float) * (size_t)B * w.ldv, st);
     if (e != hipSuccess) return (int)e;
     if (d_dustbin && (e = hipMemsetAsync(d_dustbin, 0, sizeof(float), st)) != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(sk_bwd_init_kernel, dim3((m + 1 + 3) / 4, B), dim3(256), 0, st, S, lds, dustbin, inv_reg, m, n, grad_scores, w.Za,
+    hipLaunchKernelGGL(sk_bwd_init_kernel, dim3((m + 1 + 3) / 4, B), dim3(256), 0, st, S, lds, dustbin_dev, dustbin, inv_reg, m, n, grad_scores, w.Za,
                        w.dZ, w.lda, w.du, w.ldu, w.dv[0], w.ldv);
     const int rows_grid = (m + 1 + 3) / 4 < 64 ? (m + 1 + 3) / 4 : 64;       // waves stride over the rows
     int cur = 0;

@@ -51,25 +51,26 @@ class SinkhornOT(torch.autograd.Function):
         ws = torch.empty(nbytes + 256, device=S.device, dtype=torch.uint8)
         off = (-ws.data_ptr()) % 256
         scores = torch.empty(B, m + 1, n + 1, device=S.device, dtype=torch.float32)
-        z = float(dustbin_score.detach())
+        # the learnable dustbin score is read ON the device (ABI v6): no float(tensor) here, the host never waits for the GPU mid-step
+        zdev = dustbin_score.detach().to(device=S.device, dtype=torch.float32).reshape(1).contiguous()
         with torch.cuda.device(S.device):
-            _lib.check(lib.og_sinkhorn_train_forward(Sp.data_ptr(), lds, z, B, m, n, int(num_iters), float(reg), scores.data_ptr(),
-                                                     ws.data_ptr() + off, _stream(S)), "og_sinkhorn_train_forward")
-        ctx.save_for_backward(Sp)
-        ctx.ws, ctx.off, ctx.args = ws, off, (B, m, n, lds, int(num_iters), float(reg), z)
+            _lib.check(lib.og_sinkhorn_train_forward(Sp.data_ptr(), lds, 0.0, zdev.data_ptr(), B, m, n, int(num_iters), float(reg),
+                                                     scores.data_ptr(), ws.data_ptr() + off, _stream(S)), "og_sinkhorn_train_forward")
+        ctx.save_for_backward(Sp, zdev)
+        ctx.ws, ctx.off, ctx.args = ws, off, (B, m, n, lds, int(num_iters), float(reg))
         ctx.dustbin_meta = (dustbin_score.dtype, dustbin_score.shape)
         return scores
 
     @staticmethod
     def backward(ctx, grad_scores: torch.Tensor):
         lib = _lib.load()
-        (Sp,) = ctx.saved_tensors
-        B, m, n, lds, iters, reg, z = ctx.args
+        Sp, zdev = ctx.saved_tensors
+        B, m, n, lds, iters, reg = ctx.args
         g = grad_scores.detach().to(torch.float32).contiguous()
         dS = torch.empty(B, m, lds, device=Sp.device, dtype=torch.float32)
         dz = torch.zeros(1, device=Sp.device, dtype=torch.float32)
         with torch.cuda.device(Sp.device):
-            _lib.check(lib.og_sinkhorn_backward(Sp.data_ptr(), lds, z, B, m, n, iters, reg, g.data_ptr(), ctx.ws.data_ptr() + ctx.off,
+            _lib.check(lib.og_sinkhorn_backward(Sp.data_ptr(), lds, 0.0, zdev.data_ptr(), B, m, n, iters, reg, g.data_ptr(), ctx.ws.data_ptr() + ctx.off,
                                                 dS.data_ptr(), lds, dz.data_ptr(), _stream(Sp)), "og_sinkhorn_backward")
         dtype, shape = ctx.dustbin_meta
         return dS[:, :, :n], dz.reshape(shape).to(dtype), None, None
