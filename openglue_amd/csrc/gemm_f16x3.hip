@@ -340,11 +340,19 @@ __device__ __forceinline__ void gemm_f16x3_epilogue_finish_spec(const GemmHArgs&
 template <bool HL, int EM, int NJ>
 __device__ __forceinline__ void gemm_f16x3_epilogue_fast(const GemmHArgs& g, f32x16 (&acc)[2][NJ], int tok0, int oc0, int lane, char* slab2) {
 #pragma clang fp contract(off)                  // og_split: hi and lo must see the same rounded value (og_common.h)
-    constexpr int ROWB = 128 + 16;
+    // Slab rows are exactly 128 B; the 16-byte chunk c of row r lives at chunk c ^ ((r >> 1) & 7).  Accumulator-layout accesses (a
+    // 16-lane group = 16 consecutive rows at ONE logical chunk, 8 B per lane) then touch 8 different chunks in the even rows (banks
+    // 0-31) and 8 in the odd rows (banks 32-63); whole-line accesses (16 lanes = two rows x 8 chunks, 16 B per lane) cover each
+    // row's 32 banks once: both conflict-free.  (Round 2 padded the rows to 144 B: the line accesses of rows r, r+1 overlapped in
+    // four banks and rows r, r+16 of a column access shared theirs -- 24 % of the LDS cycles of this kernel class were conflicts.)
+    constexpr int ROWB = 128;
     constexpr bool HAS_RES = EM == OG_EM_RUNTIME || EM == OG_EM_RES_HL;
     const int l31 = lane & 31, hi = lane >> 5;
     const unsigned voff = (unsigned)((lane >> 3) * (int)g.ldch * 2 + (lane & 7) * 16);       // 8 rows x 128 B per store instruction
-    const unsigned rd_off = (unsigned)((lane >> 3) * ROWB + (lane & 7) * 16);
+    // line access of instruction `it`: row it*8 + (lane >> 3) -> key ((it*8 + (lane >> 3)) >> 1) & 7 = (4 it + (lane >> 4)) & 7
+    auto rd_off = [&](int it) { return (unsigned)((lane >> 3) * ROWB + (((lane & 7) ^ ((4 * it + (lane >> 4)) & 7)) * 16)); };
+    const unsigned ckey = (unsigned)((l31 >> 1) & 7);                                          // column access: row l31
+    auto col_off = [&](int chunk) { return (unsigned)(l31 * ROWB + ((chunk ^ ckey) * 16) + hi * 8); };
     char* const out_h = reinterpret_cast<char*>(g.Ch);
     char* const out_l = reinterpret_cast<char*>(g.Cl);
     og_u32x4 raw[2][4];
@@ -377,14 +385,14 @@ __device__ __forceinline__ void gemm_f16x3_epilogue_fast(const GemmHArgs& g, f32
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int it = 0; it < 4; ++it) *reinterpret_cast<og_u32x4*>(slab2 + i * EPI_SLAB + it * 8 * ROWB + rd_off) = rrow[i][it];
+                for (int it = 0; it < 4; ++it) *reinterpret_cast<og_u32x4*>(slab2 + i * EPI_SLAB + it * 8 * ROWB + rd_off(it)) = rrow[i][it];
             if (j + 1 < NJ) load_res_rows(tok0 + (j + 1) * 32);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const char* d = slab2 + i * EPI_SLAB + l31 * ROWB + (8 * q + 4 * hi) * 2;
-                    const uint2 h2 = *reinterpret_cast<const uint2*>(d), l2 = *reinterpret_cast<const uint2*>(d + 64);
+                    const char* sb = slab2 + i * EPI_SLAB;
+                    const uint2 h2 = *reinterpret_cast<const uint2*>(sb + col_off(q)), l2 = *reinterpret_cast<const uint2*>(sb + col_off(q + 4));
                     raw[i][q] = og_u32x4{h2.x, h2.y, l2.x, l2.y};
                 }
         }
@@ -399,11 +407,11 @@ __device__ __forceinline__ void gemm_f16x3_epilogue_fast(const GemmHArgs& g, f32
                 unsigned ha, la, hb, lb;
                 og_split4(a[i][4 * q], a[i][4 * q + 1], a[i][4 * q + 2], a[i][4 * q + 3], ha, la, hb, lb);
                 if (HL) {
-                    char* d = slab2 + i * EPI_SLAB + l31 * ROWB + (8 * q + 4 * hi) * 2;
-                    *reinterpret_cast<uint2*>(d) = make_uint2(ha, hb);
-                    *reinterpret_cast<uint2*>(d + 64) = make_uint2(la, lb);
+                    char* sb = slab2 + i * EPI_SLAB;
+                    *reinterpret_cast<uint2*>(sb + col_off(q)) = make_uint2(ha, hb);
+                    *reinterpret_cast<uint2*>(sb + col_off(q + 4)) = make_uint2(la, lb);
                 } else {
-                    char* d = slab2 + l31 * ROWB + (i * 32 + 8 * q + 4 * hi) * 2;
+                    char* d = slab2 + col_off(4 * i + q);
                     *reinterpret_cast<uint2*>(d) = make_uint2(ha, hb);
                     *reinterpret_cast<uint2*>(d + EPI_SLAB) = make_uint2(la, lb);
                 }
@@ -413,7 +421,7 @@ __device__ __forceinline__ void gemm_f16x3_epilogue_fast(const GemmHArgs& g, f32
         for (int i = 0; i < 2; ++i) {
             f16x8 t[4];
 #pragma unroll
-            for (int it = 0; it < 4; ++it) t[it] = *reinterpret_cast<const f16x8*>(slab2 + i * EPI_SLAB + it * 8 * ROWB + rd_off);
+            for (int it = 0; it < 4; ++it) t[it] = *reinterpret_cast<const f16x8*>(slab2 + i * EPI_SLAB + it * 8 * ROWB + rd_off(it));
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int64_t row = (int64_t)(tok0 + j * 32 + it * 8) * g.ldch;          // scalar
