@@ -347,7 +347,8 @@ int og_batchnorm_train_forward(const float* x, int64_t ldx, int64_t rows, int32_
 int og_batchnorm_train_backward(const float* a, int64_t lda, const float* dy, int64_t lddy, int64_t rows, int32_t channels,
                                 const float* weight, const float* save_mean, const float* save_invstd, int32_t relu_mask,
                                 float* dz, int64_t lddz, float* dweight, float* dbias, void* workspace_dev, void* stream);
-/* Helpers of the 1x1-conv backward on token-major activations (dW = dZ^T X as og_gemm_nt(dZ^T, X^T); db = column sums of dZ):
+/* Helpers of the 1x1-conv backward on token-major activations (dW = dZ^T X as og_gemm_nt(dZ^T, X^T); db = column sums of dZ); kept
+ * for callers of the NT form -- openglue_amd.train uses og_gemm_kmajor (operands as they lie, bias gradient in the same launch) since v6:
  * dst[c][r] = src[r][c]; out[c] = sum_r x[r][c] (workspace: og_batchnorm_train_workspace_bytes(rows, channels) is enough). */
 int og_transpose_f32(const float* src, int64_t ld_src, int64_t rows, int32_t cols, float* dst, int64_t ld_dst, void* stream);
 int og_colsum_f32(const float* x, int64_t ldx, int64_t rows, int32_t channels, float* out, void* workspace_dev, void* stream);

@@ -392,13 +392,6 @@ def _gemm_km(dev, A, lda, sA, a_kmajor, Bp, ldb, sB, Cp, ldc, sC, M, N, K, batch
                                       torch.cuda.current_stream(dev).cuda_stream), "og_gemm_kmajor")
 
 
-def _transpose_raw(dev, src, ld_src, s_src, rows, cols, dst, ld_dst, s_dst, batch):
-    lib = _lib.load()
-    with torch.cuda.device(dev):
-        _lib.check(lib.og_transpose_f32_batched(src, ld_src, s_src, rows, cols, dst, ld_dst, s_dst, batch,
-                                                torch.cuda.current_stream(dev).cuda_stream), "og_transpose_f32_batched")
-
-
 def _r4(n: int) -> int:
     return (n + 3) // 4 * 4
 
