@@ -225,7 +225,6 @@ class Conv1x1(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, W, b):
-        from . import ops
         ctx.save_for_backward(x, W)
         return _gemm_fast(x.detach(), W.detach().contiguous(), b.detach())
 
@@ -494,7 +493,6 @@ class SoftmaxAttention(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        import os
         lib = _lib.load()
         q32, k32, v32, out = ctx.saved_tensors
         H = ctx.heads
