@@ -277,10 +277,12 @@ int og_mlp_block(int32_t D, void* xo_rows, int64_t ld, int32_t M, const void* st
 /* softmax attention (attention.py:8-19) for `batch` independent problems and H heads, operands and
  * result as split-f16 planes: q [batch][nq][ldq] (columns h*dh.. of row i = head h, PRE-SCALED by
  * dh^-0.5 * log2(e): the kernel evaluates softmax as 2^(q.k - max)), k, v [batch][nk][ld*],
- * out [batch][nq][ldo]; leading dimensions in elements.  dh in {16,32,64}. */
+ * out [batch][nq][ldo]; leading dimensions in elements.  dh in {16,32,64}.
+ * ABI v6: lse (may be NULL) [batch][num_heads][nq] receives the row log-sum-exp of the scaled scores in natural units,
+ * ln sum_j exp(dh^-0.5 q_i . k_j) -- what a backward pass that recomputes the attention matrix needs (og_attention_backward). */
 int og_attention(const void* qh, const void* ql, int64_t ldq, const void* kh, const void* kl, int64_t ldk,
                  const void* vh, const void* vl, int64_t ldv, void* oh, void* ol, int64_t ldo, int32_t batch,
-                 int32_t nq, int32_t nk, int32_t num_heads, int32_t dh, void* stream);
+                 int32_t nq, int32_t nk, int32_t num_heads, int32_t dh, float* lse, void* stream);
 
 /* log-domain Sinkhorn with implicit dustbins (superglue.py:88-111 + optimal_transport.py:20-28):
  * S [B][m][lds] (lds % 4 == 0) is the raw score matrix, `dustbin` the learnt bin score; writes

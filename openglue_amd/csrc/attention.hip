@@ -401,6 +401,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a, RD rd) {
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.f / l_tot;
     const int qi = q0 + wave * 32 + l31;
+    // row log-sum-exp of the (scaled) scores in natural units, for a backward pass that recomputes P (uniform calls only):
+    // the kernel works in base 2 (q carries log2 e): L = ln 2 (m_run + log2 l)
+    if (a.lse && hi == 0 && qi < nq) a.lse[((int64_t)z * a.num_heads + h) * nq + qi] = (m_run + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
     if (qi < nq) {
         const int64_t orow = (q_row0 + qi) * a.ldo;
 #pragma unroll
@@ -800,6 +803,9 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(AttnArgs a, RD rd
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.f / l_tot;
     const int qi = q0 + wave * 32 + l31;
+    // row log-sum-exp of the (scaled) scores in natural units, for a backward pass that recomputes P (uniform calls only):
+    // the kernel works in base 2 (q carries log2 e): L = ln 2 (m_run + log2 l)
+    if (a.lse && hi == 0 && qi < nq) a.lse[((int64_t)z * a.num_heads + h) * nq + qi] = (m_run + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
     if (qi < nq) {
         const int64_t orow = (q_row0 + qi) * a.ldo;
 #pragma unroll
@@ -889,9 +895,10 @@ extern "C" int og_debug_attn_trace(void* host_dst, size_t bytes) {
 
 extern "C" int og_attention(const void* qh, const void* ql, int64_t ldq, const void* kh, const void* kl, int64_t ldk,
                             const void* vh, const void* vl, int64_t ldv, void* oh, void* ol, int64_t ldo, int32_t batch,
-                            int32_t nq, int32_t nk, int32_t num_heads, int32_t dh, void* stream) {
+                            int32_t nq, int32_t nk, int32_t num_heads, int32_t dh, float* lse, void* stream) {
     og_clear_status();
     AttnArgs a{};
+    a.lse = lse;
     a.qh = (const _Float16*)qh; a.ql = (const _Float16*)ql; a.ldq = ldq;
     a.kh = (const _Float16*)kh; a.kl = (const _Float16*)kl; a.ldk = ldk;
     a.vh = (const _Float16*)vh; a.vl = (const _Float16*)vl; a.ldv = ldv;

@@ -198,6 +198,7 @@ struct AttnArgs {
     const RaggedDesc* rag;    // host pointer or null; with rag_mode: 1 = self (z < B image 0, else image 1),
     int rag_mode;             // 2 = cross, queries of image 0 attend image 1, 3 = cross, image 1 attends image 0
     int feat;                 // og_launch_favor_attention only: random features per head (columns of q and k; v / out have dh columns)
+    float* lse;               // optional (uniform single-geometry calls): [nz][num_heads][nq] row log-sum-exp of the scaled scores, natural units
 };
 int og_launch_attention(const AttnArgs& a, hipStream_t stream);
 int og_launch_linear_attention(const AttnArgs& a, hipStream_t stream);   // attention = 'linear' (elu+1 feature map)

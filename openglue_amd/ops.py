@@ -161,11 +161,12 @@ def mlp_block(x: torch.Tensor, o: torch.Tensor, w0: torch.Tensor, b0: torch.Tens
     return (out, rows) if return_rows else out
 
 
-def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int) -> torch.Tensor:
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int, return_lse: bool = False):
     """Multi-head softmax attention on token-major fp32 tensors q [Z,nq,D], k,v [Z,nk,D]; head h owns
     channels h*d..(h+1)*d-1.  q must already carry the d^-1/2 scale (the log2(e) factor of the kernel's
     base-2 softmax is applied here).  Operands are converted to the kernel's split-f16 planes on the
-    device; the result planes are merged back to fp32."""
+    device; the result planes are merged back to fp32.  return_lse: also the row log-sum-exp of the scaled scores
+    [Z, num_heads, nq] (natural units), straight from the kernel's online-softmax state."""
     lib = _lib.load()
     q, k, v = _req(q * 1.4426950408889634, "q"), _req(k, "k"), _req(v, "v")
     Z, nq, D = q.shape
@@ -173,10 +174,12 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int)
     (qh, ql), (kh, kl), (vh, vl) = split_f16(q), split_f16(k), split_f16(v)
     oh = torch.empty(Z, nq, D, device=q.device, dtype=torch.float16)
     ol = torch.empty_like(oh)
+    lse = torch.empty(Z, num_heads, nq, device=q.device, dtype=torch.float32) if return_lse else None
     rc = lib.og_attention(qh.data_ptr(), ql.data_ptr(), D, kh.data_ptr(), kl.data_ptr(), D, vh.data_ptr(), vl.data_ptr(), D,
-                          oh.data_ptr(), ol.data_ptr(), D, Z, nq, nk, num_heads, D // num_heads, _stream())
+                          oh.data_ptr(), ol.data_ptr(), D, Z, nq, nk, num_heads, D // num_heads,
+                          None if lse is None else lse.data_ptr(), _stream())
     _lib.check(rc, "og_attention")
-    return merge_f16(oh, ol)
+    return (merge_f16(oh, ol), lse) if return_lse else merge_f16(oh, ol)
 
 
 def sinkhorn(S: torch.Tensor, dustbin: float, iters: int, reg: float = 1.0, return_status: bool = False):

@@ -413,7 +413,7 @@ def _flash_backward_enabled(dh: int) -> bool:
     return os.environ.get("OG_TRAIN_FLASH_BWD", "1") != "0" and dh in (16, 32, 64)
 
 
-def _flash_attention_backward(q32, k32, v32, out, dout, H):
+def _flash_attention_backward(q32, k32, v32, out, dout, H, lse=None):
     """Flash backward (csrc/attention_train.hip): P is recomputed tile by tile in registers from q, k and the row log-sum-exp; nothing
     of size Nq x Nk is ever written.  Token-major tensors in and out ([B, N, D]): no head-major copies either.  -> dq, dk, dv."""
     lib = _lib.load()
@@ -424,14 +424,17 @@ def _flash_attention_backward(q32, k32, v32, out, dout, H):
     st = torch.cuda.current_stream(dev).cuda_stream
     do = dout.detach().to(torch.float32).contiguous()
     scale = dh ** -0.5
-    lse = torch.empty(B, H, Nq, device=dev, dtype=torch.float32)
+    have_lse = lse is not None                              # from the forward kernel's online-softmax state (ops.attention(return_lse=True))
+    if not have_lse:
+        lse = torch.empty(B, H, Nq, device=dev, dtype=torch.float32)
     delta = (do * out).reshape(B, Nq, H, dh).sum(-1)                                     # [B, Nq, H]
     parts = lib.og_attention_backward_parts(Nk)
     dq_part = torch.empty(parts, B, Nq, D, device=dev, dtype=torch.float32)
     dk, dv = torch.empty_like(k32), torch.empty_like(v32)
     with torch.cuda.device(dev):
-        _lib.check(lib.og_attention_train_lse(q32.data_ptr(), k32.data_ptr(), B, Nq, Nk, H, dh, scale, lse.data_ptr(), st),
-                   "og_attention_train_lse")
+        if not have_lse:
+            _lib.check(lib.og_attention_train_lse(q32.data_ptr(), k32.data_ptr(), B, Nq, Nk, H, dh, scale, lse.data_ptr(), st),
+                       "og_attention_train_lse")
         _lib.check(lib.og_attention_backward(q32.data_ptr(), k32.data_ptr(), v32.data_ptr(), do.data_ptr(), lse.data_ptr(),
                                              delta.data_ptr(), B, Nq, Nk, H, dh, scale, dq_part.data_ptr(), dk.data_ptr(),
                                              dv.data_ptr(), st), "og_attention_backward")
@@ -456,12 +459,14 @@ class SoftmaxAttention(torch.autograd.Function):
         d = D // num_heads
         q32, k32, v32 = (t.detach().to(torch.float32).contiguous() for t in (q, k, v))
         ctx.heads = num_heads
+        lse = None
         if os.environ.get("OG_TRAIN_FLASH", "1") != "0" and d in (16, 32, 64):
-            out = ops.attention(q32 * d ** -0.5, k32, v32, num_heads)
+            out, lse = ops.attention(q32 * d ** -0.5, k32, v32, num_heads, return_lse=True)
         else:
             P, vh = SoftmaxAttention._probs(q32, k32, v32, num_heads)
             out = SoftmaxAttention._pv(P, vh, B)
-        ctx.save_for_backward(q32, k32, v32, out)               # `out` is also the saved input of the out-projection conv: no extra memory
+        ctx.has_lse = lse is not None
+        ctx.save_for_backward(q32, k32, v32, out, *(() if lse is None else (lse,)))   # `out` is also the saved input of the out-projection conv
         return out
 
     @staticmethod
@@ -494,13 +499,13 @@ class SoftmaxAttention(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         lib = _lib.load()
-        q32, k32, v32, out = ctx.saved_tensors
+        q32, k32, v32, out, *rest = ctx.saved_tensors
         H = ctx.heads
         B, Nq, D = q32.shape
         Nk = k32.shape[1]
         dh = D // H
         if _flash_backward_enabled(dh):
-            return (*_flash_attention_backward(q32, k32, v32, out, dout, H), None)
+            return (*_flash_attention_backward(q32, k32, v32, out, dout, H, rest[0] if ctx.has_lse else None), None)
         P, (qh, kh, vh) = SoftmaxAttention._probs(q32, k32, v32, H)
         Z, Nq, d = qh.shape
         Nk = kh.shape[1]
@@ -553,20 +558,20 @@ class ProjectedAttention(torch.autograd.Function):
         params = tuple(t.detach() for t in (Wq, bq, Wk, bk, Wv, bv))
         D = Wq.shape[0]
         q, k, v = ProjectedAttention._project(xq, xkv, *params)
-        out = ops.attention(q.reshape(Bz, nq, D) * (D // H) ** -0.5, k.reshape(Bz, nk, D), v.reshape(Bz, nk, D), H)
+        out, lse = ops.attention(q.reshape(Bz, nq, D) * (D // H) ** -0.5, k.reshape(Bz, nk, D), v.reshape(Bz, nk, D), H, return_lse=True)
         ctx.geom = (Bz, nq, nk, H, xkv is None)
-        ctx.save_for_backward(xq, *params, out, *(() if xkv is None else (xkv,)))
+        ctx.save_for_backward(xq, *params, out, lse, *(() if xkv is None else (xkv,)))
         return out.reshape(Bz * nq, D)
 
     @staticmethod
     def backward(ctx, dout):
         Bz, nq, nk, H, is_self = ctx.geom
-        xq, Wq, bq, Wk, bk, Wv, bv, out, *rest = ctx.saved_tensors
+        xq, Wq, bq, Wk, bk, Wv, bv, out, lse, *rest = ctx.saved_tensors
         xkv = None if is_self else rest[0]
         D = Wq.shape[0]
         q, k, v = ProjectedAttention._project(xq, xkv, Wq, bq, Wk, bk, Wv, bv)
         dq, dk, dv = _flash_attention_backward(q.reshape(Bz, nq, D), k.reshape(Bz, nk, D), v.reshape(Bz, nk, D), out,
-                                               dout.reshape(Bz, nq, D), H)
+                                               dout.reshape(Bz, nq, D), H, lse)
         del q, k, v
         if is_self:
             dqkv = torch.cat([dq.reshape(-1, D), dk.reshape(-1, D), dv.reshape(-1, D)], dim=1)

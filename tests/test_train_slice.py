@@ -357,6 +357,27 @@ def test_softmax_attention_backward_against_float64(gpu_device, shape, flash_bwd
         assert err < 2e-5, (name, float(err))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 37, 53, 4, 16), (1, 130, 97, 2, 32), (2, 200, 333, 4, 64)])
+def test_row_log_sum_exp_from_both_kernels(gpu_device, shape):
+    """The row log-sum-exp the flash backward needs: from the forward kernel's online-softmax state (ops.attention(return_lse=True),
+    split-f16 scores) and from the exact-fp32 pass og_attention_train_lse, both vs float64."""
+    from openglue_amd import ops, _lib
+    B, Nq, Nk, H, d = shape
+    D = H * d
+    g = torch.Generator().manual_seed(Nq + 7 * Nk)
+    q, k, v = (torch.randn(B, n_, D, generator=g) * 1.5 for n_ in (Nq, Nk, Nk))
+    qh, kh = (t.double().reshape(B, -1, H, d).transpose(1, 2) for t in (q, k))
+    want = torch.logsumexp(qh @ kh.transpose(-1, -2) * d ** -0.5, -1)                        # [B, H, Nq]
+    qg, kg, vg = (t.to(gpu_device) for t in (q, k, v))
+    _, lse_fwd = ops.attention(qg * d ** -0.5, kg, vg, H, return_lse=True)
+    lse_bwd = torch.empty(B, H, Nq, device=gpu_device, dtype=torch.float32)
+    _lib.check(_lib.load().og_attention_train_lse(qg.data_ptr(), kg.data_ptr(), B, Nq, Nk, H, d, d ** -0.5, lse_bwd.data_ptr(),
+                                                  torch.cuda.current_stream(gpu_device).cuda_stream), "og_attention_train_lse")
+    assert (lse_fwd.cpu().double() - want).abs().max() < 2e-5
+    assert (lse_bwd.cpu().double() - want).abs().max() < 2e-5
+
+
 # ----------------------------------------------------------------------------- the other attentions / encoder in training mode (VERDICT r2 item 6)
 GV = dict(np.load(os.path.join(GOLDEN, "train_variants.npz")))
 VARIANT_CASES = {"linear": dict(descriptor_dim=64, num_stages=2, num_heads=4, num_iters=6, attention="linear"),
