@@ -211,10 +211,12 @@ struct RowBest { int* idx; float* val; int stride; };      // [batch][stride]
 int og_launch_sinkhorn(const float* S, int64_t lds, const float* dustbin_dev /*or null*/, float dustbin_host, int batch, int m, int n, int iters,
                        float reg, float* scores, void* workspace, hipStream_t stream, const RaggedDesc* rag = nullptr,
                        const RowBest* row_best = nullptr, bool trusted_padding = true);   // false: columns [n, lds) of S may hold anything
-// sinkhorn_resident.hip: the dual-stabilised iterations with the score matrices resident in registers + LDS (one launch)
+// sinkhorn_resident.hip: the dual-stabilised iterations with the plan matrices resident in registers + LDS (one launch per round of
+// co-resident pairs: n <= 4096, any batch)
 bool og_sinkhorn_resident_shape_ok(int B, int m, int n);
 size_t og_sinkhorn_resident_ws_bytes(int B, int m, int n);            // exchange granules + status word (0: shape never resident)
-bool og_sinkhorn_resident_wanted(int B, int m, int n, int mode);      // mode 1: co-resident and large enough, 2: co-resident
+bool og_sinkhorn_resident_wanted(int B, int m, int n, int mode);      // mode 1: resident-capable and large enough, 2: resident-capable
+int og_sinkhorn_resident_rounds(int B, int m, int n);                 // launches of the resident kernel for this uniform batch on this device (0: none)
 int og_launch_sinkhorn_resident(const float* S, int64_t lds, const float* zdev, float zhost, int B, int m, int n, int iters,
                                 float inv_reg, float la, float la_bin, float lb, float lb_bin, float* u, int ldu, const float* v_in,
                                 float* v_out, int ldv, void* xws, hipStream_t st, bool trusted_padding = true);

@@ -687,11 +687,17 @@ def test_favor_relu_attention_whole_path(gpu_device, D, m, n, B):
 # ----------------------------------------------------------------------------- on-chip-resident Sinkhorn iterations
 @pytest.mark.parametrize("B,m,n,iters,reg", [(3, 37, 53, 7, 1.0), (2, 64, 64, 2, 1.0), (1, 130, 1023, 20, 0.7), (2, 257, 1000, 10, 1.0),
                                              (4, 128, 1024, 30, 1.0), (1, 1, 1, 3, 1.0), (2, 300, 17, 6, 2.0), (8, 1024, 1024, 100, 1.0),
-                                             (1, 1024, 512, 100, 1.0)])
+                                             (1, 1024, 512, 100, 1.0),
+                                             # wider than one wave tile: 2 / 4 waves per row (n <= 2048 / 4096), two-hop column exchange
+                                             (2, 300, 2047, 12, 1.0), (1, 77, 4096, 8, 1.0), (3, 1100, 1500, 25, 0.8), (2, 2048, 2048, 100, 1.0),
+                                             (1, 4096, 4096, 30, 1.0), (1, 3000, 2500, 15, 1.0),
+                                             # more pairs than one launch holds: rounds of co-resident pairs (G = 8: 32 per launch; G = 32: 8)
+                                             (40, 1024, 200, 20, 1.0), (11, 2048, 1030, 10, 1.0)])
 def test_sinkhorn_resident_vs_oracle(gpu_device, monkeypatch, B, m, n, iters, reg):
-    """sinkhorn_resident.hip (scores held in registers + LDS, iterations 2..iters in one launch, column sums exchanged between
-    the workgroups of a pair through {epoch, value} granules) against the float64 oracle AND against the streaming kernels:
-    partial row blocks (m % 16, m % 128), n < 1024 (masked columns), several workgroups per pair (m > 128), 100 iterations."""
+    """sinkhorn_resident.hip (plan entries held in registers + LDS, iterations 2..iters in one launch per round of co-resident
+    pairs, column sums exchanged between the workgroups of a pair through {epoch, value} granules) against the float64 oracle AND
+    against the streaming kernels: partial row blocks (m % 16, m % 128), masked columns, several workgroups per pair, rows that
+    cross 2 or 4 waves (n > 1024), several rounds (B > pairs per launch), 100 iterations."""
     g = torch.Generator().manual_seed(m * 31 + n)
     S = _rand(g, B, m, n, scale=4.0)
     ref = _sinkhorn_ref(S, 0.7, iters, reg)
@@ -711,7 +717,7 @@ def test_sinkhorn_resident_vs_oracle(gpu_device, monkeypatch, B, m, n, iters, re
     assert (torch.logsumexp(out.double() + norm, dim=1) - lb).abs().max() < 1e-4        # column marginals exact after the last v update
 
 
-@pytest.mark.parametrize("B,m,n,iters", [(8, 1024, 1024, 60), (2, 257, 1000, 10), (3, 640, 333, 25)])
+@pytest.mark.parametrize("B,m,n,iters", [(8, 1024, 1024, 60), (2, 257, 1000, 10), (3, 640, 333, 25), (8, 2048, 2048, 40), (5, 700, 1800, 20)])
 def test_sinkhorn_resident_exchange_scopes(gpu_device, monkeypatch, B, m, n, iters):
     """The column partials travel between the workgroups of a pair either at agent scope or -- when the kernel finds all of them
     on one XCD (B a multiple of 8 with the round-robin dispatch) -- through that XCD's L2 with workgroup-scope streaming loads.
@@ -741,6 +747,28 @@ def test_sinkhorn_resident_extreme_range_and_repeatability(gpu_device, monkeypat
     assert torch.equal(a, b2)                       # fixed summation orders everywhere: bit-identical from call to call
     tol = 1e-4 + 2e-6 * ref.abs().max().item()
     assert (a.cpu().double() - ref).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize("scale,reg,z", [(25.0, 0.5, 0.7), (8.0, 0.1, -30.0), (60.0, 1.0, 50.0), (1e-3, 1.0, 0.0)])
+def test_sinkhorn_resident_refresh_on_extreme_range(gpu_device, monkeypatch, scale, reg, z):
+    """The resident state is the plan matrix in the LINEAR domain; entries below 2^-126 are lost until the workgroup re-evaluates its
+    rows from the scores, which it does when the duals have moved by more than 40 bits since the last evaluation
+    (sinkhorn_resident.hip, RS_DRIFT_BITS).  On these inputs (|S/reg| of several hundred, duals moving by 100-180 bits after the first
+    iteration) a solver WITHOUT the refresh is off by 30-60 in the log-scores (tests/emulate_sinkhorn_linear.py)."""
+    g = torch.Generator().manual_seed(int(scale * 10) + 3)
+    B, m, n, iters = 2, 96, 200, 30
+    S = _rand(g, B, m, n, scale=scale)
+    S[0, 5, :] = -4.0 * scale
+    S[1, :, 7] = 4.0 * scale
+    ref = _sinkhorn_ref(S, z, iters, reg)
+    monkeypatch.setenv("OG_SINKHORN_RESIDENT", "2")
+    out, status = ops.sinkhorn(S.to(gpu_device), z, iters, reg, return_status=True)
+    out = out.cpu()
+    assert status == 0 and bool(torch.isfinite(out).all())
+    err = (out.double() - ref).abs().max().item()
+    tol = 1e-4 + 2e-6 * ref.abs().max().item()
+    print(f"[sinkhorn resident extreme scale={scale} reg={reg} z={z}] max err {err:.2e} (tol {tol:.1e}), max |score| {ref.abs().max().item():.0f}")
+    assert err <= tol
 
 
 def test_sinkhorn_resident_timeout_is_survivable(gpu_device, monkeypatch):
