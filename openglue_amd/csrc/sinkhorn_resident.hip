@@ -62,20 +62,37 @@ typedef __attribute__((address_space(1))) unsigned rs_gu32;
 typedef __attribute__((address_space(1))) char rs_gchar;
 typedef __attribute__((address_space(1))) f32x4 rs_gf32x4;
 
-// One 8-byte granule from the L2 -- never from this CU's vector L1 (an aligned 8-byte granule cannot tear).  No wait: the caller
-// issues a batch and waits once (rs_wait_loads), the compiler does not count the loads of an asm statement.
+// A batch of 8-byte granules from the L2 -- never from this CU's vector L1 (an aligned 8-byte granule cannot tear).  The wait is
+// part of the block: the compiler does not count the loads of an asm statement, and a result register may be copied the moment the
+// statement ends (loads and wait in separate statements returned the registers' OLD contents now and then -- {epoch, 0} where they
+// had been initialised with the tag: right epoch, wrong value).
 //   agent scope (sc1): coherent over the whole device -- on this multi-XCD part every such load goes to the fabric behind the
 //   per-XCD L2s (which are not coherent with each other);
 //   XCD-local (LOCAL): the workgroups of a pair share one XCD = one L2 (verified at run time, kernel prologue).  Workgroup-scope
 //   streaming loads (sc0 nt) do not keep their line in the vector L1, so a re-poll reads the L2 again.  (sc0 alone may hit a stale
 //   L1 line for ever; buffer_inv sc1 is the guaranteed-progress fallback of the poll loops, every 64th poll.)
-template <bool LOCAL>
-__device__ __forceinline__ void rs_load_granule(rs_u64& d, const rs_gchar* base, unsigned off) {
-    if constexpr (LOCAL) asm volatile("global_load_dwordx2 %0, %1, %2 sc0 nt" : "=&v"(d) : "v"(off), "s"(base) : "memory");
-    else asm volatile("global_load_dwordx2 %0, %1, %2 sc1" : "=&v"(d) : "v"(off), "s"(base) : "memory");
+#define RS_LD(i, o) "global_load_dwordx2 %" #i ", %" #o ", %[b] " 
+template <bool LOCAL, int N>
+__device__ __forceinline__ void rs_load_granules(rs_u64 (&d)[N], const rs_gchar* base, const unsigned (&off)[N]) {
+    static_assert(N == 3 || N == 5 || N == 9, "2 W + 1 granules");
+#define RS_M3(M) asm volatile(RS_LD(0, 3) M "\n\t" RS_LD(1, 4) M "\n\t" RS_LD(2, 5) M "\n\ts_waitcnt vmcnt(0)"                                       \
+                              : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]) : "v"(off[0]), "v"(off[1]), "v"(off[2]), [b] "s"(base) : "memory")
+#define RS_M5(M) asm volatile(RS_LD(0, 5) M "\n\t" RS_LD(1, 6) M "\n\t" RS_LD(2, 7) M "\n\t" RS_LD(3, 8) M "\n\t" RS_LD(4, 9) M "\n\ts_waitcnt vmcnt(0)"      \
+                              : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4])                                                \
+                              : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), [b] "s"(base) : "memory")
+#define RS_M9(M) asm volatile(RS_LD(0, 9) M "\n\t" RS_LD(1, 10) M "\n\t" RS_LD(2, 11) M "\n\t" RS_LD(3, 12) M "\n\t" RS_LD(4, 13) M "\n\t"                 \
+                              RS_LD(5, 14) M "\n\t" RS_LD(6, 15) M "\n\t" RS_LD(7, 16) M "\n\t" RS_LD(8, 17) M "\n\ts_waitcnt vmcnt(0)"                  \
+                              : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7]), "=&v"(d[8])  \
+                              : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "v"(off[5]), "v"(off[6]), "v"(off[7]), "v"(off[8]),   \
+                                [b] "s"(base) : "memory")
+    if constexpr (N == 3) { if constexpr (LOCAL) RS_M3("sc0 nt"); else RS_M3("sc1"); }
+    else if constexpr (N == 5) { if constexpr (LOCAL) RS_M5("sc0 nt"); else RS_M5("sc1"); }
+    else { if constexpr (LOCAL) RS_M9("sc0 nt"); else RS_M9("sc1"); }
+#undef RS_M3
+#undef RS_M5
+#undef RS_M9
 }
-__device__ __forceinline__ void rs_wait_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void rs_pin(rs_u64& d) { asm volatile("" : "+v"(d)); }      // consumers stay behind the wait
+#undef RS_LD
 
 // Experiment builds only (-DOG_SK_TRACE=1): shader-cycle stamps of the phases of iterations 8..15 of every wave of the first and
 // the last workgroup of the launch, read back by og_debug_sk_trace (scripts/trace_sinkhorn.py)
@@ -91,16 +108,17 @@ __device__ unsigned og_sk_trace_buf[2][8][8][16];
 #endif
 
 // ---- which (pair, g) a workgroup is ----
-// Uniform batches: arithmetic.  G <= 32: XCD x = id % 8 hosts the pairs x, x + 8, ... ("layers"), each on G consecutive slots q = id / 8 of
-// that XCD; G > 32: pairs take G consecutive ids (spread over all XCDs: agent scope).
+// Uniform batches: arithmetic.  The G workgroups of a pair form X GROUPS of Gx (X = 1, 2, 4, 8; Gx <= 32), one group per XCD when the
+// part has 8 XCDs x 32 CUs: XCD x = id % 8, slot q = id / 8; layer = q / Gx, pair = layer * (8 / X) + x / X, group = x % X,
+// g = group * Gx + q % Gx.  layers == 0: pairs take G consecutive ids instead (few CUs; agent scope everywhere).
 struct RsUniform {
-    int G, layers;                     // workgroups per pair; layers > 0: the one-XCD-per-pair map with this many pairs per XCD, 0: consecutive ids
+    int G, Gx, X, layers;
 };
 // Ragged batches: per-pair sizes and the id -> (pair, g) table by value in the kernarg segment (no device-side table, no copy)
 struct RsRagged {
     unsigned short wg[RS_MAXWG];       // (pair << 8) | g, 0xFFFF = idle
     unsigned short gb[OG_MAX_RAGGED];  // pair of the round -> pair of the batch
-    unsigned short gbase[OG_MAX_RAGGED], G[OG_MAX_RAGGED];
+    unsigned short gbase[OG_MAX_RAGGED], G[OG_MAX_RAGGED];      // (one group per pair: G <= 32)
     int m[OG_MAX_RAGGED], n[OG_MAX_RAGGED];
     unsigned char local[OG_MAX_RAGGED];
 };
@@ -110,7 +128,8 @@ struct SkResArgs {
     float* u; int ldu;                         // [B][ldu]: duals of the rows after the first (max-subtracted) iteration, natural units; updated in place
     const float* v_in; float* v_out; int ldv;  // [B][ldv]
     char* xa;                                  // [2][slots][NC + 64] granules: column partials, one row per workgroup   } zeroed before
-    char* xb;                                  // [2][npairs][NC + 64] granules: column totals, one row per pair            } the launch
+    char* xb;                                  // [2][groups][NC + 64] granules: column totals, one row per group of a pair } the launch
+    char* xc;                                  // [2][groups][NC + 64] granules: a group's column sums (pairs of X > 1 groups)
     unsigned* status;                          // 0 / 1 = a wait timed out (sticky over the rounds of a call)
     unsigned* xcc;                             // [slots] XCC id + 1 of every workgroup, zeroed before the launch
     int force_agent_scope;                     // experiments / tests: never take the XCD-local path
@@ -119,7 +138,7 @@ struct SkResArgs {
     const float* zdev; float zhost;
     float inv_reg, la, la_bin, lb, lb_bin;     // natural units (uniform batches; ragged ones derive them from the pair's sizes)
     int m, n;                                  // uniform sizes
-    int b0, npairs, slots;                     // this round: first pair of the batch, pairs, workgroups with a pair (= granule rows)
+    int b0, npairs, slots, groups;             // this round: first pair of the batch, pairs, workgroups with a pair (= rows of xa), groups (rows of xb, xc)
     int iters;                                 // dual-stabilised iterations to run (>= 1)
     int local_ok;                              // the id map puts every pair on one XCD (to be verified)
 };
@@ -186,12 +205,15 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
 
     // ---- which pair, which of its G workgroups ----
     int r, g, G, gbase, bglob, M, N;
+    int XG = 1, Gx, xg = 0;                                 // groups of the pair, workgroups per group, my group
     bool local_hint;
     if constexpr (std::is_same<MAP, RsUniform>::value) {
         const int id = blockIdx.x;
-        G = map.G;
-        if (map.layers > 0) { const int x = id & 7, q = id >> 3; r = (q / G) * 8 + x; g = q % G; }
-        else { r = id / G; g = id % G; }
+        G = map.G; Gx = map.Gx; XG = map.X;
+        if (map.layers > 0) {
+            const int x = id & 7, q = id >> 3;
+            r = (q / Gx) * (8 / XG) + x / XG; xg = x % XG; g = xg * Gx + q % Gx;
+        } else { r = id / G; g = id % G; xg = g / Gx; }
         if (r >= a.npairs) return;                         // nobody waits for a workgroup without a pair
         gbase = r * G; bglob = a.b0 + r; M = a.m; N = a.n;
         local_hint = a.local_ok != 0;
@@ -199,9 +221,11 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
         const unsigned e = map.wg[blockIdx.x];
         if (e == 0xFFFFu) return;
         r = (int)(e >> 8); g = (int)(e & 255u);
-        G = map.G[r]; gbase = map.gbase[r]; bglob = map.gb[r]; M = map.m[r]; N = map.n[r];
+        G = map.G[r]; Gx = G; gbase = map.gbase[r]; bglob = map.gb[r]; M = map.m[r]; N = map.n[r];
         local_hint = map.local[r] != 0;
     }
+    const int gl = g - xg * Gx;                            // my index inside the group
+    const int grow = r * XG + xg;                           // my group's row of xb / xc
     float la = a.la, la_bin = a.la_bin, lb = a.lb, lb_bin = a.lb_bin;
     if constexpr (!std::is_same<MAP, RsUniform>::value) {  // as the ragged streaming kernels (sinkhorn.hip)
         const float norm = -__logf((float)(M + N));
@@ -219,13 +243,13 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
     // rows of this wave that exist: slot s is live iff s < nvalid (ONE scalar)
     const int nvalid = __builtin_amdgcn_readfirstlane(min(max(row_end - row0, 0), RS_RW));
 
-    // ---- owner geometry: workgroup g sums the partials of columns [g CW, (g + 1) CW), CW = the power of two >= NC / G, <= 512 ----
+    // ---- owner geometry: workgroup gl of a group sums the group's partials of columns [gl CW, (gl + 1) CW), CW = the power of two >= NC / Gx, <= 512 ----
     int cwl = 0;
-    while ((G << cwl) < NC) ++cwl;                         // log2 CW
+    while ((Gx << cwl) < NC) ++cwl;                        // log2 CW
     const int CW = 1 << cwl, TPC = 512 >> cwl;             // threads per column
-    const bool owner = (g << cwl) < NC;
-    const int spt = (G + TPC - 1) / TPC;                   // slots per thread: s = tid / CW + i TPC  (< 4 W)
-    const int ocol = (g << cwl) + (tid & (CW - 1)), oslot0 = tid >> cwl;
+    const bool owner = (gl << cwl) < NC;
+    const int spt = (Gx + TPC - 1) / TPC;                  // slots per thread: s = tid / CW + i TPC  (< 4 W)
+    const int ocol = (gl << cwl) + (tid & (CW - 1)), oslot0 = tid >> cwl;
 
     // ---- duals of my rows (base 2, wave-uniform) and of my columns (tid + 512 c) ----
     // per-row scalars live ACROSS THE LANES of one register: lane s < 16 holds the value of row slot s (sixteen wave-uniform copies of
@@ -243,17 +267,17 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
     __syncthreads();
     float vN2 = red[33];
 
-    // ---- do the G workgroups of this pair sit on ONE XCD (one L2)?  Dispatcher behaviour, not a contract: every workgroup
+    // ---- do the Gx workgroups of my group sit on ONE XCD (one L2)?  Dispatcher behaviour, not a contract: every workgroup
     //      publishes its XCC id (agent scope) and reads its peers'; all of them see the same table and take the same decision.
     //      A pair that is spread over XCDs exchanges its granules at agent scope (slower, always correct). ----
     bool failed = false;
     bool xcd_local = false;
     if (local_hint && !a.force_agent_scope) {
         const unsigned mine = (__builtin_amdgcn_s_getreg(20 | (31 << 11)) & 0x00F0000Fu) + 1u;      // HW_REG_XCC_ID: XCC_ID [3:0], DIE_ID [23:20]
-        rs_gu32* tab = (rs_gu32*)a.xcc + gbase;
-        if (tid == 0) __hip_atomic_store(tab + g, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        rs_gu32* tab = (rs_gu32*)a.xcc + gbase + xg * Gx;   // my group's entries
+        if (tid == 0) __hip_atomic_store(tab + gl, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned verdict = 1u;                             // 1 same, 0 different, 2 timed out
-        if (tid < G) {
+        if (tid < Gx) {
             unsigned x = 0u, spins = 0u;
             while ((x = __hip_atomic_load(tab + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
                 if (++spins > RS_SPIN_LIMIT) { verdict = 2u; __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
@@ -361,7 +385,8 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
         for (; it < a.iters && !refresh; ++it) {
             const unsigned epoch = (unsigned)it + 1u;
             const rs_gchar* xa_par = (const rs_gchar*)a.xa + (int64_t)(it & 1) * a.slots * NCX * 8;          // this parity's areas
-            const rs_gchar* xb_par = (const rs_gchar*)a.xb + ((int64_t)(it & 1) * a.npairs + r) * NCX * 8;   // ... and this pair's totals
+            const rs_gchar* xb_par = (const rs_gchar*)a.xb + ((int64_t)(it & 1) * a.groups + grow) * NCX * 8;   // ... and my group's totals
+            const rs_gchar* xc_par = (const rs_gchar*)a.xc + ((int64_t)(it & 1) * a.groups + r * XG) * NCX * 8;   // ... and the pair's group sums
             const float dcol2 = zr2 + vN2;
 
             RS_TP(0);
@@ -515,26 +540,23 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
                     }
                 }
                 RS_TP(5);
-                const rs_gchar* abase = xa_par + (int64_t)gbase * NCX * 8;          // the pair's rows (wave-uniform: an SGPR pair)
+                const rs_gchar* abase = xa_par + (int64_t)(gbase + xg * Gx) * NCX * 8;   // my group's rows (wave-uniform: an SGPR pair)
                 if (owner) {
-                    const bool dmine = g == 0 && tid < G;                             // owner 0 also sums the dustbin column
-                    const unsigned offd = (unsigned)((dmine ? tid : 0) * NCX + NC) * 8u;
+                    const bool dmine = gl == 0 && tid < Gx;                           // owner 0 also sums the dustbin column
+                    const unsigned offd = gl == 0 ? (unsigned)((dmine ? tid : 0) * NCX + NC) * 8u : (unsigned)(min(oslot0, Gx - 1) * NCX + ocol) * 8u;
                     float acc = 0.f;
                     for (int i0 = 0; i0 < spt && !failed; i0 += SB) {                 // batches of 2 W granules (one batch unless G is not a power of two)
-                        rs_u64 gr[SB], gd = tag;
+                        rs_u64 gr[SB + 1];
+                        unsigned go[SB + 1];
+#pragma unroll
+                        for (int i = 0; i < SB; ++i) go[i] = (unsigned)(min(oslot0 + (i0 + i) * TPC, Gx - 1) * NCX + ocol) * 8u;   // past Gx: any valid granule, not summed
+                        go[SB] = offd;                                                // (workgroups other than 0: a granule of their own sweep once more)
                         unsigned spins = 0;
                         for (;;) {
+                            rs_load_granules<LOCAL>(gr, abase, go);
+                            unsigned bad = 0u;
 #pragma unroll
-                            for (int i = 0; i < SB; ++i) {
-                                gr[i] = tag;
-                                if (i0 + i < spt) rs_load_granule<LOCAL>(gr[i], abase, (unsigned)(min(oslot0 + (i0 + i) * TPC, G - 1) * NCX + ocol) * 8u);   // past G: any valid granule, not summed
-                            }
-                            if (g == 0 && i0 == 0) rs_load_granule<LOCAL>(gd, abase, offd);
-                            rs_wait_loads();
-                            unsigned bad = (unsigned)(gd >> 32) ^ epoch;
-#pragma unroll
-                            for (int i = 0; i < SB; ++i) { rs_pin(gr[i]); bad |= (unsigned)(gr[i] >> 32) ^ epoch; }
-                            rs_pin(gd);
+                            for (int i = 0; i <= SB; ++i) bad |= (unsigned)(gr[i] >> 32) ^ epoch;
                             if (__builtin_amdgcn_ballot_w64(bad != 0u) == 0) break;
                             if (++spins > RS_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
                                 failed = true;
@@ -546,37 +568,77 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
                         }
 #pragma unroll
                         for (int i = 0; i < SB; ++i)
-                            if (i0 + i < spt && oslot0 + (i0 + i) * TPC < G) { const unsigned w32 = (unsigned)gr[i]; acc += __builtin_bit_cast(float, w32); }
-                        if (g == 0 && i0 == 0 && tid < 256) { const unsigned w32 = (unsigned)gd; dred[tid] = dmine ? __builtin_bit_cast(float, w32) : 0.f; }
+                            if (oslot0 + (i0 + i) * TPC < Gx) { const unsigned w32 = (unsigned)gr[i]; acc += __builtin_bit_cast(float, w32); }
+                        if (gl == 0 && i0 == 0 && tid < 256) { const unsigned w32 = (unsigned)gr[SB]; dred[tid] = dmine ? __builtin_bit_cast(float, w32) : 0.f; }
                     }
                     osum[tid] = acc;
                 }
                 __syncthreads();
                 if (owner) {
-                    if (tid < CW) {
-                        float t = osum[tid];
+                    // my columns' sums over the group (threads < CW), the dustbin column's (wave 7 of the group's workgroup 0)
+                    const bool colw = tid < CW, dustw = gl == 0 && wave == RS_NW - 1;
+                    float t = 0.f;
+                    if (colw) {
+                        t = osum[tid];
                         for (int q = 1; q < TPC; ++q) t += osum[(q << cwl) + tid];
-                        __hip_atomic_store((rs_gu64*)xb_par + ocol, tag | __builtin_bit_cast(unsigned, t), __ATOMIC_RELAXED, SCOPE);
                     }
-                    if (g == 0 && wave == RS_NW - 1) {                                // G <= 256 partials: four per lane, then the fixed DPP tree
+                    float td = 0.f;
+                    if (dustw) {                                                      // Gx <= 256 partials: four per lane, then the fixed DPP tree
                         const f32x4 d4 = *reinterpret_cast<const f32x4*>(dred + 4 * lane);
-                        const float t = rs_wave_sum((d4[0] + d4[1]) + (d4[2] + d4[3]));
-                        if (lane == 0) __hip_atomic_store((rs_gu64*)xb_par + NC, tag | __builtin_bit_cast(unsigned, t), __ATOMIC_RELAXED, SCOPE);
+                        td = rs_wave_sum((d4[0] + d4[1]) + (d4[2] + d4[3]));
                     }
+                    if (W > 1 && XG > 1 && (colw || dustw)) {             // (W == 1 with more than 32 workgroups per pair -- m > 4096 rows -- is left to the streaming kernels)
+                        // the pair is spread over X groups (XCDs): the owners of the same columns exchange their group sums at AGENT scope
+                        // (CW granules per workgroup instead of NC: the bulk of the traffic stays inside the XCDs) and add them in group order,
+                        // so every group arrives at the same bits.  CW <= 256 here (Gx >= 17): wave 7 has no columns of its own.
+                        const bool dz = !colw;
+                        const float tv = dz ? td : t;
+                        const int cc = dz ? NC : ocol;
+                        if (colw || lane == 0) __hip_atomic_store((rs_gu64*)(xc_par + (int64_t)xg * NCX * 8) + cc, tag | __builtin_bit_cast(unsigned, tv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        float tsum = 0.f;
+                        unsigned spins = 0;
+                        auto cross = [&](auto N_) {
+                            constexpr int NX = decltype(N_)::value;                   // X + 1 granules (the last one twice)
+                            rs_u64 gx[NX];
+                            unsigned xo[NX];
+#pragma unroll
+                            for (int i = 0; i < NX; ++i) xo[i] = (unsigned)((i < NX - 1 ? i : 0) * NCX + cc) * 8u;
+                            for (;;) {
+                                rs_load_granules<false>(gx, xc_par, xo);
+                                unsigned bad = 0u;
+#pragma unroll
+                                for (int i = 0; i < NX; ++i) bad |= (unsigned)(gx[i] >> 32) ^ epoch;
+                                if (__builtin_amdgcn_ballot_w64(bad != 0u) == 0) break;
+                                if (++spins > RS_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                                    failed = true;
+                                    __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    break;
+                                }
+                                __builtin_amdgcn_s_sleep(1);
+                            }
+#pragma unroll
+                            for (int i = 0; i < NX - 1; ++i) { const unsigned w32 = (unsigned)gx[i]; tsum += __builtin_bit_cast(float, w32); }
+                        };
+                        if (XG == 2) cross(std::integral_constant<int, 3>{});
+                        else cross(std::integral_constant<int, 5>{});               // XG == 4 (the launcher admits nothing wider)
+                        if (dz) td = tsum; else t = tsum;
+                    }
+                    if (colw) __hip_atomic_store((rs_gu64*)xb_par + ocol, tag | __builtin_bit_cast(unsigned, t), __ATOMIC_RELAXED, SCOPE);
+                    if (dustw && lane == 0) __hip_atomic_store((rs_gu64*)xb_par + NC, tag | __builtin_bit_cast(unsigned, td), __ATOMIC_RELAXED, SCOPE);
                 }
                 RS_TP(6);
                 {
-                    rs_u64 gt[CPT], gn = tag;
+                    rs_u64 gt[CPT + 1];
+                    unsigned to[CPT + 1];
+#pragma unroll
+                    for (int c = 0; c < CPT; ++c) to[c] = (unsigned)(tid + 512 * c) * 8u;
+                    to[CPT] = (unsigned)NC * 8u;
                     unsigned spins = 0;
                     for (;;) {
+                        rs_load_granules<LOCAL>(gt, xb_par, to);
+                        unsigned bad = 0u;
 #pragma unroll
-                        for (int c = 0; c < CPT; ++c) rs_load_granule<LOCAL>(gt[c], xb_par, (unsigned)(tid + 512 * c) * 8u);
-                        rs_load_granule<LOCAL>(gn, xb_par, (unsigned)NC * 8u);
-                        rs_wait_loads();
-                        unsigned bad = (unsigned)(gn >> 32) ^ epoch;
-#pragma unroll
-                        for (int c = 0; c < CPT; ++c) { rs_pin(gt[c]); bad |= (unsigned)(gt[c] >> 32) ^ epoch; }
-                        rs_pin(gn);
+                        for (int c = 0; c <= CPT; ++c) bad |= (unsigned)(gt[c] >> 32) ^ epoch;
                         if (__builtin_amdgcn_ballot_w64(bad != 0u) == 0) break;
                         if (++spins > RS_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
                             failed = true;
@@ -588,7 +650,7 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
                     }
 #pragma unroll
                     for (int c = 0; c < CPT; ++c) { const unsigned w32 = (unsigned)gt[c]; colsum[c] = __builtin_bit_cast(float, w32); }
-                    { const unsigned w32 = (unsigned)gn; colsumN = __builtin_bit_cast(float, w32); }
+                    { const unsigned w32 = (unsigned)gt[CPT]; colsumN = __builtin_bit_cast(float, w32); }
                 }
             };
             if (xcd_local) exchange(std::true_type{}); else exchange(std::false_type{});
@@ -681,29 +743,32 @@ int rs_num_cus() {
     return n;
 }
 
-// geometry of one pair: W (column tiles per workgroup; 0 = not resident-capable), G (workgroups)
-struct RsGeom { int W, G; };
+// geometry of one pair: W (column tiles per workgroup; 0 = not resident-capable), G workgroups in X groups of Gx
+struct RsGeom { int W, G, Gx, X; };
 RsGeom rs_geom(int m, int n) {
-    RsGeom q{0, 0};
+    RsGeom q{0, 0, 0, 1};
     if (m <= 0 || n <= 0 || n > 4 * RS_SEG) return q;
     q.W = n <= RS_SEG ? 1 : n <= 2 * RS_SEG ? 2 : 4;
     const int RB = RS_RW * RS_NW / q.W;
     q.G = (m + RB - 1) / RB;
-    if (q.G < 2 * q.W) q.G = 2 * q.W;                     // an owner sums at most 512 columns: NC / G <= 512
-    if (q.G > RS_MAXWG) q.W = 0;
+    if (q.G < 2 * q.W) q.G = 2 * q.W;                     // an owner sums at most 512 columns: NC / Gx <= 512
+    if (q.G > RS_MAXWG) { q.W = 0; return q; }
+    while (q.X * 32 < q.G) q.X *= 2;                       // one group per XCD (32 CUs)
+    if (q.X > 4 || (q.X > 1 && q.W == 1)) { q.W = 0; return q; }      // more than 128 workgroups per pair, or m > 4096 with n <= 1024: streaming kernels
+    q.Gx = (q.G + q.X - 1) / q.X;
+    q.G = q.X * q.Gx;                                      // (a few workgroups more, each with fewer rows)
     return q;
 }
 // uniform batch: pairs per launch with `cus` CUs (0 = never)
 int rs_pairs_per_round(const RsGeom& q, int cus) {
     if (q.W == 0 || cus < 8) return 0;
-    const int wgs = cus < RS_MAXWG ? cus : RS_MAXWG;
-    if (q.G <= 32 && wgs >= 256) return 8 * (32 / q.G);   // one XCD per pair, 32 CUs per XCD
-    return wgs / q.G;
+    if (cus >= 256) return (8 / q.X) * (32 / q.Gx);        // the one-group-per-XCD map
+    return q.X == 1 ? cus / q.G : 0;
 }
 
-size_t rs_area_bytes(int W, int slots, int npairs) {    // status + xcc table, then the two exchange areas
+size_t rs_area_bytes(int W, int slots, int groups) {    // status + xcc table, then the three exchange areas
     const size_t NCX = (size_t)RS_SEG * W + RS_PAD;
-    return 256 + (size_t)RS_MAXWG * sizeof(unsigned) + (size_t)2 * slots * NCX * 8 + (size_t)2 * npairs * NCX * 8;
+    return 256 + (size_t)RS_MAXWG * sizeof(unsigned) + (size_t)2 * slots * NCX * 8 + (size_t)4 * groups * NCX * 8;
 }
 
 template <int W, class MAP>
@@ -720,7 +785,7 @@ bool og_sinkhorn_resident_shape_ok(int B, int m, int n) {
 size_t og_sinkhorn_resident_ws_bytes(int B, int m, int n) {
     if (!og_sinkhorn_resident_shape_ok(B, m, n)) return 0;
     const RsGeom q = rs_geom(m, n);
-    return rs_area_bytes(q.W, RS_MAXWG, B < RS_MAXPAIRS ? B : RS_MAXPAIRS);
+    return rs_area_bytes(q.W, RS_MAXWG, RS_MAXPAIRS);
 }
 
 // launches the resident kernel would need for this uniform batch on this device (0 = not possible)
@@ -760,17 +825,22 @@ int og_launch_sinkhorn_resident(const float* S, int64_t lds, const float* zdev, 
     a.m = m; a.n = n; a.iters = iters;
     a.sanitize_pad = (n & 3) && !trusted_padding;
     const size_t NCX = (size_t)RS_SEG * q.W + RS_PAD;
+    const bool xcd_map = rs_num_cus() >= 256;
     for (int b0 = 0; b0 < B; b0 += per) {
         const int np = B - b0 < per ? B - b0 : per;
-        a.b0 = b0; a.npairs = np; a.slots = np * q.G;
+        a.b0 = b0; a.npairs = np; a.slots = np * q.G; a.groups = np * q.X;
         a.xb = a.xa + (size_t)2 * a.slots * NCX * 8;
+        a.xc = a.xb + (size_t)2 * a.groups * NCX * 8;
         // epochs start at 1: every tag (and every XCC entry) must read 0 first
-        e = hipMemsetAsync(a.xcc, 0, RS_MAXWG * sizeof(unsigned) + (size_t)2 * a.slots * NCX * 8 + (size_t)2 * np * NCX * 8, st);
+        e = hipMemsetAsync(a.xcc, 0, RS_MAXWG * sizeof(unsigned) + (size_t)2 * a.slots * NCX * 8 + (size_t)4 * a.groups * NCX * 8, st);
         if (e != hipSuccess) return (int)e;
-        RsUniform map{q.G, 0};
+        RsUniform map{q.G, q.Gx, q.X, 0};
         int grid = np * q.G;
         a.local_ok = 0;
-        if (q.G <= 32 && ppr == 8 * (32 / q.G)) { map.layers = (np + 7) / 8; grid = 8 * map.layers * q.G; a.local_ok = 1; }
+        if (xcd_map) {
+            const int ppl = 8 / q.X;                       // pairs per layer
+            map.layers = (np + ppl - 1) / ppl; grid = 8 * map.layers * q.Gx; a.local_ok = 1;
+        }
         if (q.W == 1) rs_launch<1>(a, map, grid, st);
         else if (q.W == 2) rs_launch<2>(a, map, grid, st);
         else rs_launch<4>(a, map, grid, st);

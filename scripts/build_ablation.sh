@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/.."
 tag=$1; shift
 tmp=$(mktemp -d)
-for f in gemm_f32 gemm_f16x3 mlp_fused attention linear_attention sinkhorn sinkhorn_resident sinkhorn_train batchnorm_train matches features api; do
+for f in $(python -c 'from openglue_amd.build import SOURCES; print(" ".join(s[:-4] for s in SOURCES))'); do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -fPIC -O3 -Wno-unused-function "$@" -c openglue_amd/csrc/$f.hip -o $tmp/$f.o &
 done
 wait
