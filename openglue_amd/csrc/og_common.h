@@ -217,6 +217,12 @@ bool og_sinkhorn_resident_shape_ok(int B, int m, int n);
 size_t og_sinkhorn_resident_ws_bytes(int B, int m, int n);            // exchange granules + status word (0: shape never resident)
 bool og_sinkhorn_resident_wanted(int B, int m, int n, int mode);      // mode 1: resident-capable and large enough, 2: resident-capable
 int og_sinkhorn_resident_rounds(int B, int m, int n);                 // launches of the resident kernel for this uniform batch on this device (0: none)
+// ragged batches: every pair gets the geometry of its own (m_b, n_b); pairs are packed into launches of at most one pair-group per XCD slot range
+bool og_sinkhorn_resident_ragged_wanted(const RaggedDesc& rd, int mode);
+int og_launch_sinkhorn_resident_ragged(const float* S, int64_t lds, const float* zdev, float zhost, const RaggedDesc& rd, int m_max, int n_max, int iters,
+                                       float inv_reg, float* u, int ldu, const float* v_in, float* v_out, int ldv, void* xws, hipStream_t st,
+                                       bool trusted_padding = true);
+static inline bool og_sinkhorn_resident_ragged_wanted(const RaggedNone&, int) { return false; }
 int og_launch_sinkhorn_resident(const float* S, int64_t lds, const float* zdev, float zhost, int B, int m, int n, int iters,
                                 float inv_reg, float la, float la_bin, float lb, float lb_bin, float* u, int ldu, const float* v_in,
                                 float* v_out, int ldv, void* xws, hipStream_t st, bool trusted_padding = true);

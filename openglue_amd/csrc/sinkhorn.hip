@@ -679,16 +679,23 @@ void launch_sweep_fast(const float* S, int64_t lds, int B, int m, int n, const f
 // 0 and otherwise solves the problem AGAIN from u = v = 0 -- ONE workgroup per pair, all `iters` max-subtracted iterations exactly
 // as optimal_transport.py:22-26 with the dustbin row / column in closed form -- leaving u, v where the scores kernel reads them
 // and status = 2 ("recomputed by the fallback, scores valid").  Slow (two sweeps of the pair's matrix per iteration from one CU:
-// milliseconds), never wrong.  n <= 1024 (resident shapes): one column per thread.
+// milliseconds), never wrong.  n <= 4096 (resident shapes): up to four columns per thread; ragged batches take their sizes from rd.
+template <class RD>
 __global__ __launch_bounds__(1024) void sinkhorn_fallback_kernel(const float* __restrict__ S, int64_t lds, int64_t strideS, int M, int N,
                                                                  const float* __restrict__ zdev, float zhost, float inv_reg, float la,
                                                                  float la_bin, float lb, float lb_bin, float* __restrict__ u, int ldu,
-                                                                 float* __restrict__ v, int ldv, int iters, unsigned* status) {
+                                                                 float* __restrict__ v, int ldv, int iters, unsigned* status, RD rd) {
     if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
     __shared__ float uL[8196];          // m + 1 duals when they fit (else they stay in global memory)
-    __shared__ float vL[1028];
+    __shared__ float vL[4100];
     __shared__ float red[2][16];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (rd.B > 0) {                     // ragged: this pair's own size and marginals (as the ragged streaming kernels)
+        M = rd.off0[b + 1] - rd.off0[b];
+        N = rd.off1[b + 1] - rd.off1[b];
+        const float norm = -__logf((float)(M + N));
+        la = norm; lb = norm; la_bin = norm + __logf((float)N); lb_bin = norm + __logf((float)M);
+    }
     const float* Sb = S + (int64_t)b * strideS;
     float* ub = u + (int64_t)b * ldu;
     float* vb = v + (int64_t)b * ldv;
@@ -725,18 +732,17 @@ __global__ __launch_bounds__(1024) void sinkhorn_fallback_kernel(const float* __
             const float l = block_lse(mx, sm);
             if (tid == 0) uw[M] = la_bin - l;
         }
-        __syncthreads();
-        if (uw != ub) __threadfence_block();
-        // columns: v_j = log b_j - LSE_i (S_ij / reg + u_i), the dustbin row (z + u_M) included; one column per thread, rows streamed
-        if (tid < N) {
+        __syncthreads();                 // (also orders the global-memory u of very tall pairs inside the workgroup)
+        // columns: v_j = log b_j - LSE_i (S_ij / reg + u_i), the dustbin row (z + u_M) included; columns tid, tid + 1024, ...; rows streamed
+        for (int j = tid; j < N; j += 1024) {
             float mx = zr + uw[M], sm = 1.f;
             for (int i = 0; i < M; ++i) {
-                const float x = Sb[(int64_t)i * lds + tid] * inv_reg + uw[i];
+                const float x = Sb[(int64_t)i * lds + j] * inv_reg + uw[i];
                 const float nm = fmaxf(mx, x);
                 sm = sm * expf(mx - nm) + expf(x - nm);
                 mx = nm;
             }
-            vb[tid] = lb - (mx + logf(sm));
+            vb[j] = lb - (mx + logf(sm));
         }
         float nv;
         {   // the dustbin column
@@ -745,7 +751,7 @@ __global__ __launch_bounds__(1024) void sinkhorn_fallback_kernel(const float* __
             nv = lb_bin - block_lse(mx, sm);
         }
         __syncthreads();
-        if (tid < N) vL[tid] = vb[tid];
+        for (int j = tid; j < N; j += 1024) vL[j] = vb[j];
         if (tid == 0) { vL[N] = nv; vb[N] = nv; }
         __syncthreads();
     }
@@ -796,7 +802,9 @@ int sinkhorn_run(const float* S, int64_t lds, const float* zdev, float dustbin, 
     // off; 2: whenever it is co-resident (tests)
     const char* rm_env = getenv("OG_SINKHORN_RESIDENT");          // read per call: the parity tests switch it
     const int resident_mode = rm_env ? atoi(rm_env) : 1;
-    const bool resident = std::is_same<RD, RaggedNone>::value && !robust_only && iters > 1 && og_sinkhorn_resident_wanted(B, m, n, resident_mode);
+    bool resident = !robust_only && iters > 1;
+    if constexpr (std::is_same<RD, RaggedNone>::value) resident = resident && og_sinkhorn_resident_wanted(B, m, n, resident_mode);
+    else resident = resident && og_sinkhorn_resident_ws_bytes(B, m, n) > 0 && og_sinkhorn_resident_ragged_wanted(rd, resident_mode);
     // Geometry of the dual-stabilised streaming sweeps (uniform batches): the largest 32 / 64 / 128 rows per workgroup that still gives
     // >= 512 workgroups -- half the column partials to write and merge per doubling (2048 columns x 32 pairs: 11.6 -> 9.2 ms per 100
     // iterations at 128 rows with streaming loads; 4096 x 8 pairs: 11.4 -> 9.5 at 64; below 512 workgroups the chip runs dry: 16.6 ms at
@@ -824,13 +832,20 @@ int sinkhorn_run(const float* S, int64_t lds, const float* zdev, float dustbin, 
             if (ft && atoi(ft) != 0) {
                 e = hipMemsetAsync(status, 1, sizeof(unsigned), st);
                 if (e != hipSuccess) return (int)e;
-            } else if (int rc = og_launch_sinkhorn_resident(S, lds, zdev, dustbin, B, m, n, iters - 1, inv_reg, la, la_bin, lb, lb_bin, w.u, w.ldu,
-                                                            w.v[cur], w.v[cur ^ 1], w.ldv, status, st, trusted_padding))
-                return rc;
+            } else {
+                int rc;
+                if constexpr (std::is_same<RD, RaggedNone>::value)
+                    rc = og_launch_sinkhorn_resident(S, lds, zdev, dustbin, B, m, n, iters - 1, inv_reg, la, la_bin, lb, lb_bin, w.u, w.ldu, w.v[cur],
+                                                     w.v[cur ^ 1], w.ldv, status, st, trusted_padding);
+                else
+                    rc = og_launch_sinkhorn_resident_ragged(S, lds, zdev, dustbin, rd, m, n, iters - 1, inv_reg, w.u, w.ldu, w.v[cur], w.v[cur ^ 1],
+                                                            w.ldv, status, st, trusted_padding);
+                if (rc) return rc;
+            }
             cur ^= 1;
             // the safety net: a no-op while status == 0, else the whole solve again by one workgroup per pair (status -> 2)
-            hipLaunchKernelGGL(sinkhorn_fallback_kernel, dim3(B), dim3(1024), 0, st, S, lds, (int64_t)m * lds, m, n, zdev, dustbin, inv_reg, la,
-                               la_bin, lb, lb_bin, w.u, w.ldu, w.v[cur], w.ldv, iters, status);
+            hipLaunchKernelGGL(sinkhorn_fallback_kernel<RD>, dim3(B), dim3(1024), 0, st, S, lds, (int64_t)m * lds, m, n, zdev, dustbin, inv_reg, la,
+                               la_bin, lb, lb_bin, w.u, w.ldu, w.v[cur], w.ldv, iters, status, rd);
             break;
         }
         if (it > 0 && !robust_only) {     // dual-stabilised form: valid once one max-subtracted iteration has been done

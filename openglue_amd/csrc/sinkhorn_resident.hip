@@ -94,6 +94,35 @@ __device__ __forceinline__ void rs_load_granules(rs_u64 (&d)[N], const rs_gchar*
 }
 #undef RS_LD
 
+// A thread's NCOL adjacent columns of one granule row: 16-byte stores of two {value, epoch} granules (a torn 16-byte store is two
+// whole granules), and the matching sweep: NCOL / 2 16-byte loads + the dustbin column's granule, polled as one batch.
+typedef unsigned rs_u32x4 __attribute__((ext_vector_type(4)));
+template <bool LOCAL>
+__device__ __forceinline__ void rs_store_pair(const rs_gchar* base, unsigned off, float v0, float v1, unsigned epoch) {
+    const rs_u32x4 q = {__builtin_bit_cast(unsigned, v0), epoch, __builtin_bit_cast(unsigned, v1), epoch};
+    if constexpr (LOCAL) asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(off), "v"(q), "s"(base) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, %2 sc1" :: "v"(off), "v"(q), "s"(base) : "memory");
+}
+template <bool LOCAL, int NQ>
+__device__ __forceinline__ void rs_load_totals(rs_u32x4 (&q)[NQ], rs_u64& d, const rs_gchar* base, unsigned off, unsigned offd) {
+    static_assert(NQ == 1 || NQ == 2 || NQ == 4, "2, 4 or 8 columns per thread");
+#define RS_T1(M) asm volatile("global_load_dwordx4 %0, %2, %4 " M "\n\tglobal_load_dwordx2 %1, %3, %4 " M "\n\ts_waitcnt vmcnt(0)"                      \
+                              : "=&v"(q[0]), "=&v"(d) : "v"(off), "v"(offd), "s"(base) : "memory")
+#define RS_T2(M) asm volatile("global_load_dwordx4 %0, %3, %5 " M "\n\tglobal_load_dwordx4 %1, %3, %5 offset:16 " M "\n\t"                           \
+                              "global_load_dwordx2 %2, %4, %5 " M "\n\ts_waitcnt vmcnt(0)"                                                         \
+                              : "=&v"(q[0]), "=&v"(q[1]), "=&v"(d) : "v"(off), "v"(offd), "s"(base) : "memory")
+#define RS_T4(M) asm volatile("global_load_dwordx4 %0, %5, %7 " M "\n\tglobal_load_dwordx4 %1, %5, %7 offset:16 " M "\n\t"                           \
+                              "global_load_dwordx4 %2, %5, %7 offset:32 " M "\n\tglobal_load_dwordx4 %3, %5, %7 offset:48 " M "\n\t"                \
+                              "global_load_dwordx2 %4, %6, %7 " M "\n\ts_waitcnt vmcnt(0)"                                                         \
+                              : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(d) : "v"(off), "v"(offd), "s"(base) : "memory")
+    if constexpr (NQ == 1) { if constexpr (LOCAL) RS_T1("sc0 nt"); else RS_T1("sc1"); }
+    else if constexpr (NQ == 2) { if constexpr (LOCAL) RS_T2("sc0 nt"); else RS_T2("sc1"); }
+    else { if constexpr (LOCAL) RS_T4("sc0 nt"); else RS_T4("sc1"); }
+#undef RS_T1
+#undef RS_T2
+#undef RS_T4
+}
+
 // Experiment builds only (-DOG_SK_TRACE=1): shader-cycle stamps of the phases of iterations 8..15 of every wave of the first and
 // the last workgroup of the launch, read back by og_debug_sk_trace (scripts/trace_sinkhorn.py)
 #ifndef OG_SK_TRACE
@@ -183,7 +212,7 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
     constexpr int WC = W, WR = RS_NW / W;  // wave tiles of the workgroup: WR rows x WC columns
     constexpr int RB = RS_RW * WR;         // rows per workgroup
     constexpr int PS = 4 / W;              // column-partial buffers of NC floats in the 16 KB of Pbuf
-    constexpr int CPT = NC / 512;          // columns per thread in the phases that own columns (tid + 512 c)
+    constexpr int CPT = NC / 512;          // columns per thread in the phases that own columns: tid CPT + c, c < CPT (adjacent: 16-byte granule pairs)
     constexpr int SB = 2 * W;              // granules per thread and batch of an owner's sweep (at most two batches: < 4 W slots per thread)
     static_assert(W == 1 || W == 2 || W == 4, "1024, 2048 or 4096 columns");
     (void)RB;
@@ -191,7 +220,8 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
     // The small, hot arrays sit at LOW LDS addresses (ds_read/ds_write immediates are 16 bits).
     __shared__ __attribute__((aligned(16))) float smem[256 + 512 + 256 + (W == 1 ? NC : 0) + PS * NC + RS_NW * RS_LR * RS_SEG];
     float* red = smem;                                     // [256] block reductions: [0,8) max, [8,16) sums, [16,24) dustbin-column partials,
-                                                           //   [24,32) drift, [32] u_M, [40] xcd word, [128, 256) row partials [wave][16]
+                                                           //   [24,32) + [88,96) row drift (by parity), [32] u_M, [33] v_N, [40,48) column drift,
+                                                           //   [48,56) time-out flags, [128, 256) row partials [wave][16]
     float* osum = smem + 256;                              // [512] owner: per-thread partial sums of a column's slots
     float* dred = osum + 512;                              // [256] owner 0: the dustbin-column partials of the G workgroups
     float* Pbuf = dred + 256 + (W == 1 ? NC : 0);          // [PS][NC] per-wave column partials, two rounds
@@ -232,9 +262,11 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
         la = norm; lb = norm; la_bin = norm + __logf((float)N); lb_bin = norm + __logf((float)M);
     }
     const int mb = (M + G - 1) / G;                        // rows per workgroup (<= RB)
-    const float c2 = a.inv_reg * RS_LOG2E;
-    const float zr2 = (a.zdev ? a.zdev[0] : a.zhost) * c2;
-    const float la2 = la * RS_LOG2E, la_bin2 = la_bin * RS_LOG2E, lb2 = lb * RS_LOG2E, lb_bin2 = lb_bin * RS_LOG2E;
+    // (wave-uniform floats computed by the vector ALU stay in VECTOR registers unless moved: every one of these would cost a VGPR
+    // for the whole loop, next to the 192 of E)
+    const float c2 = rs_uniform(a.inv_reg * RS_LOG2E);
+    const float zr2 = rs_uniform((a.zdev ? a.zdev[0] : a.zhost) * c2);
+    const float la2 = rs_uniform(la * RS_LOG2E), la_bin2 = rs_uniform(la_bin * RS_LOG2E), lb2 = rs_uniform(lb * RS_LOG2E), lb_bin2 = rs_uniform(lb_bin * RS_LOG2E);
     const float* Sb = a.S + (int64_t)bglob * a.strideS;
     float* ub = a.u + (int64_t)bglob * a.ldu;
     const int row0 = g * mb + wr * RS_RW;                  // global row of this wave's slot 0
@@ -260,12 +292,12 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
     float vv[CPT];
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
-        const int j = tid + 512 * c;
+        const int j = tid * CPT + c;
         vv[c] = j < N ? a.v_in[(int64_t)bglob * a.ldv + j] * RS_LOG2E : OG_NEG_INF;
     }
     if (tid == 0) red[33] = a.v_in[(int64_t)bglob * a.ldv + N] * RS_LOG2E;      // the dual of the dustbin COLUMN
     __syncthreads();
-    float vN2 = red[33];
+    float vN2 = rs_uniform(red[33]);
 
     // ---- do the Gx workgroups of my group sit on ONE XCD (one L2)?  Dispatcher behaviour, not a contract: every workgroup
     //      publishes its XCC id (agent scope) and reads its peers'; all of them see the same table and take the same decision.
@@ -317,13 +349,14 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
 #endif
     f32x4 er[RS_RR][4];                                    // the register-resident rows of E
     float uM2 = 0.f;                                       // dual of the dustbin ROW (every workgroup, identically)
+    float vsh = 0.f;                                       // max_j v_j of the previous iteration: the shift of the log-sum-exp of v
     float drift = 0.f;                                     // bound (bits) on the growth of any of my entries since they were evaluated
     int it = 0;
     while (!failed) {
         // ================= (re)evaluate E = 2^(s + v + u) from the scores: at the start, and after a refresh request =================
         // columns n..NC-1 do not exist: their v is -inf, so their entries vanish whatever (finite) bytes the loads fetched
 #pragma unroll
-        for (int c = 0; c < CPT; ++c) X[tid + 512 * c] = vv[c];
+        for (int c = 0; c < CPT; ++c) X[tid * CPT + c] = vv[c];
         __syncthreads();
         {
             f32x4 xv[4];
@@ -361,7 +394,7 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
             __syncthreads();                               // every wave has read X (the v of its columns)
             if (lane == 0) red[wave] = mx;
 #pragma unroll
-            for (int c = 0; c < CPT; ++c) X[tid + 512 * c] = 1.f;       // g = 1: the first pass 1 after an evaluation rescales nothing
+            for (int c = 0; c < CPT; ++c) X[tid * CPT + c] = 1.f;       // g = 1: the first pass 1 after an evaluation rescales nothing
             __syncthreads();
             mx = red[0];
 #pragma unroll
@@ -375,7 +408,8 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
             float svt = red[8];
 #pragma unroll
             for (int w = 1; w < RS_NW; ++w) svt += red[8 + w];
-            uM2 = la_bin2 - (zr2 + mx + __builtin_amdgcn_logf(svt));
+            uM2 = rs_uniform(la_bin2 - (zr2 + mx + __builtin_amdgcn_logf(svt)));
+            vsh = rs_uniform(mx);
             __syncthreads();                               // red[] is reused by the loop
         }
         drift = 0.f;
@@ -387,7 +421,7 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
             const rs_gchar* xa_par = (const rs_gchar*)a.xa + (int64_t)(it & 1) * a.slots * NCX * 8;          // this parity's areas
             const rs_gchar* xb_par = (const rs_gchar*)a.xb + ((int64_t)(it & 1) * a.groups + grow) * NCX * 8;   // ... and my group's totals
             const rs_gchar* xc_par = (const rs_gchar*)a.xc + ((int64_t)(it & 1) * a.groups + r * XG) * NCX * 8;   // ... and the pair's group sums
-            const float dcol2 = zr2 + vN2;
+            const float dcol2 = rs_uniform(zr2 + vN2);
 
             RS_TP(0);
             // ---- (1) pass 1: E *= g, row sums ----
@@ -502,7 +536,7 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
 #pragma unroll
                     for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(pb + 256 * k) = cs[k];
                 }
-                if (lane == 0) { red[16 + wave] = wc == 0 ? usum : 0.f; red[24 + wave] = dumax; }
+                if (lane == 0) { red[16 + wave] = wc == 0 ? usum : 0.f; red[24 + 64 * (it & 1) + wave] = dumax; }     // (drift maxima: read after the last barrier of the iteration, hence two copies)
                 __syncthreads();
                 if (wr >= PS) {
 #pragma unroll
@@ -513,9 +547,9 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
             float tot[CPT];
 #pragma unroll
             for (int c = 0; c < CPT; ++c) {
-                tot[c] = Pbuf[tid + 512 * c];
+                tot[c] = Pbuf[tid * CPT + c];
 #pragma unroll
-                for (int p = 1; p < PS; ++p) tot[c] += Pbuf[p * NC + tid + 512 * c];
+                for (int p = 1; p < PS; ++p) tot[c] += Pbuf[p * NC + tid * CPT + c];
             }
             RS_TP(4);
             // ---- (4) publish my partials: row gbase + g of the parity's area, 8-byte {epoch, value} granules, relaxed stores (the vector
@@ -529,9 +563,10 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
                 constexpr int SCOPE = LOCAL ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_AGENT;
                 const rs_u64 tag = (rs_u64)epoch << 32;
                 {
-                    rs_gu64* mine = (rs_gu64*)(xa_par + (int64_t)(gbase + g) * NCX * 8);
+                    const rs_gchar* mrow = xa_par + (int64_t)(gbase + g) * NCX * 8;
+                    rs_gu64* mine = (rs_gu64*)mrow;
 #pragma unroll
-                    for (int c = 0; c < CPT; ++c) __hip_atomic_store(mine + tid + 512 * c, tag | __builtin_bit_cast(unsigned, tot[c]), __ATOMIC_RELAXED, SCOPE);
+                    for (int c = 0; c < CPT; c += 2) rs_store_pair<LOCAL>(mrow, (unsigned)(tid * CPT + c) * 8u, tot[c], tot[c + 1], epoch);
                     if (tid == 0) {
                         float us = red[16];
 #pragma unroll
@@ -628,17 +663,14 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
                 }
                 RS_TP(6);
                 {
-                    rs_u64 gt[CPT + 1];
-                    unsigned to[CPT + 1];
-#pragma unroll
-                    for (int c = 0; c < CPT; ++c) to[c] = (unsigned)(tid + 512 * c) * 8u;
-                    to[CPT] = (unsigned)NC * 8u;
+                    rs_u32x4 gq[CPT / 2];
+                    rs_u64 gn;
                     unsigned spins = 0;
                     for (;;) {
-                        rs_load_granules<LOCAL>(gt, xb_par, to);
-                        unsigned bad = 0u;
+                        rs_load_totals<LOCAL>(gq, gn, xb_par, (unsigned)(tid * CPT) * 8u, (unsigned)NC * 8u);
+                        unsigned bad = (unsigned)(gn >> 32) ^ epoch;
 #pragma unroll
-                        for (int c = 0; c <= CPT; ++c) bad |= (unsigned)(gt[c] >> 32) ^ epoch;
+                        for (int c = 0; c < CPT / 2; ++c) bad |= (gq[c][1] ^ epoch) | (gq[c][3] ^ epoch);
                         if (__builtin_amdgcn_ballot_w64(bad != 0u) == 0) break;
                         if (++spins > RS_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
                             failed = true;
@@ -649,8 +681,13 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
                         __builtin_amdgcn_s_sleep(1);
                     }
 #pragma unroll
-                    for (int c = 0; c < CPT; ++c) { const unsigned w32 = (unsigned)gt[c]; colsum[c] = __builtin_bit_cast(float, w32); }
-                    { const unsigned w32 = (unsigned)gt[CPT]; colsumN = __builtin_bit_cast(float, w32); }
+                    for (int c = 0; c < CPT / 2; ++c) {
+                        // (through scalars: __builtin_bit_cast applied to a vector ELEMENT reads element 0 whatever the index, hipcc 7.2)
+                        const unsigned w0 = gq[c][0], w1 = gq[c][2];
+                        colsum[2 * c] = __builtin_bit_cast(float, w0);
+                        colsum[2 * c + 1] = __builtin_bit_cast(float, w1);
+                    }
+                    { const unsigned w32 = (unsigned)gn; colsumN = __builtin_bit_cast(float, w32); }
                 }
             };
             if (xcd_local) exchange(std::true_type{}); else exchange(std::false_type{});
@@ -661,7 +698,7 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
             float dvmax = 0.f;
 #pragma unroll
             for (int c = 0; c < CPT; ++c) {
-                const int j = tid + 512 * c;
+                const int j = tid * CPT + c;
                 float gj = 1.f;
                 if (j < N) {
                     const float vo = vv[c];
@@ -680,34 +717,33 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
                 red[32] = uM2;
             }
             {
-                float mx = vNn;
+                // ONE reduction round: the sum of 2^(v - shift) with the PREVIOUS iteration's maximum as the shift (a dual moves by a few
+                // bits per iteration -- at most log2(m + n) + 1 -- so nothing can overflow and the sum cannot vanish), this iteration's
+                // maximum for the next one, the two drift maxima and the time-out flags of the eight waves
+                float mx = vNn, sv = __builtin_amdgcn_exp2f(vNn - vsh);                 // 2^-inf = 0
 #pragma unroll
-                for (int c = 0; c < CPT; ++c) mx = fmaxf(mx, vv[c]);
+                for (int c = 0; c < CPT; ++c) { mx = fmaxf(mx, vv[c]); sv += __builtin_amdgcn_exp2f(vv[c] - vsh); }
                 mx = rs_wave_max(mx);
-                dvmax = rs_wave_max(dvmax);
-                if (lane == 0) { red[wave] = mx; red[40 + wave] = dvmax; }
-                __syncthreads();
-                mx = red[0];
-                float dm = red[40], um = red[24];
-#pragma unroll
-                for (int w = 1; w < RS_NW; ++w) { mx = fmaxf(mx, red[w]); dm = fmaxf(dm, red[40 + w]); um = fmaxf(um, red[24 + w]); }
-                drift += dm + um;
-                float sv = __builtin_amdgcn_exp2f(vNn - mx);                            // 2^-inf = 0
-#pragma unroll
-                for (int c = 0; c < CPT; ++c) sv += __builtin_amdgcn_exp2f(vv[c] - mx);
                 sv = rs_wave_sum(sv);
-                if (lane == 0) red[8 + wave] = sv;
+                dvmax = rs_wave_max(dvmax);
+                const bool wfail = __builtin_amdgcn_ballot_w64(failed) != 0;
+                if (lane == 0) { red[wave] = mx; red[8 + wave] = sv; red[40 + wave] = dvmax; red[48 + wave] = wfail ? 1.f : 0.f; }
                 __syncthreads();
-                float svt = red[8];
+                const float* rk = red + 24 + 64 * (it & 1);
+                mx = red[0];
+                float svt = red[8], dm = red[40], um = rk[0], fl = red[48];
 #pragma unroll
-                for (int w = 1; w < RS_NW; ++w) svt += red[8 + w];
-                uM2 = la_bin2 - (zr2 + mx + __builtin_amdgcn_logf(svt));
-                vN2 = red[33];
+                for (int w = 1; w < RS_NW; ++w) { mx = fmaxf(mx, red[w]); svt += red[8 + w]; dm = fmaxf(dm, red[40 + w]); um = fmaxf(um, rk[w]); fl += red[48 + w]; }
+                drift = rs_uniform(drift + (dm + um));
+                uM2 = rs_uniform(la_bin2 - (zr2 + vsh + __builtin_amdgcn_logf(svt)));
+                vsh = rs_uniform(mx);
+                vN2 = rs_uniform(red[33]);
+                failed = fl != 0.f;                        // a peer never arrived: leave together (status = 1)
             }
             RS_TP(8);
             refresh = drift > RS_DRIFT_BITS;               // workgroup-uniform (every input of drift is)
-            if (__syncthreads_or(failed)) { failed = true; break; }      // a peer never arrived: leave together (status = 1)
             RS_TP(9);
+            if (failed) break;
         }
         if (failed || it >= a.iters) break;
         // refresh: the loop above left with ++it done; E is re-evaluated from S with the current duals at the top
@@ -718,7 +754,7 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
     if (g == 0) {
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
-            const int j = tid + 512 * c;
+            const int j = tid * CPT + c;
             if (j < N) a.v_out[(int64_t)bglob * a.ldv + j] = vv[c] * RS_LN2;
         }
         if (tid == 0) { a.v_out[(int64_t)bglob * a.ldv + N] = vN2 * RS_LN2; ub[M] = red[32] * RS_LN2; }
@@ -847,3 +883,84 @@ int og_launch_sinkhorn_resident(const float* S, int64_t lds, const float* zdev, 
     }
     return og_launch_status();
 }
+
+// ---- ragged batches: every pair gets the geometry of its own size; pairs of one width class W are packed into launches in which
+//      each pair sits on ONE XCD (first fit, largest first: 8 XCDs x 32 slots), the classes run one after the other ----
+namespace {
+struct RsPlanPair { int b, W, G; };
+// false: some pair has no resident geometry (or needs more than one XCD): the caller streams the whole batch
+bool rs_ragged_plan(const RaggedDesc& rd, RsPlanPair* pp) {
+    if (rd.B <= 0 || rd.B > OG_MAX_RAGGED || rs_num_cus() < 256) return false;
+    for (int b = 0; b < rd.B; ++b) {
+        const RsGeom q = rs_geom(rd.off0[b + 1] - rd.off0[b], rd.off1[b + 1] - rd.off1[b]);
+        if (q.W == 0 || q.X != 1) return false;
+        pp[b] = RsPlanPair{b, q.W, q.G};
+    }
+    return true;
+}
+}  // namespace
+
+bool og_sinkhorn_resident_ragged_wanted(const RaggedDesc& rd, int mode) {
+    if (mode <= 0) return false;
+    RsPlanPair pp[OG_MAX_RAGGED];
+    if (!rs_ragged_plan(rd, pp)) return false;
+    if (mode >= 2) return true;
+    int64_t elems = 0;
+    for (int b = 0; b < rd.B; ++b) elems += (int64_t)(rd.off0[b + 1] - rd.off0[b]) * (rd.off1[b + 1] - rd.off1[b]);
+    return elems >= (int64_t)1 << 18;
+}
+
+int og_launch_sinkhorn_resident_ragged(const float* S, int64_t lds, const float* zdev, float zhost, const RaggedDesc& rd, int m_max, int n_max, int iters,
+                                       float inv_reg, float* u, int ldu, const float* v_in, float* v_out, int ldv, void* xws, hipStream_t st,
+                                       bool trusted_padding) {
+    if (!S || !u || !v_in || !v_out || !xws || iters < 1) return OG_E_INVALID;
+    RsPlanPair pp[OG_MAX_RAGGED];
+    if (!rs_ragged_plan(rd, pp)) return OG_E_SHAPE;
+    hipError_t e = hipMemsetAsync(xws, 0, 256, st);                                // the status word: sticky over the launches
+    if (e != hipSuccess) return (int)e;
+    SkResArgs a{};
+    a.S = S; a.lds = lds; a.strideS = (int64_t)m_max * lds;
+    a.u = u; a.ldu = ldu; a.v_in = v_in; a.v_out = v_out; a.ldv = ldv;
+    a.status = (unsigned*)xws;
+    a.xcc = (unsigned*)((char*)xws + 256);
+    a.xa = (char*)xws + 256 + RS_MAXWG * sizeof(unsigned);
+    { const char* ev = getenv("OG_SINKHORN_AGENT_SCOPE"); a.force_agent_scope = ev && atoi(ev) != 0; }
+    a.zdev = zdev; a.zhost = zhost; a.inv_reg = inv_reg;
+    a.m = m_max; a.n = n_max; a.iters = iters; a.local_ok = 1;
+    a.sanitize_pad = !trusted_padding;                                             // (per-pair n: any of them may end inside a 16-byte chunk)
+    // largest pairs first (stable: ties keep the batch order)
+    for (int i = 1; i < rd.B; ++i) { const RsPlanPair t = pp[i]; int j = i; while (j > 0 && pp[j - 1].G < t.G) { pp[j] = pp[j - 1]; --j; } pp[j] = t; }
+    bool done[OG_MAX_RAGGED] = {};
+    for (int W = 1; W <= 4; W *= 2) {
+        for (;;) {                                                                  // one launch per pass
+            RsRagged map;
+            for (int i = 0; i < RS_MAXWG; ++i) map.wg[i] = 0xFFFFu;
+            int used[8] = {0, 0, 0, 0, 0, 0, 0, 0}, np = 0, slots = 0, qmax = 0;
+            for (int i = 0; i < rd.B; ++i) {
+                if (done[i] || pp[i].W != W) continue;
+                int x = -1;
+                for (int k = 0; k < 8; ++k) if (used[k] + pp[i].G <= 32 && (x < 0 || used[k] < used[x])) x = k;      // the emptiest XCD that still fits
+                if (x < 0) continue;
+                const int b = pp[i].b;
+                map.gb[np] = (unsigned short)b; map.G[np] = (unsigned short)pp[i].G; map.gbase[np] = (unsigned short)slots;
+                map.m[np] = rd.off0[b + 1] - rd.off0[b]; map.n[np] = rd.off1[b + 1] - rd.off1[b]; map.local[np] = 1;
+                for (int g = 0; g < pp[i].G; ++g) map.wg[x + 8 * (used[x] + g)] = (unsigned short)((np << 8) | g);
+                used[x] += pp[i].G; if (used[x] > qmax) qmax = used[x];
+                slots += pp[i].G; ++np; done[i] = true;
+            }
+            if (np == 0) break;
+            const size_t NCX = (size_t)RS_SEG * W + RS_PAD;
+            a.b0 = 0; a.npairs = np; a.slots = slots; a.groups = np;
+            a.xb = a.xa + (size_t)2 * a.slots * NCX * 8;
+            a.xc = a.xb + (size_t)2 * a.groups * NCX * 8;
+            e = hipMemsetAsync(a.xcc, 0, RS_MAXWG * sizeof(unsigned) + (size_t)2 * a.slots * NCX * 8 + (size_t)4 * a.groups * NCX * 8, st);
+            if (e != hipSuccess) return (int)e;
+            const int grid = 8 * qmax;
+            if (W == 1) rs_launch<1>(a, map, grid, st);
+            else if (W == 2) rs_launch<2>(a, map, grid, st);
+            else rs_launch<4>(a, map, grid, st);
+        }
+    }
+    return og_launch_status();
+}
+
