@@ -100,8 +100,10 @@ typedef unsigned rs_u32x4 __attribute__((ext_vector_type(4)));
 template <bool LOCAL>
 __device__ __forceinline__ void rs_store_pair(const rs_gchar* base, unsigned off, float v0, float v1, unsigned epoch) {
     const rs_u32x4 q = {__builtin_bit_cast(unsigned, v0), epoch, __builtin_bit_cast(unsigned, v1), epoch};
-    if constexpr (LOCAL) asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(off), "v"(q), "s"(base) : "memory");
-    else asm volatile("global_store_dwordx4 %0, %1, %2 sc1" :: "v"(off), "v"(q), "s"(base) : "memory");
+    // (the trailing s_nop: a VMEM store of more than 8 bytes must not be followed at once by a write of its data registers; the
+    // compiler's hazard recognizer does not look inside inline asm, and it does reuse q for the next pair)
+    if constexpr (LOCAL) asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" :: "v"(off), "v"(q), "s"(base) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" :: "v"(off), "v"(q), "s"(base) : "memory");
 }
 template <bool LOCAL, int NQ>
 __device__ __forceinline__ void rs_load_totals(rs_u32x4 (&q)[NQ], rs_u64& d, const rs_gchar* base, unsigned off, unsigned offd) {
@@ -199,9 +201,47 @@ __device__ __forceinline__ float rs_wave_max(float v) {
     v = fmaxf(v, rs_dpp_keep<0x143, 0xC>(v));
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// Eight rows at once: p[k] = this lane's partial sum of row k.  Returns, in EVERY lane, the total of row (lane & 7): three
+// reduce-scatter steps (the lane pair / quad / octet exchanges what the other half keeps: 8 -> 4 -> 2 -> 1 registers), then plain
+// sums over the remaining lane bits.  25 vector instructions against 8 x 13 for eight 64-lane trees; fixed order.
+__device__ __forceinline__ float rs_reduce8(const float (&p)[8], int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+    float t[4], w[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = (b0 ? p[2 * k + 1] : p[2 * k]) + rs_dpp<0xB1, 0xF>(b0 ? p[2 * k] : p[2 * k + 1]);        // quad_perm [1,0,3,2]
+#pragma unroll
+    for (int k = 0; k < 2; ++k) w[k] = (b1 ? t[2 * k + 1] : t[2 * k]) + rs_dpp<0x4E, 0xF>(b1 ? t[2 * k] : t[2 * k + 1]);        // quad_perm [2,3,0,1]
+    const float send = b2 ? w[0] : w[1];
+    float z = (b2 ? w[1] : w[0]) + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, send), 0x101F));   // lane ^ 4
+    z += rs_dpp<0x128, 0xF>(z);                                                  // row_ror:8 = lane ^ 8
+    {
+        const unsigned zi = __builtin_bit_cast(unsigned, z);
+        const auto r16 = __builtin_amdgcn_permlane16_swap(zi, zi, false, false);  // rows of 16 lanes: (z0, z0, z2, z2) and (z1, z1, z3, z3)
+        const unsigned a0 = r16[0], a1 = r16[1];
+        z = __builtin_bit_cast(float, a0) + __builtin_bit_cast(float, a1);
+        const unsigned zj = __builtin_bit_cast(unsigned, z);
+        const auto r32 = __builtin_amdgcn_permlane32_swap(zj, zj, false, false);  // halves: (lo, lo) and (hi, hi)
+        const unsigned c0 = r32[0], c1 = r32[1];
+        z = __builtin_bit_cast(float, c0) + __builtin_bit_cast(float, c1);
+    }
+    return z;
+}
 __device__ __forceinline__ float rs_uniform(float v) {      // a value every lane holds -> an SGPR
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
+
+// Everything a thread derives from its id -- lane, column offsets, LDS addresses, its place in an owner's sweep -- is RE-DERIVED from
+// an opaque copy of the id where it is used: hoisted out of the iteration loop each of these would hold a register for the whole
+// loop (next to the 192 of E), i.e. be spilled and re-loaded from scratch memory in every iteration.
+#define RS_THREAD_LOCALS                                                                                                        \
+    int tq_ = threadIdx.x;                                                                                                     \
+    asm volatile("" : "+v"(tq_));                                                                                              \
+    const int tid = tq_, lane = tid & 63;                                                                                      \
+    const int colb = wc * RS_SEG + 4 * lane;                  /* my lane's 16 columns of the pair: colb + 256 k + e */          \
+    const float* Xl = X + colb;                               /* ... of X: + 256 k (immediate offsets) */                       \
+    float* Sw = Srows + wave * RS_LR * RS_SEG + 4 * lane;     /* this wave's LDS rows: + 1024 s + 256 k (immediates within 16 KB) */ \
+    const int ocol = (gl << cwl) + (tid & (CW - 1)), oslot0 = tid >> cwl;                                                      \
+    (void)colb; (void)Xl; (void)Sw; (void)ocol; (void)oslot0
 
 // The 12 register-resident rows of a wave are an ordinary array of 192 floats (fully unrolled, static indices only).
 // Audit after every edit: no scratch traffic inside the iteration loop (hipcc -Rpass-analysis=kernel-resource-usage).
@@ -281,14 +321,12 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
     const int CW = 1 << cwl, TPC = 512 >> cwl;             // threads per column
     const bool owner = (gl << cwl) < NC;
     const int spt = (Gx + TPC - 1) / TPC;                  // slots per thread: s = tid / CW + i TPC  (< 4 W)
-    const int ocol = (gl << cwl) + (tid & (CW - 1)), oslot0 = tid >> cwl;
 
     // ---- duals of my rows (base 2, wave-uniform) and of my columns (tid + 512 c) ----
     // per-row scalars live ACROSS THE LANES of one register: lane s < 16 holds the value of row slot s (sixteen wave-uniform copies of
     // each would cost 48 SGPRs and sixteen-fold scalar arithmetic)
     float urv = (lane < RS_RW && row0 + lane < row_end) ? ub[row0 + lane] * RS_LOG2E : 0.f;
     auto lane_value = [](float v, int s) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), s)); };
-    auto set_lane = [&](float old, float val, int s) { return lane == s ? val : old; };     // val is wave-uniform
     float vv[CPT];
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
@@ -321,10 +359,8 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
         xcd_local = __syncthreads_and(verdict == 1u) != 0;
     }
 
-    // my lane's 16 columns of the pair: wc * 1024 + 256 k + 4 lane + e
-    const int colb = wc * RS_SEG + 4 * lane;
     // raw scores of one row segment (rows past the end: row 0's bytes, never used).  (scalar row base + 32-bit lane offset) addressing
-    auto load_row_raw = [&](int row, f32x4 (&x)[4]) {
+    auto load_row_raw = [&](int row, f32x4 (&x)[4], int colb) {
         const uint64_t v = (uint64_t)(uintptr_t)(Sb + (int64_t)(row < row_end ? row : 0) * a.lds);      // wave-uniform: pinned to an SGPR pair
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi32 = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
         const rs_gchar* rp = (const rs_gchar*)(uintptr_t)(((uint64_t)hi32 << 32) | lo);                    // global address space: global_load, not flat_load
@@ -342,8 +378,6 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
         }
     };
 
-    const float* Xl = X + colb;                            // this lane's columns of X: + 256 k (immediate offsets)
-    float* Sw = Srows + wave * RS_LR * RS_SEG + 4 * lane;  // this wave's LDS rows: + 1024 s + 256 k (immediates within 16 KB)
 #if OG_SK_TRACE
     const int tsel = blockIdx.x == 0 ? 0 : (r == a.npairs - 1 && g == G - 1) ? 1 : -1;
 #endif
@@ -353,6 +387,7 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
     float drift = 0.f;                                     // bound (bits) on the growth of any of my entries since they were evaluated
     int it = 0;
     while (!failed) {
+        RS_THREAD_LOCALS;
         // ================= (re)evaluate E = 2^(s + v + u) from the scores: at the start, and after a refresh request =================
         // columns n..NC-1 do not exist: their v is -inf, so their entries vanish whatever (finite) bytes the loads fetched
 #pragma unroll
@@ -368,7 +403,7 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
                 // through scratch at every join): rows past the end read row 0's bytes with u = -inf, i.e. hold zeros
                 if (s < RS_RR || s < nvalid) {
                     f32x4 x[4];
-                    load_row_raw(row0 + s, x);
+                    load_row_raw(row0 + s, x, colb);
                     const float u = s < nvalid ? lane_value(urv, s) : OG_NEG_INF;
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
@@ -417,6 +452,7 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
         bool refresh = false;
 #pragma unroll 1
         for (; it < a.iters && !refresh; ++it) {
+            RS_THREAD_LOCALS;
             const unsigned epoch = (unsigned)it + 1u;
             const rs_gchar* xa_par = (const rs_gchar*)a.xa + (int64_t)(it & 1) * a.slots * NCX * 8;          // this parity's areas
             const rs_gchar* xb_par = (const rs_gchar*)a.xb + ((int64_t)(it & 1) * a.groups + grow) * NCX * 8;   // ... and my group's totals
@@ -425,44 +461,48 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
 
             RS_TP(0);
             // ---- (1) pass 1: E *= g, row sums ----
-            float rsv = 1.f;                               // lane s: row sum of slot s
+            float rsv;                                     // lane l: row sum of slot l & 15
             {
                 f32x4 xr[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) xr[k] = *reinterpret_cast<const f32x4*>(Xl + 256 * k);
+                float zA, zB;
 #pragma unroll
-                for (int s = 0; s < RS_RR; ++s) {
-                    {
+                for (int half = 0; half < 2; ++half) {
+                    float ps[8];                               // this lane's partial sums of eight rows
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int s = 8 * half + q;
                         rs_f32x2 sum2 = {0.f, 0.f};
+                        if (s < RS_RR) {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k)
+                            for (int k = 0; k < 4; ++k)
 #pragma unroll
-                            for (int e = 0; e < 4; e += 2) {
-                                const rs_f32x2 t = rs_f32x2{er[s][k][e], er[s][k][e + 1]} * rs_f32x2{xr[k][e], xr[k][e + 1]};
-                                er[s][k][e] = t[0]; er[s][k][e + 1] = t[1];
-                                sum2 += t;
+                                for (int e = 0; e < 4; e += 2) {
+                                    const rs_f32x2 t = rs_f32x2{er[s < RS_RR ? s : 0][k][e], er[s < RS_RR ? s : 0][k][e + 1]} * rs_f32x2{xr[k][e], xr[k][e + 1]};
+                                    er[s < RS_RR ? s : 0][k][e] = t[0]; er[s < RS_RR ? s : 0][k][e + 1] = t[1];
+                                    sum2 += t;
+                                }
+                        } else if (s < nvalid) {
+                            const int sl = s - RS_RR;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                f32x4 x = *reinterpret_cast<const f32x4*>(Sw + sl * RS_SEG + 256 * k);
+#pragma unroll
+                                for (int e = 0; e < 4; e += 2) {
+                                    const rs_f32x2 t = rs_f32x2{x[e], x[e + 1]} * rs_f32x2{xr[k][e], xr[k][e + 1]};
+                                    x[e] = t[0]; x[e + 1] = t[1];
+                                    sum2 += t;
+                                }
+                                *reinterpret_cast<f32x4*>(Sw + sl * RS_SEG + 256 * k) = x;
                             }
-                        rsv = set_lane(rsv, rs_wave_sum(sum2[0] + sum2[1]), s);
-                    }
-                }
-#pragma unroll
-                for (int sl = 0; sl < RS_LR; ++sl) {
-                    if (RS_RR + sl < nvalid) {
-                        rs_f32x2 sum2 = {0.f, 0.f};
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            f32x4 x = *reinterpret_cast<const f32x4*>(Sw + sl * RS_SEG + 256 * k);
-#pragma unroll
-                            for (int e = 0; e < 4; e += 2) {
-                                const rs_f32x2 t = rs_f32x2{x[e], x[e + 1]} * rs_f32x2{xr[k][e], xr[k][e + 1]};
-                                x[e] = t[0]; x[e + 1] = t[1];
-                                sum2 += t;
-                            }
-                            *reinterpret_cast<f32x4*>(Sw + sl * RS_SEG + 256 * k) = x;
                         }
-                        rsv = set_lane(rsv, rs_wave_sum(sum2[0] + sum2[1]), RS_RR + sl);
+                        ps[q] = sum2[0] + sum2[1];
                     }
+                    const float z = rs_reduce8(ps, lane);
+                    if (half == 0) zA = z; else zB = z;
                 }
+                rsv = (lane & 8) ? zB : zA;
             }
             RS_TP(1);
             if constexpr (WC > 1) {                        // the rows cross WC waves: partial sums through LDS, fixed order
@@ -750,6 +790,8 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
     }
 
     // ---- results in natural units: u of my rows, and (workgroup 0 of the pair) v and u_M ----
+    {
+    RS_THREAD_LOCALS;
     if (wc == 0 && lane < nvalid) ub[row0 + lane] = urv * RS_LN2;
     if (g == 0) {
 #pragma unroll
@@ -758,6 +800,7 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
             if (j < N) a.v_out[(int64_t)bglob * a.ldv + j] = vv[c] * RS_LN2;
         }
         if (tid == 0) { a.v_out[(int64_t)bglob * a.ldv + N] = vN2 * RS_LN2; ub[M] = red[32] * RS_LN2; }
+    }
     }
 }
 
@@ -927,7 +970,8 @@ int og_launch_sinkhorn_resident_ragged(const float* S, int64_t lds, const float*
     { const char* ev = getenv("OG_SINKHORN_AGENT_SCOPE"); a.force_agent_scope = ev && atoi(ev) != 0; }
     a.zdev = zdev; a.zhost = zhost; a.inv_reg = inv_reg;
     a.m = m_max; a.n = n_max; a.iters = iters; a.local_ok = 1;
-    a.sanitize_pad = !trusted_padding;                                             // (per-pair n: any of them may end inside a 16-byte chunk)
+    (void)trusted_padding;
+    a.sanitize_pad = 1;     // columns [n_b, lds) of a ragged pair's rows were never written by anybody: they may hold NaN / Inf
     // largest pairs first (stable: ties keep the batch order)
     for (int i = 1; i < rd.B; ++i) { const RsPlanPair t = pp[i]; int j = i; while (j > 0 && pp[j - 1].G < t.G) { pp[j] = pp[j - 1]; --j; } pp[j] = t; }
     bool done[OG_MAX_RAGGED] = {};
