@@ -146,12 +146,11 @@ struct RsUniform {
     int G, Gx, X, layers;
 };
 // Ragged batches: per-pair sizes and the id -> (pair, g) table by value in the kernarg segment (no device-side table, no copy)
-struct RsRagged {
-    unsigned short wg[RS_MAXWG];       // (pair << 8) | g, 0xFFFF = idle
-    unsigned short gb[OG_MAX_RAGGED];  // pair of the round -> pair of the batch
-    unsigned short gbase[OG_MAX_RAGGED], G[OG_MAX_RAGGED];      // (one group per pair: G <= 32)
+struct RsRagged {                      // 32-bit entries only: the 16-bit tables of the first version came back wrong for ODD indices
+    int wg[RS_MAXWG];                  // (pair << 8) | g, -1 = idle        (dynamic indexing of sub-dword kernel-argument arrays, hipcc 7.2)
+    int gb[OG_MAX_RAGGED];             // pair of the round -> pair of the batch
+    int gbase[OG_MAX_RAGGED], G[OG_MAX_RAGGED];      // (one group per pair: G <= 32)
     int m[OG_MAX_RAGGED], n[OG_MAX_RAGGED];
-    unsigned char local[OG_MAX_RAGGED];
 };
 
 struct SkResArgs {
@@ -288,11 +287,11 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
         gbase = r * G; bglob = a.b0 + r; M = a.m; N = a.n;
         local_hint = a.local_ok != 0;
     } else {
-        const unsigned e = map.wg[blockIdx.x];
-        if (e == 0xFFFFu) return;
-        r = (int)(e >> 8); g = (int)(e & 255u);
+        const int e = map.wg[blockIdx.x];
+        if (e < 0) return;
+        r = e >> 8; g = e & 255;
         G = map.G[r]; Gx = G; gbase = map.gbase[r]; bglob = map.gb[r]; M = map.m[r]; N = map.n[r];
-        local_hint = map.local[r] != 0;
+        local_hint = true;
     }
     const int gl = g - xg * Gx;                            // my index inside the group
     const int grow = r * XG + xg;                           // my group's row of xb / xc
@@ -978,7 +977,7 @@ int og_launch_sinkhorn_resident_ragged(const float* S, int64_t lds, const float*
     for (int W = 1; W <= 4; W *= 2) {
         for (;;) {                                                                  // one launch per pass
             RsRagged map;
-            for (int i = 0; i < RS_MAXWG; ++i) map.wg[i] = 0xFFFFu;
+            for (int i = 0; i < RS_MAXWG; ++i) map.wg[i] = -1;
             int used[8] = {0, 0, 0, 0, 0, 0, 0, 0}, np = 0, slots = 0, qmax = 0;
             for (int i = 0; i < rd.B; ++i) {
                 if (done[i] || pp[i].W != W) continue;
@@ -986,9 +985,9 @@ int og_launch_sinkhorn_resident_ragged(const float* S, int64_t lds, const float*
                 for (int k = 0; k < 8; ++k) if (used[k] + pp[i].G <= 32 && (x < 0 || used[k] < used[x])) x = k;      // the emptiest XCD that still fits
                 if (x < 0) continue;
                 const int b = pp[i].b;
-                map.gb[np] = (unsigned short)b; map.G[np] = (unsigned short)pp[i].G; map.gbase[np] = (unsigned short)slots;
-                map.m[np] = rd.off0[b + 1] - rd.off0[b]; map.n[np] = rd.off1[b + 1] - rd.off1[b]; map.local[np] = 1;
-                for (int g = 0; g < pp[i].G; ++g) map.wg[x + 8 * (used[x] + g)] = (unsigned short)((np << 8) | g);
+                map.gb[np] = b; map.G[np] = pp[i].G; map.gbase[np] = slots;
+                map.m[np] = rd.off0[b + 1] - rd.off0[b]; map.n[np] = rd.off1[b + 1] - rd.off1[b];
+                for (int g = 0; g < pp[i].G; ++g) map.wg[x + 8 * (used[x] + g)] = (np << 8) | g;
                 used[x] += pp[i].G; if (used[x] > qmax) qmax = used[x];
                 slots += pp[i].G; ++np; done[i] = true;
             }
