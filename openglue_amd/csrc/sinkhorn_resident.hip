@@ -5,19 +5,22 @@
 // loaded ONCE and iterated in ONE launch; larger batches run as a sequence of such rounds (32 pairs of 1024 x 1024, 8 pairs of
 // 2048 x 2048 or 2 pairs of 4096 x 4096 per round).  Round 4 rewrite of the round-2/3 kernel, two changes of substance:
 //
-// (1) LINEAR-DOMAIN resident state.  After the max-subtracted first iteration (sinkhorn.hip) every plan entry
-//         E_ij = 2^(s_ij + u_i + v_j),   s = S/reg * log2 e, duals in base 2,
-//     is <= max(a_i, b_j) < 1 and stays so under every half-update.  The resident matrix is E itself, rescaled in place:
-//         pass 1:  E_ij *= g_j ;  rowsum_i = sum_j E_ij + 2^(z + v_N + u_i) ;  u_i' = u_i + log2 a_i - log2 rowsum_i ;  f_i = 2^(u_i' - u_i)
-//         pass 2:  E_ij *= f_i ;  colsum_j = sum_i E_ij + 2^(z + v_j + u_M') ;  v_j' = v_j + log2 b_j - log2 colsum_j ;  g_j = 2^(v_j' - v_j)
-//     -- the same recursion as optimal_transport.py:24-26 in exact arithmetic, 4 packed-fp32 flops per entry and iteration instead
-//     of 2 adds + 1 exponential + 1 add + 1 fma; the factors are the exponentials of the ACTUAL (rounded) dual increments, so E
-//     tracks the duals and nothing drifts apart (tests/emulate_sinkhorn_linear.py: 6e-6 .. 2e-5 on the log-scores after 100
-//     iterations, below the reference's own fp32 solver).  What the linear domain cannot represent are entries below 2^-126: they
-//     are gone for good, whereas the log-domain recursion could bring them back.  A conservative bound on the growth of ANY entry
-//     since it was last evaluated from the scores, drift = sum_t (max_i du_i^+ + max_j dv_j^+), is kept per workgroup; beyond
-//     RS_DRIFT_BITS = 40 bits the workgroup re-reads its rows of S and re-evaluates E = 2^(s + u + v) (a refresh is a no-op in exact
-//     arithmetic, so workgroups refresh independently).  Ordinary problems never refresh; |S/reg| of several hundred does 2-4 times.
+// (1) LINEAR-DOMAIN resident state, never rewritten.  After the max-subtracted first iteration (sinkhorn.hip) every plan entry
+//         P_ij = 2^(s_ij + u_i + v_j),   s = S/reg * log2 e, duals in base 2,
+//     is <= max(a_i, b_j) < 1 and stays so under every half-update.  The resident matrix is E = P as it was when the workgroup last
+//     EVALUATED it from the scores; the plan of the moment is P_ij = E_ij F_i C_j with the row factors F_i = 2^(u_i - u_i at the
+//     evaluation) (one register, a row per lane) and the column factors C_j = 2^(v_j - v_j at the evaluation) (an LDS vector):
+//         pass 1:  rowsum_i = F_i sum_j E_ij C_j + 2^(z + v_N + u_i) ;  u_i' = u_i + log2 a_i - log2 rowsum_i ;  F_i *= 2^(u_i' - u_i)
+//         pass 2:  colsum_j = C_j sum_i E_ij F_i + 2^(z + v_j + u_M') ;  v_j' = v_j + log2 b_j - log2 colsum_j ;  C_j *= 2^(v_j' - v_j)
+//     -- the same recursion as optimal_transport.py:24-26 in exact arithmetic, TWO packed-fp32 fmas per entry and iteration (the
+//     round-3 kernel: 2 adds + 1 exponential + 1 add + 1 fma) and no store; the factors are products of the exponentials of the
+//     ACTUAL (rounded) dual increments, so the plan tracks the duals (tests/emulate_sinkhorn_linear.py: ~1e-5 on the log-scores
+//     after 100 iterations, the level of the reference's own fp32 solver).  What the linear domain cannot represent are entries
+//     below 2^-126 at the time of the evaluation: they are zero until the next one, whereas the log-domain recursion could bring
+//     them back.  A bound on how far ANY factor product has moved, drift = sum_t (max_i |du_i| + max_j |dv_j|), is kept per
+//     workgroup; beyond RS_DRIFT_BITS = 40 bits the workgroup re-reads its rows of S and re-evaluates E = 2^(s + u + v) with
+//     F = C = 1 (a no-op in exact arithmetic, so workgroups refresh independently): a lost entry is below 2^-86 then, against
+//     marginals of 2^-14.  Ordinary problems never refresh; |S/reg| of several hundred does 5-7 times in 30 iterations.
 //     Nothing is streamed from memory inside the loop: 12 of a wave's 16 rows live in registers (192), 4 in LDS.
 //
 // (2) ANY WIDTH UP TO 4096 COLUMNS, ANY NUMBER OF WORKGROUPS PER PAIR.  A wave always owns a 16-row x 1024-column tile (16 floats per lane
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
     float* osum = smem + 256;                              // [512] owner: per-thread partial sums of a column's slots
     float* dred = osum + 512;                              // [256] owner 0: the dustbin-column partials of the G workgroups
     float* Pbuf = dred + 256 + (W == 1 ? NC : 0);          // [PS][NC] per-wave column partials, two rounds
-    float* X = W == 1 ? dred + 256 : Pbuf;                 // [NC] the column factors g_j of this iteration (W > 1: a barrier separates its
+    float* X = W == 1 ? dred + 256 : Pbuf;                 // [NC] the column factors C_j, re-written every iteration (W > 1: a barrier separates its
                                                            //   last read from the first write of Pbuf, so they share the space)
     float* Srows = Pbuf + PS * NC;                         // [wave][RS_LR][1024]
 
@@ -326,7 +329,9 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
     // each would cost 48 SGPRs and sixteen-fold scalar arithmetic)
     float urv = (lane < RS_RW && row0 + lane < row_end) ? ub[row0 + lane] * RS_LOG2E : 0.f;
     auto lane_value = [](float v, int s) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), s)); };
-    float vv[CPT];
+    float vv[CPT];                                         // v of my columns (base 2)
+    float cj[CPT];                                         // ... and their factors C_j since the evaluation
+    float Frv = 1.f;                                       // lane s: F of row slot s
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
         const int j = tid * CPT + c;
@@ -428,7 +433,7 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
             __syncthreads();                               // every wave has read X (the v of its columns)
             if (lane == 0) red[wave] = mx;
 #pragma unroll
-            for (int c = 0; c < CPT; ++c) X[tid * CPT + c] = 1.f;       // g = 1: the first pass 1 after an evaluation rescales nothing
+            for (int c = 0; c < CPT; ++c) { cj[c] = 1.f; X[tid * CPT + c] = 1.f; }      // C = 1 (and F = 1) right after an evaluation
             __syncthreads();
             mx = red[0];
 #pragma unroll
@@ -447,6 +452,7 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
             __syncthreads();                               // red[] is reused by the loop
         }
         drift = 0.f;
+        Frv = 1.f;
 
         bool refresh = false;
 #pragma unroll 1
@@ -459,8 +465,8 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
             const float dcol2 = rs_uniform(zr2 + vN2);
 
             RS_TP(0);
-            // ---- (1) pass 1: E *= g, row sums ----
-            float rsv;                                     // lane l: row sum of slot l & 15
+            // ---- (1) pass 1: sum_j E_ij C_j of my 16 rows ----
+            float rsv;                                     // lane l: sum_j E C of slot l & 15 (times F below)
             {
                 f32x4 xr[4];
 #pragma unroll
@@ -478,22 +484,15 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
                             for (int k = 0; k < 4; ++k)
 #pragma unroll
                                 for (int e = 0; e < 4; e += 2) {
-                                    const rs_f32x2 t = rs_f32x2{er[s < RS_RR ? s : 0][k][e], er[s < RS_RR ? s : 0][k][e + 1]} * rs_f32x2{xr[k][e], xr[k][e + 1]};
-                                    er[s < RS_RR ? s : 0][k][e] = t[0]; er[s < RS_RR ? s : 0][k][e + 1] = t[1];
-                                    sum2 += t;
+                                    sum2 += rs_f32x2{er[s < RS_RR ? s : 0][k][e], er[s < RS_RR ? s : 0][k][e + 1]} * rs_f32x2{xr[k][e], xr[k][e + 1]};
                                 }
                         } else if (s < nvalid) {
                             const int sl = s - RS_RR;
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
-                                f32x4 x = *reinterpret_cast<const f32x4*>(Sw + sl * RS_SEG + 256 * k);
+                                const f32x4 x = *reinterpret_cast<const f32x4*>(Sw + sl * RS_SEG + 256 * k);
 #pragma unroll
-                                for (int e = 0; e < 4; e += 2) {
-                                    const rs_f32x2 t = rs_f32x2{x[e], x[e + 1]} * rs_f32x2{xr[k][e], xr[k][e + 1]};
-                                    x[e] = t[0]; x[e + 1] = t[1];
-                                    sum2 += t;
-                                }
-                                *reinterpret_cast<f32x4*>(Sw + sl * RS_SEG + 256 * k) = x;
+                                for (int e = 0; e < 4; e += 2) sum2 += rs_f32x2{x[e], x[e + 1]} * rs_f32x2{xr[k][e], xr[k][e + 1]};
                             }
                         }
                         ps[q] = sum2[0] + sum2[1];
@@ -515,55 +514,48 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
                 }
             }
             // ---- new u of my rows, the row factors f, the dustbin-column partial (lanes 0..15, one row each) ----
-            float frv, usum, dumax;
+            float usum, dumax;
             {
                 const bool live = lane < nvalid;
                 const float pd = __builtin_amdgcn_exp2f(dcol2 + urv);              // the row's dustbin-column entry with the old u
-                const float un = urv + la2 - __builtin_amdgcn_logf(rsv + pd);
+                const float un = urv + la2 - __builtin_amdgcn_logf(Frv * rsv + pd);
                 const float du = un - urv;
                 const float f = __builtin_amdgcn_exp2f(du);
                 usum = rs_wave_sum(live ? pd * f : 0.f);                            // sum_i 2^(z + v_N + u_i')
-                dumax = rs_wave_max(live ? du : 0.f);
-                frv = live ? f : 0.f;
+                dumax = rs_wave_max(live ? __builtin_fabsf(du) : 0.f);
+                Frv = live ? Frv * f : 0.f;                                         // (rows that do not exist: F = 0, E = 0)
                 urv = live ? un : urv;
             }
             RS_TP(2);
-            // ---- (2) pass 2: E *= f, column partials of my 16 rows ----
+            // ---- (2) pass 2: sum_i E_ij F_i over my 16 rows ----
             f32x4 cs[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) cs[k] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < RS_RR; ++s) {
-                {
-                    const float f_ = lane_value(frv, s);
-                    const rs_f32x2 ff = {f_, f_};
+                const float f_ = lane_value(Frv, s);
+                const rs_f32x2 ff = {f_, f_};
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
+                for (int k = 0; k < 4; ++k)
 #pragma unroll
-                        for (int e = 0; e < 4; e += 2) {
-                            const rs_f32x2 t = rs_f32x2{er[s][k][e], er[s][k][e + 1]} * ff;
-                            er[s][k][e] = t[0]; er[s][k][e + 1] = t[1];
-                            const rs_f32x2 c = rs_f32x2{cs[k][e], cs[k][e + 1]} + t;
-                            cs[k][e] = c[0]; cs[k][e + 1] = c[1];
-                        }
-                }
+                    for (int e = 0; e < 4; e += 2) {
+                        const rs_f32x2 c = rs_f32x2{cs[k][e], cs[k][e + 1]} + rs_f32x2{er[s][k][e], er[s][k][e + 1]} * ff;
+                        cs[k][e] = c[0]; cs[k][e + 1] = c[1];
+                    }
             }
 #pragma unroll
             for (int sl = 0; sl < RS_LR; ++sl) {
                 if (RS_RR + sl < nvalid) {
-                    const float f_ = lane_value(frv, RS_RR + sl);
+                    const float f_ = lane_value(Frv, RS_RR + sl);
                     const rs_f32x2 ff = {f_, f_};
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        f32x4 x = *reinterpret_cast<const f32x4*>(Sw + sl * RS_SEG + 256 * k);
+                        const f32x4 x = *reinterpret_cast<const f32x4*>(Sw + sl * RS_SEG + 256 * k);
 #pragma unroll
                         for (int e = 0; e < 4; e += 2) {
-                            const rs_f32x2 t = rs_f32x2{x[e], x[e + 1]} * ff;
-                            x[e] = t[0]; x[e + 1] = t[1];
-                            const rs_f32x2 c = rs_f32x2{cs[k][e], cs[k][e + 1]} + t;
+                            const rs_f32x2 c = rs_f32x2{cs[k][e], cs[k][e + 1]} + rs_f32x2{x[e], x[e + 1]} * ff;
                             cs[k][e] = c[0]; cs[k][e + 1] = c[1];
                         }
-                        *reinterpret_cast<f32x4*>(Sw + sl * RS_SEG + 256 * k) = x;
                     }
                 }
             }
@@ -738,16 +730,15 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
 #pragma unroll
             for (int c = 0; c < CPT; ++c) {
                 const int j = tid * CPT + c;
-                float gj = 1.f;
                 if (j < N) {
                     const float vo = vv[c];
-                    const float vn = vo + lb2 - __builtin_amdgcn_logf(colsum[c] + __builtin_amdgcn_exp2f(zr2 + vo + uM2));
+                    const float vn = vo + lb2 - __builtin_amdgcn_logf(cj[c] * colsum[c] + __builtin_amdgcn_exp2f(zr2 + vo + uM2));
                     const float dv = vn - vo;
-                    gj = __builtin_amdgcn_exp2f(dv);
-                    dvmax = fmaxf(dvmax, dv);
+                    cj[c] *= __builtin_amdgcn_exp2f(dv);
+                    dvmax = fmaxf(dvmax, __builtin_fabsf(dv));
                     vv[c] = vn;
                 }
-                X[j] = gj;
+                X[j] = cj[c];
             }
             float vNn = OG_NEG_INF;
             if (tid == 0) {

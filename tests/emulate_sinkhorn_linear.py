@@ -94,6 +94,47 @@ def linear_sinkhorn(S, z, iters, reg, refresh_every=0, flush_denormals=True, dri
     return scores, {"refreshes": n_refresh, "max_Du": float(Du.abs().max()), "max_Dv": float(Dv.abs().max()), "zeros": float((E == 0).float().mean())}
 
 
+def lazy_sinkhorn(S, z, iters, reg, drift_bits=40.0):
+    """The form the kernel runs since round 4: E stays as evaluated; the row factors F_i = 2^(sum du_i) and column factors
+    C_j = 2^(sum dv_j) since the evaluation are kept beside it and applied inside the sums (2 fmas per entry and iteration, no
+    store).  Two-sided drift bound: re-evaluate when sum_t (max_i |du_i| + max_j |dv_j|) exceeds drift_bits."""
+    B, m, n = S.shape
+    u1, v1, la, lb, Sa = first_iteration_fp32(S, z, reg)
+    if iters == 1:
+        return (Sa + u1[:, :, None] + v1[:, None, :] + math.log(m + n)), {}
+    tiny = torch.finfo(F).tiny
+    s2 = (Sa[:, :m, :n] * LOG2E).to(F)
+    zr2 = np.float32(z / reg * LOG2E)
+    la2, lb2 = la * LOG2E, lb * LOG2E
+    u, v = (u1 * LOG2E).to(F), (v1 * LOG2E).to(F)
+    def fresh():
+        E = torch.exp2((s2 + v[:, None, :n]) + u[:, :m, None])
+        return torch.where(E < tiny, torch.zeros_like(E), E)
+    E = fresh(); Fr = torch.ones(B, m, dtype=F); C = torch.ones(B, n, dtype=F)
+    drift = torch.zeros(B, dtype=F); nref = 0
+    for it in range(iters - 1):
+        pd = torch.exp2(zr2 + v[:, n:n + 1] + u[:, :m])
+        rowsum = Fr * (E * C[:, None, :]).sum(dim=2) + pd
+        un = u[:, :m] + la2[:, :m] - torch.log2(rowsum)
+        du = un - u[:, :m]
+        f = torch.exp2(du)
+        Fr = Fr * f
+        uM = la2[:, m] - (zr2 + torch.logsumexp(v * LN2, dim=1) * LOG2E)
+        T = (E * Fr[:, :, None]).sum(dim=1)
+        colsum = C * T + torch.exp2(zr2 + v[:, :n] + uM[:, None])
+        dcolsum = (pd * f).sum(dim=1) + torch.exp2(zr2 + v[:, n] + uM)
+        vn = v[:, :n] + lb2[:, :n] - torch.log2(colsum)
+        dv = vn - v[:, :n]
+        C = C * torch.exp2(dv)
+        u = torch.cat([un, uM[:, None]], dim=1)
+        v = torch.cat([vn, (v[:, n] + lb2[:, n] - torch.log2(dcolsum))[:, None]], dim=1)
+        drift += du.abs().amax(dim=1) + dv.abs().amax(dim=1)
+        if bool((drift > drift_bits).any()):
+            E = fresh(); Fr = torch.ones_like(Fr); C = torch.ones_like(C); drift.zero_(); nref += 1
+    un, vn = u * LN2, v * LN2
+    return (Sa + un[:, :, None]) + vn[:, None, :] + math.log(m + n), {"refreshes": nref}
+
+
 def rand_scores(B, m, n, scale, seed):
     g = torch.Generator().manual_seed(seed)
     return torch.randn(B, m, n, generator=g, dtype=F) * scale
@@ -101,6 +142,9 @@ def rand_scores(B, m, n, scale, seed):
 
 def report(tag, S, z, iters, reg, **kw):
     ref = orc.matching_log_probs(S.double(), torch.tensor(z, dtype=torch.float64), iters, reg)
+    if not kw:
+        lz, li = lazy_sinkhorn(S, z, iters, reg)
+        print(f"[{tag}] it={iters} reg={reg} LAZY factors (the kernel's form): err {(lz.double() - ref).abs().max().item():.2e} {li}")
     out, info = linear_sinkhorn(S, z, iters, reg, **kw)
     err = (out.double() - ref).abs().max().item()
     # the log-domain fp32 solver of the reference itself as the yardstick
