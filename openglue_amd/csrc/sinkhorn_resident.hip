@@ -581,6 +581,8 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
                 tot[c] = Pbuf[tid * CPT + c];
 #pragma unroll
                 for (int p = 1; p < PS; ++p) tot[c] += Pbuf[p * NC + tid * CPT + c];
+                tot[c] *= cj[c];                           // the partial sums of the PLAN leave the workgroup: C_j is this workgroup's own (the
+                                                           // workgroups of a pair evaluate E at different times, so their factors differ)
             }
             RS_TP(4);
             // ---- (4) publish my partials: row gbase + g of the parity's area, 8-byte {epoch, value} granules, relaxed stores (the vector
@@ -732,7 +734,7 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
                 const int j = tid * CPT + c;
                 if (j < N) {
                     const float vo = vv[c];
-                    const float vn = vo + lb2 - __builtin_amdgcn_logf(cj[c] * colsum[c] + __builtin_amdgcn_exp2f(zr2 + vo + uM2));
+                    const float vn = vo + lb2 - __builtin_amdgcn_logf(colsum[c] + __builtin_amdgcn_exp2f(zr2 + vo + uM2));
                     const float dv = vn - vo;
                     cj[c] *= __builtin_amdgcn_exp2f(dv);
                     dvmax = fmaxf(dvmax, __builtin_fabsf(dv));
