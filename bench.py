@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Benchmark of the SuperGlue hot path on MI355X: matched image-pairs / second.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C1|C3|C4|C5] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C1|C3|C4|C5] [--batch PAIRS_PER_GPU | --global-batch PAIRS]
+                    [--no-cpu-baseline]
 
 With --gpus N > 1 and no torch.distributed environment the script re-executes itself under
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` (one process per GPU,
@@ -40,9 +41,23 @@ SUSTAINED_F16_MFMA_TFLOPS = 1670.0
 # Counter summaries collected by SEPARATE rocprofv3 --pmc passes (scripts/gpu_pmc.sh + parse_pmc.py, scripts/gpu_traffic.sh +
 # parse_traffic.py) and committed under profiles/.  They are NOT measured by this run: every block pasted from them into the JSON
 # line carries its source file and the commit it was collected on.
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
-TRAFFIC_SUMMARY = os.path.join(ROOT, "profiles", "r03_traffic_c2.json")
-TRAFFIC_BY_CONFIG = {"C3": os.path.join(ROOT, "profiles", "r03_traffic_c3.json"), "C4": os.path.join(ROOT, "profiles", "r03_traffic_c4.json")}
+def _newest(*names):
+    for n in names:
+        p = os.path.join(ROOT, "profiles", n)
+        if os.path.exists(p):
+            return p
+    return os.path.join(ROOT, "profiles", names[-1])
+
+
+PMC_SUMMARY = _newest("r04_pmc_summary.json", "r03_pmc_summary.json")
+TRAFFIC_SUMMARY = _newest("r04_traffic_c2.json", "r03_traffic_c2.json")
+TRAFFIC_BY_CONFIG = {"C3": _newest("r04_traffic_c3.json", "r03_traffic_c3.json"), "C4": _newest("r04_traffic_c4.json", "r03_traffic_c4.json")}
+# oracle (the port bench.py times on the GPU box) vs the unmodified reference, timed side by side in the BUILD container where
+# /root/reference exists (scripts/port_vs_reference.py); pasted into cpu_baseline with its source
+PORT_VS_REFERENCE = os.path.join(ROOT, "profiles", "r04_port_vs_reference.json")
+ARITHMETIC = ("f32 inputs / outputs; GNN 1x1 convs, attention QK^T and PV, final projection and score matrix as split-f16 x3 MFMA "
+              "(x = hi + lo binary16, Ah.Bh + Ah.Bl + Al.Bh into one fp32 accumulator: fp32-class accuracy); keypoint-encoder MLP exact "
+              "fp32 MFMA; softmax, Sinkhorn and match extraction fp32 VALU")
 
 
 def algorithmic_counts(cfg_kw, m, n):
@@ -81,89 +96,86 @@ def _load_json(path):
         return {}
 
 
-def roofline_block(counts_per_step, stages, launches, num_iters, measured_on_this_workload, sinkhorn_resident, traffic_path=None):
-    """Per-kernel-class roofline objects.  achieved = algorithmic work per step / class time (HIP events on the launch
-    stream, median of 3 profiled steps) = algorithmic work per launch / average launch duration.
-    sinkhorn_resident: the schedule the library took for this shape (og_sinkhorn_schedule), not a guess from bracket counts."""
+def roofline_block(counts_per_step, stages, launches, num_iters, measured_on_this_workload, sinkhorn_launches, traffic_path=None):
+    """One roofline object PER KERNEL (the profiled step brackets every launch of the MFMA kernels separately: og_forward_profiled).
+    achieved = algorithmic work per step / the kernel's time per step (HIP events on the launch stream, median of 3 profiled steps)
+    = algorithmic work per launch / average launch duration.  Returns (the kernel with the largest time share, the others).
+    sinkhorn_launches: resident-kernel launches the library schedules for this shape (og_sinkhorn_schedule; 0 = streaming)."""
     pmc = _load_json(PMC_SUMMARY) if measured_on_this_workload else {}
     tpath = TRAFFIC_SUMMARY if measured_on_this_workload else traffic_path      # counter summaries exist for C2 (PMC + traffic) and C3 / C4 (traffic)
     tj = _load_json(tpath) if tpath else {}
     src_pmc = {"source": os.path.relpath(PMC_SUMMARY, ROOT), "collected_at_commit": pmc.get("_commit"), "measured_in_this_run": False}
     src_tr = {"source": os.path.relpath(tpath, ROOT) if tpath else None, "collected_at_commit": tj.get("_commit"), "measured_in_this_run": False}
-    # the split-f16 GEMM class = the stand-alone GEMM launches + the fused message-MLP launches (same arithmetic, same pipe)
-    gemm_ms = stages["gemm_f16x3"] + stages.get("mlp_fused", 0.0)
-    gemm_launches = launches["gemm_f16x3"] + launches.get("mlp_fused", 0)
-    cls_ms = {"gemm_f16x3": gemm_ms, "gemm_f32": stages["gemm_f32"], "attention": stages["attention"], "sinkhorn": stages["sinkhorn"]}
-    # real kernel launches of the Sinkhorn bracket: resident = first-iteration sweep + combine, resident kernel, safety net, scores
-    sk_launches = 5 if sinkhorn_resident else 2 * num_iters + 1
-    cls_launches = {"gemm_f16x3": gemm_launches, "gemm_f32": launches["gemm_f32"], "attention": launches["attention"], "sinkhorn": sk_launches}
-    per_step = {  # kernel class -> (algorithmic work per step, unit scale, bound, peak, unit, kernels)
-        "gemm_f16x3": (counts_per_step["gemm_f16x3_flops"], 1e12, "mfma", PEAK_F16_MFMA_TFLOPS, "TFLOP/s",
-                       "mlp_fused_kernel (fc.0 -> ReLU -> fc.3 + residual, hidden activation in registers) / gemm_nt_f16x3_big2_kernel (256x256 tiles: q/k/v) / "
-                       "gemm_nt_f16x3_kernel (128-token tiles) / gemm_nt_f16x3_big_kernel (batched score matrix): GNN 1x1 convs, last encoder conv, "
-                       "final projection, score matrix; split-f16 3-pass MFMA: executes 3x the algorithmic flops"),
-        "gemm_f32": (counts_per_step["gemm_f32_flops"], 1e12, "mfma", PEAK_F32_MFMA_TFLOPS, "TFLOP/s",
-                     "gemm_nt_f32_kernel (keypoint-encoder MLP without its last conv; exact fp32 MFMA)"),
-        "attention": (counts_per_step["attention_flops"], 1e12, "mfma", PEAK_F16_MFMA_TFLOPS, "TFLOP/s",
-                      "attention_dma_kernel (dh = 64, 32: K/V tiles by LDS-DMA) / attention_kernel (dh = 16): split-f16 flash attention, executes 3x the algorithmic flops"),
+    mlp_ms = stages.get("mlp_fused", 0.0)
+    # kernel -> (profiler stage, algorithmic work per step, peak, PMC / traffic key, description)
+    kernels = {
+        "attention_dma_kernel": ("attention", counts_per_step["attention_flops"], PEAK_F16_MFMA_TFLOPS, "attention",
+                                 "split-f16 flash attention (dh = 64, 32: K/V tiles by LDS-DMA; dh = 16: attention_kernel); executes 3x the algorithmic flops"),
+        "gemm_nt_f16x3 (stand-alone)": ("gemm_f16x3", counts_per_step["gemm_f16x3_flops"] - (counts_per_step["mlp_flops"] if mlp_ms > 0 else 0.0),
+                                        PEAK_F16_MFMA_TFLOPS, "gemm_f16x3_standalone",
+                                        "gemm_nt_f16x3_big2_kernel (256x256 tiles: q/k/v projections) / gemm_nt_f16x3_kernel (128-token tiles: last encoder "
+                                        "conv, final projection; the message MLP when it is not fused) / gemm_nt_f16x3_big_kernel (batched score matrix); "
+                                        "split-f16 3-pass MFMA: executes 3x the algorithmic flops"),
+        "gemm_nt_f32_kernel": ("gemm_f32", counts_per_step["gemm_f32_flops"], PEAK_F32_MFMA_TFLOPS, "gemm_f32",
+                               "keypoint-encoder MLP without its last conv; exact fp32 MFMA"),
     }
-    roofs = {}
-    for k, (work, scale, bound, peak, unit, kern) in per_step.items():
-        ms = cls_ms[k]
-        ach = work / (ms * 1e-3) / scale if ms > 0 else 0.0
-        nl = max(1, cls_launches[k])
-        roofs[k] = {"kernel": kern, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
-                    "frac": round(ach / peak, 4), "traffic": None, "class_ms_per_step": round(ms, 3),
-                    "launches_per_step": cls_launches[k], "avg_launch_ms": round(ms / nl, 4),
-                    "algorithmic_work_per_launch": round(work / nl / scale, 6)}
-        if bound == "mfma" and peak == PEAK_F16_MFMA_TFLOPS:
+    if mlp_ms > 0:
+        kernels["mlp_fused_kernel"] = ("mlp_fused", counts_per_step["mlp_flops"], PEAK_F16_MFMA_TFLOPS, "mlp_fused",
+                                       "message MLP of a GNN layer (fc.0 -> ReLU -> fc.3 + residual) in one launch, hidden activation in registers; "
+                                       "split-f16 3-pass MFMA: executes 3x the algorithmic flops")
+    roofs, ms_of = {}, {}
+    for name, (stage, work, peak, key, desc) in kernels.items():
+        ms = stages[stage]
+        nl = max(1, launches[stage])
+        ach = work / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        r = {"kernel": name, "what": desc, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+             "traffic": None, "ms_per_step": round(ms, 3), "launches_per_step": launches[stage], "avg_launch_ms": round(ms / nl, 4),
+             "algorithmic_work_per_launch_tflop": round(work / nl / 1e12, 6)}
+        if peak == PEAK_F16_MFMA_TFLOPS:
             # the split-f16 kernels execute 3 MFMA passes per algorithmic product: their ceiling is a third of the pipe's rate
-            roofs[k]["executed_tflops"] = round(3.0 * ach, 1)
-            roofs[k]["sustained_peak_measured"] = SUSTAINED_F16_MFMA_TFLOPS
-            roofs[k]["executed_frac_of_sustained"] = round(3.0 * ach / SUSTAINED_F16_MFMA_TFLOPS, 4)
-        if k in tj and isinstance(tj[k], dict) and "hbm_bytes_per_launch" in tj[k]:
-            roofs[k]["traffic"] = tj[k]["hbm_bytes_per_launch"]
-            roofs[k]["traffic_source"] = src_tr
-        if k in pmc:       # SQ counter summary of the same kernels (separate rocprofv3 --pmc passes)
-            roofs[k]["mfma_busy_frac"] = pmc[k].get("mfma_busy_frac")
-            roofs[k]["pmc"] = dict({kk: vv for kk, vv in pmc[k].items() if kk != "mfma_busy_frac"}, **src_pmc)
-    if stages.get("mlp_fused", 0.0) > 0:
-        g = roofs["gemm_f16x3"]
-        mlp_ms, mlp_n = stages["mlp_fused"], max(1, launches["mlp_fused"])
-        g["mlp_fused"] = {"ms_per_step": round(mlp_ms, 3), "launches_per_step": launches["mlp_fused"], "avg_launch_ms": round(mlp_ms / mlp_n, 4),
-                          "algorithmic_tflops": round(counts_per_step["mlp_flops"] / (mlp_ms * 1e-3) / 1e12, 1)}
-        g["standalone_gemms"] = {"ms_per_step": round(stages["gemm_f16x3"], 3), "launches_per_step": launches["gemm_f16x3"],
-                                 "algorithmic_tflops": round((counts_per_step["gemm_f16x3_flops"] - counts_per_step["mlp_flops"]) / max(stages["gemm_f16x3"] * 1e-3, 1e-9) / 1e12, 1)}
-    # ---- Sinkhorn.  Streaming schedule: HBM roofline on what it has to move (one read of S per iteration + column partials + scores).
-    #      Resident schedule: the matrices stay on chip, so there is no meaningful HBM roofline; the kernel is bound by vector-ALU
-    #      issue.  Reported: SURVEY 8(d) bytes / time (survey_equivalent: may exceed the HBM peak -- that is the point), counter bytes
-    #      / time as the HBM fraction (from the committed traffic summary, tagged), and the VALU-issue fraction from the committed PMC
-    #      summary (SQ_INSTS_VALU x 4 cycles / (busy cycles x SIMDs)) as the bounding figure.
+            r["executed_tflops"] = round(3.0 * ach, 1)
+            r["sustained_peak_measured"] = SUSTAINED_F16_MFMA_TFLOPS
+            r["executed_frac_of_sustained"] = round(3.0 * ach / SUSTAINED_F16_MFMA_TFLOPS, 4)
+        if key in tj and isinstance(tj[key], dict) and "hbm_bytes_per_launch" in tj[key]:
+            r["traffic"] = tj[key]["hbm_bytes_per_launch"]
+            r["traffic_source"] = src_tr
+        if key in pmc:       # SQ counter summary of the same kernel (separate rocprofv3 --pmc passes)
+            r["mfma_busy_frac"] = pmc[key].get("mfma_busy_frac")
+            r["pmc"] = dict({kk: vv for kk, vv in pmc[key].items() if kk != "mfma_busy_frac"}, **src_pmc)
+        roofs[name] = r
+        ms_of[name] = ms
+    # ---- Sinkhorn (one profiler bracket around the whole stage).  Streaming schedule: HBM roofline on what it has to move (one read of
+    #      S per iteration + column partials + scores).  Resident schedule: the plan matrices stay on chip (registers + LDS) for all
+    #      iterations after the first; HBM sees S once per launch plus the scores, so the HBM fraction says little -- reported are the
+    #      SURVEY 8(d) bytes / time (may exceed the HBM peak: that is the point of residency), the counter bytes / time, and the
+    #      iteration rate, which is bound by the cross-workgroup exchange latency (profiles/r04_e_sinkhorn_lazy_trace.log).
     ms = stages["sinkhorn"]
-    sk = {"schedule": "resident" if sinkhorn_resident else "streaming", "class_ms_per_step": round(ms, 3), "launches_per_step": sk_launches,
+    resident = sinkhorn_launches > 0
+    sk_launches = 4 + sinkhorn_launches if resident else 2 * num_iters + 1   # first-iteration sweep + combine, resident launches, safety net, scores
+    sk = {"kernel": "sinkhorn", "schedule": "resident" if resident else "streaming", "ms_per_step": round(ms, 3), "launches_per_step": sk_launches,
           "stage_brackets": launches.get("sinkhorn", 1)}
     if ms > 0:
         sk["survey_equivalent_gbs"] = round(counts_per_step["sinkhorn_bytes_survey"] / (ms * 1e-3) / 1e9, 1)
         one_sweep = counts_per_step["sinkhorn_bytes"] / (ms * 1e-3) / 1e9
-        if sinkhorn_resident:
-            sk.update(kernel="sinkhorn_resident_kernel (iterations 2..iters in one launch, score matrices in registers + LDS) + first-iteration "
-                             "sweep/combine, safety net (no-op), sinkhorn_scores", bound="valu", unit="fraction of VALU issue slots", peak=1.0)
-            key = "sinkhorn_resident" if "sinkhorn_resident" in pmc else "sinkhorn"
-            vf = (pmc.get(key) or {}).get("valu_issue_frac")
-            sk["achieved"] = vf
-            sk["frac"] = vf
-            if vf is not None:
+        if resident:
+            sk.update(what=f"sinkhorn_resident_kernel x {sinkhorn_launches} (iterations 2..iters of a round of co-resident pairs in one launch, plan entries in "
+                           "registers + LDS, column sums exchanged through {epoch, value} granules) + first-iteration sweep/combine, safety net (no-op), "
+                           "sinkhorn_scores", bound="hbm", unit="GB/s", peak=PEAK_HBM_GBS,
+                      achieved=sk["survey_equivalent_gbs"], frac=round(sk["survey_equivalent_gbs"] / PEAK_HBM_GBS, 4),
+                      note="achieved = SURVEY 8(d) algorithmic bytes (two sweeps of the augmented matrix per iteration) / stage time; the resident "
+                           "schedule does not move them, so the figure may exceed the HBM peak", us_per_iteration=round(ms * 1e3 / max(1, num_iters - 1) / max(1, sinkhorn_launches), 2))
+            key = "sinkhorn_resident"
+            if key in pmc:
                 sk["pmc"] = dict({kk: vv for kk, vv in pmc[key].items()}, **src_pmc)
             tb = (tj.get("sinkhorn_resident") or {}).get("hbm_bytes_per_launch")
             sk["traffic"] = tb
             if tb:
-                sk["hbm_counter_gbs"] = round(tb / (ms * 1e-3) / 1e9, 1)
-                sk["hbm_frac_of_peak"] = round(tb / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
+                sk["hbm_counter_gbs"] = round(tb * sinkhorn_launches / (ms * 1e-3) / 1e9, 1)
                 sk["traffic_source"] = src_tr
             sk["streaming_one_sweep_equivalent_gbs"] = round(one_sweep, 1)
         else:
-            sk.update(kernel="sinkhorn_sweep(_fast) + sinkhorn_combine(_fast) per iteration, then sinkhorn_scores; one stage bracket incl. launch gaps; "
-                             "algorithmic bytes = ONE read of S per iteration + column partials + scores write",
+            sk.update(what="sinkhorn_sweep(_fast) + sinkhorn_combine(_fast) per iteration, then sinkhorn_scores; one stage bracket incl. launch gaps; "
+                           "algorithmic bytes = ONE read of S per iteration + column partials + scores write",
                       bound="hbm", unit="GB/s", peak=PEAK_HBM_GBS, achieved=round(one_sweep, 1), frac=round(one_sweep / PEAK_HBM_GBS, 4),
                       algorithmic_gb_per_step=round(counts_per_step["sinkhorn_bytes"] / 1e9, 3))
             if "sinkhorn_sweep" in tj and "sinkhorn_combine" in tj:
@@ -172,9 +184,12 @@ def roofline_block(counts_per_step, stages, launches, num_iters, measured_on_thi
             else:
                 sk["traffic"] = None
     roofs["sinkhorn"] = sk
-    dominant = max(per_step, key=lambda k: cls_ms[k])
+    ms_of["sinkhorn"] = ms
+    total = sum(ms_of.values()) or 1.0
+    for k in roofs:
+        roofs[k]["time_share"] = round(ms_of[k] / total, 4)
+    dominant = max(ms_of, key=lambda k: ms_of[k])          # the single kernel with the largest time share
     roof = roofs.pop(dominant)
-    roof["class"] = dominant
     return roof, roofs
 
 
@@ -246,7 +261,9 @@ def cpu_baseline(cfg, sd, cfg_kw, m, n, budget_s=24.0):
             orc.match_pairs(sd, cfg, data, MATCH_THRESHOLD)
         dt = (time.perf_counter() - t0) / reps
     single = 1.0 / dt
+    pvr = _load_json(PORT_VS_REFERENCE)
     out = {"value": round(single, 4), "unit": "image-pairs/s", "cores": best_t, "kind": "port",
+           "port_vs_reference": dict(pvr, source=os.path.relpath(PORT_VS_REFERENCE, ROOT), measured_in_this_run=False) if pvr else None,
            "host_threads": ncpu, "physical_cores": nphys,
            "single_process": {"pairs_per_s": round(single, 4), "threads": best_t, "ms_per_pair": round(dt * 1e3, 1)},
            "sample": f"{reps} x 1 pair of the same workload (B=1, torch-CPU oracle, {best_t} of {ncpu} host threads), {dt * 1e3:.0f} ms/pair"}
@@ -311,11 +328,34 @@ def _timed_steps(step, args, dist_on, dev):
     return dt, out
 
 
+def _step_spread(step, steps, dev):
+    """min / median / max of the per-step times of `steps` further steps: one HIP event pair per step on the launch stream (torch's
+    current stream = the stream every kernel of the step is enqueued on), read after ONE synchronisation at the end -- the steps run
+    back to back exactly like the timed region that defines `value`."""
+    st = torch.cuda.current_stream(dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    ev[0].record(st)
+    for i in range(steps):
+        step()
+        ev[i + 1].record(st)
+    torch.cuda.synchronize()
+    ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
+    return {"min": round(ms[0], 3), "median": round(ms[len(ms) // 2], 3), "max": round(ms[-1], 3), "steps": steps,
+            "how": "HIP event pairs on the launch stream around every step of a second back-to-back run"}
+
+
+def _rccl_block(dist_on):
+    if not dist_on:
+        return {"backend": None, "world_size": 1, "note": "single process: no process group, no collective"}
+    import torch.distributed as dist
+    return {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "collective": "one gather of the match lists to rank 0 per step"}
+
+
 def bench_ragged(args, world, rank, dev, dist_on=False):
     """BASELINE configs[4]: ragged pairs with 512-2048 keypoints per image, 16 per GPU, cost-balanced over the ranks, through
     the token-packed ragged path (SuperGlue.match_ragged_packed -> og_forward_ragged)."""
     kw = dict(syn.CONFIGS["C2"]); kw.pop("kpts"); kw.pop("batch")
-    per_gpu = args.batch or 16
+    per_gpu = args.batch or (args.global_batch // world if args.global_batch else 16)
     total = per_gpu * world
     lens = syn.ragged_lengths(total, 512, 2048, seed=0)
     costs = [sharding.pair_cost(m, n) for m, n in lens]
@@ -351,13 +391,18 @@ def bench_ragged(args, world, rank, dev, dist_on=False):
             model.match_ragged_packed(packed, MATCH_THRESHOLD, both_sides=False, _profile=(ms, cnt))
             return _stage_dict(ms, cnt)
         stages, launches = _median_stages(run_profiled)
-        roof, roof2 = roofline_block(counts, stages, launches, kw["num_iters"], False, False)      # ragged batches always stream
+        a0 = (C.c_int32 * len(my_lens))(*[a for a, _ in my_lens]); a1 = (C.c_int32 * len(my_lens))(*[b for _, b in my_lens])
+        sk_launches = int(_lib.load().og_sinkhorn_schedule_ragged(len(my_lens), a0, a1, kw["num_iters"])) if len(my_lens) <= 64 else 0
+        roof, roof2 = roofline_block(counts, stages, launches, kw["num_iters"], False, sk_launches)
         line = {"metric": "image-pairs/sec (C5 ragged 512-2048 kpts)", "value": round(total * args.steps / dt, 2), "unit": "image-pairs/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "step_ms_spread": _step_spread(step, args.steps, dev),
+                "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": f"BASELINE configs[4]: {total} ragged pairs ({per_gpu}/GPU), 512-2048 kpts/image, 256-dim, 9 stages, "
                                        "100 Sinkhorn iters, token-packed ragged kernels (og_forward_ragged), LPT cost-balanced over ranks",
+                           "arithmetic": ARITHMETIC, "global_batch": total,
                            "mean_kpts": round(sum(a + b for a, b in lens) / (2 * total), 1), "pairs_per_gpu": per_gpu},
+                "rccl": _rccl_block(dist_on),
                 "roofline": roof, "roofline_other": roof2, "stages_ms": {k: round(v, 3) for k, v in stages.items()},
                 "algorithmic": {"gflop_per_step_rank0": round(counts["total_flops"] / 1e9, 2),
                                 "sinkhorn_gb_per_step_rank0": round(counts["sinkhorn_bytes"] / 1e9, 3)},
@@ -417,10 +462,12 @@ def _dry_run(args, world, rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="C2", choices=sorted(syn.CONFIGS) + ["C5"])
     ap.add_argument("--batch", type=int, default=None, help="pairs per GPU (default: the config's)")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="pairs of the whole job, split evenly over the ranks (BASELINE: C3 256, C4 64, C5 128 over 8 GPUs) -- strong scaling")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -450,6 +497,10 @@ def main():
     (m, n), B = kw.pop("kpts"), kw.pop("batch")
     if args.batch:
         B = args.batch
+    elif args.global_batch:
+        if args.global_batch % world:
+            raise SystemExit(f"--global-batch {args.global_batch} is not a multiple of the {world} ranks")
+        B = args.global_batch // world
     cfg = syn.make_config(**kw)
     sd = syn.make_state_dict(cfg, seed=0)
     model = SuperGlue(cfg).eval()
@@ -478,19 +529,22 @@ def main():
             model.match(data, MATCH_THRESHOLD, both_sides=True, _profile=(ms, cnt))
             return _stage_dict(ms, cnt)
         stages, launches = _median_stages(run_profiled)
-        resident = bool(_lib.load().og_sinkhorn_schedule(B, m, n, kw["num_iters"]))
+        sk_launches = int(_lib.load().og_sinkhorn_schedule(B, m, n, kw["num_iters"]))
         std_batch = B == syn.CONFIGS[args.config]["batch"]
-        roof, roof2 = roofline_block(counts, stages, launches, kw["num_iters"], args.config == "C2" and std_batch, resident,
+        roof, roof2 = roofline_block(counts, stages, launches, kw["num_iters"], args.config == "C2" and std_batch, sk_launches,
                                      TRAFFIC_BY_CONFIG.get(args.config) if std_batch else None)
         line = {
             "metric": "image-pairs/sec (1024 kpts, 256-dim, 9 GNN layers)" if args.config == "C2" else f"image-pairs/sec ({args.config})",
             "value": round(value, 2), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 3), "step_ms_spread": _step_spread(step, args.steps, dev),
+            "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[{'1' if args.config == 'C2' else args.config}]: {m}x{n} kpts, {kw['descriptor_dim']}-dim, "
                                    f"{kw['num_stages']} self+cross stages, {kw['num_heads']} heads, {kw['num_iters']} Sinkhorn iters, "
                                    f"batch={B} pairs/GPU, random-init weights, seeded synthetic keypoints/descriptors",
+                       "arithmetic": ARITHMETIC, "global_batch": world * B,
                        "pairs_per_gpu": B, "kpts": [m, n], "parallelism": f"pairs sharded over {world} GPU(s), 1 RCCL gather"},
+            "rccl": _rccl_block(dist_on),
             "roofline": roof, "roofline_other": roof2,
             "stages_ms": {k: round(v, 3) for k, v in stages.items()},
             "algorithmic": {"gflop_per_pair": round(c1["total_flops"] / 1e9, 2), "sinkhorn_gb_per_pair": round(c1["sinkhorn_bytes"] / 1e9, 3),

@@ -294,22 +294,25 @@ int og_sinkhorn(const float* S, int64_t lds, float dustbin, int32_t batch, int32
 /* Diagnostics (synchronises the device, copies 4 bytes): state of the last og_sinkhorn / og_forward Sinkhorn stage that ran on
  * this Sinkhorn workspace (every call resets it).
  *   0 = completed normally (streaming kernels, or the on-chip-resident kernel without incident);
- *   2 = a cross-workgroup wait of the on-chip-resident iteration kernel timed out (its batch * ceil(m/128) workgroups must be
+ *   2 = a cross-workgroup wait of the on-chip-resident iteration kernel timed out (the workgroups of a launch must be
  *       co-resident; the launcher checks that against the CU count, but another stream or process holding CUs can still break it)
  *       and the safety-net kernel enqueued behind it solved the problem again, one workgroup per pair: the scores are VALID, the
  *       call was slow (milliseconds);
  *   3 = a NON-FINITE value was written to the scores: something upstream overflowed or was NaN -- an activation beyond the binary16
  *       range of the split-f16 operands (|x| >= 65504), non-finite inputs.  The scores are invalid;
  *   1 = timed out and not recomputed (cannot happen with this build's launch sequence; scores invalid); -1 = bad arguments.
- * When the batch fits (batch * ceil(m/128) <= #CUs, n <= 1024, >= 16 MB of scores; OG_SINKHORN_RESIDENT=0 disables, =2 drops
- * the size threshold) iterations 2..iters run in ONE launch with the score matrices held in registers + LDS.
- * OG_SINKHORN_FORCE_TIMEOUT=1 (tests) makes that launch behave as if it had timed out. */
+ * For n <= 4096 and at least 2^18 matrix entries per call (OG_SINKHORN_RESIDENT=0 disables, =2 drops the size threshold) iterations
+ * 2..iters run with the plan matrices held in registers + LDS, one launch per round of co-resident pairs (csrc/sinkhorn_resident.hip).
+ * OG_SINKHORN_FORCE_TIMEOUT=1 (tests) makes those launches behave as if they had timed out. */
 int og_sinkhorn_status(const void* sinkhorn_workspace_dev, int32_t batch, int32_t m, int32_t n);
 /* Which schedule og_sinkhorn / og_forward take for a UNIFORM batch of this shape in this process (environment switches and the
- * device's CU count included): 1 = first iteration streaming + ONE on-chip-resident launch for iterations 2..iters (+ the safety-net
- * and scores kernels: 6 launches), 0 = streaming (2 launches per iteration + 1).  Ragged batches always stream.  bench.py uses it to
- * name the kernels its Sinkhorn bracket timed. */
+ * device's CU count included): k >= 1 = first iteration streaming, then k launches of the on-chip-resident kernel for iterations
+ * 2..iters (one per round of co-resident pairs: 32 pairs of 1024 x 1024, 8 of 2048 x 2048, 2 of 4096 x 4096 on 256 CUs) + the
+ * safety-net and scores kernels; 0 = streaming (2 launches per iteration + 1).  bench.py uses it to name what its Sinkhorn bracket
+ * timed.  og_sinkhorn_schedule_ragged: the same for a ragged batch (host arrays of per-pair sizes, batch <= OG_MAX_RAGGED): pairs are
+ * grouped by width class and packed one pair per XCD slot range; 0 when any pair has no resident geometry. */
 int og_sinkhorn_schedule(int32_t batch, int32_t m, int32_t n, int32_t iters);
+int og_sinkhorn_schedule_ragged(int32_t batch, const int32_t* lens0, const int32_t* lens1, int32_t iters);
 /* The same check for the workspace of an og_forward / og_forward_ragged call with this shape (for ragged calls: the shape
  * that was passed, i.e. the maxima).  SYNCHRONISES the device.  Return values as og_sinkhorn_status. */
 int og_forward_status(const og_shape* shape, const void* workspace_dev);

@@ -221,7 +221,7 @@ int og_sinkhorn_resident_rounds(int B, int m, int n);                 // launche
 bool og_sinkhorn_resident_ragged_wanted(const RaggedDesc& rd, int mode);
 int og_launch_sinkhorn_resident_ragged(const float* S, int64_t lds, const float* zdev, float zhost, const RaggedDesc& rd, int m_max, int n_max, int iters,
                                        float inv_reg, float* u, int ldu, const float* v_in, float* v_out, int ldv, void* xws, hipStream_t st,
-                                       bool trusted_padding = true);
+                                       bool trusted_padding = true, int* count_only = nullptr);    // count_only: no work, *count_only = launches it would take
 static inline bool og_sinkhorn_resident_ragged_wanted(const RaggedNone&, int) { return false; }
 int og_launch_sinkhorn_resident(const float* S, int64_t lds, const float* zdev, float zhost, int B, int m, int n, int iters,
                                 float inv_reg, float la, float la_bin, float lb, float lb_bin, float* u, int ldu, const float* v_in,

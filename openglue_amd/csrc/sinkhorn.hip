@@ -924,7 +924,26 @@ extern "C" int og_sinkhorn_schedule(int32_t batch, int32_t m, int32_t n, int32_t
     static const bool robust_only = [] { const char* e = getenv("OG_SINKHORN_ROBUST"); return e && atoi(e) != 0; }();
     const char* rm_env = getenv("OG_SINKHORN_RESIDENT");
     const int resident_mode = rm_env ? atoi(rm_env) : 1;
-    return (!robust_only && iters > 1 && og_sinkhorn_resident_wanted(batch, m, n, resident_mode)) ? 1 : 0;
+    return (!robust_only && iters > 1 && og_sinkhorn_resident_wanted(batch, m, n, resident_mode)) ? og_sinkhorn_resident_rounds(batch, m, n) : 0;
+}
+
+extern "C" int og_sinkhorn_schedule_ragged(int32_t batch, const int32_t* lens0, const int32_t* lens1, int32_t iters) {
+    static const bool robust_only = [] { const char* e = getenv("OG_SINKHORN_ROBUST"); return e && atoi(e) != 0; }();
+    if (batch <= 0 || batch > OG_MAX_RAGGED || !lens0 || !lens1 || robust_only || iters <= 1) return 0;
+    const char* rm_env = getenv("OG_SINKHORN_RESIDENT");
+    const int resident_mode = rm_env ? atoi(rm_env) : 1;
+    RaggedDesc rd{};
+    rd.B = batch;
+    int mmax = 0, nmax = 0;
+    for (int b = 0; b < batch; ++b) {
+        rd.off0[b + 1] = rd.off0[b] + lens0[b]; rd.off1[b + 1] = rd.off1[b] + lens1[b];
+        if (lens0[b] > mmax) mmax = lens0[b];
+        if (lens1[b] > nmax) nmax = lens1[b];
+    }
+    if (og_sinkhorn_resident_ws_bytes(batch, mmax, nmax) == 0 || !og_sinkhorn_resident_ragged_wanted(rd, resident_mode)) return 0;
+    int launches = 0;
+    if (og_launch_sinkhorn_resident_ragged(nullptr, 0, nullptr, 0.f, rd, mmax, nmax, iters - 1, 1.f, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, true, &launches)) return 0;
+    return launches;
 }
 
 extern "C" int og_sinkhorn_status(const void* workspace_dev, int32_t batch, int32_t m, int32_t n) {

@@ -947,11 +947,12 @@ bool og_sinkhorn_resident_ragged_wanted(const RaggedDesc& rd, int mode) {
 
 int og_launch_sinkhorn_resident_ragged(const float* S, int64_t lds, const float* zdev, float zhost, const RaggedDesc& rd, int m_max, int n_max, int iters,
                                        float inv_reg, float* u, int ldu, const float* v_in, float* v_out, int ldv, void* xws, hipStream_t st,
-                                       bool trusted_padding) {
-    if (!S || !u || !v_in || !v_out || !xws || iters < 1) return OG_E_INVALID;
+                                       bool trusted_padding, int* count_only) {
+    if (!count_only && (!S || !u || !v_in || !v_out || !xws || iters < 1)) return OG_E_INVALID;
     RsPlanPair pp[OG_MAX_RAGGED];
     if (!rs_ragged_plan(rd, pp)) return OG_E_SHAPE;
-    hipError_t e = hipMemsetAsync(xws, 0, 256, st);                                // the status word: sticky over the launches
+    if (count_only) *count_only = 0;
+    hipError_t e = count_only ? hipSuccess : hipMemsetAsync(xws, 0, 256, st);      // the status word: sticky over the launches
     if (e != hipSuccess) return (int)e;
     SkResArgs a{};
     a.S = S; a.lds = lds; a.strideS = (int64_t)m_max * lds;
@@ -985,6 +986,7 @@ int og_launch_sinkhorn_resident_ragged(const float* S, int64_t lds, const float*
                 slots += pp[i].G; ++np; done[i] = true;
             }
             if (np == 0) break;
+            if (count_only) { ++*count_only; continue; }
             const size_t NCX = (size_t)RS_SEG * W + RS_PAD;
             a.b0 = 0; a.npairs = np; a.slots = slots; a.groups = np;
             a.xb = a.xa + (size_t)2 * a.slots * NCX * 8;
@@ -997,6 +999,6 @@ int og_launch_sinkhorn_resident_ragged(const float* S, int64_t lds, const float*
             else rs_launch<4>(a, map, grid, st);
         }
     }
-    return og_launch_status();
+    return count_only ? 0 : og_launch_status();
 }
 
