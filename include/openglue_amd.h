@@ -291,7 +291,10 @@ size_t og_sinkhorn_workspace_bytes(int32_t batch, int32_t m, int32_t n);
 int og_sinkhorn(const float* S, int64_t lds, float dustbin, int32_t batch, int32_t m, int32_t n,
                 int32_t iters, float reg, float* scores, void* workspace_dev, void* stream);
 
-/* Diagnostics (synchronises the device, copies 4 bytes): state of the last og_sinkhorn / og_forward Sinkhorn stage that ran on
+/* Diagnostics: state of the last og_sinkhorn / og_forward Sinkhorn stage that ran on this workspace.  Copies two words on a private stream
+ * after the work ALREADY ENQUEUED ON THE NULL STREAM has finished (an event, no device-wide synchronisation: other streams keep running and
+ * are not waited for -- a caller that launched on its own stream synchronises that stream first, as openglue_amd/superglue.py does).
+ * State of the last og_sinkhorn / og_forward Sinkhorn stage that ran on
  * this Sinkhorn workspace (every call resets it).
  *   0 = completed normally (streaming kernels, or the on-chip-resident kernel without incident);
  *   2 = a cross-workgroup wait of the on-chip-resident iteration kernel timed out (the workgroups of a launch must be
@@ -314,7 +317,7 @@ int og_sinkhorn_status(const void* sinkhorn_workspace_dev, int32_t batch, int32_
 int og_sinkhorn_schedule(int32_t batch, int32_t m, int32_t n, int32_t iters);
 int og_sinkhorn_schedule_ragged(int32_t batch, const int32_t* lens0, const int32_t* lens1, int32_t iters);
 /* The same check for the workspace of an og_forward / og_forward_ragged call with this shape (for ragged calls: the shape
- * that was passed, i.e. the maxima).  SYNCHRONISES the device.  Return values as og_sinkhorn_status. */
+ * that was passed, i.e. the maxima).  Waits like og_sinkhorn_status (NULL stream only).  Return values as og_sinkhorn_status. */
 int og_forward_status(const og_shape* shape, const void* workspace_dev);
 
 /* ---- training slice of the optimal-transport layer (reference: autograd through superglue.py:88-111 +

@@ -28,7 +28,8 @@ namespace {
 
 constexpr int TOK = 128;
 constexpr int BKH = 32;          // k per tile (halves)
-constexpr int EPI_SLAB = 32 * 144;   // per-wave epilogue scratch: one 32-token slice, rows of (128 B + 16 B pad)
+constexpr int EPI_SLAB = 32 * 144;   // per-wave epilogue scratch for one 32-token slice: sized for the padded rows (128 B + 16 B) of the slow epilogues;
+                                     // the fast 256-tile epilogue uses 128-byte swizzled rows inside it (gemm_nt_f16x3_big epilogue, rd_off)
 
 // Compile-time ablations of the LDS-DMA kernel (scripts/build_ablation.sh; results are wrong by construction):
 // 1 = no global stores, 2 = every block reads token tile 0 (operands L2-resident), 4 = no MFMA,

@@ -44,7 +44,8 @@ constexpr int WSTAGE = 32768;                 // one weight stage: 32 fragments 
 constexpr int XSTAGE = MT * 128;              // one 32-channel k-group of the token tile: 128 rows x (64 B hi | 64 B lo)
 constexpr int XOFF = 3 * WSTAGE;
 constexpr int BOFF = XOFF + 3 * XSTAGE;       // biases * 256 (fp32): b0' [2D] then b3' [D]
-constexpr int EPI_SLAB = 32 * 144;            // epilogue scratch: one 32-token slice, rows of (128 B + 16 B pad)
+constexpr int EPI_SLAB = 32 * 144;            // epilogue scratch per 32-token slice (the epilogue writes 128-byte swizzled rows into it; the
+                                              // size is the padded-row one of gemm_f16x3.hip, which shares the staging code)
 
 // Compile-time ablations (scripts/build_mlp_ablation.sh; results wrong by construction): 1 = no global stores, 4 = no MFMA,
 // 8 = no LDS-DMA after the prologue, 32 = no token LDS-DMA after the prologue.
@@ -595,7 +596,7 @@ int og_launch_mlp_fused(const MlpFusedArgs& a, int D, hipStream_t stream) {
     if (!a.XO || !a.wstream || !a.b0 || !a.b3 || a.M <= 0) return OG_E_INVALID;
     if (!og_mlp_fused_supported(D)) return OG_E_SHAPE;
     if (((uintptr_t)a.XO & 15) || ((uintptr_t)a.wstream & 15) || (a.ld & 7) || a.ld < 4 * (int64_t)D) return OG_E_ALIGN;
-    if ((int64_t)a.M * a.ld * 2 >= (int64_t)1 << 32) return OG_E_SHAPE;             // 32-bit lane offsets
+    if ((int64_t)MT * a.ld * 2 >= (int64_t)1 << 31) return OG_E_SHAPE;              // 32-bit lane offsets are relative to the TILE's first row (baseX is 64-bit)
     if (!(a.scale != 0.f) || !std::isfinite(a.scale)) return OG_E_INVALID;
     const int tiles = (a.M + MT - 1) / MT;
     hipLaunchKernelGGL(mlp_fused_kernel<256>, dim3(tiles), dim3(512), 0, stream, a);

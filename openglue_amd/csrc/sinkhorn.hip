@@ -946,16 +946,28 @@ extern "C" int og_sinkhorn_schedule_ragged(int32_t batch, const int32_t* lens0, 
     return launches;
 }
 
+// Reads the two status words with ONE stream-ordered copy each on a private non-blocking stream created for the call -- after
+// waiting, through an event recorded on the NULL stream, for the work the caller has already enqueued there; callers on other
+// streams synchronise their stream first (openglue_amd/superglue.py does).  No device-wide synchronisation, nothing left behind.
 extern "C" int og_sinkhorn_status(const void* workspace_dev, int32_t batch, int32_t m, int32_t n) {
     if (!workspace_dev || batch <= 0 || m <= 0 || n <= 0 || n > 8192) return -1;
-    if (hipDeviceSynchronize() != hipSuccess) return -1;
-    unsigned bad = 0;
     const SinkhornWs w = sk_layout(const_cast<void*>(workspace_dev), batch, m, n);
-    if (hipMemcpy(&bad, w.flags, sizeof(bad), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    const bool has_res = og_sinkhorn_resident_ws_bytes(batch, m, n) != 0;
+    unsigned bad = 0, st = 0;
+    hipStream_t q = nullptr;
+    if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) return -1;
+    int rc = 0;
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, nullptr) != hipSuccess ||
+        hipStreamWaitEvent(q, ev, 0) != hipSuccess) rc = -1;
+    if (!rc && hipMemcpyAsync(&bad, w.flags, sizeof(bad), hipMemcpyDeviceToHost, q) != hipSuccess) rc = -1;
+    if (!rc && has_res && hipMemcpyAsync(&st, sk_resident_ws(const_cast<void*>(workspace_dev), batch, m, n), sizeof(st), hipMemcpyDeviceToHost, q) != hipSuccess) rc = -1;
+    if (!rc && hipStreamSynchronize(q) != hipSuccess) rc = -1;
+    if (ev) (void)hipEventDestroy(ev);
+    (void)hipStreamDestroy(q);
+    if (rc) return rc;
     if (bad) return 3;                                  // non-finite scores were written
-    if (og_sinkhorn_resident_ws_bytes(batch, m, n) == 0) return 0;
-    unsigned st = 0;
-    if (hipMemcpy(&st, sk_resident_ws(const_cast<void*>(workspace_dev), batch, m, n), sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (!has_res) return 0;
     return st == 0 ? 0 : st == 2 ? 2 : 1;
 }
 

@@ -198,6 +198,7 @@ def sinkhorn(S: torch.Tensor, dustbin: float, iters: int, reg: float = 1.0, retu
                          ws.data_ptr(), _stream())
     _lib.check(rc, "og_sinkhorn")
     if return_status:        # og_sinkhorn_status: 0 = ok; 2 = the resident kernel timed out and the fallback recomputed (valid); 1 = invalid
+        torch.cuda.current_stream(S.device).synchronize()       # og_sinkhorn_status waits for the NULL stream only
         return out, int(lib.og_sinkhorn_status(ws.data_ptr(), B, m, n))
     return out
 

@@ -218,7 +218,8 @@ class SuperGlue(nn.Module):
         if last is None:
             return 0
         shape, ws = last
-        with torch.cuda.device(ws.device):          # og_forward_status synchronises the CURRENT device
+        with torch.cuda.device(ws.device):
+            torch.cuda.current_stream(ws.device).synchronize()      # og_forward_status only waits for the NULL stream: the call's own stream is ours to drain
             rc = _lib.load().og_forward_status(C.byref(shape), ws.data_ptr())
         if rc == 2:
             import warnings
@@ -444,7 +445,7 @@ class SuperGlue(nn.Module):
             with torch.cuda.device(dev):
                 pk = self._pack(dev)
                 ws = self._get_workspace(dev, ("ragged", B, max(l0), max(l1)), lib.og_workspace_bytes(C.byref(shape)))
-                self._last_call = None            # ragged calls always take the streaming Sinkhorn schedule: nothing to check
+                self._last_call = (shape, ws)     # the ragged path takes the resident Sinkhorn schedule too: check_status() covers it
                 scores = torch.empty(n_scores, device=dev, dtype=torch.float32)
                 m0 = torch.empty(T0, device=dev, dtype=torch.int64)
                 s0 = torch.empty(T0, device=dev, dtype=torch.float32)

@@ -147,9 +147,8 @@ def _transpose_pad(x: torch.Tensor, mult: int = 4) -> torch.Tensor:
     return out
 
 
-# The 1x1 convs of the training step run on the split-f16 3-pass MFMA GEMM of the inference path (fp32-class accuracy at ~3x the rate
-# of the exact-fp32 MFMA kernel: DESIGN.md 4.1) whenever the contraction length is a multiple of 32; OG_TRAIN_F16X3=0 keeps everything on
-# the exact-fp32 kernel.  Gradients can be far below the binary16 range (an NLL averaged over thousands of keypoints: 1e-7 ... 1e-3), so
+# The 1x1 convs of the training step run on the exact-fp32 MFMA kernel by DEFAULT; OG_TRAIN_F16X3=1 moves them to the split-f16 3-pass
+# MFMA GEMM of the inference path (fp32-class accuracy at ~3x the rate: DESIGN.md 4.1) wherever the contraction length is a multiple of 32.  Gradients can be far below the binary16 range (an NLL averaged over thousands of keypoints: 1e-7 ... 1e-3), so
 # a gradient operand is multiplied by a power of two that brings its largest entry to ~2^11 before the (hi, lo) split and the product is
 # scaled back -- exact, and computed ON THE DEVICE (no host synchronisation).
 def _use_f16x3() -> bool:
@@ -208,7 +207,7 @@ def _conv_backward(x: torch.Tensor, W: torch.Tensor, dz: torch.Tensor, need_dx: 
     lib = _lib.load()
     T, Cout = dz.shape
     dx = None
-    if need_dx and _use_f16x3():
+    if need_dx and _use_f16x3() and Cout % 32 == 0:                                              # (K = Cout must be a multiple of 32 on BOTH operands)
         dx = _gemm_fast(dz, _transpose_pad(W, 32), scale_a=True)                                 # [T, Cout] x [Cin, Cout]^T
     elif need_dx:                                                                                # dz [T, Cout] x W [Cout][Cin] as it lies (k-major B)
         Cin = W.shape[1]
