@@ -15,7 +15,7 @@ import torch
 from openglue_amd import ops, synthetic as syn
 from openglue_amd.superglue import SuperGlue
 from oracle import superglue_oracle as orc
-from tests.util import GOLDEN, MATCH_THRESHOLD, load_case, to_device
+from tests.util import GOLDEN, MATCH_THRESHOLD, load_case, parity_note, to_device
 
 pytestmark = pytest.mark.gpu
 
@@ -348,7 +348,7 @@ def test_forward_against_reference_fixture(gpu_device, name):
     ndiff, unexplained, _ = _index_agreement(out["matches0"], out["scores"], sd, cfg, data)
     assert unexplained == 0, f"{name}: {ndiff} rows differ, {unexplained} not explained by near-ties"
     same = out["matches0"].numpy() == z["matches0"]
-    print(f"[{name}] scores err {err:.2e}; matches0 identical on {same.mean() * 100:.2f}% rows ({ndiff} near-tie exemptions)")
+    parity_note(f"[{name}] scores err {err:.2e}; matches0 identical on {same.mean() * 100:.2f}% rows exempt={ndiff}")
     # extraction itself is exact given the GPU's own scores
     want = orc.extract_matches(out["scores"], MATCH_THRESHOLD)
     assert torch.equal(out["matches0"], want["matches0"]) and torch.equal(out["matches1"], want["matches1"])
@@ -450,7 +450,7 @@ def test_full_size_c2_batch_properties(gpu_device):
         assert bad == 0, f"pairs {p0}..{p0 + 7}: {ndiff} rows differ, {bad} not explained by float64 near-ties"
         worst = max(worst, (s_cpu[p0:p0 + 8].double() - o64["scores"]).abs().max().item())
         exempt += ndiff
-    print(f"[C2 B=32] all 32 pairs: scores err {worst:.2e}; {exempt} near-tie exemptions of {B * m} rows")
+    parity_note(f"[C2 B=32] all 32 pairs: scores err {worst:.2e} exempt={exempt} of {B * m} rows")
     assert worst < TOL_SCORES
 
 

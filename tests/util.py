@@ -31,3 +31,11 @@ def load_case(name):
 
 def to_device(data, device):
     return {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in data.items()}
+
+
+PARITY_NOTES = []      # printed by conftest.pytest_terminal_summary
+
+
+def parity_note(text: str):
+    PARITY_NOTES.append(text)
+    print(text)
