@@ -441,7 +441,9 @@ def _dry_run(args, world, rank):
     os.environ.setdefault("MASTER_PORT", "29511")
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    lens = syn.ragged_lengths(3 * world, 8, 32, seed=0)
+    if args.global_batch and args.global_batch % world:
+        raise SystemExit(f"--global-batch {args.global_batch} is not a multiple of the {world} ranks")
+    lens = syn.ragged_lengths(args.global_batch or 3 * world, 8, 32, seed=0)      # --global-batch: the job's size is fixed, ranks split it
 
     def stub(ids):
         return [{"matches0": torch.full((lens[i][0],), i, dtype=torch.int64), "matching_scores0": torch.full((lens[i][0],), 0.5)}
@@ -452,7 +454,8 @@ def _dry_run(args, world, rank):
     dt = time.perf_counter() - t0
     if rank == 0:
         ok = all(bool((got["matches0"][i, :lens[i][0]] == i).all()) for i in range(len(lens)))
-        print(json.dumps({"metric": "dry run (no GPU, gloo, stub matcher)", "dry_run": True, "n_gpus": world, "steps": args.steps,
+        print(json.dumps({"metric": "dry run (no GPU, gloo, stub matcher)", "dry_run": True, "n_gpus": world, "steps": args.steps, "global_batch": len(lens),
+                          "scaling": "strong" if args.global_batch else "weak",
                           "gather_ok": ok, "value": round(len(lens) * args.steps / dt, 1), "unit": "stub-pairs/s"}), flush=True)
     if world > 1:
         dist.barrier()

@@ -17,15 +17,14 @@ import torch.distributed as dist
 
 def pair_cost(m: int, n: int, desc_dim: int = 256, num_stages: int = 9, iters: int = 100) -> float:
     """Estimated seconds of one pair on an MI355X: the algorithmic work of each kernel class over the rate that
-    class MEASURES on this path (round 3, BENCH / profiles/r03_*): split-f16 GEMMs incl. the fused message MLP ~330 algorithmic
-    TFLOP/s, flash attention ~305, streaming Sinkhorn (ragged batches never take the resident schedule) one read of the score
-    matrix per iteration at ~5.8 TB/s.  Only the RATIOS matter: the figure balances ragged pairs over the ranks (LPT)."""
+    class MEASURES on this path (round 4, profiles/r04_*): split-f16 GEMMs incl. the fused message MLP ~330 algorithmic TFLOP/s, flash
+    attention ~305, Sinkhorn on the resident schedule (ragged batches take it too since round 4) ~18 TB/s of the one-read-per-
+    iteration equivalent.  Only the RATIOS matter: the figure balances ragged pairs over the ranks (LPT)."""
     D, L = desc_dim, num_stages
     gemm = L * 40.0 * D * D * (m + n) + 2.0 * D * D * (m + n) + 2.0 * m * n * D
     attn = L * (4.0 * D * (m * m + n * n) + 8.0 * D * m * n)
-    rb = (m + 31) // 32
-    sink = 4.0 * (m * n * (iters + 1) + 2 * rb * n * iters + (m + 1) * (n + 1))
-    return gemm / 330e12 + attn / 305e12 + sink / 5.8e12
+    sink = 4.0 * (m * n * (iters + 1) + (m + 1) * (n + 1))
+    return gemm / 330e12 + attn / 305e12 + sink / 18e12
 
 
 def shard_pairs(num_pairs: int, world_size: int, costs: Optional[Sequence[float]] = None) -> List[List[int]]:

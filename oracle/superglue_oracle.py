@@ -377,6 +377,43 @@ def nll_criterion(scores: torch.Tensor, gt_matches0: torch.Tensor, gt_matches1: 
     return (matched + 0.5 * (un0 + un1)) / scores.size(0)
 
 
+def pairwise_cosine_dist(x1: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
+    """utils/misc.py:106-113: half of the cosine distance, (1 - cos) / 2 = |x1/|x1| - x2/|x2||^2 / 4, for every pair of rows."""
+    a = torch.nn.functional.normalize(x1, dim=-1)
+    b = torch.nn.functional.normalize(x2, dim=-1)
+    return 0.25 * (a[..., :, None, :] - b[..., None, :, :]).pow(2).sum(-1)
+
+
+def metric_criterion(ctx0: torch.Tensor, ctx1: torch.Tensor, gt_matches0: torch.Tensor, gt_matches1: torch.Tensor, margin: float) -> torch.Tensor:
+    """The 'metric_loss' entry of utils/losses.py:7-93 for margin != None, on the channel-first context descriptors [B, D, n] the
+    model returns: (a) matched keypoints: triplet loss against the closest NON-matching descriptor of the other image, both ways
+    (losses.py:55-74; the negatives come from a detached copy of the distances with the positives masked by +inf);
+    (b) unmatched keypoints of either image: hinge on the distance to their closest descriptor in the other image (losses.py:77-93);
+    each term averaged per pair like the NLL, the total divided by the batch size."""
+    dist = pairwise_cosine_dist(ctx0.transpose(2, 1).contiguous(), ctx1.transpose(2, 1).contiguous())        # [B, m, n]
+
+    def mean_w(batch_idx):
+        _, inv, counts = torch.unique_consecutive(batch_idx, return_inverse=True, return_counts=True)
+        return (1 / counts)[inv]
+    zero = torch.zeros((), dtype=dist.dtype, device=dist.device)
+    b, i0 = torch.where(gt_matches0 >= 0)
+    i1 = gt_matches0[b, i0]
+    w = mean_w(b)
+    d_ap = dist[b, i0, i1]
+    dd = dist.detach().clone()
+    dd[b, i0, i1] = float("inf")
+    i0_closest_to_1 = torch.argmin(dd, dim=1)            # [B, n]
+    i1_closest_to_0 = torch.argmin(dd, dim=2)            # [B, m]
+    d_an0 = dist[b, i0, i1_closest_to_0[b, i0]]
+    d_an1 = dist[b, i0_closest_to_1[b, i1], i1]
+    matched = (torch.maximum(d_ap - d_an0 + margin, zero) * w).sum() + (torch.maximum(d_ap - d_an1 + margin, zero) * w).sum()
+    b, i0 = torch.where(gt_matches0 == -1)
+    un0 = (torch.maximum(-dist[b, i0, torch.argmin(dist, dim=2)[b, i0]] + margin, zero) * mean_w(b)).sum()
+    b, i1 = torch.where(gt_matches1 == -1)
+    un1 = (torch.maximum(-dist[b, torch.argmin(dist, dim=1)[b, i1], i1] + margin, zero) * mean_w(b)).sum()
+    return (matched + un0 + un1) / ctx0.size(0)
+
+
 def batchnorm_train(x: torch.Tensor, weight, bias, running_mean, running_var, momentum: float = 0.1, eps: float = 1e-5):
     """nn.BatchNorm1d in training mode (reference models/utils.py:55 inside FeedForwardNet; semantics of
     torch.nn.functional.batch_norm(training=True), restated with plain tensor ops) on token-major x [..., C] like the rest of

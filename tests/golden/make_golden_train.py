@@ -4,6 +4,7 @@
     python tests/golden/make_golden_train.py             # writes tests/golden/train_ot.npz, train_mlp.npz, train_model.npz
     python tests/golden/make_golden_train.py eval_grad   # eval_grad.npz
     python tests/golden/make_golden_train.py variants    # train_variants.npz (linear / FAVOR attention, Siren encoder in train mode)
+    python tests/golden/make_golden_train.py margin      # train_margin.npz (criterion with margin = 0.2: the metric loss on context_descriptors)
 
 train_ot: the optimal-transport layer of the reference (SuperGlue.get_matching_probs, superglue.py:88-111, calling
 log_otp_solver, optimal_transport.py:20-28) on seeded score matrices, differentiated by autograd through two losses:
@@ -161,6 +162,40 @@ def main_model():
     np.savez_compressed(os.path.join(HERE, "train_model.npz"), **out)
 
 
+MARGIN, NLL_WEIGHT, METRIC_WEIGHT = 0.2, 1.0, 0.5
+
+
+def main_margin():
+    """train_margin: the reference training step of matching_module.py:99-105 with a METRIC loss: criterion(..., margin=0.2)
+    (utils/losses.py:7-93: triplet / margin terms on the pairwise cosine distance of context_descriptors0/1, utils/misc.py:106-113),
+    L = nll_weight * loss + metric_weight * metric_loss.  Gradients reach the parameters through `scores` AND, directly, through
+    `context_descriptors{0,1}` -- the path the margin=None fixtures never exercise."""
+    out = {}
+    name, kw, B, m, n = MODEL_CASES[0]
+    cfg = syn.make_config(**kw)
+    sd = syn.make_state_dict(cfg, seed=len(name))
+    ref = RefSuperGlue(cfg)
+    ref.load_state_dict(sd)
+    ref.train()
+    data = syn.make_batch(B, m, n, cfg["descriptor_dim"], 1, seed=3 + len(name))
+    data["local_descriptors0"].requires_grad_(True); data["local_descriptors1"].requires_grad_(True)
+    g = torch.Generator().manual_seed(11)
+    gt0, gt1 = gt_matches(B, m, n, g)
+    y = ref(data)
+    lo = criterion({"gt_matches0": gt0, "gt_matches1": gt1}, y, margin=MARGIN)
+    total = NLL_WEIGHT * lo["loss"] + METRIC_WEIGHT * lo["metric_loss"]
+    total.backward()
+    out["scores"] = y["scores"].detach().numpy(); out["ctx0"] = y["context_descriptors0"].detach().numpy(); out["ctx1"] = y["context_descriptors1"].detach().numpy()
+    out["loss"] = np.float32(lo["loss"].item()); out["metric_loss"] = np.float32(lo["metric_loss"].item()); out["total"] = np.float32(total.item())
+    out["gt0"] = gt0.numpy(); out["gt1"] = gt1.numpy()
+    out["grad_desc0"] = data["local_descriptors0"].grad.numpy().copy(); out["grad_desc1"] = data["local_descriptors1"].grad.numpy().copy()
+    for k_, p_ in ref.named_parameters():
+        out[f"grad_{k_}"] = (p_.grad if p_.grad is not None else torch.zeros_like(p_)).numpy().copy()
+    out["meta"] = np.array([B, m, n], np.int64); out["weights"] = np.array([MARGIN, NLL_WEIGHT, METRIC_WEIGHT], np.float32)
+    print("margin fixture: nll", lo["loss"].item(), "metric", lo["metric_loss"].item())
+    np.savez_compressed(os.path.join(HERE, "train_margin.npz"), **out)
+
+
 def main_eval_grad():
     """eval_grad: the reference SuperGlue in EVAL mode under autograd (its forward is differentiable with BatchNorm on running
     statistics: fine-tuning on frozen statistics), L = criterion NLL: scores, loss, gradients w.r.t. every parameter and the
@@ -233,5 +268,7 @@ if __name__ == "__main__":
         main_eval_grad()
     elif sys.argv[1:] == ["variants"]:
         main_variants()
+    elif sys.argv[1:] == ["margin"]:
+        main_margin()
     else:
         main()

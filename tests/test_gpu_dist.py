@@ -1,4 +1,6 @@
-"""The RCCL path on the box the driver has: ONE GPU, backend "nccl" at world size 1.  The 2/4/8-GPU scaling run
+"""The RCCL path.  On the box the driver usually has -- ONE GPU -- backend "nccl" at world size 1; the moment two or more
+GPUs are visible, test_two_ranks_over_rccl_equal_one_gpu additionally runs the sharded job on 2 ranks under torch.distributed.run and
+compares the gathered match lists with the single-GPU result.  The 2/4/8-GPU scaling run
 is the driver's; what can be proven here is that the collective path loads RCCL, moves the payload and re-assembles it, both through
 sharding.gather_matches(always_collective=True) and through bench.py (OG_BENCH_FORCE_DIST=1).  Each check runs in its own process:
 a process group must not leak into the other tests."""
@@ -66,3 +68,58 @@ def test_bench_with_the_collective_forced(gpu_device):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 1 and line["value"] > 0 and "roofline" in line
     print("forced-collective bench:", line["value"], line["unit"], line["ms_per_step"], "ms/step")
+
+
+_TWO_RANKS = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from openglue_amd import sharding, synthetic as syn
+from openglue_amd.superglue import SuperGlue
+rank, world, lr = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+dev = torch.device("cuda", lr); torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+cfg = syn.make_config(descriptor_dim=64, num_stages=2, num_heads=4, num_iters=20, side_info_size=1)
+model = SuperGlue(cfg).eval(); model.load_state_dict(syn.make_state_dict(cfg, seed=0)); model.to(dev)
+P = 7                                           # not a multiple of the world size: ranks get 4 and 3 pairs
+shards = sharding.shard_pairs(P, world)
+mine = shards[rank]
+data = syn.make_batch(len(mine), 300, 260, 64, 1, seed=9, first_pair=mine[0], device=dev)       # pair i of the job is seeded by i
+out = model.match(data, 0.2)
+got = sharding.gather_matches({"matches0": out["matches0"], "matching_scores0": out["matching_scores0"]}, mine, P, dst=0)
+torch.cuda.synchronize()
+if rank == 0:
+    whole = model.match(syn.make_batch(P, 300, 260, 64, 1, seed=9, first_pair=0, device=dev), 0.2)      # the same job on ONE GPU
+    assert torch.equal(got["matches0"], whole["matches0"]), "gathered match lists differ from the single-GPU result"
+    assert torch.equal(got["matching_scores0"], whole["matching_scores0"])
+    print("RCCL_WORLD", dist.get_world_size(), dist.get_backend(), "OK", int((whole["matches0"] >= 0).sum()), "matches")
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_ranks_over_rccl_equal_one_gpu(gpu_device, tmp_path):
+    """>= 2 GPUs visible: the sharded job on 2 ranks (one process per GPU, torch.distributed.run, backend nccl = RCCL over xGMI), ONE
+    gather of the match lists on rank 0, bit-identical to the same job on one GPU (pairs are independent: SURVEY.md 8e)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip(f"needs 2 GPUs, {torch.cuda.device_count()} visible (the driver's scaling run covers N > 1 on the 8-GPU node)")
+    script = tmp_path / "two_ranks.py"
+    script.write_text(_TWO_RANKS % ROOT)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", str(script)], env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "RCCL_WORLD 2 nccl OK" in r.stdout
+
+
+def test_bench_two_gpus(gpu_device):
+    """>= 2 GPUs visible: `python bench.py --gpus 2` re-executes itself under torch.distributed.run and prints ONE line with n_gpus = 2
+    and the RCCL block filled in."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip(f"needs 2 GPUs, {torch.cuda.device_count()} visible")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--batch", "8"],
+                       env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl"]["backend"] == "nccl" and line["rccl"]["world_size"] == 2 and line["value"] > 0

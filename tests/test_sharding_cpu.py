@@ -171,6 +171,14 @@ def test_eight_rank_dry_run_of_the_bench_plumbing():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["dry_run"] is True and d["n_gpus"] == 8 and d["gather_ok"] is True
+    # --global-batch: the BASELINE batch of a config split over the ranks (C3: 256 over 8), fixed job size = strong scaling
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--global-batch", "10"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["global_batch"] == 10 and d["scaling"] == "strong" and d["gather_ok"] is True
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--global-batch", "9"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0                    # 9 pairs do not split over 2 ranks
 
 
 def test_pair_cost_orders_pairs_like_the_measured_classes():

@@ -293,6 +293,81 @@ def test_training_step_against_reference_autograd(gpu_device, name):
             assert np.abs(b.cpu().numpy() - G[f"{name}_buf_{k}"]).max() < 1e-5, k
 
 
+# ----------------------------------------------------------------------------- metric loss (criterion with margin): gradients through context_descriptors
+GM = np.load(os.path.join(GOLDEN, "train_margin.npz"))
+
+
+def _margin_case():
+    from openglue_amd import synthetic as syn
+    name, kw = next(iter(MODEL_CASES.items()))
+    cfg = syn.make_config(**kw)
+    sd = syn.make_state_dict(cfg, seed=len(name))
+    B, m, n = (int(v) for v in GM["meta"])
+    data = syn.make_batch(B, m, n, cfg["descriptor_dim"], 1, seed=3 + len(name))
+    margin, wn, wm = (float(v) for v in GM["weights"])
+    return cfg, sd, data, torch.from_numpy(GM["gt0"]), torch.from_numpy(GM["gt1"]), margin, wn, wm
+
+
+def test_oracle_metric_loss_matches_the_reference():
+    """CPU: criterion(..., margin=0.2) of the reference (utils/losses.py:7-93) = oracle nll_criterion + metric_criterion: both loss
+    values, and the gradients of L = nll_weight * loss + metric_weight * metric_loss w.r.t. every parameter and the descriptors --
+    part of which enters through context_descriptors{0,1} directly (matching_module.py:99-105)."""
+    cfg, sd, data, gt0, gt1, margin, wn, wm = _margin_case()
+    params = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in sd.items()}
+    data["local_descriptors0"].requires_grad_(True); data["local_descriptors1"].requires_grad_(True)
+    out = orc.superglue_forward(params, cfg, data, train_stats={})
+    nll = orc.nll_criterion(out["scores"], gt0, gt1)
+    met = orc.metric_criterion(out["context_descriptors0"], out["context_descriptors1"], gt0, gt1, margin)
+    assert abs(nll.item() - float(GM["loss"])) < 1e-3 and abs(met.item() - float(GM["metric_loss"])) < 1e-4
+    assert float(GM["metric_loss"]) > 0.5                        # the hinge terms are active: the fixture does exercise the path
+    (wn * nll + wm * met).backward()
+    for key, got in (("desc0", data["local_descriptors0"].grad), ("desc1", data["local_descriptors1"].grad)):
+        want = GM[f"grad_{key}"]
+        assert np.abs(got.numpy() - want).max() < 1e-3 * np.abs(want).max() + 1e-7, key
+    checked = 0
+    for k, p in params.items():
+        if f"grad_{k}" in GM and p.requires_grad:
+            want = GM[f"grad_{k}"]
+            got = p.grad.numpy() if p.grad is not None else np.zeros_like(want)
+            assert np.abs(got - want).max() < 1e-3 * np.abs(want).max() + 1e-6, k
+            checked += 1
+    assert checked >= 40
+
+
+@pytest.mark.gpu
+def test_training_step_with_metric_loss_against_reference_autograd(gpu_device):
+    """HIP: the training step with the reference's metric loss on top of the NLL.  The loss itself is the caller's (torch ops on the
+    model's outputs, like utils/losses.py); what is checked is that the gradient arriving at `context_descriptors{0,1}` -- an OUTPUT
+    of the HIP forward that the margin=None fixtures only use through `scores` -- flows back through the final projection, the GNN and
+    the encoder to every parameter exactly as under the reference's autograd."""
+    from openglue_amd.superglue import SuperGlue
+    cfg, sd, data, gt0, gt1, margin, wn, wm = _margin_case()
+    model = SuperGlue(cfg)
+    model.load_state_dict(sd)
+    model = model.to(gpu_device).train()
+    dd = {k: (v.to(gpu_device) if torch.is_tensor(v) else v) for k, v in data.items()}
+    dd["local_descriptors0"].requires_grad_(True); dd["local_descriptors1"].requires_grad_(True)
+    out = model(dd)
+    assert np.abs(out["context_descriptors1"].detach().cpu().numpy() - GM["ctx1"]).max() < 1e-4
+    g0, g1 = gt0.to(gpu_device), gt1.to(gpu_device)
+    nll = orc.nll_criterion(out["scores"], g0, g1)
+    met = orc.metric_criterion(out["context_descriptors0"], out["context_descriptors1"], g0, g1, margin)
+    assert abs(met.item() - float(GM["metric_loss"])) < 1e-3 * abs(float(GM["metric_loss"]))
+    (wn * nll + wm * met).backward()
+    worst, worst_k = 0.0, ""
+    for key, got in (("desc0", dd["local_descriptors0"].grad), ("desc1", dd["local_descriptors1"].grad)):
+        want = GM[f"grad_{key}"]
+        e = np.abs(got.cpu().numpy() - want).max() / np.abs(want).max()
+        if e > worst: worst, worst_k = e, key
+    for k, p in model.named_parameters():
+        want = GM[f"grad_{k}"]
+        got = p.grad.cpu().numpy() if p.grad is not None else np.zeros_like(want)
+        e = np.abs(got - want).max() / max(np.abs(want).max(), 1e-8)
+        if np.abs(want).max() > 1e-7 and e > worst: worst, worst_k = e, k
+    print(f"[train margin] nll {nll.item():.4f} metric {met.item():.4f}; worst relative gradient error {worst:.2e} ({worst_k})")
+    assert worst < 1e-3
+
+
 # ----------------------------------------------------------------------------- og_gemm_kmajor: the backward products on the operands as they lie
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(3, 100, 52, 64, False), (2, 132, 256, 37, True), (1, 64, 12, 301, True), (5, 260, 68, 1024, True),
