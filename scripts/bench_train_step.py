@@ -24,6 +24,14 @@ def step():
     loss = orc.nll_criterion(out["scores"], gt0, gt1)
     loss.backward()
     return loss
+def nll_static(scores):
+    """utils/losses.py:7-53 (margin None) with masks instead of torch.where: no data-dependent shapes, no host synchronisation -- the
+    form a captured step needs.  Same value as orc.nll_criterion."""
+    inner = scores[:, :-1, :-1]
+    m0 = (gt0 >= 0); u0 = (gt0 == -1); u1 = (gt1 == -1)
+    picked = inner.gather(2, gt0.clamp_min(0)[:, :, None])[:, :, 0]
+    per = lambda val, mask: (-(val * mask).sum(1) / mask.sum(1).clamp_min(1)).sum()
+    return (per(picked, m0.float()) + 0.5 * (per(scores[:, :-1, -1], u0.float()) + per(scores[:, -1, :-1], u1.float()))) / scores.size(0)
 step(); torch.cuda.synchronize()
 t0 = time.time(); n = 3
 for _ in range(n): loss = step()
@@ -31,3 +39,14 @@ torch.cuda.synchronize()
 dt = (time.time() - t0) / n
 print(f"training step B={B} pairs x {N} kpts, 9 stages, {IT} Sinkhorn iterations: {dt * 1e3:.1f} ms per step ({B / dt:.1f} pairs/s); loss {loss.item():.4f}; "
       f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+eager_grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+from openglue_amd.train import GraphedTrainStep
+gs = GraphedTrainStep(model, data, lambda out: nll_static(out["scores"]))
+gl = gs(); torch.cuda.synchronize()
+t0 = time.time(); n = 10
+for _ in range(n): gl = gs()
+torch.cuda.synchronize()
+dg = (time.time() - t0) / n
+worst = max(float((p.grad - eager_grads[k]).abs().max() / eager_grads[k].abs().max().clamp_min(1e-12)) for k, p in model.named_parameters() if k in eager_grads)
+print(f"the same step as ONE hipGraph replay (openglue_amd.train.GraphedTrainStep): {dg * 1e3:.1f} ms per step ({B / dg:.1f} pairs/s); loss {gl.item():.4f}; "
+      f"worst relative difference of a parameter gradient to the eager step {worst:.1e}")

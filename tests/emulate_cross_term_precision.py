@@ -8,6 +8,7 @@ with q8 = identity (the kernels as built), MX-style fp8 e4m3 (one power-of-two s
 per row, or "drop" (plain f16 operands), everything accumulated in float64, and the log-scores are compared with the float64 oracle on the golden cases.
 
     python tests/emulate_cross_term_precision.py [case ...]
+    python tests/emulate_cross_term_precision.py --attention-only [case ...]     # round 4: only the attention kernel's cross products in 8 bits
 """
 import os
 import sys
@@ -60,7 +61,44 @@ def conv1x1(x, sd, prefix):
     W, b = orc._w(sd, prefix + ".weight", x.dtype), orc._w(sd, prefix + ".bias", x.dtype)
     if not prefix.startswith("attention_gnn"):          # encoder / final projection: exact-fp32 MFMA or not under test here
         return x @ W.T + b
+    if ATTN_ONLY:                                       # the convs as built: all three f16 passes
+        xh, xl = split(x); wh, wl = split(W * 256.0)
+        return (xh @ wh.T + xh @ wl.T + xl @ wh.T) / 256.0 + b
     return mm(x, W * 256.0) / 256.0 + b                 # weights are stored as hi/lo of 256 w (og_pack_weights)
+
+
+ATTN_ONLY = False     # round 4: quantise the correction products of the ATTENTION kernel only, the convs stay split-f16 x3
+
+
+def q_rows(x, mode):
+    """8-bit operand of one MFMA accumulation: ONE scale per row over the whole contraction it takes part in (the integer / fp8 matrix
+    instructions have no per-element scales: a scale that varies along k cannot be folded back after the sum)."""
+    amax = x.abs().amax(-1, keepdim=True).clamp_min(1e-300)
+    if mode == "int8":
+        scale = amax / 127.0
+        return torch.round(x / scale) * scale
+    scale = torch.exp2(torch.ceil(torch.log2(amax / 448.0)))       # fp8 e4m3 with a power-of-two row scale
+    return (x / scale).to(torch.float32).to(torch.float8_e4m3fn).to(torch.float64) * scale
+
+
+def mm_attn(a, b, tile=None):
+    """a [..., M, K] @ b [..., N, K]^T as the flash kernel would run it with 8-bit correction products: the hi.hi product in f16, the two
+    cross products with 8-bit operands; tile = the key-tile length of P V (scales per (row, key tile): every tile is its own integer
+    accumulation, converted and added to the fp32 accumulator), None = one accumulation over the whole K (Q K^T: K = head size)."""
+    ah, al = split(a)
+    bh, bl = split(b)
+    out = ah @ bh.transpose(-1, -2)
+    if MODE == "drop":
+        return out
+    if MODE == "exact":
+        return out + ah @ bl.transpose(-1, -2) + al @ bh.transpose(-1, -2)
+    if tile is None:
+        return out + q_rows(ah, MODE) @ q_rows(bl, MODE).transpose(-1, -2) + q_rows(al, MODE) @ q_rows(bh, MODE).transpose(-1, -2)
+    K = a.shape[-1]
+    for k0 in range(0, K, tile):
+        sl = slice(k0, min(K, k0 + tile))
+        out = out + q_rows(ah[..., sl], MODE) @ q_rows(bl[..., sl], MODE).transpose(-1, -2) + q_rows(al[..., sl], MODE) @ q_rows(bh[..., sl], MODE).transpose(-1, -2)
+    return out
 
 
 def softmax_attention(q, k, v, num_heads, operand_dtype=None):
@@ -69,6 +107,11 @@ def softmax_attention(q, k, v, num_heads, operand_dtype=None):
     qh = q.view(B, nq, num_heads, d).transpose(1, 2) * d ** -0.5
     kh = k.view(B, -1, num_heads, d).transpose(1, 2)
     vh = v.view(B, -1, num_heads, d).transpose(1, 2)
+    if ATTN_ONLY:
+        logits = mm_attn(qh, kh)
+        p = torch.exp(logits - logits.amax(-1, keepdim=True))
+        o = mm_attn(p, vh.transpose(-1, -2), tile=64) / p.sum(-1, keepdim=True)
+        return o.transpose(1, 2).reshape(B, nq, D)
     logits = mm(qh, kh)
     p = torch.exp(logits - logits.amax(-1, keepdim=True))
     o = mm(p, vh.transpose(-1, -2)) / p.sum(-1, keepdim=True)
@@ -76,8 +119,13 @@ def softmax_attention(q, k, v, num_heads, operand_dtype=None):
 
 
 def main():
-    global MODE
-    cases = sys.argv[1:] or ["c1", "flags", "mid"]
+    global MODE, ATTN_ONLY
+    args = sys.argv[1:]
+    if args and args[0] == "--attention-only":
+        ATTN_ONLY = True
+        args = args[1:]
+        print("correction products of the ATTENTION kernel only (Qh.Kl + Ql.Kh per head, Ph.Vl + Pl.Vh per 64-key tile), convs split-f16 x3; kill criterion: flags <= 5e-4")
+    cases = args or ["c1", "flags", "mid"]
     torch.set_num_threads(os.cpu_count() or 8)
     for name in cases:
         z, cfg, sd, data = load_case(name)
