@@ -885,7 +885,9 @@ class GraphedTrainStep:
             optimizer.step()
 
     loss_fn must not synchronise (no torch.where / nonzero / .item(): use masks -- scripts/bench_train_step.py has the NLL of
-    utils/losses.py:7-53 in that form).  Shapes are frozen at capture time, like the reference under torch.compile / CUDA graphs."""
+    utils/losses.py:7-53 in that form).  Shapes are frozen at capture time, like the reference under torch.compile / CUDA graphs.
+    Drop every reference to losses / outputs of earlier EAGER steps before constructing this (torch keeps the AccumulateGrad nodes of
+    a live autograd graph on the stream they were created on -- the default stream -- and running them inside the capture aborts it)."""
 
     def __init__(self, model, data, loss_fn, warmup: int = 2):
         if not model.training:

@@ -40,6 +40,7 @@ dt = (time.time() - t0) / n
 print(f"training step B={B} pairs x {N} kpts, 9 stages, {IT} Sinkhorn iterations: {dt * 1e3:.1f} ms per step ({B / dt:.1f} pairs/s); loss {loss.item():.4f}; "
       f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
 eager_grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+del loss                  # the eager step's autograd graph (AccumulateGrad nodes on the default stream) must not outlive into the capture
 from openglue_amd.train import GraphedTrainStep
 gs = GraphedTrainStep(model, data, lambda out: nll_static(out["scores"]))
 gl = gs(); torch.cuda.synchronize()

@@ -388,21 +388,24 @@ def test_graphed_training_step_equals_eager(gpu_device):
         return (per(picked, (g0 >= 0).float()) + 0.5 * (per(sc[:, :-1, -1], (g0 == -1).float()) + per(sc[:, -1, :-1], (g1 == -1).float()))) / sc.size(0)
     model.zero_grad(set_to_none=True)
     le = nll_static(model(dd)); le.backward()
-    assert abs(le.item() - orc.nll_criterion(model(dd)["scores"], g0, g1).item()) < 1e-4 * abs(le.item())      # the mask form is the same loss
+    with torch.no_grad():
+        assert abs(le.item() - orc.nll_criterion(model(dd)["scores"], g0, g1).item()) < 1e-4 * abs(le.item())      # the mask form is the same loss
     eager = {k: p.grad.clone() for k, p in model.named_parameters()}
+    le_val = le.item()
+    del le                # nothing of the eager step's autograd graph may stay alive: its AccumulateGrad nodes belong to the default stream
     step = GraphedTrainStep(model, dd, nll_static)
     for _ in range(2):
         lg = step()
     torch.cuda.synchronize()
-    assert abs(lg.item() - le.item()) < 1e-5 * abs(le.item())
+    assert abs(lg.item() - le_val) < 1e-5 * abs(le_val)
     worst = max(float((p.grad - eager[k]).abs().max() / eager[k].abs().max().clamp_min(1e-12)) for k, p in model.named_parameters())
-    print(f"[graphed step] loss {lg.item():.5f} (eager {le.item():.5f}); worst relative gradient difference {worst:.1e}")
+    print(f"[graphed step] loss {lg.item():.5f} (eager {le_val:.5f}); worst relative gradient difference {worst:.1e}")
     assert worst < 1e-4
     other = _model_case("base")[2]
     other["local_descriptors0"] = other["local_descriptors0"] * 0.5            # a different batch of the same shape
     step.load({k: (v.to(gpu_device) if torch.is_tensor(v) else v) for k, v in other.items()})
     l2 = step(); torch.cuda.synchronize()
-    assert abs(l2.item() - le.item()) > 1e-3 * abs(le.item())                   # the replay read the new inputs
+    assert abs(l2.item() - le_val) > 1e-3 * abs(le_val)                           # the replay read the new inputs
 
 
 # ----------------------------------------------------------------------------- og_gemm_kmajor: the backward products on the operands as they lie
