@@ -783,8 +783,8 @@ def superglue_forward_train(model, data, frozen_bn: bool = False):
     T0, T1 = B * m, B * n
 
     def encoder_input(k, s, wh):
-        wh1 = torch.tensor([wh[0] - 1.0, wh[1] - 1.0], device=k.device, dtype=torch.float32)
-        kn = 2.0 * k.to(torch.float32) / wh1 - 1.0                                  # superglue.py:74-78
+        kf = 2.0 * k.to(torch.float32)                                              # superglue.py:74-78; host scalars as divisors: a tensor built from
+        kn = torch.stack([kf[..., 0] / (wh[0] - 1.0), kf[..., 1] / (wh[1] - 1.0)], dim=-1) - 1.0   # them would be a host-to-device copy (not capturable)
         inp = torch.cat([kn, s.to(torch.float32).reshape(k.shape[0], k.shape[1], -1)], dim=-1)
         return inp.reshape(-1, inp.shape[-1])
 
