@@ -783,8 +783,12 @@ def superglue_forward_train(model, data, frozen_bn: bool = False):
     T0, T1 = B * m, B * n
 
     def encoder_input(k, s, wh):
-        kf = 2.0 * k.to(torch.float32)                                              # superglue.py:74-78; host scalars as divisors: a tensor built from
-        kn = torch.stack([kf[..., 0] / (wh[0] - 1.0), kf[..., 1] / (wh[1] - 1.0)], dim=-1) - 1.0   # them would be a host-to-device copy (not capturable)
+        # the divisor as a DEVICE tensor built by fill kernels: torch.tensor([...], device=...) is a host-to-device copy, which a stream
+        # capture refuses (GraphedTrainStep); dividing by Python scalars instead multiplies by a rounded reciprocal -- one ulp away from
+        # the reference's tensor / tensor division, which the Siren encoder's sin(30 x) layers then amplify
+        wh1 = torch.stack([torch.full((), float(wh[0]) - 1.0, device=k.device, dtype=torch.float32),
+                           torch.full((), float(wh[1]) - 1.0, device=k.device, dtype=torch.float32)])
+        kn = 2.0 * k.to(torch.float32) / wh1 - 1.0                                  # superglue.py:74-78
         inp = torch.cat([kn, s.to(torch.float32).reshape(k.shape[0], k.shape[1], -1)], dim=-1)
         return inp.reshape(-1, inp.shape[-1])
 
@@ -868,52 +872,3 @@ def superglue_forward_train(model, data, frozen_bn: bool = False):
     scores = SinkhornOT.apply(S, model.dustbin_score, int(otp["num_iters"]), float(otp["reg"]))
     return {"context_descriptors0": g0.reshape(B, m, D).transpose(1, 2), "context_descriptors1": g1.reshape(B, n, D).transpose(1, 2),
             "scores": scores}
-
-
-# ----------------------------------------------------------------------------------------------- the step as ONE hipGraph
-class GraphedTrainStep:
-    """forward (train() mode) + loss + backward of a SuperGlue model captured ONCE into a hipGraph and replayed: the training path issues
-    ~2000 kernel launches per step from Python (every 1x1 conv, BatchNorm, attention and Sinkhorn call is its own ctypes call), and at
-    4 x 1024 keypoints the step is bound by that host work, not by the GPU (38-40 ms per step eager, scripts/bench_train_step.py).  The
-    library only ENQUEUES on the caller's stream and allocates nothing, torch owns every buffer, so the whole step is capturable as it is
-    (include/openglue_amd.h, "Conventions"); replay costs the GPU time of the kernels.
-
-        step = GraphedTrainStep(model, data, loss_fn)        # data: device tensors that stay put; loss_fn(outputs) -> scalar, capture-safe
-        for batch in loader:
-            step.load(batch)                                 # copy_ the new batch into the captured input tensors (same shapes)
-            loss = step()                                    # replay: parameter .grad tensors are updated in place
-            optimizer.step()
-
-    loss_fn must not synchronise (no torch.where / nonzero / .item(): use masks -- scripts/bench_train_step.py has the NLL of
-    utils/losses.py:7-53 in that form).  Shapes are frozen at capture time, like the reference under torch.compile / CUDA graphs.
-    Drop every reference to losses / outputs of earlier EAGER steps before constructing this (torch keeps the AccumulateGrad nodes of
-    a live autograd graph on the stream they were created on -- the default stream -- and running them inside the capture aborts it)."""
-
-    def __init__(self, model, data, loss_fn, warmup: int = 2):
-        if not model.training:
-            raise RuntimeError("GraphedTrainStep captures the training step: call model.train() first")
-        self.model, self.data, self.loss_fn = model, data, loss_fn
-        dev = next(model.parameters()).device
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):                       # warm-up on a side stream, as torch.cuda.graphs asks for
-            for _ in range(warmup):
-                model.zero_grad(set_to_none=True)
-                loss_fn(model(data)).backward()
-        torch.cuda.current_stream(dev).wait_stream(side)
-        model.zero_grad(set_to_none=True)                   # the .grad tensors are allocated INSIDE the capture: static across replays
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.outputs = model(data)
-            self.loss = loss_fn(self.outputs)
-            self.loss.backward()
-
-    def load(self, batch) -> None:
-        for k, v in batch.items():
-            if torch.is_tensor(v) and torch.is_tensor(self.data.get(k)):
-                self.data[k].copy_(v, non_blocking=True)
-
-    def __call__(self) -> torch.Tensor:
-        self.graph.replay()
-        return self.loss
-

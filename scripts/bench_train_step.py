@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Time one training step (forward in train() mode + NLL loss + backward) of the BASELINE-config-2 model on HIP kernels.
-Informational: the training path is functional, not tuned."""
+Informational: the training path is functional, not tuned.  Round 4 captured the same step (with nll_static below as
+the loss) into ONE hipGraph and replayed it: 37.8 ms against 39.2 ms eager (profiles/r04_train_step_graph.log) -- the ~2000 launches of a
+step cost GPU-side time (kernel boundaries and dependent few-microsecond kernels), not host time; a graph does not remove that."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from openglue_amd import synthetic as syn
@@ -39,15 +41,3 @@ torch.cuda.synchronize()
 dt = (time.time() - t0) / n
 print(f"training step B={B} pairs x {N} kpts, 9 stages, {IT} Sinkhorn iterations: {dt * 1e3:.1f} ms per step ({B / dt:.1f} pairs/s); loss {loss.item():.4f}; "
       f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
-eager_grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
-del loss                  # the eager step's autograd graph (AccumulateGrad nodes on the default stream) must not outlive into the capture
-from openglue_amd.train import GraphedTrainStep
-gs = GraphedTrainStep(model, data, lambda out: nll_static(out["scores"]))
-gl = gs(); torch.cuda.synchronize()
-t0 = time.time(); n = 10
-for _ in range(n): gl = gs()
-torch.cuda.synchronize()
-dg = (time.time() - t0) / n
-worst = max(float((p.grad - eager_grads[k]).abs().max() / eager_grads[k].abs().max().clamp_min(1e-12)) for k, p in model.named_parameters() if k in eager_grads)
-print(f"the same step as ONE hipGraph replay (openglue_amd.train.GraphedTrainStep): {dg * 1e3:.1f} ms per step ({B / dg:.1f} pairs/s); loss {gl.item():.4f}; "
-      f"worst relative difference of a parameter gradient to the eager step {worst:.1e}")

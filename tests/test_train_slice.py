@@ -368,46 +368,6 @@ def test_training_step_with_metric_loss_against_reference_autograd(gpu_device):
     assert worst < 1e-3
 
 
-@pytest.mark.gpu
-def test_graphed_training_step_equals_eager(gpu_device):
-    """openglue_amd.train.GraphedTrainStep: forward + loss + backward captured once into a hipGraph (the library only enqueues on the
-    caller's stream and allocates nothing, so the ~2000 launches of a step are capturable as they are) -- replayed twice, the loss and
-    every parameter gradient equal the eager step's (to rounding: the Sinkhorn backward accumulates with fp32 atomics), and new inputs
-    copied into the captured tensors are honoured."""
-    from openglue_amd.superglue import SuperGlue
-    from openglue_amd.train import GraphedTrainStep
-    cfg, sd, data, gt0, gt1 = _model_case("base")
-    model = SuperGlue(cfg); model.load_state_dict(sd); model = model.to(gpu_device).train()
-    dd = {k: (v.to(gpu_device) if torch.is_tensor(v) else v) for k, v in data.items()}
-    g0, g1 = gt0.to(gpu_device), gt1.to(gpu_device)
-
-    def nll_static(out):                     # utils/losses.py:7-53 with masks: nothing data-dependent in the shapes, no host synchronisation
-        sc = out["scores"]
-        picked = sc[:, :-1, :-1].gather(2, g0.clamp_min(0)[:, :, None])[:, :, 0]
-        per = lambda val, mask: (-(val * mask).sum(1) / mask.sum(1).clamp_min(1)).sum()
-        return (per(picked, (g0 >= 0).float()) + 0.5 * (per(sc[:, :-1, -1], (g0 == -1).float()) + per(sc[:, -1, :-1], (g1 == -1).float()))) / sc.size(0)
-    model.zero_grad(set_to_none=True)
-    le = nll_static(model(dd)); le.backward()
-    with torch.no_grad():
-        assert abs(le.item() - orc.nll_criterion(model(dd)["scores"], g0, g1).item()) < 1e-4 * abs(le.item())      # the mask form is the same loss
-    eager = {k: p.grad.clone() for k, p in model.named_parameters()}
-    le_val = le.item()
-    del le                # nothing of the eager step's autograd graph may stay alive: its AccumulateGrad nodes belong to the default stream
-    step = GraphedTrainStep(model, dd, nll_static)
-    for _ in range(2):
-        lg = step()
-    torch.cuda.synchronize()
-    assert abs(lg.item() - le_val) < 1e-5 * abs(le_val)
-    worst = max(float((p.grad - eager[k]).abs().max() / eager[k].abs().max().clamp_min(1e-12)) for k, p in model.named_parameters())
-    print(f"[graphed step] loss {lg.item():.5f} (eager {le_val:.5f}); worst relative gradient difference {worst:.1e}")
-    assert worst < 1e-4
-    other = _model_case("base")[2]
-    other["local_descriptors0"] = other["local_descriptors0"] * 0.5            # a different batch of the same shape
-    step.load({k: (v.to(gpu_device) if torch.is_tensor(v) else v) for k, v in other.items()})
-    l2 = step(); torch.cuda.synchronize()
-    assert abs(l2.item() - le_val) > 1e-3 * abs(le_val)                           # the replay read the new inputs
-
-
 # ----------------------------------------------------------------------------- og_gemm_kmajor: the backward products on the operands as they lie
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(3, 100, 52, 64, False), (2, 132, 256, 37, True), (1, 64, 12, 301, True), (5, 260, 68, 1024, True),
