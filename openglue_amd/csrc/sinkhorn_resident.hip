@@ -51,6 +51,7 @@ static_assert(RS_RR + RS_LR == RS_RW, "sixteen row slots per wave");
 constexpr int RS_NW = 8;               // waves per workgroup
 constexpr int RS_SEG = 1024;           // columns of a wave's tile (16 per lane)
 constexpr int RS_PAD = 64;             // granule rows are NC + 64 long: the dustbin column sits at index NC
+constexpr int RS_RREC = 136;           // granules of a tile's row record: 128 partial row sums, (sum, shift) of 2^v, the dustbin column's dual
 constexpr int RS_MAXWG = 256;          // workgroups per launch at most (= CUs of the part; the launcher checks the real count)
 constexpr int RS_MAXPAIRS = 128;       // pairs per launch at most (G >= 2)
 constexpr unsigned RS_SPIN_LIMIT = 1u << 21;
@@ -162,7 +163,7 @@ struct SkResArgs {
     const float* v_in; float* v_out; int ldv;  // [B][ldv]
     char* xa;                                  // [2][slots][NC + 64] granules: column partials, one row per workgroup   } zeroed before
     char* xb;                                  // [2][groups][NC + 64] granules: column totals, one row per group of a pair } the launch
-    char* xc;                                  // [2][groups][NC + 64] granules: a group's column sums (pairs of X > 1 groups)
+    char* xc;                                  // [2][groups][32][RS_RREC] granules: the row records of the tiles (pairs of X > 1 column blocks)
     unsigned* status;                          // 0 / 1 = a wait timed out (sticky over the rounds of a call)
     unsigned* xcc;                             // [slots] XCC id + 1 of every workgroup, zeroed before the launch
     int force_agent_scope;                     // experiments / tests: never take the XCD-local path
@@ -296,8 +297,12 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
         G = map.G[r]; Gx = G; gbase = map.gbase[r]; bglob = map.gb[r]; M = map.m[r]; N = map.n[r];
         local_hint = true;
     }
-    const int gl = g - xg * Gx;                            // my index inside the group
-    const int grow = r * XG + xg;                           // my group's row of xb / xc
+    const int gl = g - xg * Gx;                            // my index inside the group (= my row block)
+    const int grow = r * XG + xg;                           // my group's row of xb
+    // column blocks: group xg of a pair owns the columns [xg NC, xg NC + NC) of its matrices -- a pair wider than one workgroup tile is
+    // a 2-D grid of tiles (XG column blocks x Gx row blocks); Nl = my columns that exist
+    const int c0 = xg * NC;
+    const int Nl = min(max(N - c0, 0), NC);
     float la = a.la, la_bin = a.la_bin, lb = a.lb, lb_bin = a.lb_bin;
     if constexpr (!std::is_same<MAP, RsUniform>::value) {  // as the ragged streaming kernels (sinkhorn.hip)
         const float norm = -__logf((float)(M + N));
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
         const int j = tid * CPT + c;
-        vv[c] = j < N ? a.v_in[(int64_t)bglob * a.ldv + j] * RS_LOG2E : OG_NEG_INF;
+        vv[c] = j < Nl ? a.v_in[(int64_t)bglob * a.ldv + c0 + j] * RS_LOG2E : OG_NEG_INF;
     }
     if (tid == 0) red[33] = a.v_in[(int64_t)bglob * a.ldv + N] * RS_LOG2E;      // the dual of the dustbin COLUMN
     __syncthreads();
@@ -370,7 +375,7 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
         const rs_gchar* rp = (const rs_gchar*)(uintptr_t)(((uint64_t)hi32 << 32) | lo);                    // global address space: global_load, not flat_load
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const unsigned o = (unsigned)(colb + 256 * k < N ? colb + 256 * k : 0) * 4u;      // clamped to a valid address
+            const unsigned o = (unsigned)(colb + 256 * k < Nl ? c0 + colb + 256 * k : 0) * 4u;      // clamped to a valid address
             x[k] = *(const rs_gf32x4*)(rp + o);
         }
         if (a.sanitize_pad) {                              // wave-uniform; only the one chunk that straddles column N has anything to clear
@@ -378,7 +383,7 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
             for (int k = 0; k < 4; ++k)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (colb + 256 * k + e >= N) x[k][e] = 0.f;
+                    if (colb + 256 * k + e >= Nl) x[k][e] = 0.f;
         }
     };
 
@@ -388,6 +393,7 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
     f32x4 er[RS_RR][4];                                    // the register-resident rows of E
     float uM2 = 0.f;                                       // dual of the dustbin ROW (every workgroup, identically)
     float vsh = 0.f;                                       // max_j v_j of the previous iteration: the shift of the log-sum-exp of v
+    float lse_sum = 0.f, lse_shift = 0.f;                  // XG > 1: sum_j 2^(v_j - lse_shift) over MY column block, published at the next row hop
     float drift = 0.f;                                     // bound (bits) on the growth of any of my entries since they were evaluated
     int it = 0;
     while (!failed) {
@@ -426,7 +432,7 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
         }
         // the dustbin-row dual from the current v: u_M' = log2 a_M - (z + LSE2_{j<=N} v_j)
         {
-            float mx = tid == 0 ? vN2 : OG_NEG_INF;
+            float mx = (tid == 0 && xg == 0) ? vN2 : OG_NEG_INF;      // (the dustbin column's dual enters the sum of column block 0)
 #pragma unroll
             for (int c = 0; c < CPT; ++c) mx = fmaxf(mx, vv[c]);
             mx = rs_wave_max(mx);
@@ -438,7 +444,8 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
             mx = red[0];
 #pragma unroll
             for (int w = 1; w < RS_NW; ++w) mx = fmaxf(mx, red[w]);
-            float sv = tid == 0 ? __builtin_amdgcn_exp2f(vN2 - mx) : 0.f;
+            mx = fmaxf(mx, -1.0e30f);                      // (a column block without columns: every v is -inf; keep the shift finite)
+            float sv = (tid == 0 && xg == 0) ? __builtin_amdgcn_exp2f(vN2 - mx) : 0.f;
 #pragma unroll
             for (int c = 0; c < CPT; ++c) sv += __builtin_amdgcn_exp2f(vv[c] - mx);     // 2^-inf = 0
             sv = rs_wave_sum(sv);
@@ -447,8 +454,9 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
             float svt = red[8];
 #pragma unroll
             for (int w = 1; w < RS_NW; ++w) svt += red[8 + w];
-            uM2 = rs_uniform(la_bin2 - (zr2 + mx + __builtin_amdgcn_logf(svt)));
+            uM2 = rs_uniform(la_bin2 - (zr2 + mx + __builtin_amdgcn_logf(svt)));       // (XG > 1: replaced at the first row hop by the sum over the column blocks)
             vsh = rs_uniform(mx);
+            lse_sum = rs_uniform(svt); lse_shift = vsh;
             __syncthreads();                               // red[] is reused by the loop
         }
         drift = 0.f;
@@ -461,8 +469,8 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
             const unsigned epoch = (unsigned)it + 1u;
             const rs_gchar* xa_par = (const rs_gchar*)a.xa + (int64_t)(it & 1) * a.slots * NCX * 8;          // this parity's areas
             const rs_gchar* xb_par = (const rs_gchar*)a.xb + ((int64_t)(it & 1) * a.groups + grow) * NCX * 8;   // ... and my group's totals
-            const rs_gchar* xc_par = (const rs_gchar*)a.xc + ((int64_t)(it & 1) * a.groups + r * XG) * NCX * 8;   // ... and the pair's group sums
-            const float dcol2 = rs_uniform(zr2 + vN2);
+            // ... and the row records of the pair's tiles: [column block][row block][RS_RREC granules]
+            const rs_gchar* xr_par = (const rs_gchar*)a.xc + ((int64_t)(it & 1) * a.groups + r * XG) * (int64_t)(32 * RS_RREC * 8);
 
             RS_TP(0);
             // ---- (1) pass 1: sum_j E_ij C_j of my 16 rows ----
@@ -513,12 +521,70 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
                     for (int c = 1; c < WC; ++c) rsv += rq[c * RS_RW];
                 }
             }
+            float rowp = Frv * rsv;                        // lane s: the PLAN's row sum over my columns (F is this workgroup's own)
+            if (XG > 1) {
+                // ---- the row hop: a row crosses the XG column blocks of its row block.  Every tile publishes a record of RS_RREC granules
+                //      -- its 128 partial row sums, the (sum, shift) of 2^v over its columns (for the dustbin-row dual) and, column block
+                //      0, the dual of the dustbin column -- and reads the XG records of its row block; sums in block order, so the XG
+                //      tiles arrive at the same bits.  AGENT scope: the column blocks of a pair sit on different XCDs (the bulk of the
+                //      traffic -- the column exchange of a block -- stays inside one). ----
+                const rs_u64 tag = (rs_u64)epoch << 32;
+                rs_gu64* mine = (rs_gu64*)(xr_par + ((int64_t)xg * 32 + gl) * (RS_RREC * 8));
+                if (wc == 0 && lane < RS_RW) __hip_atomic_store(mine + wr * RS_RW + lane, tag | __builtin_bit_cast(unsigned, rowp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (wave == 0 && lane >= 16 && lane < 19) {
+                    const float ex = lane == 16 ? lse_sum : lane == 17 ? lse_shift : vN2;
+                    __hip_atomic_store(mine + 128 + (lane - 16), tag | __builtin_bit_cast(unsigned, ex), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                // lane s < 16: granule wr 16 + s of every block; lane 16 + 3 b + k: extra k of block b; the others: an own granule again
+                float got[4];
+                auto hop = [&](auto N_) {
+                    constexpr int NX = decltype(N_)::value;                       // XG + 1 loads (the last one a repeat)
+                    rs_u64 gx[NX];
+                    unsigned xo[NX];
+                    const int e3 = lane - 16, eb = e3 / 3, ek = e3 - 3 * eb;
+                    const bool isx = lane >= 16 && eb < XG;
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) {
+                        const int b = i < NX - 1 ? i : 0;
+                        const int gi = lane < RS_RW ? wr * RS_RW + lane : isx ? 128 + ek : wr * RS_RW;
+                        xo[i] = (unsigned)(((isx ? eb : b) * 32 + gl) * RS_RREC + gi) * 8u;
+                    }
+                    unsigned spins = 0;
+                    for (;;) {
+                        rs_load_granules<false>(gx, xr_par, xo);
+                        unsigned bad = 0u;
+#pragma unroll
+                        for (int i = 0; i < NX; ++i) bad |= (unsigned)(gx[i] >> 32) ^ epoch;
+                        if (__builtin_amdgcn_ballot_w64(bad != 0u) == 0) break;
+                        if (++spins > RS_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                            failed = true;
+                            __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+#pragma unroll
+                    for (int i = 0; i < NX - 1; ++i) { const unsigned w32 = (unsigned)gx[i]; got[i] = __builtin_bit_cast(float, w32); }
+#pragma unroll
+                    for (int i = NX - 1; i < 4; ++i) got[i] = 0.f;
+                };
+                if (XG == 2) hop(std::integral_constant<int, 3>{}); else hop(std::integral_constant<int, 5>{});
+                rowp = (got[0] + got[1]) + (got[2] + got[3]);                      // lanes < 16: the row sums over ALL columns
+                // the extras (lane 16 + 3 b + k holds extra k of block b in got[0]): dustbin-row dual from the blocks' (sum, shift) pairs
+                float smax = lane_value(got[0], 17);
+                for (int b = 1; b < XG; ++b) smax = fmaxf(smax, lane_value(got[0], 17 + 3 * b));
+                float tot2 = 0.f;
+                for (int b = 0; b < XG; ++b) tot2 += lane_value(got[0], 16 + 3 * b) * __builtin_amdgcn_exp2f(lane_value(got[0], 17 + 3 * b) - smax);
+                uM2 = rs_uniform(la_bin2 - (zr2 + smax + __builtin_amdgcn_logf(tot2)));
+                vN2 = lane_value(got[0], 18);                                       // block 0's dual of the dustbin column
+            }
+            const float dcol2 = rs_uniform(zr2 + vN2);
             // ---- new u of my rows, the row factors f, the dustbin-column partial (lanes 0..15, one row each) ----
             float usum, dumax;
             {
                 const bool live = lane < nvalid;
                 const float pd = __builtin_amdgcn_exp2f(dcol2 + urv);              // the row's dustbin-column entry with the old u
-                const float un = urv + la2 - __builtin_amdgcn_logf(Frv * rsv + pd);
+                const float un = urv + la2 - __builtin_amdgcn_logf(rowp + pd);
                 const float du = un - urv;
                 const float f = __builtin_amdgcn_exp2f(du);
                 usum = rs_wave_sum(live ? pd * f : 0.f);                            // sum_i 2^(z + v_N + u_i')
@@ -567,7 +633,7 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
 #pragma unroll
                     for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(pb + 256 * k) = cs[k];
                 }
-                if (lane == 0) { red[16 + wave] = wc == 0 ? usum : 0.f; red[24 + 64 * (it & 1) + wave] = dumax; }     // (drift maxima: read after the last barrier of the iteration, hence two copies)
+                if (lane == 0) { red[16 + wave] = (wc == 0 && xg == 0) ? usum : 0.f; red[24 + 64 * (it & 1) + wave] = dumax; }     // (drift maxima: read after the last barrier of the iteration, hence two copies)
                 __syncthreads();
                 if (wr >= PS) {
 #pragma unroll
@@ -655,42 +721,6 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
                         const f32x4 d4 = *reinterpret_cast<const f32x4*>(dred + 4 * lane);
                         td = rs_wave_sum((d4[0] + d4[1]) + (d4[2] + d4[3]));
                     }
-                    if (W > 1 && XG > 1 && (colw || dustw)) {             // (W == 1 with more than 32 workgroups per pair -- m > 4096 rows -- is left to the streaming kernels)
-                        // the pair is spread over X groups (XCDs): the owners of the same columns exchange their group sums at AGENT scope
-                        // (CW granules per workgroup instead of NC: the bulk of the traffic stays inside the XCDs) and add them in group order,
-                        // so every group arrives at the same bits.  CW <= 256 here (Gx >= 17): wave 7 has no columns of its own.
-                        const bool dz = !colw;
-                        const float tv = dz ? td : t;
-                        const int cc = dz ? NC : ocol;
-                        if (colw || lane == 0) __hip_atomic_store((rs_gu64*)(xc_par + (int64_t)xg * NCX * 8) + cc, tag | __builtin_bit_cast(unsigned, tv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        float tsum = 0.f;
-                        unsigned spins = 0;
-                        auto cross = [&](auto N_) {
-                            constexpr int NX = decltype(N_)::value;                   // X + 1 granules (the last one twice)
-                            rs_u64 gx[NX];
-                            unsigned xo[NX];
-#pragma unroll
-                            for (int i = 0; i < NX; ++i) xo[i] = (unsigned)((i < NX - 1 ? i : 0) * NCX + cc) * 8u;
-                            for (;;) {
-                                rs_load_granules<false>(gx, xc_par, xo);
-                                unsigned bad = 0u;
-#pragma unroll
-                                for (int i = 0; i < NX; ++i) bad |= (unsigned)(gx[i] >> 32) ^ epoch;
-                                if (__builtin_amdgcn_ballot_w64(bad != 0u) == 0) break;
-                                if (++spins > RS_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-                                    failed = true;
-                                    __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                    break;
-                                }
-                                __builtin_amdgcn_s_sleep(1);
-                            }
-#pragma unroll
-                            for (int i = 0; i < NX - 1; ++i) { const unsigned w32 = (unsigned)gx[i]; tsum += __builtin_bit_cast(float, w32); }
-                        };
-                        if (XG == 2) cross(std::integral_constant<int, 3>{});
-                        else cross(std::integral_constant<int, 5>{});               // XG == 4 (the launcher admits nothing wider)
-                        if (dz) td = tsum; else t = tsum;
-                    }
                     if (colw) __hip_atomic_store((rs_gu64*)xb_par + ocol, tag | __builtin_bit_cast(unsigned, t), __ATOMIC_RELAXED, SCOPE);
                     if (dustw && lane == 0) __hip_atomic_store((rs_gu64*)xb_par + NC, tag | __builtin_bit_cast(unsigned, td), __ATOMIC_RELAXED, SCOPE);
                 }
@@ -732,7 +762,7 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
 #pragma unroll
             for (int c = 0; c < CPT; ++c) {
                 const int j = tid * CPT + c;
-                if (j < N) {
+                if (j < Nl) {
                     const float vo = vv[c];
                     const float vn = vo + lb2 - __builtin_amdgcn_logf(colsum[c] + __builtin_amdgcn_exp2f(zr2 + vo + uM2));
                     const float dv = vn - vo;
@@ -744,8 +774,8 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
             }
             float vNn = OG_NEG_INF;
             if (tid == 0) {
-                vNn = vN2 + lb_bin2 - __builtin_amdgcn_logf(colsumN + __builtin_amdgcn_exp2f(zr2 + vN2 + uM2));
-                red[33] = vNn;
+                if (xg == 0) vNn = vN2 + lb_bin2 - __builtin_amdgcn_logf(colsumN + __builtin_amdgcn_exp2f(zr2 + vN2 + uM2));
+                red[33] = xg == 0 ? vNn : vN2;               // (the other column blocks receive the new dual at the next row hop)
                 red[32] = uM2;
             }
             {
@@ -766,8 +796,10 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
                 float svt = red[8], dm = red[40], um = rk[0], fl = red[48];
 #pragma unroll
                 for (int w = 1; w < RS_NW; ++w) { mx = fmaxf(mx, red[w]); svt += red[8 + w]; dm = fmaxf(dm, red[40 + w]); um = fmaxf(um, rk[w]); fl += red[48 + w]; }
+                mx = fmaxf(mx, -1.0e30f);
                 drift = rs_uniform(drift + (dm + um));
-                uM2 = rs_uniform(la_bin2 - (zr2 + vsh + __builtin_amdgcn_logf(svt)));
+                if (XG == 1) uM2 = rs_uniform(la_bin2 - (zr2 + vsh + __builtin_amdgcn_logf(svt)));
+                lse_sum = rs_uniform(svt); lse_shift = vsh;     // XG > 1: my block's part of the sum, combined at the next row hop
                 vsh = rs_uniform(mx);
                 vN2 = rs_uniform(red[33]);
                 failed = fl != 0.f;                        // a peer never arrived: leave together (status = 1)
@@ -784,14 +816,14 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
     // ---- results in natural units: u of my rows, and (workgroup 0 of the pair) v and u_M ----
     {
     RS_THREAD_LOCALS;
-    if (wc == 0 && lane < nvalid) ub[row0 + lane] = urv * RS_LN2;
-    if (g == 0) {
+    if (wc == 0 && xg == 0 && lane < nvalid) ub[row0 + lane] = urv * RS_LN2;
+    if (gl == 0) {                                          // row block 0 of every column block: its slice of v
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
             const int j = tid * CPT + c;
-            if (j < N) a.v_out[(int64_t)bglob * a.ldv + j] = vv[c] * RS_LN2;
+            if (j < Nl) a.v_out[(int64_t)bglob * a.ldv + c0 + j] = vv[c] * RS_LN2;
         }
-        if (tid == 0) { a.v_out[(int64_t)bglob * a.ldv + N] = vN2 * RS_LN2; ub[M] = red[32] * RS_LN2; }
+        if (tid == 0 && xg == 0) { a.v_out[(int64_t)bglob * a.ldv + N] = vN2 * RS_LN2; ub[M] = red[32] * RS_LN2; }
     }
     }
 }
@@ -814,20 +846,20 @@ int rs_num_cus() {
     return n;
 }
 
-// geometry of one pair: W (column tiles per workgroup; 0 = not resident-capable), G workgroups in X groups of Gx
+// geometry of one pair: W = wave tiles per row of a workgroup tile (tile = 128 / W rows x 1024 W columns; 0 = not resident-capable),
+// X column blocks of Gx row blocks each (G = X Gx workgroups).  One column block per XCD: Gx <= 32.
 struct RsGeom { int W, G, Gx, X; };
 RsGeom rs_geom(int m, int n) {
     RsGeom q{0, 0, 0, 1};
     if (m <= 0 || n <= 0 || n > 4 * RS_SEG) return q;
-    q.W = n <= RS_SEG ? 1 : n <= 2 * RS_SEG ? 2 : 4;
-    const int RB = RS_RW * RS_NW / q.W;
-    q.G = (m + RB - 1) / RB;
-    if (q.G < 2 * q.W) q.G = 2 * q.W;                     // an owner sums at most 512 columns: NC / Gx <= 512
-    if (q.G > RS_MAXWG) { q.W = 0; return q; }
-    while (q.X * 32 < q.G) q.X *= 2;                       // one group per XCD (32 CUs)
-    if (q.X > 4 || (q.X > 1 && q.W == 1)) { q.W = 0; return q; }      // more than 128 workgroups per pair, or m > 4096 with n <= 1024: streaming kernels
-    q.Gx = (q.G + q.X - 1) / q.X;
-    q.G = q.X * q.Gx;                                      // (a few workgroups more, each with fewer rows)
+    auto rows = [&](int W) { const int RB = RS_RW * RS_NW / W; int g = (m + RB - 1) / RB; return g < 2 * W ? 2 * W : g; };   // an owner sums <= 512 columns
+    // the widest tile whose row blocks still fit one XCD; narrower tiles = more column blocks = a row hop per iteration
+    if (n <= RS_SEG) { q.W = 1; q.X = 1; }
+    else if (n <= 2 * RS_SEG) { if (rows(2) <= 32) { q.W = 2; q.X = 1; } else { q.W = 1; q.X = 2; } }
+    else { if (rows(4) <= 32) { q.W = 4; q.X = 1; } else if (rows(2) <= 32) { q.W = 2; q.X = 2; } else { q.W = 1; q.X = 4; } }
+    q.Gx = rows(q.W);
+    if (q.Gx > 32) { q.W = 0; return q; }                  // more than 4096 rows: streaming kernels
+    q.G = q.X * q.Gx;
     return q;
 }
 // uniform batch: pairs per launch with `cus` CUs (0 = never)
@@ -837,9 +869,9 @@ int rs_pairs_per_round(const RsGeom& q, int cus) {
     return q.X == 1 ? cus / q.G : 0;
 }
 
-size_t rs_area_bytes(int W, int slots, int groups) {    // status + xcc table, then the three exchange areas
+size_t rs_area_bytes(int W, int slots, int groups) {    // status + xcc table, then the exchange areas (column partials, column totals, row records)
     const size_t NCX = (size_t)RS_SEG * W + RS_PAD;
-    return 256 + (size_t)RS_MAXWG * sizeof(unsigned) + (size_t)2 * slots * NCX * 8 + (size_t)4 * groups * NCX * 8;
+    return 256 + (size_t)RS_MAXWG * sizeof(unsigned) + (size_t)2 * slots * NCX * 8 + (size_t)2 * groups * NCX * 8 + (size_t)2 * groups * 32 * RS_RREC * 8;
 }
 
 template <int W, class MAP>
@@ -903,7 +935,7 @@ int og_launch_sinkhorn_resident(const float* S, int64_t lds, const float* zdev, 
         a.xb = a.xa + (size_t)2 * a.slots * NCX * 8;
         a.xc = a.xb + (size_t)2 * a.groups * NCX * 8;
         // epochs start at 1: every tag (and every XCC entry) must read 0 first
-        e = hipMemsetAsync(a.xcc, 0, RS_MAXWG * sizeof(unsigned) + (size_t)2 * a.slots * NCX * 8 + (size_t)4 * a.groups * NCX * 8, st);
+        e = hipMemsetAsync(a.xcc, 0, RS_MAXWG * sizeof(unsigned) + (size_t)2 * a.slots * NCX * 8 + (size_t)2 * a.groups * NCX * 8 + (size_t)2 * a.groups * 32 * RS_RREC * 8, st);
         if (e != hipSuccess) return (int)e;
         RsUniform map{q.G, q.Gx, q.X, 0};
         int grid = np * q.G;
@@ -991,7 +1023,7 @@ int og_launch_sinkhorn_resident_ragged(const float* S, int64_t lds, const float*
             a.b0 = 0; a.npairs = np; a.slots = slots; a.groups = np;
             a.xb = a.xa + (size_t)2 * a.slots * NCX * 8;
             a.xc = a.xb + (size_t)2 * a.groups * NCX * 8;
-            e = hipMemsetAsync(a.xcc, 0, RS_MAXWG * sizeof(unsigned) + (size_t)2 * a.slots * NCX * 8 + (size_t)4 * a.groups * NCX * 8, st);
+            e = hipMemsetAsync(a.xcc, 0, RS_MAXWG * sizeof(unsigned) + (size_t)2 * a.slots * NCX * 8 + (size_t)2 * a.groups * NCX * 8, st);   // (ragged pairs: one column block, no row records)
             if (e != hipSuccess) return (int)e;
             const int grid = 8 * qmax;
             if (W == 1) rs_launch<1>(a, map, grid, st);

@@ -691,6 +691,9 @@ def test_favor_relu_attention_whole_path(gpu_device, D, m, n, B):
                                              # wider than one wave tile: 2 / 4 waves per row (n <= 2048 / 4096), two-hop column exchange
                                              (2, 300, 2047, 12, 1.0), (1, 77, 4096, 8, 1.0), (3, 1100, 1500, 25, 0.8), (2, 2048, 2048, 100, 1.0),
                                              (1, 4096, 4096, 30, 1.0), (1, 3000, 2500, 15, 1.0),
+                                             # pairs as 2-D grids of tiles (column blocks on different XCDs, a row hop per iteration): 2 x 24 tiles of
+                                             # 64 x 2048, 2 x 20 tiles of 128 x 1024
+                                             (1, 1500, 3000, 12, 1.0), (2, 2500, 1800, 10, 1.0),
                                              # more pairs than one launch holds: rounds of co-resident pairs (G = 8: 32 per launch; G = 32: 8)
                                              (40, 1024, 200, 20, 1.0), (11, 2048, 1030, 10, 1.0)])
 def test_sinkhorn_resident_vs_oracle(gpu_device, monkeypatch, B, m, n, iters, reg):
@@ -717,7 +720,7 @@ def test_sinkhorn_resident_vs_oracle(gpu_device, monkeypatch, B, m, n, iters, re
     assert (torch.logsumexp(out.double() + norm, dim=1) - lb).abs().max() < 1e-4        # column marginals exact after the last v update
 
 
-@pytest.mark.parametrize("B,m,n,iters", [(8, 1024, 1024, 60), (2, 257, 1000, 10), (3, 640, 333, 25), (8, 2048, 2048, 40), (5, 700, 1800, 20)])
+@pytest.mark.parametrize("B,m,n,iters", [(8, 1024, 1024, 60), (2, 257, 1000, 10), (3, 640, 333, 25), (8, 2048, 2048, 40), (5, 700, 1800, 20), (1, 2200, 2100, 8)])
 def test_sinkhorn_resident_exchange_scopes(gpu_device, monkeypatch, B, m, n, iters):
     """The column partials travel between the workgroups of a pair either at agent scope or -- when the kernel finds all of them
     on one XCD (B a multiple of 8 with the round-robin dispatch) -- through that XCD's L2 with workgroup-scope streaming loads.
