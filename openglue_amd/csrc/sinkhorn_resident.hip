@@ -308,7 +308,7 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
         const float norm = -__logf((float)(M + N));
         la = norm; lb = norm; la_bin = norm + __logf((float)N); lb_bin = norm + __logf((float)M);
     }
-    const int mb = (M + G - 1) / G;                        // rows per workgroup (<= RB)
+    const int mb = (M + Gx - 1) / Gx;                      // rows per workgroup (<= RB): the rows are split over the Gx row blocks of a column block
     // (wave-uniform floats computed by the vector ALU stay in VECTOR registers unless moved: every one of these would cost a VGPR
     // for the whole loop, next to the 192 of E)
     const float c2 = rs_uniform(a.inv_reg * RS_LOG2E);
@@ -316,8 +316,8 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
     const float la2 = rs_uniform(la * RS_LOG2E), la_bin2 = rs_uniform(la_bin * RS_LOG2E), lb2 = rs_uniform(lb * RS_LOG2E), lb_bin2 = rs_uniform(lb_bin * RS_LOG2E);
     const float* Sb = a.S + (int64_t)bglob * a.strideS;
     float* ub = a.u + (int64_t)bglob * a.ldu;
-    const int row0 = g * mb + wr * RS_RW;                  // global row of this wave's slot 0
-    const int row_end = min(M, (g + 1) * mb);              // rows >= row_end belong to the next workgroup (or do not exist)
+    const int row0 = gl * mb + wr * RS_RW;                 // global row of this wave's slot 0
+    const int row_end = min(M, (gl + 1) * mb);             // rows >= row_end belong to the next workgroup (or do not exist)
     rs_gu32* status = (rs_gu32*)a.status;
     // rows of this wave that exist: slot s is live iff s < nvalid (ONE scalar)
     const int nvalid = __builtin_amdgcn_readfirstlane(min(max(row_end - row0, 0), RS_RW));
