@@ -3,7 +3,8 @@
 // Replaces the iteration loop of log_otp_solver (reference optimal_transport.py:24-26).  256 CUs x (512 KB of VGPRs + 160 KB of
 // LDS) = 172 MB; a round of pairs whose score matrices fill at most 128 MB (256 workgroups x 128 rows x 1024 columns of fp32) is
 // loaded ONCE and iterated in ONE launch; larger batches run as a sequence of such rounds (32 pairs of 1024 x 1024, 8 pairs of
-// 2048 x 2048 or 2 pairs of 4096 x 4096 per round).  Round 4 rewrite of the round-2/3 kernel, two changes of substance:
+// 2048 x 2048 or 2 pairs of 4096 x 4096 per round; ragged pairs packed one column block per XCD slot range).  Round 4 rewrite of the
+// round-2/3 kernel, two changes of substance:
 //
 // (1) LINEAR-DOMAIN resident state, never rewritten.  After the max-subtracted first iteration (sinkhorn.hip) every plan entry
 //         P_ij = 2^(s_ij + u_i + v_j),   s = S/reg * log2 e, duals in base 2,
@@ -23,19 +24,27 @@
 //     marginals of 2^-14.  Ordinary problems never refresh; |S/reg| of several hundred does 5-7 times in 30 iterations.
 //     Nothing is streamed from memory inside the loop: 12 of a wave's 16 rows live in registers (192), 4 in LDS.
 //
-// (2) ANY WIDTH UP TO 4096 COLUMNS, ANY NUMBER OF WORKGROUPS PER PAIR.  A wave always owns a 16-row x 1024-column tile (16 floats per lane
-//     and row); the 8 waves of a workgroup form WR x WC tiles (W = WC = 1, 2, 4 for n <= 1024, 2048, 4096: 128 x 1024, 64 x 2048,
-//     32 x 4096 entries per workgroup).  Row sums cross the WC waves of a row through LDS (one barrier: pass 1 and pass 2 are
-//     decoupled because E is resident), column sums cross the G workgroups of a pair in two hops: every workgroup publishes its NC
-//     column partials as 8-byte {epoch, value} granules (cdna_hip_programming.md Guideline 16, form R2: the data is the flag),
-//     the OWNER of a slice of columns sums the G partials of its columns in a fixed order and publishes the totals, everybody
-//     reads the NC totals: 2 NC granules read per workgroup and iteration whatever G is (the round-3 kernel read G x NC, which
-//     is 512 KB per workgroup at G = 32).  Every workgroup then computes ALL new v_j redundantly and bit-identically.
+// (2) ANY SIZE UP TO 4096 x 4096: A PAIR IS A 2-D GRID OF WORKGROUP TILES.  A wave always owns a 16-row x 1024-column tile (16 floats
+//     per lane and row); the 8 waves of a workgroup form WR x WC wave tiles (W = WC = 1, 2, 4: workgroup tiles of 128 x 1024, 64 x 2048,
+//     32 x 4096 entries); a pair is X column blocks x Gx row blocks of such tiles, X Gx <= 128 workgroups (rs_geom: the widest tile whose
+//     Gx <= 32 row blocks fit one XCD; 4096 x 4096 = 4 x 32 tiles of 128 x 1024).
+//     * Row sums cross the WC waves of a row through LDS (one barrier: pass 1 and pass 2 are decoupled because E is resident) and,
+//       when X > 1, the X column blocks of a row block in ONE hop: every tile publishes a record of its 128 partial row sums as 8-byte
+//       {epoch, value} granules (cdna_hip_programming.md Guideline 16, form R2: the data is the flag) and reads the X records of its row
+//       block at AGENT scope -- 1 KB per tile and iteration is all that crosses XCDs.  (The first version of this round kept the pair's
+//       column sums crossing XCDs instead: 32 KB of granules written and 64 KB read per workgroup and iteration at n = 4096 saturated the
+//       L2s: 31.6k cycles per iteration against 18.3k now, profiles/r04_e_* vs r04_i_*.)
+//     * Column sums cross the Gx row blocks of a column block -- all on one XCD -- in two hops: every workgroup publishes its NC column
+//       partials, the OWNER of a slice of columns sums the Gx partials of its columns in a fixed order and publishes the totals,
+//       everybody reads the NC totals: 2 NC granules read per workgroup and iteration whatever Gx is (the round-3 kernel read Gx x NC).
+//       Every workgroup of the column block then computes the new v_j of the block's columns redundantly and bit-identically.
+//     * The dustbin column's dual lives in column block 0 and travels to the other blocks in the row record, as do the blocks' shares of
+//       the log-sum-exp of v that the dustbin ROW's dual needs.
 //     Granules are double-buffered by epoch parity; every spin is bounded (status word: 1 = a wait timed out -> the safety-net
 //     kernel of sinkhorn.hip recomputes the batch); all workgroups of a round must be co-resident: one 512-thread workgroup per CU
 //     (~150 KB of LDS), at most #CUs workgroups per launch, checked by the launcher.
-//     Workgroups are dealt to the XCDs round-robin by linear id; the id -> (pair, g) map puts the workgroups of a pair on ONE XCD
-//     when G <= 32, and the exchange then goes through that XCD's L2 (verified at run time; otherwise agent scope).
+//     Workgroups are dealt to the XCDs round-robin by linear id; the id -> (pair, block, row block) map puts a column block on ONE
+//     XCD, and its column exchange then goes through that XCD's L2 (verified at run time; otherwise agent scope).
 #include <stdlib.h>
 #include <math.h>
 #include <type_traits>
