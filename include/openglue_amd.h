@@ -316,6 +316,10 @@ int og_sinkhorn_status(const void* sinkhorn_workspace_dev, int32_t batch, int32_
  * grouped by width class and packed one pair per XCD slot range; 0 when any pair has no resident geometry. */
 int og_sinkhorn_schedule(int32_t batch, int32_t m, int32_t n, int32_t iters);
 int og_sinkhorn_schedule_ragged(int32_t batch, const int32_t* lens0, const int32_t* lens1, int32_t iters);
+/* How the on-chip-resident schedule tiles ONE pair of m x n keypoints on a part with 8 XCDs x 32 CUs (host arithmetic only, no device):
+ * out4 = {W, X, Gx, pairs per launch} -- workgroup tiles of (128 / W) rows x (1024 W) columns, X column blocks (one per XCD) x Gx row blocks;
+ * returns 0, or OG_E_SHAPE when the shape has no resident geometry (more than 4096 rows or columns: streaming kernels). */
+int og_sinkhorn_resident_geometry(int32_t m, int32_t n, int32_t* out4);
 /* The same check for the workspace of an og_forward / og_forward_ragged call with this shape (for ragged calls: the shape
  * that was passed, i.e. the maxima).  Waits like og_sinkhorn_status (NULL stream only).  Return values as og_sinkhorn_status. */
 int og_forward_status(const og_shape* shape, const void* workspace_dev);

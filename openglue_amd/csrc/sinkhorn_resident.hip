@@ -900,6 +900,16 @@ size_t og_sinkhorn_resident_ws_bytes(int B, int m, int n) {
     return rs_area_bytes(q.W, RS_MAXWG, RS_MAXPAIRS);
 }
 
+// The tile geometry of one pair on a part with 8 XCDs x 32 CUs (pure host arithmetic, no device needed: CPU tests): out = {W, X, Gx,
+// pairs per launch}; returns 0, or OG_E_SHAPE when the shape has no resident geometry.
+extern "C" int og_sinkhorn_resident_geometry(int32_t m, int32_t n, int32_t* out4) {
+    if (!out4) return OG_E_INVALID;
+    const RsGeom q = rs_geom(m, n);
+    if (q.W == 0) return OG_E_SHAPE;
+    out4[0] = q.W; out4[1] = q.X; out4[2] = q.Gx; out4[3] = rs_pairs_per_round(q, 256);
+    return 0;
+}
+
 // launches the resident kernel would need for this uniform batch on this device (0 = not possible)
 int og_sinkhorn_resident_rounds(int B, int m, int n) {
     if (!og_sinkhorn_resident_shape_ok(B, m, n)) return 0;

@@ -228,3 +228,31 @@ def test_openglue_matcher_contract_on_cpu():
             "descriptors0": torch.randn(1, 8, 64), "descriptors1": torch.randn(1, 9, 64), "image0_size": [640, 480], "image1_size": [640, 480]}
     with pytest.raises(RuntimeError, match="no CPU path"):
         pipe(data)
+
+
+def test_resident_sinkhorn_tile_geometry():
+    """Host arithmetic of csrc/sinkhorn_resident.hip (rs_geom / rs_pairs_per_round), no device involved: how a pair is cut into workgroup
+    tiles on 8 XCDs x 32 CUs -- {W, X column blocks, Gx row blocks, pairs per launch} -- for the BASELINE shapes and the edges."""
+    import ctypes as C
+    lib = _lib.load()
+    def geom(m, n):
+        out = (C.c_int32 * 4)()
+        rc = lib.og_sinkhorn_resident_geometry(m, n, out)
+        return rc, tuple(out)
+    assert geom(1024, 1024) == (0, (1, 1, 8, 32))        # C2: 8 tiles of 128 x 1024 per pair, 32 pairs per launch (4 per XCD)
+    assert geom(2048, 2048) == (0, (2, 1, 32, 8))        # C3: 32 tiles of 64 x 2048, one pair per XCD
+    assert geom(4096, 4096) == (0, (1, 4, 32, 2))        # C4: 4 column blocks x 32 row blocks of 128 x 1024, 2 pairs per launch
+    assert geom(77, 4096) == (0, (4, 1, 8, 32))          # short and wide: 32 x 4096 tiles, at least 2 W workgroups (an owner sums <= 512 columns)
+    assert geom(1500, 3000) == (0, (2, 2, 24, 4))        # 2 x 24 tiles of 64 x 2048
+    assert geom(2500, 1800) == (0, (1, 2, 20, 4))        # 2 x 20 tiles of 128 x 1024
+    assert geom(1, 1) == (0, (1, 1, 2, 128))
+    assert geom(512, 2048)[1][:3] == (2, 1, 8)
+    for m, n in [(4097, 1024), (1024, 4097), (0, 5), (8192, 8192)]:
+        assert geom(m, n)[0] == -2, (m, n)
+    # every geometry fits the part: X Gx workgroups per pair, pairs per launch x that <= 256
+    for m in (1, 100, 129, 1000, 2049, 4096):
+        for n in (1, 1024, 1025, 2048, 2049, 4096):
+            rc, (W, X, Gx, ppr) = geom(m, n)
+            assert rc == 0 and Gx <= 32 and X * Gx * ppr <= 256 and ppr >= 1
+            assert X * 1024 * W >= n and Gx * (128 // W) >= m
+
