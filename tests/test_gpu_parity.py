@@ -720,6 +720,24 @@ def test_sinkhorn_resident_vs_oracle(gpu_device, monkeypatch, B, m, n, iters, re
     assert (torch.logsumexp(out.double() + norm, dim=1) - lb).abs().max() < 1e-4        # column marginals exact after the last v update
 
 
+@pytest.mark.parametrize("B,m,n,iters", [(1, 2, 257, 2), (2, 711, 2027, 2), (5, 65, 2128, 8), (5, 127, 511, 12), (5, 1025, 3071, 2), (1, 1024, 2992, 8),
+                                         (9, 1382, 3071, 3), (2, 3071, 257, 3), (1, 2663, 762, 5), (9, 2427, 65, 8), (3, 257, 438, 12), (1, 15, 2048, 5),
+                                         (5, 1915, 33, 3), (1, 1224, 46, 12), (1, 1023, 1024, 8), (1, 17, 190, 12), (1, 127, 2047, 5), (9, 257, 4095, 5),
+                                         (3, 4096, 3000, 3), (2, 3100, 4096, 3)])
+def test_sinkhorn_resident_edge_shapes(gpu_device, monkeypatch, B, m, n, iters):
+    """A fixed pseudo-random draw of shapes around the tile edges (16 rows per wave, 128 / 64 / 32 rows per workgroup, 1024 columns per wave
+    tile, 2 and 4 column blocks, one row, one column block almost empty, several rounds): every geometry rs_geom can produce, against the
+    float64 oracle."""
+    g = torch.Generator().manual_seed(B * 1000003 + m * 4099 + n)
+    S = _rand(g, B, m, n, scale=4.0)
+    ref = _sinkhorn_ref(S, 0.3, iters, 0.9)
+    monkeypatch.setenv("OG_SINKHORN_RESIDENT", "2")
+    out, status = ops.sinkhorn(S.to(gpu_device), 0.3, iters, 0.9, return_status=True)
+    assert status == 0
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err < 1e-4, err
+
+
 @pytest.mark.parametrize("B,m,n,iters", [(8, 1024, 1024, 60), (2, 257, 1000, 10), (3, 640, 333, 25), (8, 2048, 2048, 40), (5, 700, 1800, 20), (1, 2200, 2100, 8)])
 def test_sinkhorn_resident_exchange_scopes(gpu_device, monkeypatch, B, m, n, iters):
     """The column partials travel between the workgroups of a pair either at agent scope or -- when the kernel finds all of them
@@ -903,7 +921,9 @@ def test_sinkhorn_resident_ignores_dirty_padding_columns(gpu_device, monkeypatch
     Sp = Sp.to(gpu_device)
     ws = torch.empty(lib.og_sinkhorn_workspace_bytes(B, m, n), device=gpu_device, dtype=torch.uint8)
     out = torch.empty(B, m + 1, n + 1, device=gpu_device)
-    assert lib.og_sinkhorn_schedule(B, m, n, iters) == 1
+    assert lib.og_sinkhorn_schedule(B, m, n, iters) == 1           # one resident launch
+    assert lib.og_sinkhorn_schedule(64, 1024, 1024, 100) == 2 and lib.og_sinkhorn_schedule(32, 2048, 2048, 100) == 4 and lib.og_sinkhorn_schedule(8, 4096, 4096, 100) == 4
+    assert lib.og_sinkhorn_schedule(4, 5000, 100, 100) == 0          # more than 4096 rows: streaming
     _lib.check(lib.og_sinkhorn(Sp.data_ptr(), 1024, 0.7, B, m, n, iters, 1.0, out.data_ptr(), ws.data_ptr(), torch.cuda.current_stream().cuda_stream), "og_sinkhorn")
     assert lib.og_sinkhorn_status(ws.data_ptr(), B, m, n) == 0
     assert torch.isfinite(out).all()
