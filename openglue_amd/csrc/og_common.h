@@ -220,12 +220,12 @@ int og_sinkhorn_resident_rounds(int B, int m, int n);                 // launche
 // ragged batches: every pair gets the geometry of its own (m_b, n_b); pairs are packed into launches of at most one pair-group per XCD slot range
 bool og_sinkhorn_resident_ragged_wanted(const RaggedDesc& rd, int mode);
 int og_launch_sinkhorn_resident_ragged(const float* S, int64_t lds, const float* zdev, float zhost, const RaggedDesc& rd, int m_max, int n_max, int iters,
-                                       float inv_reg, float* u, int ldu, const float* v_in, float* v_out, int ldv, void* xws, hipStream_t st,
-                                       bool trusted_padding = true, int* count_only = nullptr);    // count_only: no work, *count_only = launches it would take
+                                       float inv_reg, float* u, int ldu, const float* v_in, float* v_out, int ldv, void* xws, unsigned* status,
+                                       hipStream_t st, bool trusted_padding = true, int* count_only = nullptr);    // count_only: no work, *count_only = launches it would take
 static inline bool og_sinkhorn_resident_ragged_wanted(const RaggedNone&, int) { return false; }
 int og_launch_sinkhorn_resident(const float* S, int64_t lds, const float* zdev, float zhost, int B, int m, int n, int iters,
                                 float inv_reg, float la, float la_bin, float lb, float lb_bin, float* u, int ldu, const float* v_in,
-                                float* v_out, int ldv, void* xws, hipStream_t st, bool trusted_padding = true);
+                                float* v_out, int ldv, void* xws, unsigned* status /* zeroed by the caller */, hipStream_t st, bool trusted_padding = true);
 int og_launch_matches(const float* scores, int batch, int m, int n, float thr, int64_t* matches0,
                       float* ms0, int64_t* matches1, float* ms1, void* workspace, hipStream_t stream,
                       const RaggedDesc* rag = nullptr, bool rows_done = false);      // rows_done: og_matches_row_best() was filled already

@@ -39,7 +39,8 @@ inline SinkhornGeom sk_geom(int n) {
 struct SinkhornWs {
     float* u;       // [B][ldu]
     float* v[2];    // [B][ldv] ping-pong
-    unsigned* flags; // [4] zeroed with u, v on every call: [0] != 0 = a non-finite value reached the scores (og_sinkhorn_status 3)
+    unsigned* flags; // [4] zeroed with u, v on every call: [0] != 0 = a non-finite value reached the scores (og_sinkhorn_status 3); [1] = the status
+                     // word of the resident schedule (0 / 1 timed out / 2 recomputed by the safety net): no memset of its own
     float* pm;      // [B][RB][ldp] partial column max
     float* ps;      // [B][RB][ldp] partial column sum-exp
     int ldu, ldv, ldp, RB;
@@ -818,16 +819,11 @@ int sinkhorn_run(const float* S, int64_t lds, const float* zdev, float dustbin, 
     }
     { const char* e = getenv("OG_SK_FAST_ROWS"); if (e && (atoi(e) == 32 || atoi(e) == 64 || atoi(e) == 128)) fast_rows = atoi(e); }
     { const char* e = getenv("OG_SK_FAST_NT"); if (e) fast_nt = atoi(e) != 0; }
-    // The status word of this workspace (og_sinkhorn_status) describes THIS call: the resident launcher zeroes it with its exchange
-    // area; every other schedule zeroes it here (it would otherwise hold whatever an earlier call or the allocator left there).
-    if (!resident && og_sinkhorn_resident_ws_bytes(B, m, n) > 0) {
-        e = hipMemsetAsync(sk_resident_ws(workspace, B, m, n), 0, sizeof(unsigned), st);
-        if (e != hipSuccess) return (int)e;
-    }
     for (int it = 0; it < iters; ++it) {
         const float* vin = w.v[cur];
         if (it > 0 && resident) {         // iterations 2 .. iters in ONE launch, S read once (sinkhorn_resident.hip)
-            unsigned* status = (unsigned*)sk_resident_ws(workspace, B, m, n);
+            unsigned* status = w.flags + 1;          // zeroed with u, v, flags[0] at the top of every call
+            void* xws = sk_resident_ws(workspace, B, m, n);
             const char* ft = getenv("OG_SINKHORN_FORCE_TIMEOUT");     // tests: behave as if a peer workgroup never arrived
             if (ft && atoi(ft) != 0) {
                 e = hipMemsetAsync(status, 1, sizeof(unsigned), st);
@@ -836,10 +832,10 @@ int sinkhorn_run(const float* S, int64_t lds, const float* zdev, float dustbin, 
                 int rc;
                 if constexpr (std::is_same<RD, RaggedNone>::value)
                     rc = og_launch_sinkhorn_resident(S, lds, zdev, dustbin, B, m, n, iters - 1, inv_reg, la, la_bin, lb, lb_bin, w.u, w.ldu, w.v[cur],
-                                                     w.v[cur ^ 1], w.ldv, status, st, trusted_padding);
+                                                     w.v[cur ^ 1], w.ldv, xws, status, st, trusted_padding);
                 else
                     rc = og_launch_sinkhorn_resident_ragged(S, lds, zdev, dustbin, rd, m, n, iters - 1, inv_reg, w.u, w.ldu, w.v[cur], w.v[cur ^ 1],
-                                                            w.ldv, status, st, trusted_padding);
+                                                            w.ldv, xws, status, st, trusted_padding);
                 if (rc) return rc;
             }
             cur ^= 1;
@@ -942,7 +938,7 @@ extern "C" int og_sinkhorn_schedule_ragged(int32_t batch, const int32_t* lens0, 
     }
     if (og_sinkhorn_resident_ws_bytes(batch, mmax, nmax) == 0 || !og_sinkhorn_resident_ragged_wanted(rd, resident_mode)) return 0;
     int launches = 0;
-    if (og_launch_sinkhorn_resident_ragged(nullptr, 0, nullptr, 0.f, rd, mmax, nmax, iters - 1, 1.f, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, true, &launches)) return 0;
+    if (og_launch_sinkhorn_resident_ragged(nullptr, 0, nullptr, 0.f, rd, mmax, nmax, iters - 1, 1.f, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, true, &launches)) return 0;
     return launches;
 }
 
@@ -961,7 +957,7 @@ extern "C" int og_sinkhorn_status(const void* workspace_dev, int32_t batch, int3
     if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, nullptr) != hipSuccess ||
         hipStreamWaitEvent(q, ev, 0) != hipSuccess) rc = -1;
     if (!rc && hipMemcpyAsync(&bad, w.flags, sizeof(bad), hipMemcpyDeviceToHost, q) != hipSuccess) rc = -1;
-    if (!rc && has_res && hipMemcpyAsync(&st, sk_resident_ws(const_cast<void*>(workspace_dev), batch, m, n), sizeof(st), hipMemcpyDeviceToHost, q) != hipSuccess) rc = -1;
+    if (!rc && has_res && hipMemcpyAsync(&st, w.flags + 1, sizeof(st), hipMemcpyDeviceToHost, q) != hipSuccess) rc = -1;
     if (!rc && hipStreamSynchronize(q) != hipSuccess) rc = -1;
     if (ev) (void)hipEventDestroy(ev);
     (void)hipStreamDestroy(q);

@@ -928,18 +928,17 @@ bool og_sinkhorn_resident_wanted(int B, int m, int n, int mode) {
 
 int og_launch_sinkhorn_resident(const float* S, int64_t lds, const float* zdev, float zhost, int B, int m, int n, int iters,
                                 float inv_reg, float la, float la_bin, float lb, float lb_bin, float* u, int ldu, const float* v_in,
-                                float* v_out, int ldv, void* xws, hipStream_t st, bool trusted_padding) {
-    if (!S || !u || !v_in || !v_out || !xws || iters < 1 || !og_sinkhorn_resident_shape_ok(B, m, n)) return OG_E_INVALID;
+                                float* v_out, int ldv, void* xws, unsigned* status, hipStream_t st, bool trusted_padding) {
+    if (!S || !u || !v_in || !v_out || !xws || !status || iters < 1 || !og_sinkhorn_resident_shape_ok(B, m, n)) return OG_E_INVALID;
     const RsGeom q = rs_geom(m, n);
     const int ppr = rs_pairs_per_round(q, rs_num_cus());
     if (ppr <= 0) return OG_E_SHAPE;
     const int rounds = (B + ppr - 1) / ppr, per = (B + rounds - 1) / rounds;      // balanced rounds
-    hipError_t e = hipMemsetAsync(xws, 0, 256, st);                                // the status word: sticky over the rounds
-    if (e != hipSuccess) return (int)e;
+    hipError_t e = hipSuccess;                                                     // (the status word is the caller's, zeroed with its duals: sticky over the rounds)
     SkResArgs a{};
     a.S = S; a.lds = lds; a.strideS = (int64_t)m * lds;
     a.u = u; a.ldu = ldu; a.v_in = v_in; a.v_out = v_out; a.ldv = ldv;
-    a.status = (unsigned*)xws;
+    a.status = status;
     a.xcc = (unsigned*)((char*)xws + 256);
     a.xa = (char*)xws + 256 + RS_MAXWG * sizeof(unsigned);
     { const char* ev = getenv("OG_SINKHORN_AGENT_SCOPE"); a.force_agent_scope = ev && atoi(ev) != 0; }       // read per call: the tests switch it
@@ -997,18 +996,17 @@ bool og_sinkhorn_resident_ragged_wanted(const RaggedDesc& rd, int mode) {
 }
 
 int og_launch_sinkhorn_resident_ragged(const float* S, int64_t lds, const float* zdev, float zhost, const RaggedDesc& rd, int m_max, int n_max, int iters,
-                                       float inv_reg, float* u, int ldu, const float* v_in, float* v_out, int ldv, void* xws, hipStream_t st,
-                                       bool trusted_padding, int* count_only) {
-    if (!count_only && (!S || !u || !v_in || !v_out || !xws || iters < 1)) return OG_E_INVALID;
+                                       float inv_reg, float* u, int ldu, const float* v_in, float* v_out, int ldv, void* xws, unsigned* status,
+                                       hipStream_t st, bool trusted_padding, int* count_only) {
+    if (!count_only && (!S || !u || !v_in || !v_out || !xws || !status || iters < 1)) return OG_E_INVALID;
     RsPlanPair pp[OG_MAX_RAGGED];
     if (!rs_ragged_plan(rd, pp)) return OG_E_SHAPE;
     if (count_only) *count_only = 0;
-    hipError_t e = count_only ? hipSuccess : hipMemsetAsync(xws, 0, 256, st);      // the status word: sticky over the launches
-    if (e != hipSuccess) return (int)e;
+    hipError_t e = hipSuccess;
     SkResArgs a{};
     a.S = S; a.lds = lds; a.strideS = (int64_t)m_max * lds;
     a.u = u; a.ldu = ldu; a.v_in = v_in; a.v_out = v_out; a.ldv = ldv;
-    a.status = (unsigned*)xws;
+    a.status = status;
     a.xcc = (unsigned*)((char*)xws + 256);
     a.xa = (char*)xws + 256 + RS_MAXWG * sizeof(unsigned);
     { const char* ev = getenv("OG_SINKHORN_AGENT_SCOPE"); a.force_agent_scope = ev && atoi(ev) != 0; }
