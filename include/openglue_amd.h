@@ -185,6 +185,16 @@ int og_forward(const og_shape* shape, const og_inputs* in, const void* packed_de
 int og_forward_tap(const og_shape* shape, const og_inputs* in, const void* packed_dev, void* workspace_dev,
                    const og_outputs* out, void* stream, int32_t tap, float* tap_x);
 
+/* Per-stage entries SURVEY.md 8(b) names beside og_sinkhorn / og_attention / og_mlp_block / og_extract_matches:
+ * og_keypoint_encoder -- superglue.py:44-55 with positional_encoding.py:16-19 and the normalisation of :74-78: x = local_descriptors +
+ *   encoder(normalised keypoints, side info) for all B*m + B*n tokens (image-0 sets first), fp32 [T][D] -- exactly what og_forward_tap(tap = 0)
+ *   copies out, without running the rest of the path (outputs: none but x_out; workspace and packed weights as og_forward).
+ * og_scores -- superglue.py:64, 80-86: S[b] = g0[b] g1[b]^T * D^-1/2 for token-major fp32 descriptors g0 [B][m][D], g1 [B][n][D] into
+ *   S [B][m][lds] (lds >= n, multiple of 4), exact fp32 MFMA (og_gemm_nt).  og_forward forms the same product from the (hi, lo) rows its
+ *   final projection leaves, on the split-f16 kernel. */
+int og_keypoint_encoder(const og_shape* shape, const og_inputs* in, const void* packed_dev, void* workspace_dev, float* x_out, void* stream);
+int og_scores(const float* g0, const float* g1, int32_t batch, int32_t m, int32_t n, int32_t D, float* S, int64_t lds, void* stream);
+
 /* Ragged batch (BASELINE config 5): pair b has lens0[b] keypoints in image 0 and lens1[b] in image 1
  * (host arrays, batch <= OG_MAX_RAGGED; shape->m / shape->n are the maxima).  Every tensor is PACKED without
  * padding in pair order: keypoints0 [sum m_b][2], descriptors0 [sum m_b][D], ..., scores = the

@@ -106,6 +106,8 @@ SYMBOLS = {
     "og_mlp_block": (C.c_int, [_i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "og_attention": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32,
                                _i32, _vp, _vp]),
+    "og_keypoint_encoder": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "og_scores": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
     "og_sinkhorn_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "og_sinkhorn_status": (C.c_int, [_vp, _i32, _i32, _i32]),
     "og_sinkhorn_schedule": (C.c_int, [_i32, _i32, _i32, _i32]),

@@ -398,12 +398,15 @@ struct Scope {
 
 int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_dev, void* workspace_dev,
                  const og_outputs* outp, void* stream, Profiler* prof, const RaggedDesc* rag = nullptr,
-                 const EncoderRagged* er0 = nullptr, const EncoderRagged* er1 = nullptr, int tap = -1, float* tap_x = nullptr) {
+                 const EncoderRagged* er0 = nullptr, const EncoderRagged* er1 = nullptr, int tap = -1, float* tap_x = nullptr,
+                 bool encoder_only = false) {
+    static const og_outputs no_outputs{};
+    if (encoder_only && !outp) outp = &no_outputs;          // og_keypoint_encoder: stops after tap 0, writes nothing but tap_x
     if (!shape || !in || !packed_dev || !workspace_dev || !outp) return OG_E_INVALID;
     if (int e = check_shape(shape)) return e;
     og_clear_status();
     const og_shape& s = *shape;
-    if (!in->keypoints0 || !in->keypoints1 || !in->descriptors0 || !in->descriptors1 || !outp->scores) return OG_E_INVALID;
+    if (!in->keypoints0 || !in->keypoints1 || !in->descriptors0 || !in->descriptors1 || (!outp->scores && !encoder_only)) return OG_E_INVALID;
     if (s.side_info > 0 && (!in->side_info0 || !in->side_info1)) return OG_E_INVALID;
     if ((outp->matches0 == nullptr) != (outp->matching_scores0 == nullptr)) return OG_E_INVALID;
     if ((outp->matches1 == nullptr) != (outp->matching_scores1 == nullptr)) return OG_E_INVALID;
@@ -509,6 +512,7 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
         return og_launch_merge_f16_hl(XO, T, D, D4, tap_x, D, st);
     };
     if ((rc = tap_here(0))) return rc;
+    if (encoder_only) return og_launch_status();
 
     // ---- 2. attentional GNN (attention_gnn.py:84-93) ----
     const int dh = D / s.num_heads;
@@ -665,6 +669,21 @@ extern "C" int og_forward_tap(const og_shape* shape, const og_inputs* in, const 
                               const og_outputs* outp, void* stream, int32_t tap, float* tap_x) {
     if (!shape || tap < 0 || tap > 2 * shape->num_stages || !tap_x || ((uintptr_t)tap_x & 15)) return OG_E_INVALID;
     return forward_impl(shape, in, packed_dev, workspace_dev, outp, stream, nullptr, nullptr, nullptr, nullptr, tap, tap_x);
+}
+
+// include/openglue_amd.h: the keypoint-encoder stage on its own (SURVEY.md 8b names it among the per-stage entries)
+extern "C" int og_keypoint_encoder(const og_shape* shape, const og_inputs* in, const void* packed_dev, void* workspace_dev, float* x_out,
+                                   void* stream) {
+    if (!shape || !x_out || ((uintptr_t)x_out & 15)) return OG_E_INVALID;
+    return forward_impl(shape, in, packed_dev, workspace_dev, nullptr, stream, nullptr, nullptr, nullptr, nullptr, 0, x_out, true);
+}
+
+// include/openglue_amd.h: the raw score matrices of a batch of pairs, exact fp32 (the whole path forms them from (hi, lo) rows it already holds)
+extern "C" int og_scores(const float* g0, const float* g1, int32_t batch, int32_t m, int32_t n, int32_t D, float* S, int64_t lds, void* stream) {
+    if (!g0 || !g1 || !S || batch <= 0 || m <= 0 || n <= 0 || D <= 0) return OG_E_INVALID;
+    if ((D & 3) || lds < n || (lds & 3)) return OG_E_SHAPE;
+    return og_gemm_nt(g0, D, (int64_t)m * D, g1, D, (int64_t)n * D, S, lds, (int64_t)m * lds, m, n, D, batch, nullptr, 0, nullptr, 0, nullptr,
+                      (float)pow((double)D, -0.5), stream);
 }
 
 namespace {

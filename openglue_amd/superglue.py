@@ -350,6 +350,12 @@ class SuperGlue(nn.Module):
             o = _lib.og_outputs(ptr("scores"), ptr("context_descriptors0"), ptr("context_descriptors1"),
                                 ptr("matches0"), ptr("matching_scores0"), ptr("matches1"), ptr("matching_scores1"))
             st = torch.cuda.current_stream(dev).cuda_stream
+            if _tap == "encoder":    # the keypoint-encoder stage alone (og_keypoint_encoder): nothing else runs, nothing else is written
+                out = {"_tap_x": torch.empty(B * (m + n), D, device=dev, dtype=torch.float32)}
+                rc = lib.og_keypoint_encoder(C.byref(shape), C.byref(inp), packed.data_ptr(), ws.data_ptr(), out["_tap_x"].data_ptr(), st)
+                _lib.check(rc, "og_keypoint_encoder")
+                out["_bmn"] = (B, m, n)
+                return out
             if _tap is not None:     # per-stage parity tests: the residual stream at one stage boundary (og_forward_tap)
                 out["_tap_x"] = torch.empty(B * (m + n), D, device=dev, dtype=torch.float32)
                 rc = lib.og_forward_tap(C.byref(shape), C.byref(inp), packed.data_ptr(), ws.data_ptr(), C.byref(o), st, int(_tap),
@@ -369,6 +375,15 @@ class SuperGlue(nn.Module):
         out = self._run(data, want_matches=False, match_threshold=0.2, both_sides=False, _tap=tap)
         B, _, m = out["context_descriptors0"].shape
         n = out["context_descriptors1"].shape[2]
+        x = out["_tap_x"]
+        return x[:B * m].view(B, m, -1), x[B * m:].view(B, n, -1)
+
+    @torch.no_grad()
+    def encode_keypoints(self, data: Mapping):
+        """local_descriptors + keypoint_encoder(normalised keypoints, side info) (superglue.py:44-55, 74-78; positional_encoding.py:16-19)
+        through og_keypoint_encoder: only that stage runs.  Returns (x0 [B, m, D], x1 [B, n, D]) -- what enters the attentional GNN."""
+        out = self._run(data, want_matches=False, match_threshold=0.2, both_sides=False, _tap="encoder")
+        B, m, n = out["_bmn"]
         x = out["_tap_x"]
         return x[:B * m].view(B, m, -1), x[B * m:].view(B, n, -1)
 

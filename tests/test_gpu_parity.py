@@ -886,6 +886,31 @@ def test_keypoint_encoder_against_stored_encoder0(gpu_device, name):
     assert err < 2e-5 * scale
 
 
+def test_keypoint_encoder_and_scores_stage_entries(gpu_device):
+    """og_keypoint_encoder (the encoder stage alone) = og_forward_tap(0), bit for bit, and within the bar of the oracle's
+    local_descriptors + keypoint_encoder (superglue.py:44-55); og_scores (exact fp32) = g0 g1^T D^-1/2 (superglue.py:64, 80-86)."""
+    import ctypes as C
+    from openglue_amd import _lib
+    z, cfg, sd, data = load_case("mid")
+    model = _build(cfg, sd, gpu_device)
+    dd = to_device(data, gpu_device)
+    x0, x1 = model.encode_keypoints(dd)
+    t0, t1 = model.forward_tap(dd, 0)
+    assert torch.equal(x0, t0) and torch.equal(x1, t1)
+    with torch.no_grad():
+        kn0 = orc.normalize_keypoints(data["keypoints0"], *orc._image_wh(data, 0))
+        want0 = data["local_descriptors0"] + orc.keypoint_encoder(kn0, data["side_info0"], sd, cfg)
+    assert (x0.cpu() - want0).abs().max() < 1e-4 * max(1.0, want0.abs().max().item())
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    B, m, n, D = 3, 70, 53, 64
+    g0, g1 = _rand(g, B, m, D).to(gpu_device), _rand(g, B, n, D).to(gpu_device)
+    S = torch.empty(B, m, 56, device=gpu_device)
+    _lib.check(lib.og_scores(g0.data_ptr(), g1.data_ptr(), B, m, n, D, S.data_ptr(), 56, torch.cuda.current_stream().cuda_stream), "og_scores")
+    want = (g0.double() @ g1.double().transpose(1, 2)) * D ** -0.5
+    assert (S[:, :, :n].double() - want).abs().max() < 1e-5
+
+
 @pytest.mark.parametrize("tag,scale", [("unit", 1.0), ("x4", 4.0)])
 def test_forward_on_trained_like_checkpoint_fixture(gpu_device, tag, scale):
     """A checkpoint with the statistics training produces and random initialisation never does (dead BatchNorm channels whose
