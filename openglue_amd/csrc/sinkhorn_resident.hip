@@ -1017,22 +1017,36 @@ int og_launch_sinkhorn_resident_ragged(const float* S, int64_t lds, const float*
     // largest pairs first (stable: ties keep the batch order)
     for (int i = 1; i < rd.B; ++i) { const RsPlanPair t = pp[i]; int j = i; while (j > 0 && pp[j - 1].G < t.G) { pp[j] = pp[j - 1]; --j; } pp[j] = t; }
     bool done[OG_MAX_RAGGED] = {};
-    for (int W = 1; W <= 4; W *= 2) {
+    for (int W = 4; W >= 1; W /= 2) {                                               // widest class first: its launches take narrower pairs along
         for (;;) {                                                                  // one launch per pass
             RsRagged map;
             for (int i = 0; i < RS_MAXWG; ++i) map.wg[i] = -1;
             int used[8] = {0, 0, 0, 0, 0, 0, 0, 0}, np = 0, slots = 0, qmax = 0;
-            for (int i = 0; i < rd.B; ++i) {
-                if (done[i] || pp[i].W != W) continue;
+            auto place = [&](int i, int G) {
                 int x = -1;
-                for (int k = 0; k < 8; ++k) if (used[k] + pp[i].G <= 32 && (x < 0 || used[k] < used[x])) x = k;      // the emptiest XCD that still fits
-                if (x < 0) continue;
+                for (int k = 0; k < 8; ++k) if (used[k] + G <= 32 && (x < 0 || used[k] < used[x])) x = k;      // the emptiest XCD that still fits
+                if (x < 0) return;
                 const int b = pp[i].b;
-                map.gb[np] = b; map.G[np] = pp[i].G; map.gbase[np] = slots;
+                map.gb[np] = b; map.G[np] = G; map.gbase[np] = slots;
                 map.m[np] = rd.off0[b + 1] - rd.off0[b]; map.n[np] = rd.off1[b + 1] - rd.off1[b];
-                for (int g = 0; g < pp[i].G; ++g) map.wg[x + 8 * (used[x] + g)] = (np << 8) | g;
-                used[x] += pp[i].G; if (used[x] > qmax) qmax = used[x];
-                slots += pp[i].G; ++np; done[i] = true;
+                for (int g = 0; g < G; ++g) map.wg[x + 8 * (used[x] + g)] = (np << 8) | g;
+                used[x] += G; if (used[x] > qmax) qmax = used[x];
+                slots += G; ++np; done[i] = true;
+            };
+            for (int i = 0; i < rd.B; ++i)
+                if (!done[i] && pp[i].W == W) place(i, pp[i].G);
+            if (np > 0) {
+                // free XCD slots of this launch take pairs of the NARROWER classes along, cut into this launch's tiles (a 128 x 1024 pair as
+                // 64 x 2048 tiles leaves half of every wave row empty, but a launch costs ~0.5 ms whatever it holds: the 16 pairs of the C5
+                // draw take 2 launches instead of 3)
+                const int RB = RS_RW * RS_NW / W;
+                for (int i = 0; i < rd.B; ++i) {
+                    if (done[i] || pp[i].W >= W) continue;
+                    const int b = pp[i].b, mrows = rd.off0[b + 1] - rd.off0[b];
+                    int G = (mrows + RB - 1) / RB;
+                    if (G < 2 * W) G = 2 * W;
+                    if (G <= 32) place(i, G);
+                }
             }
             if (np == 0) break;
             if (count_only) { ++*count_only; continue; }
