@@ -29,6 +29,16 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
 
 
+# On gfx950 a packed-fp32 VALU instruction (v_pk_add/mul/fma_f32) does not issue while the matrix pipe of its SIMD is busy: next to
+# the MFMA stream of another wave every other VALU class still gets an issue slot every ~14 cycles, packed fp32 gets none
+# (scripts/probes/mfma_valu_classes.hip, profiles/r04_probe_mfma_valu_classes.log).  In the attention kernel, whose two waves per SIMD
+# alternate softmax (VALU) and MFMA phases, the compiler's packed rescale / row-sum arithmetic therefore serialised the waves: the
+# device pass of that file is compiled without the feature (-3.5 % kernel time at C2; the Sinkhorn kernels, which have no MFMA and
+# live on packed fp32, keep it).  The host pass does not know the feature and says so; harmless.
+_NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+PER_FILE_FLAGS = {"attention.hip": _NO_PACKED_FP32}
+
+
 def _stale(target: str, deps) -> bool:
     if not os.path.exists(target):
         return True
@@ -48,8 +58,8 @@ def build(force: bool = False, debug: bool = False, verbose: bool = True) -> str
         sp = os.path.join(CSRC, src)
         op = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
         objs.append(op)
-        if force or _stale(op, [sp, *headers]):
-            jobs.append([hipcc, *flags, "-c", sp, "-o", op])
+        if force or _stale(op, [sp, *headers, os.path.abspath(__file__)]):
+            jobs.append([hipcc, *flags, *PER_FILE_FLAGS.get(src, []), "-c", sp, "-o", op])
 
     def run(cmd):
         if verbose:
@@ -57,8 +67,9 @@ def build(force: bool = False, debug: bool = False, verbose: bool = True) -> str
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
-        if r.stderr.strip() and verbose:
-            print(r.stderr, file=sys.stderr)
+        err = "\n".join(l for l in r.stderr.splitlines() if "is not a recognized feature for this target" not in l)   # the host pass, see above
+        if err.strip() and verbose:
+            print(err, file=sys.stderr)
 
     with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
         list(ex.map(run, jobs))

@@ -42,11 +42,21 @@ typedef __attribute__((address_space(1))) const void og_glb_void;
 
 constexpr int KV_TILE = 64;
 constexpr int Q_TILE = 128;
-constexpr float RESCALE_THR = 11.f;          // base-2 exponent headroom before the running max is advanced
+constexpr float RESCALE_THR = 11.f;          // base-2 exponent headroom before the running max is advanced (register-staged kernel)
+#ifndef OG_ATTN_SUMLIMIT
+#define OG_ATTN_SUMLIMIT 32768.f
+#endif
+constexpr float SUM_LIMIT = OG_ATTN_SUMLIMIT;         // attention_dma_kernel: the running max moves when the 32 exponentials of a lane in one tile add up to more than 2^15
 
 // Experiment builds only (scripts/build_ablation.sh attn_trace -DOG_ATTN_TRACE=1): per-segment shader-cycle stamps of
 // all four waves of two workgroups, read back by og_debug_attn_trace().  The sched_barriers around the stamps
 // perturb the schedule; compare the traced build's kernel time with the normal one before trusting a breakdown.
+#ifndef OG_ATTN_PKSUM
+#define OG_ATTN_PKSUM 0       // experiments: 1 = the row sum as packed-fp32 adds (rounds 1-3)
+#endif
+#ifndef OG_ATTN_MAXFIRST
+#define OG_ATTN_MAXFIRST 0    // experiments: 1 = tile maximum in front of every tile's exponentials (rounds 1-3)
+#endif
 #ifndef OG_ATTN_TRACE
 #define OG_ATTN_TRACE 0
 #endif
@@ -691,13 +701,73 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(AttnArgs a, RD rd
 
         OG_TP(2);
         // ---- online softmax over keys, base 2 (this lane: 32 of the tile's 64 keys of ONE query) ----
-        float mt = s[0][0];
+        // The scores arrive as s - m_run, so the common path is: 32 exponentials, their (hi, lo) split and the row sum -- nothing else.
+        // Whether the running max has to move is read off the SUM the tile needs anyway (round 4; before: a 22-instruction max tree +
+        // a cross-lane exchange in front of every tile's exponentials): a lane whose 32 exponentials add up to <= 2^15 holds no p above
+        // 2^15 (inside binary16, so the split is exact).  Otherwise -- tile 0, or a row whose maximum grew by more than ~2^10 over
+        // m_run -- the wave takes the slow path: tile maximum, new running max, rescale of l and O, and the exponentials again.
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 pfw[2][2], plw[2][2];                       // packed (hi, hi) / (lo, lo) pairs: [key block][k-step of 16 keys]
+        float tsum = 0.f;
+        // Row sum: FOUR plain v_add_f32 chains.  NOT v_pk_add_f32: on gfx950 a packed-fp32 instruction does not issue while the matrix
+        // pipe of its SIMD is busy -- beside a saturated MFMA stream of the other wave every other VALU class still gets a slot every
+        // ~14 cycles, packed fp32 gets none (scripts/probes/mfma_valu_classes.hip, profiles/r04_probe_mfma_valu_classes.log) -- so 16
+        // packed adds per tile tied this wave's softmax to the gaps of the other wave's MFMA phases.
+        auto exp_split = [&]() {
+#if OG_ATTN_PKSUM
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 psum2 = {0.f, 0.f};
+#else
+            float ps0 = 0.f, ps1 = 0.f, ps2 = 0.f, ps3 = 0.f;
+            // a C add the compiler schedules itself (it knows the wait state between a transcendental and a VALU reading its result; an
+            // inline-asm v_add_f32 right behind its v_exp_f32 read stale lanes), made opaque so that the SLP vectoriser cannot pair it
+            auto add1 = [](float& acc, float x) { acc += x; asm("" : "+v"(acc)); };
+#endif
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[kb][r]);
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));          // max of s - m_run over the tile; finite: every tile holds >= 1 valid key
-        if (kt == 0 || __any(mt > RESCALE_THR)) {        // wave-uniform; rare after the first tile
+                for (int r = 0; r < 16; r += 4) {
+                    const float p0 = __builtin_amdgcn_exp2f(s[kb][r]);
+                    const float p1 = __builtin_amdgcn_exp2f(s[kb][r + 1]);
+                    const float p2 = __builtin_amdgcn_exp2f(s[kb][r + 2]);
+                    const float p3 = __builtin_amdgcn_exp2f(s[kb][r + 3]);
+#if OG_ATTN_PKSUM
+                    psum2 += f32x2{p0, p1};
+                    psum2 += f32x2{p2, p3};
+#else
+                    add1(ps0, p0); add1(ps1, p1); add1(ps2, p2); add1(ps3, p3);
+#endif
+                    unsigned ha, la, hb, lb;
+                    og_split4(p0, p1, p2, p3, ha, la, hb, lb);      // og_common.h: 3 instructions per pair, hazard-safe
+                    pfw[kb][r >> 3][(r & 7) >> 1] = ha; pfw[kb][r >> 3][((r & 7) >> 1) + 1] = hb;
+                    plw[kb][r >> 3][(r & 7) >> 1] = la; plw[kb][r >> 3][((r & 7) >> 1) + 1] = lb;
+                }
+#if OG_ATTN_PKSUM
+            tsum = psum2[0] + psum2[1];
+#else
+            tsum = (ps0 + ps1) + (ps2 + ps3);
+#endif
+        };
+        bool redo = kt == 0;                              // the first tile replaces the arbitrary start value of m_run
+#if !OG_ATTN_MAXFIRST
+        if (!redo) {
+            exp_split();
+            redo = __any(!(tsum <= SUM_LIMIT));           // wave-uniform; catches inf and NaN too
+        }
+#endif
+        float mt = 0.f;
+        if (OG_ATTN_MAXFIRST || redo) {
+            mt = s[0][0];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[kb][r]);
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));      // max of s - m_run over the tile; finite: every tile holds >= 1 valid key
+#if OG_ATTN_MAXFIRST
+            redo = redo || __any(mt > RESCALE_THR);
+#endif
+        }
+        if (redo) {
             const float delta = kt == 0 ? mt : fmaxf(mt, 0.f);       // new running max = m_run + delta
             m_run += delta;
 #pragma unroll
@@ -715,27 +785,13 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(AttnArgs a, RD rd
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[kb][r] -= delta;
         }
+        if (OG_ATTN_MAXFIRST || redo) exp_split();
+        l_run += tsum;
         f16x8 pf[2][2], pl[2][2];
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        f32x2 psum2 = {0.f, 0.f};                   // two partial row sums: one packed add per pair of exponentials
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; r += 4) {
-                const float p0 = __builtin_amdgcn_exp2f(s[kb][r]);       // <= 2^RESCALE_THR
-                const float p1 = __builtin_amdgcn_exp2f(s[kb][r + 1]);
-                const float p2 = __builtin_amdgcn_exp2f(s[kb][r + 2]);
-                const float p3 = __builtin_amdgcn_exp2f(s[kb][r + 3]);
-                psum2 += f32x2{p0, p1};
-                psum2 += f32x2{p2, p3};
-                unsigned ha, la, hb, lb;
-                og_split4(p0, p1, p2, p3, ha, la, hb, lb);      // og_common.h: 3 instructions per pair, hazard-safe
-                unsigned* pfw = reinterpret_cast<unsigned*>(&pf[kb][r >> 3]);
-                unsigned* plw = reinterpret_cast<unsigned*>(&pl[kb][r >> 3]);
-                pfw[(r & 7) >> 1] = ha; pfw[((r & 7) >> 1) + 1] = hb;
-                plw[(r & 7) >> 1] = la; plw[((r & 7) >> 1) + 1] = lb;
-            }
-        l_run += psum2[0] + psum2[1];
+            for (int t = 0; t < 2; ++t) { pf[kb][t] = __builtin_bit_cast(f16x8, pfw[kb][t]); pl[kb][t] = __builtin_bit_cast(f16x8, plw[kb][t]); }
 
         OG_TP(3);
         // ---- O^T += V^T P^T of the same tile: group g = (key block kb, half t); A operand element e of lane (dv, hi) is

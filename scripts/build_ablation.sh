@@ -6,7 +6,8 @@ cd "$(dirname "$0")/.."
 tag=$1; shift
 tmp=$(mktemp -d)
 for f in $(python -c 'from openglue_amd.build import SOURCES; print(" ".join(s[:-4] for s in SOURCES))'); do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -fPIC -O3 -Wno-unused-function "$@" -c openglue_amd/csrc/$f.hip -o $tmp/$f.o &
+  per=$(python -c "from openglue_amd.build import PER_FILE_FLAGS; print(' '.join(PER_FILE_FLAGS.get('$f.hip', [])))")
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -fPIC -O3 -Wno-unused-function $per "$@" -c openglue_amd/csrc/$f.hip -o $tmp/$f.o 2> >(grep -v "not a recognized feature" >&2) &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o openglue_amd/lib/libog_$tag.so $tmp/*.o
