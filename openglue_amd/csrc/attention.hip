@@ -455,6 +455,24 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a, RD rd) {
 // Measured alternative (git history): one 8-wave workgroup whose two halves alternate matrix and softmax
 // phases between barriers, sharing the K/V ring -- 30 % slower: on this part the MFMA and VALU issue of the two waves of a
 // SIMD add up (tile period ~ 2 x (1536 MFMA + ~1200 VALU cycles)) whatever the phase alignment.
+// Timing experiment only (-DOG_ATTN_ABL16=1, results WRONG): every 32x32x16 MFMA of attention_dma_kernel issued as two 16x16x32 MFMAs on the first
+// eight accumulator registers -- the same flops and matrix-pipe cycles in the form that costs less energy (scripts/probes/mfma_energy.hip).
+#ifndef OG_ATTN_ABL16
+#define OG_ATTN_ABL16 0
+#endif
+__device__ __forceinline__ f32x16 og_attn_mfma(f16x8 a, f16x8 b, f32x16 c) {
+#if OG_ATTN_ABL16
+    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+    f32x4_ c0 = __builtin_shufflevector(c, c, 0, 1, 2, 3), c1 = __builtin_shufflevector(c, c, 4, 5, 6, 7);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c1, 0, 0, 0);
+    c[0] = c0[0]; c[1] = c0[1]; c[2] = c0[2]; c[3] = c0[3]; c[4] = c1[0]; c[5] = c1[1]; c[6] = c1[2]; c[7] = c1[3];
+    return c;
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
+}
+
 template <int DH, class RD>
 __global__ __launch_bounds__(256, 2) void attention_dma_kernel(AttnArgs a, RD rd) {      // (dh = 32 would fit three workgroups per CU: measured 4 % slower)
     static_assert(DH == 64 || DH == 32, "head rows of 128 or 64 bytes");
@@ -661,9 +679,9 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(AttnArgs a, RD rd
                 static_for<6>([&](auto M) {
                     constexpr int m = decltype(M)::value, kb = m & 1, pass = m >> 1;
                     // the first MFMA of a chain takes -m_run (negm) as its C operand: no accumulator initialisation
-                    if constexpr (pass == 0) sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[cb][kb], qh[c], c == 0 ? negm : sacc[kb], 0, 0, 0);
-                    else if constexpr (pass == 1) sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[cb][kb], ql[c], sacc[kb], 0, 0, 0);
-                    else sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[cb][kb], qh[c], sacc[kb], 0, 0, 0);
+                    if constexpr (pass == 0) sacc[kb] = og_attn_mfma(kl[cb][kb], qh[c], c == 0 ? negm : sacc[kb]);
+                    else if constexpr (pass == 1) sacc[kb] = og_attn_mfma(kh[cb][kb], ql[c], sacc[kb]);
+                    else sacc[kb] = og_attn_mfma(kh[cb][kb], qh[c], sacc[kb]);
                     fence();
                     if constexpr (m < 4) {
                         if constexpr (c + 1 < NCH) {
@@ -814,9 +832,9 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(AttnArgs a, RD rd
             }
             static_for<3 * NDV>([&](auto M) {
                 constexpr int m = decltype(M)::value, d = m % NDV, pass = m / NDV;
-                if constexpr (pass == 0) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[d], pf[kb][t], oacc[d], 0, 0, 0);
-                else if constexpr (pass == 1) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[d], pl[kb][t], oacc[d], 0, 0, 0);
-                else oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[d], pf[kb][t], oacc[d], 0, 0, 0);
+                if constexpr (pass == 0) oacc[d] = og_attn_mfma(vl[d], pf[kb][t], oacc[d]);
+                else if constexpr (pass == 1) oacc[d] = og_attn_mfma(vh[d], pl[kb][t], oacc[d]);
+                else oacc[d] = og_attn_mfma(vh[d], pf[kb][t], oacc[d]);
                 fence();
                 if constexpr (2 * m < 4 * NDV && g + 1 < 4) {                  // the next group's 4 NDV reads, two behind each MFMA
                     read_v1(std::integral_constant<int, g + 1>{}, std::integral_constant<int, 2 * m>{});

@@ -55,6 +55,9 @@ constexpr int EPI_SLAB = 32 * 144;            // epilogue scratch per 32-token s
 // Experiment builds only (-DOG_MLP_TRACE=1): shader-cycle stamps of every wave at every stage hand-over (before the DMA wait, after
 // it, after the barrier), kept in the lanes of three VGPRs (stamp of stage s in lane s) and written out at the end
 // (og_debug_mlp_trace, scripts/trace_mlp.py).
+#ifndef OG_MLP_ABL16
+#define OG_MLP_ABL16 0
+#endif
 #ifndef OG_MLP_TRACE
 #define OG_MLP_TRACE 0
 #endif
@@ -296,6 +299,16 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpFusedArgs g) {
 #define OG_SB() __builtin_amdgcn_sched_barrier(0)
 #if OG_MLP_ABL & 4
 #define OG_MM(acc_, a_, b_) asm volatile("" ::"v"(a_), "v"(b_))
+#elif OG_MLP_ABL16     // timing experiment, results WRONG: two 16x16x32 MFMAs (same flops, same pipe cycles) on the first eight accumulator registers
+#define OG_MM(acc_, a_, b_)                                                                                   \
+    {                                                                                                        \
+        typedef float f32x4_ __attribute__((ext_vector_type(4)));                                            \
+        f32x4_ c0_ = __builtin_shufflevector(acc_, acc_, 0, 1, 2, 3), c1_ = __builtin_shufflevector(acc_, acc_, 4, 5, 6, 7);   \
+        c0_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_, b_, c0_, 0, 0, 0);                                  \
+        c1_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_, b_, c1_, 0, 0, 0);                                  \
+        acc_[0] = c0_[0]; acc_[1] = c0_[1]; acc_[2] = c0_[2]; acc_[3] = c0_[3];                              \
+        acc_[4] = c1_[0]; acc_[5] = c1_[1]; acc_[6] = c1_[2]; acc_[7] = c1_[3];                              \
+    }
 #else
 #define OG_MM(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, acc_, 0, 0, 0)
 #endif
@@ -539,6 +552,238 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpFusedArgs g) {
 #endif
 }
 
+
+// =================================================================================================================================
+// mlp_small_kernel -- the same layer for FEW token rows (the reference's inference.py regime: one or a few image pairs).
+// mlp_fused_kernel gives a 128-token tile to one workgroup: 9216 MFMAs on one CU, 46 us per launch whether the batch holds 2048 or
+// 8192 token rows (profiles/r04_small_batch_kernel_stats_B*.csv: 1.26 of the 3.3 ms of a single-pair step).  Here a workgroup owns 32
+// tokens and its 8 waves split the HIDDEN dimension (64 of the 512 hidden channels each), so a launch spreads over four times as
+// many CUs and a wave issues 288 MFMAs instead of 1152:
+//   * the 32 token rows [x ; O] (64 KB of hl32 rows) are copied to LDS once (rows padded by 16 B: conflict-free ds_read_b128);
+//   * wave w: fc.0 for hidden blocks 2w, 2w+1 over all 32 k-steps; accumulators -> ReLU -> (hi, lo) -> B fragments as in the big
+//     kernel, handed to the other waves through LDS (64 KB);
+//   * wave w: fc.3 for OUTPUT block w over all 512 hidden channels (two accumulator chains), + bias, + residual (read back from the
+//     rows), (hi, lo) split, store.  [First version: every wave kept PARTIAL fc.3 sums of all eight output blocks over its own 64 hidden
+//     channels and the partial sums met in LDS in two rounds -- 256 KB written and read, two more barriers: 20k of the 41k cycles of a
+//     workgroup (scripts/trace_mlp_small.py).]
+//   * weight fragments come straight from the big kernel's fragment-major stream (every fragment is 1 KiB contiguous, so a lane's
+//     16 bytes sit at fragment base + 16 lane: one coalesced global_load_dwordx4 per fragment, no LDS staging -- no two waves share
+//     a fragment), a few k-steps ahead of their MFMAs.
+// Bound: the 1.5 MB weight stream every workgroup pulls from L2 (~64 B/clk per CU).
+constexpr int SM_T = 32;                       // tokens per workgroup
+constexpr int SM_ROW = 4 * 256 * 2 + 16;       // bytes of one padded LDS row: 4D halves + 16
+
+template <int D>
+__global__ __launch_bounds__(512) void mlp_small_kernel(MlpFusedArgs g) {
+    static_assert(D == 256, "8 waves x 2 hidden blocks of 32 = 2D; 8 output blocks");
+    __shared__ __attribute__((aligned(16))) char smem[SM_T * SM_ROW + 16 * 2 * 2 * 1024];      // the token tile (66 KB) + the hidden activation as B fragments (64 KB)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int t0 = blockIdx.x * SM_T;
+    char* const rows = reinterpret_cast<char*>(g.XO);
+    const int64_t ldb = g.ld * 2;              // row stride in bytes
+#if OG_MLP_TRACE
+    unsigned ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define OG_ST(i_) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ts[i_] = (unsigned)__builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
+#else
+#define OG_ST(i_) do {} while (0)
+#endif
+    OG_ST(0);
+
+    // fragment addresses in the big kernel's stream (og_pack_mlp_stream): hidden block hb = 8 a + 4 q + i
+    const int a = wave >> 2, q = (wave >> 1) & 1, i0 = 2 * (wave & 1);
+    // Weight fragments: inline-asm loads (scalar base + 16 lane) counted by hand -- left to the compiler every load sank down to its
+    // use and each k-step waited for a full L2 round trip.  All asm statements carry a memory clobber, so no compiler-issued
+    // vector-memory operation moves across them; the compiler's own loads (token rows, bias) are all issued AFTER the first fragments
+    // and waited for by the compiler before the main loop, where they could only make a counted wait stricter.
+    unsigned lane16 = (unsigned)lane * 16u;
+    asm volatile("" : "+v"(lane16));
+    auto sbase = [](const char* p) {
+        const uint64_t v = (uint64_t)(uintptr_t)p;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi32 = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        return reinterpret_cast<const char*>((uintptr_t)(((uint64_t)hi32 << 32) | lo));
+    };
+    auto ldfrag = [&](f16x8& dst, const char* base) { asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(lane16), "s"(base) : "memory"); };
+    auto frag0 = [&](f16x8& dst, int j, int kg, int t, int part) {       // W0' rows of hidden block 2 wave + j, k-step (kg, t)
+        ldfrag(dst, sbase(g.wstream + (int64_t)(24 * q + kg) * WSTAGE + ((((a * 2 + t) * 4 + i0 + j) * 2 + part) << 10)));
+    };
+    // "all but the n youngest loads have landed" (n a multiple of 4); the operands tie the wait to the registers it releases
+    auto wait4 = [](int n, f16x8& r0, f16x8& r1, f16x8& r2, f16x8& r3) {
+        if (n >= 16) asm volatile("s_waitcnt vmcnt(16)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) :: "memory");
+        else if (n == 12) asm volatile("s_waitcnt vmcnt(12)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) :: "memory");
+        else if (n == 8) asm volatile("s_waitcnt vmcnt(8)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) :: "memory");
+        else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) :: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) :: "memory");
+    };
+    constexpr int PF = 5;                      // k-steps of W0' fragments in flight (4 fragments each): 20 KB per wave
+    f16x8 wf[PF][4];
+#pragma unroll
+    for (int ks = 0; ks < PF; ++ks)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) frag0(wf[ks][f], f >> 1, ks >> 1, ks & 1, f & 1);
+
+    // ---- token tile -> LDS: thread (row tid >> 4, 16-byte column tid & 15 + 16 j) ----
+    {
+        int r = t0 + (tid >> 4);
+        if (r > g.M - 1) r = g.M - 1;          // rows past the matrix are clamped (computed, never stored)
+        const char* src = rows + (int64_t)r * ldb + (tid & 15) * 16;
+        char* dst = smem + (tid >> 4) * SM_ROW + (tid & 15) * 16;
+        og_u32x4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const og_u32x4*>(src + j * 256);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *reinterpret_cast<og_u32x4*>(dst + j * 256) = v[j];
+    }
+    const float sc0 = g.scales_dev ? g.scales_dev[0] : g.scale, sc3 = g.scales_dev ? g.scales_dev[1] : g.scale;
+    const float is0 = 1.f / sc0;
+
+    // ================= fc.0: acc0[j] = b0' / s0 + W0'[hidden block 2 wave + j] . [x ; O], 32 k-steps =================
+    f32x16 acc0[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(g.b0 + 32 * (2 * wave + j) + 8 * qq + 4 * hi);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc0[j][4 * qq + e] = b[e] * is0;
+        }
+    OG_ST(1);
+    __syncthreads();                           // the token tile is in LDS
+    OG_ST(2);
+    const char* const xrow = smem + l31 * SM_ROW + hi * 16;
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) {
+        const int kg = ks >> 1, t = ks & 1, slot = ks % PF;
+        const f16x8 xh = *reinterpret_cast<const f16x8*>(xrow + kg * 128 + t * 32);
+        const f16x8 xl = *reinterpret_cast<const f16x8*>(xrow + kg * 128 + t * 32 + 64);
+        const int younger = 32 - 1 - ks < PF - 1 ? 4 * (32 - 1 - ks) : 4 * (PF - 1);
+        wait4(younger, wf[slot][0], wf[slot][1], wf[slot][2], wf[slot][3]);
+        // the two accumulator chains alternate (fragment 2 j + part: part 0 = hi, 1 = lo)
+        acc0[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[slot][1], xh, acc0[0], 0, 0, 0);
+        acc0[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[slot][3], xh, acc0[1], 0, 0, 0);
+        acc0[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[slot][0], xl, acc0[0], 0, 0, 0);
+        acc0[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[slot][2], xl, acc0[1], 0, 0, 0);
+        acc0[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[slot][0], xh, acc0[0], 0, 0, 0);
+        acc0[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[slot][2], xh, acc0[1], 0, 0, 0);
+        if (ks + PF < 32) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f) frag0(wf[slot][f], f >> 1, (ks + PF) >> 1, (ks + PF) & 1, f & 1);
+        }
+    }
+
+    OG_ST(3);
+    char* const hid = smem + SM_T * SM_ROW;
+    // ================= fc.3: wave w owns OUTPUT block w over all 512 hidden channels: 32 k-steps, two accumulator chains =================
+    // W3' fragment (output block i, hidden block hb = 8 a' + 4 q' + j', k-step t): stage 24 q' + 16 + 2 j' + t, fragment (a' 8 + i) 2 + part
+    auto frag3 = [&](f16x8& dst, int hb, int t, int part) {
+        ldfrag(dst, sbase(g.wstream + (int64_t)(24 * ((hb >> 2) & 1) + 16 + 2 * (hb & 3) + t) * WSTAGE + ((((hb >> 3) * 8 + wave) * 2 + part) << 10)));
+    };
+    constexpr int PF3 = 4;                     // steps of two k-steps (4 fragments) in flight
+    f16x8 w3f[PF3][4];
+    auto frag3_step = [&](f16x8 (&dst)[4], int n) {          // step n = hidden block n, k-steps t = 0, 1: (t0 hi, t0 lo, t1 hi, t1 lo)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) frag3(dst[f], n, f >> 1, f & 1);
+    };
+#pragma unroll
+    for (int n = 0; n < PF3; ++n) frag3_step(w3f[n], n);
+    // bias and residual of this wave's block for the epilogue (the compiler's loads: younger than the fragments above, see the note at the top)
+    const int tok = t0 + l31;
+    const bool live = tok < g.M;
+    char* const orow = rows + (int64_t)(live ? tok : 0) * ldb + wave * 128;      // hl32 row: 64 B hi | 64 B lo per 32 channels
+    f32x4 bias3[4];
+    uint2 rxh[4], rxl[4];
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+        const int ch = 8 * qq + 4 * hi;        // first of this lane's 4 consecutive channels of register group qq
+        bias3[qq] = *reinterpret_cast<const f32x4*>(g.b3 + 32 * wave + ch);
+        rxh[qq] = *reinterpret_cast<const uint2*>(orow + ch * 2);
+        rxl[qq] = *reinterpret_cast<const uint2*>(orow + ch * 2 + 64);
+    }
+    // ================= hidden activation -> (hi, lo) B fragments (element e of k-step t = accumulator register 8 t + e, as the stream is
+    //                   packed), handed to the other waves through LDS: [hidden block][t][part][lane] x 16 B, 64 KB =================
+    {
+#pragma clang fp contract(off)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                og_u32x4 h4, l4;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int r0 = 8 * t + 4 * h;
+                    float c0 = fmaxf(acc0[j][r0] * sc0, 0.f), c1 = fmaxf(acc0[j][r0 + 1] * sc0, 0.f);
+                    float c2 = fmaxf(acc0[j][r0 + 2] * sc0, 0.f), c3 = fmaxf(acc0[j][r0 + 3] * sc0, 0.f);
+                    asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));      // og_split4 must see ONE rounded product
+                    unsigned ha, la, hb, lb;
+                    og_split4(c0, c1, c2, c3, ha, la, hb, lb);
+                    h4[2 * h] = ha; h4[2 * h + 1] = hb; l4[2 * h] = la; l4[2 * h + 1] = lb;
+                }
+                char* d = hid + ((((2 * wave + j) * 2 + t) * 2) << 10) + lane * 16;
+                *reinterpret_cast<og_u32x4*>(d) = h4;
+                *reinterpret_cast<og_u32x4*>(d + 1024) = l4;
+            }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // epilogue operands and the first fragments are here; from now on the counts are exact again
+    OG_ST(4);
+    __syncthreads();                           // the hidden fragments of all waves are in LDS
+    OG_ST(5);
+    f32x16 acc3[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc3[c][r] = 0.f;
+    const char* const hrd = hid + lane * 16;
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+        const int slot = n % PF3;
+        const f16x8 bh0 = *reinterpret_cast<const f16x8*>(hrd + (((n * 2 + 0) * 2) << 10)), bl0 = *reinterpret_cast<const f16x8*>(hrd + (((n * 2 + 0) * 2 + 1) << 10));
+        const f16x8 bh1 = *reinterpret_cast<const f16x8*>(hrd + (((n * 2 + 1) * 2) << 10)), bl1 = *reinterpret_cast<const f16x8*>(hrd + (((n * 2 + 1) * 2 + 1) << 10));
+        const int younger = n < PF3 ? 0 : (16 - 1 - n < PF3 - 1 ? 4 * (16 - 1 - n) : 4 * (PF3 - 1));      // the first PF3 steps were waited for above
+        if (n >= PF3) wait4(younger, w3f[slot][0], w3f[slot][1], w3f[slot][2], w3f[slot][3]);
+        acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3f[slot][1], bh0, acc3[0], 0, 0, 0);
+        acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3f[slot][3], bh1, acc3[1], 0, 0, 0);
+        acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3f[slot][0], bl0, acc3[0], 0, 0, 0);
+        acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3f[slot][2], bl1, acc3[1], 0, 0, 0);
+        acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3f[slot][0], bh0, acc3[0], 0, 0, 0);
+        acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3f[slot][2], bh1, acc3[1], 0, 0, 0);
+        if (n + PF3 < 16) frag3_step(w3f[slot], n + PF3);
+    }
+    OG_ST(6);
+
+    // ================= epilogue: x <- (acc / S3 + b3') + x, written back as (hi, lo) halves: 8 bytes per register group and plane =================
+    {
+#pragma clang fp contract(off)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const _Float16* xhh = reinterpret_cast<const _Float16*>(&rxh[qq]);
+            const _Float16* xlh = reinterpret_cast<const _Float16*>(&rxl[qq]);
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = (acc3[0][4 * qq + e] + acc3[1][4 * qq + e]) * sc3;
+                v[e] = v[e] + bias3[qq][e];
+                v[e] = v[e] + ((float)xhh[e] + (float)xlh[e]);
+                asm volatile("" : "+v"(v[e]));
+            }
+            unsigned ha, la, hb, lb;
+            og_split4(v[0], v[1], v[2], v[3], ha, la, hb, lb);
+            if (live) {
+                char* const px = orow + (8 * qq + 4 * hi) * 2;
+                *reinterpret_cast<uint2*>(px) = make_uint2(ha, hb);
+                *reinterpret_cast<uint2*>(px + 64) = make_uint2(la, lb);
+            }
+        }
+    }
+#if OG_MLP_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    OG_ST(7);
+    if (lane == 0 && blockIdx.x < OG_MT_BLOCKS)
+        for (int i = 0; i < 8; ++i) og_mlp_trace_buf[blockIdx.x][wave][0][i] = ts[i];
+#endif
+#undef OG_ST
+}
+
 }  // namespace
 
 // ---- host side ----------------------------------------------------------------------------------------------------------------
@@ -592,12 +837,24 @@ bool og_pack_mlp_stream(int D, const double* W0, const double* W3, void* out, do
     return ok;
 }
 
+// Few token rows: 32-token workgroups whose waves split the hidden dimension (mlp_small_kernel).  Up to 8192 rows = 256 workgroups, one
+// round of the chip; above that the 128-token tiles of mlp_fused_kernel stream the weights four times less often.  OG_MLP_SMALL=0 / 1 forces.
+bool og_mlp_small_wanted(int M) {
+    static const int mode = [] { const char* e = getenv("OG_MLP_SMALL"); return e ? atoi(e) : -1; }();
+    if (mode >= 0) return mode != 0;
+    return M <= 8192;
+}
+
 int og_launch_mlp_fused(const MlpFusedArgs& a, int D, hipStream_t stream) {
     if (!a.XO || !a.wstream || !a.b0 || !a.b3 || a.M <= 0) return OG_E_INVALID;
     if (!og_mlp_fused_supported(D)) return OG_E_SHAPE;
     if (((uintptr_t)a.XO & 15) || ((uintptr_t)a.wstream & 15) || (a.ld & 7) || a.ld < 4 * (int64_t)D) return OG_E_ALIGN;
     if ((int64_t)MT * a.ld * 2 >= (int64_t)1 << 31) return OG_E_SHAPE;              // 32-bit lane offsets are relative to the TILE's first row (baseX is 64-bit)
     if (!(a.scale != 0.f) || !std::isfinite(a.scale)) return OG_E_INVALID;
+    if (og_mlp_small_wanted(a.M)) {
+        hipLaunchKernelGGL(mlp_small_kernel<256>, dim3((a.M + SM_T - 1) / SM_T), dim3(512), 0, stream, a);
+        return og_launch_status();
+    }
     const int tiles = (a.M + MT - 1) / MT;
     hipLaunchKernelGGL(mlp_fused_kernel<256>, dim3(tiles), dim3(512), 0, stream, a);
     return og_launch_status();

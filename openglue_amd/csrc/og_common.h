@@ -181,7 +181,8 @@ bool og_mlp_fused_supported(int D);
 bool og_mlp_fused_enabled(int D);                    // supported and not switched off (OG_MLP_FUSED=0)
 size_t og_mlp_stream_bytes(int D);
 bool og_pack_mlp_stream(int D, const double* W0, const double* W3, void* out, double S0 = OG_W_SCALE, double S3 = OG_W_SCALE);   // false: a weight does not fit binary16
-int og_launch_mlp_fused(const MlpFusedArgs& a, int D, hipStream_t stream);
+int og_launch_mlp_fused(const MlpFusedArgs& a, int D, hipStream_t stream);      // picks mlp_small_kernel (32-token workgroups) when og_mlp_small_wanted(M)
+bool og_mlp_small_wanted(int M);
 
 struct AttnArgs {
     const _Float16* qh; const _Float16* ql; int64_t ldq;     // leading dimensions in halves

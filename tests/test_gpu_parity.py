@@ -106,7 +106,7 @@ def test_gemm_nt_f16x3_gnn_forms(gpu_device, M, N, K, form):
     assert torch.isfinite(out).all()
 
 
-@pytest.mark.parametrize("M", [128, 4096, 32768, 777, 1])
+@pytest.mark.parametrize("M", [128, 4096, 32768, 777, 1, 8192, 8320, 33])       # <= 8192 rows: mlp_small_kernel (32-token workgroups), above: 128-token tiles
 def test_mlp_block_fused_vs_float64(gpu_device, M):
     """og_mlp_block (csrc/mlp_fused.hip): x + W3 relu(W0 [x ; O] + b0) + b3 in ONE launch with the hidden activation in registers
     (attention_gnn.py:53-55 + models/utils.py:48-58 after the folds of og_pack_weights) -- against float64 and against the two
