@@ -22,6 +22,7 @@ struct PackedLayout {
     // offsets inside a layer block (float units); weights in the hl32 row format: [N][2K] halves = N*K floats
     int64_t o_wqkv, o_bqkv, o_w0, o_b0, o_w3, o_b3;
     int64_t o_wmlp;                             // fragment-major stream of mlp_fused.hip (W0' then W3' per hidden half), -1: none
+    int64_t o_wqkvs;                            // fragment-major copy of the q | k | v matrix for proj_small_kernel (few token rows), -1: none
     int64_t o_scale;                            // per layer: accumulator multipliers {1 / S_qkv, 1 / S_0, 1 / S_3, 0} of its three split-f16 matrices
     int64_t scales;                             // {1 / S_wp, 1 / S_enc_whl}: final projection, last encoder conv
     int64_t wp, bp, alpha, dustbin;
@@ -65,6 +66,10 @@ PackedLayout packed_layout(const og_shape& s) {
     L.o_scale = lo; lo = al64(lo + 4);
     L.o_wmlp = -1;
     if (og_mlp_fused_supported((int)D)) { L.o_wmlp = lo; lo = al64(lo + (int64_t)(og_mlp_stream_bytes((int)D) / 4)); }
+    L.o_wqkvs = -1;
+    if (!(s.flags & OG_FLAG_FAVOR_RELU) && og_proj_stream_bytes(qkv_width(s), (int)D)) {
+        L.o_wqkvs = lo; lo = al64(lo + (int64_t)(og_proj_stream_bytes(qkv_width(s), (int)D) / 4));
+    }
     L.layer_stride = lo;
     L.layer0 = off; off += lo * 2 * s.num_stages;
     L.wp = off; off = al64(off + D * D);
@@ -304,7 +309,9 @@ extern "C" int og_pack_weights(const og_shape* shape, const og_params* P, void* 
             for (int i = 0; i < D; ++i) bqkv[row0 + i] = (float)(proj[p]->bias[i] * sc);
         }
         float* scl = base + L.o_scale;      // {1 / S_qkv, 1 / S_0, 1 / S_3, 0}
-        ok &= put_matrix(Wqkv, Wqd.data(), qkv_width(s), D, scl + 0);
+        double Sq = OG_W_SCALE;
+        ok &= put_matrix(Wqkv, Wqd.data(), qkv_width(s), D, scl + 0, &Sq);
+        if (L.o_wqkvs >= 0) ok &= og_pack_proj_stream(qkv_width(s), D, Wqd.data(), base + L.o_wqkvs, Sq);
         // fc.0 on y = [x ; msg] (or [x - msg ; msg] with use_offset, attention_gnn.py:51-54), msg = Wo O + bo:
         //   W0 y = W0a x + Wm (Wo O + bo),  Wm = W0b (- W0a)   ->  [W0a | Wm Wo] [x ; O] + (b0 + Wm bo)
         if (!lp.fc0.weight || !lp.fc0.bias || !lp.out_proj.weight || !lp.out_proj.bias || !lp.fc3.weight || !lp.fc3.bias)
@@ -534,7 +541,19 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
     // q / k / v projections of token rows [r0, r0 + R): columns [c0, c1) of the q | k | v planes = rows [c0, c1) of the packed
     // projection matrix.  One launch; with favor_relu the feature blocks (columns < 2 WQ) carry the ReLU of the feature map and the
     // value block does not, so a range that spans both is two launches.
+    // Few rows (<= 8192 per launch, the single-pair regime): proj_small_kernel, 32-token workgroups over a fragment-major copy of the
+    // matrix -- 17.5 us per launch of the 128-token tile GEMM otherwise, 36 launches per step.  OG_PROJ_SMALL=0 / 1 forces.
+    auto proj_small_ok = [&](int64_t R) {
+        static const int mode = [] { const char* e = getenv("OG_PROJ_SMALL"); return e ? atoi(e) : -1; }();
+        return L.o_wqkvs >= 0 && !favor && (mode >= 0 ? mode != 0 : R <= 8192) && R < ((int64_t)1 << 30);
+    };
+    auto proj_small = [&](const float* lw, int64_t r0, int64_t R, int split_row, int a0, int a1, int b0, int b1) -> int {
+        Scope sc(prof, OG_STAGE_GEMM_F16X3);
+        return og_launch_proj_small(XO + r0 * D4, D4, (int)R, (const char*)(lw + L.o_wqkvs), lw + L.o_bqkv, lw + L.o_scale,
+                                    QKVh + r0 * QW, QKVl + r0 * QW, QW, split_row, a0, a1, b0, b1, st);
+    };
     auto qkv_proj = [&](const float* lw, int64_t r0, int64_t R, int c0, int c1) -> int {
+        if (proj_small_ok(R) && c0 % 32 == 0 && c1 % 32 == 0) return proj_small(lw, r0, R, 0, 0, 0, c0 / 32, c1 / 32);
         const int cut = favor ? 2 * WQ : c1;
         const int ca[2] = {c0, c0 < cut && cut < c1 ? cut : c1}, cb[2] = {ca[1], c1};
         for (int part = 0; part < 2; ++part) {
@@ -582,7 +601,9 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
                 g.M = (int)T; g.N = QW; g.K = D; g.scale = (float)(1.0 / OG_W_SCALE); g.scale_dev = lw + L.o_scale; g.bias = lw + L.o_bqkv;
                 g.Ch = QKVh; g.Cl = QKVl; g.ldch = QW; g.c_hl = 0; g.ldc = D; g.ldr = D; g.ldrh = D4;
                 g.split_row = (int)T0; g.split_n = WQ;
-                if (!favor && !rag && T < (int64_t)1 << 30 && og_gemm_f16x3_row_split_ok(g)) {
+                if (proj_small_ok(T) && T0 % 32 == 0 && WQ % 32 == 0) {      // rows of image 0: the q blocks only
+                    if ((rc = proj_small(lw, 0, T, (int)T0, 0, WQ / 32, 0, QW / 32))) return rc;
+                } else if (!favor && !rag && T < (int64_t)1 << 30 && og_gemm_f16x3_row_split_ok(g)) {
                     Scope sc(prof, OG_STAGE_GEMM_F16X3);
                     if ((rc = og_launch_gemm_f16x3(g, st))) return rc;
                 } else {

@@ -784,6 +784,143 @@ __global__ __launch_bounds__(512) void mlp_small_kernel(MlpFusedArgs g) {
 #undef OG_ST
 }
 
+
+// =================================================================================================================================
+// proj_small_kernel -- a 1x1 conv of the residual stream (the q / k / v projections) for FEW token rows, in the style of mlp_small_kernel:
+// a workgroup owns 32 token rows, copies their x halves (32 KB of hl32 rows) to LDS, and its 8 waves split the OUTPUT blocks of 32
+// channels (wave w: blocks c0 + w, c0 + w + 8, c0 + w + 16 below c1), each over all 16 k-steps, weight fragments straight from a
+// fragment-major stream (og_pack_proj_stream).  Output: (hi, lo) planes.  The 128-token tile GEMM it replaces takes 17.5 us per launch at
+// 2048 or 8192 rows (profiles/r04_small_batch_kernel_stats_B*.csv: 36 launches per step).  Workgroups whose first row is below
+// `split_row` use the block range [a0, a1), the others [b0, b1) -- the cross layer's "q of image 0, q | k | v of image 1" in one launch.
+constexpr int PS_ROW = 256 * 2 * 2 + 16;       // bytes of one padded LDS row: the x half of an hl32 row (2D halves) + 16
+
+struct ProjSmallArgs {
+    const _Float16* X; int64_t ld;             // [M] hl32 rows, the first 2D halves = x
+    int M;
+    const char* wstream;                       // og_pack_proj_stream
+    const float* bias;                         // [N]
+    const float* scale_dev;                    // DEVICE: 1 / pre-scale of the matrix
+    _Float16* Ch; _Float16* Cl; int64_t ldc;   // output planes [M][ldc]
+    int split_row, a0, a1, b0, b1;             // block ranges (units of 32 output channels)
+};
+
+template <int NB>
+__device__ __forceinline__ void proj_small_run(const ProjSmallArgs& g, const char* smem, int wave, int lane, int cb0, int t0) {
+    const int l31 = lane & 31, hi = lane >> 5;
+    unsigned lane16 = (unsigned)lane * 16u;
+    asm volatile("" : "+v"(lane16));
+    auto sbase = [](const char* p) {
+        const uint64_t v = (uint64_t)(uintptr_t)p;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi32 = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        return reinterpret_cast<const char*>((uintptr_t)(((uint64_t)hi32 << 32) | lo));
+    };
+    // fragment (block i, k-step ks, part): ((i * 16 + ks) * 2 + part) KiB
+    auto frag = [&](f16x8& dst, int b, int ks, int part) {
+        const char* base = sbase(g.wstream + ((((int64_t)(cb0 + wave + 8 * b) * 16 + ks) * 2 + part) << 10));
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(lane16), "s"(base) : "memory");
+    };
+    constexpr int PF = 4, FPS = 2 * NB;        // k-steps in flight, fragments per k-step
+    f16x8 wf[PF][FPS];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the tile copy's loads are done; from here on the counts are mine
+#pragma unroll
+    for (int ks = 0; ks < PF; ++ks)
+#pragma unroll
+        for (int f = 0; f < FPS; ++f) frag(wf[ks][f], f >> 1, ks, f & 1);
+    f32x16 acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+    const char* const xrow = smem + l31 * PS_ROW + hi * 16;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        const int slot = ks % PF;
+        const f16x8 xh = *reinterpret_cast<const f16x8*>(xrow + (ks >> 1) * 128 + (ks & 1) * 32);
+        const f16x8 xl = *reinterpret_cast<const f16x8*>(xrow + (ks >> 1) * 128 + (ks & 1) * 32 + 64);
+        const int ysteps = 16 - 1 - ks < PF - 1 ? 16 - 1 - ks : PF - 1;       // k-steps younger than this one still in flight
+        // "all but the ysteps * FPS youngest loads have landed"
+        if constexpr (NB == 1) {
+            if (ysteps == 3) asm volatile("s_waitcnt vmcnt(6)" : "+v"(wf[slot][0]), "+v"(wf[slot][1]) :: "memory");
+            else if (ysteps == 2) asm volatile("s_waitcnt vmcnt(4)" : "+v"(wf[slot][0]), "+v"(wf[slot][1]) :: "memory");
+            else if (ysteps == 1) asm volatile("s_waitcnt vmcnt(2)" : "+v"(wf[slot][0]), "+v"(wf[slot][1]) :: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(wf[slot][0]), "+v"(wf[slot][1]) :: "memory");
+        } else if constexpr (NB == 2) {
+            if (ysteps == 3) asm volatile("s_waitcnt vmcnt(12)" : "+v"(wf[slot][0]), "+v"(wf[slot][1]), "+v"(wf[slot][2]), "+v"(wf[slot][3]) :: "memory");
+            else if (ysteps == 2) asm volatile("s_waitcnt vmcnt(8)" : "+v"(wf[slot][0]), "+v"(wf[slot][1]), "+v"(wf[slot][2]), "+v"(wf[slot][3]) :: "memory");
+            else if (ysteps == 1) asm volatile("s_waitcnt vmcnt(4)" : "+v"(wf[slot][0]), "+v"(wf[slot][1]), "+v"(wf[slot][2]), "+v"(wf[slot][3]) :: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(wf[slot][0]), "+v"(wf[slot][1]), "+v"(wf[slot][2]), "+v"(wf[slot][3]) :: "memory");
+        } else {
+            if (ysteps == 3) asm volatile("s_waitcnt vmcnt(18)" : "+v"(wf[slot][0]), "+v"(wf[slot][1]), "+v"(wf[slot][2]), "+v"(wf[slot][3]), "+v"(wf[slot][4]), "+v"(wf[slot][5]) :: "memory");
+            else if (ysteps == 2) asm volatile("s_waitcnt vmcnt(12)" : "+v"(wf[slot][0]), "+v"(wf[slot][1]), "+v"(wf[slot][2]), "+v"(wf[slot][3]), "+v"(wf[slot][4]), "+v"(wf[slot][5]) :: "memory");
+            else if (ysteps == 1) asm volatile("s_waitcnt vmcnt(6)" : "+v"(wf[slot][0]), "+v"(wf[slot][1]), "+v"(wf[slot][2]), "+v"(wf[slot][3]), "+v"(wf[slot][4]), "+v"(wf[slot][5]) :: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(wf[slot][0]), "+v"(wf[slot][1]), "+v"(wf[slot][2]), "+v"(wf[slot][3]), "+v"(wf[slot][4]), "+v"(wf[slot][5]) :: "memory");
+        }
+        // pass-major: the accumulator chains alternate
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[slot][2 * b + 1], xh, acc[b], 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[slot][2 * b], xl, acc[b], 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[slot][2 * b], xh, acc[b], 0, 0, 0);
+        if (ks + PF < 16) {
+#pragma unroll
+            for (int f = 0; f < FPS; ++f) frag(wf[slot][f], f >> 1, ks + PF, f & 1);
+        }
+    }
+    // ---- epilogue: acc / S + bias as (hi, lo) halves, 8 bytes per register group and plane ----
+    const float sc = g.scale_dev[0];
+    const int tok = t0 + l31;
+    if (tok < g.M) {
+#pragma clang fp contract(off)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int col0 = 32 * (cb0 + wave + 8 * b);
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int ch = col0 + 8 * qq + 4 * hi;
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(g.bias + ch);
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[b][4 * qq + e] * sc;
+                    v[e] = v[e] + bv[e];
+                    asm volatile("" : "+v"(v[e]));
+                }
+                unsigned ha, la, hb, lb;
+                og_split4(v[0], v[1], v[2], v[3], ha, la, hb, lb);
+                *reinterpret_cast<uint2*>(g.Ch + (int64_t)tok * g.ldc + ch) = make_uint2(ha, hb);
+                *reinterpret_cast<uint2*>(g.Cl + (int64_t)tok * g.ldc + ch) = make_uint2(la, lb);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void proj_small_kernel(ProjSmallArgs g) {
+    __shared__ __attribute__((aligned(16))) char smem[SM_T * PS_ROW];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t0 = blockIdx.x * SM_T;
+    const int cb0 = t0 < g.split_row ? g.a0 : g.b0, cb1 = t0 < g.split_row ? g.a1 : g.b1;
+    if (cb1 <= cb0) return;
+    // ---- x halves of the token rows -> LDS: thread (row tid >> 4, 16-byte column tid & 15 + 16 j), 1 KiB per row ----
+    {
+        int r = t0 + (tid >> 4);
+        if (r > g.M - 1) r = g.M - 1;
+        const char* src = reinterpret_cast<const char*>(g.X) + (int64_t)r * g.ld * 2 + (tid & 15) * 16;
+        char* dst = smem + (tid >> 4) * PS_ROW + (tid & 15) * 16;
+        og_u32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const og_u32x4*>(src + j * 256);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<og_u32x4*>(dst + j * 256) = v[j];
+    }
+    __syncthreads();
+    const int mine = (cb1 - cb0 - wave + 7) / 8;             // blocks cb0 + wave + 8 b < cb1 (wave-uniform)
+    if (mine >= 3) proj_small_run<3>(g, smem, wave, lane, cb0, t0);
+    else if (mine == 2) proj_small_run<2>(g, smem, wave, lane, cb0, t0);
+    else if (mine == 1) proj_small_run<1>(g, smem, wave, lane, cb0, t0);
+}
+
 }  // namespace
 
 // ---- host side ----------------------------------------------------------------------------------------------------------------
@@ -889,4 +1026,39 @@ extern "C" int og_mlp_block(int32_t D, void* xo_rows, int64_t ld, int32_t M, con
     MlpFusedArgs a{};
     a.XO = (_Float16*)xo_rows; a.ld = ld; a.M = M; a.wstream = (const char*)stream_dev; a.b0 = b0; a.b3 = b3; a.scale = (float)(1.0 / OG_W_SCALE);
     return og_launch_mlp_fused(a, D, (hipStream_t)stream);
+}
+
+// ---- the small-batch projection (proj_small_kernel) ----
+// Fragment-major stream of an [N][256] matrix (N a multiple of 32), standard k order: fragment ((i * 16 + ks) * 2 + part), lane l =
+// (rho = l & 31, h = l >> 5), element e = S w[32 i + rho][16 ks + 8 h + e] as (hi, lo) halves (the lo fragment follows the hi fragment).
+size_t og_proj_stream_bytes(int N, int K) { return (K == 256 && N % 32 == 0) ? (size_t)N * K * 4 : 0; }
+
+bool og_pack_proj_stream(int N, int K, const double* W, void* out, double S) {
+    if (!og_proj_stream_bytes(N, K)) return false;
+    _Float16* o = (_Float16*)out;
+    bool ok = true;
+    for (int i = 0; i < N / 32; ++i)
+        for (int ks = 0; ks < K / 16; ++ks)
+            for (int l = 0; l < 64; ++l)
+                for (int e = 0; e < 8; ++e) {
+                    double w = W[(int64_t)(32 * i + (l & 31)) * K + 16 * ks + 8 * (l >> 5) + e] * S;
+                    if (!(fabs(w) <= 65504.0)) { ok = false; w = 0.0; }
+                    const _Float16 hi = (_Float16)w;
+                    _Float16* base = o + ((int64_t)(i * (K / 16) + ks) * 2) * 512 + l * 8 + e;
+                    base[0] = hi;
+                    base[512] = (_Float16)(w - (double)hi);
+                }
+    return ok;
+}
+
+// Rows [0, M) of X (hl32 rows, x half) times columns [32 a0, 32 a1) of the packed matrix for rows below split_row, [32 b0, 32 b1) for the
+// others (split_row must be a multiple of 32 unless it is 0 or >= M); planes Ch / Cl [M][ldc].
+int og_launch_proj_small(const _Float16* X, int64_t ld, int M, const char* wstream, const float* bias, const float* scale_dev,
+                         _Float16* Ch, _Float16* Cl, int64_t ldc, int split_row, int a0, int a1, int b0, int b1, hipStream_t stream) {
+    if (!X || !wstream || !bias || !scale_dev || !Ch || !Cl || M <= 0) return OG_E_INVALID;
+    if (((uintptr_t)X & 15) || ((uintptr_t)wstream & 15) || (ld & 7) || (ldc & 3) || ((uintptr_t)Ch & 7) || ((uintptr_t)Cl & 7)) return OG_E_ALIGN;
+    if (split_row > 0 && split_row < M && (split_row % SM_T)) return OG_E_SHAPE;
+    ProjSmallArgs g{X, ld, M, wstream, bias, scale_dev, Ch, Cl, ldc, split_row, a0, a1, b0, b1};
+    hipLaunchKernelGGL(proj_small_kernel, dim3((M + SM_T - 1) / SM_T), dim3(512), 0, stream, g);
+    return og_launch_status();
 }

@@ -183,6 +183,11 @@ size_t og_mlp_stream_bytes(int D);
 bool og_pack_mlp_stream(int D, const double* W0, const double* W3, void* out, double S0 = OG_W_SCALE, double S3 = OG_W_SCALE);   // false: a weight does not fit binary16
 int og_launch_mlp_fused(const MlpFusedArgs& a, int D, hipStream_t stream);      // picks mlp_small_kernel (32-token workgroups) when og_mlp_small_wanted(M)
 bool og_mlp_small_wanted(int M);
+// the q / k / v projections for few token rows (mlp_fused.hip: proj_small_kernel), a fragment-major copy of the packed matrix
+size_t og_proj_stream_bytes(int N, int K);
+bool og_pack_proj_stream(int N, int K, const double* W, void* out, double S);
+int og_launch_proj_small(const _Float16* X, int64_t ld, int M, const char* wstream, const float* bias, const float* scale_dev,
+                         _Float16* Ch, _Float16* Cl, int64_t ldc, int split_row, int a0, int a1, int b0, int b1, hipStream_t stream);
 
 struct AttnArgs {
     const _Float16* qh; const _Float16* ql; int64_t ldq;     // leading dimensions in halves

@@ -413,7 +413,8 @@ def test_full_size_c2_batch_properties(gpu_device):
     # a smaller tile: same arithmetic, different reduction orders, so rounding noise only (scores ~ -26,
     # 100 iterations); both sit inside TOL_SCORES of the oracle, see (5)
     assert (s1[0] - s[5]).abs().max() < 2e-4
-    # with the schedule pinned the only batch-size dependence left is the GEMM tile choice
+    # with the schedule pinned the only batch-size dependence left is the kernel choice: B = 1 runs the 32-token small-batch kernels for the
+    # message MLP and the q / k / v projections (mlp_small_kernel, proj_small_kernel: other summation orders), B = 32 the 128 / 256-token tiles
     import os
     prev = os.environ.get("OG_SINKHORN_RESIDENT")
     os.environ["OG_SINKHORN_RESIDENT"] = "0"
@@ -425,7 +426,7 @@ def test_full_size_c2_batch_properties(gpu_device):
             os.environ.pop("OG_SINKHORN_RESIDENT")
         else:
             os.environ["OG_SINKHORN_RESIDENT"] = prev
-    assert (sa[0] - sb[5]).abs().max() < 5e-5
+    assert (sa[0] - sb[5]).abs().max() < 1e-4
     # (3) permuting the keypoints of image 1 permutes the columns of scores
     perm = torch.randperm(n, generator=torch.Generator().manual_seed(3))
     dp = dict(one)
