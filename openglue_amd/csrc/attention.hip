@@ -473,8 +473,11 @@ __device__ __forceinline__ f32x16 og_attn_mfma(f16x8 a, f16x8 b, f32x16 c) {
 #endif
 }
 
-template <int DH, class RD>
-__global__ __launch_bounds__(256, 2) void attention_dma_kernel(AttnArgs a, RD rd) {      // (dh = 32 would fit three workgroups per CU: measured 4 % slower)
+// KS = 2 (few workgroups: one or a few image pairs, og_launch_attention): an 8-wave workgroup whose two halves take the two halves of the KEY
+// range of the same 128 queries, each with its own K/V ring, and merge their (O, m, l) through LDS at the end -- a workgroup is alone on
+// its CU then, and its latency is the number of key tiles a wave walks through (16 at 1024 keys: 26 us per launch at any small batch).
+template <int DH, class RD, int KS = 1>
+__global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void attention_dma_kernel(AttnArgs a, RD rd) {      // (dh = 32 would fit three workgroups per CU: measured 4 % slower)
     static_assert(DH == 64 || DH == 32, "head rows of 128 or 64 bytes");
     constexpr int NDV = DH / 32, NCH = DH / 16;
     constexpr int ROWB = DH * 2;                    // bytes of a head row of one plane: a full 128-byte line (dh = 64) or half of one
@@ -483,7 +486,8 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(AttnArgs a, RD rd
     constexpr int NPI = 16 / RPI;                   // DMA pieces per wave and plane: the wave fills rows [16w, 16w + 16)
     constexpr int PLANE = KV_TILE * ROWB;           // bytes: 64 keys x one head row
     constexpr int BUFB = 4 * PLANE;                 // Kh | Kl | Vh | Vl
-    __shared__ __attribute__((aligned(1024))) char smem[2 * BUFB];
+    static_assert(KS == 1 || KS == 2, "key split");
+    __shared__ __attribute__((aligned(1024))) char smem_all[KS * 2 * BUFB];
 
     const int id = blockIdx.x;
     const int xcd = id & 7, local = id >> 3;
@@ -509,8 +513,23 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(AttnArgs a, RD rd
     if (q0 >= nq) return;
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = KS == 2 ? wave_all >> 2 : 0;        // which half of the key range
+    const int wave = KS == 2 ? wave_all & 3 : wave_all;  // 32-query block inside the 128-query tile
     const int l31 = lane & 31, hi = lane >> 5;
+    char* const smem = smem_all + half * 2 * BUFB;
+    // key tiles of this half: [t_begin, t_begin + ntiles) of the problem's ceil(nk / 64); everything below sees only "its" keys
+    const int nk_all = nk;
+    int ntiles_other = 0;                                 // KS = 2: tiles of the other half (the halves must meet at the same barriers)
+    if constexpr (KS == 2) {
+        const int nt_all = (nk_all + KV_TILE - 1) / KV_TILE, t_half = (nt_all + 1) / 2;
+        const int t_begin = half ? t_half : 0, t_end = half ? nt_all : t_half;
+        ntiles_other = half ? t_half : nt_all - t_half;
+        kv_row0 += (int64_t)t_begin * KV_TILE;
+        const int k_end = t_end * KV_TILE < nk_all ? t_end * KV_TILE : nk_all;
+        nk = k_end - t_begin * KV_TILE;                   // <= 0: the second half of a one-tile problem
+        if (nk < 0) nk = 0;
+    }
 
     // ---- DMA pieces: wave w fills rows [16w, 16w+16) of each of the four planes, NPI pieces of RPI rows each.  Chunk swizzles
     //      (on the LDS row r): dh = 64: K chunk ^ ((r >> 1) & 7), V chunk ^ (((r >> 1) & 1) << 2); dh = 32 (64-byte rows, four
@@ -591,7 +610,8 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(AttnArgs a, RD rd
             issue_pair(kt, BUF, std::integral_constant<int, (j >> 1)>{}, std::integral_constant<int, (j & 1)>{});
         });
     };
-    issue_tile(0, std::integral_constant<int, 0>{});
+    const int ntiles = (nk + KV_TILE - 1) / KV_TILE;
+    if (ntiles > 0) issue_tile(0, std::integral_constant<int, 0>{});
 
     // ---- Q fragments (B operand): lane (query l31, k-group hi) holds Q[q][16c + 8hi + e] ----
     f16x8 qh[NCH], ql[NCH];
@@ -628,7 +648,6 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(AttnArgs a, RD rd
     // fragment registers, double-buffered by hand: K [buf][key block], V [buf][dv block] as two transposed halves
     f16x8 kh[2][2], kl[2][2];
     s16x4 vh0[2][NDV], vh1[2][NDV], vl0[2][NDV], vl1[2][NDV];
-    const int ntiles = (nk + KV_TILE - 1) / KV_TILE;
 
 #if OG_ATTN_TRACE
     const int tsel = blockIdx.x == 8 * 40 ? 0 : blockIdx.x == 8 * 41 + 3 ? 1 : -1;     // two workgroups somewhere in the middle
@@ -858,7 +877,7 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(AttnArgs a, RD rd
             for (int i = 0; i < 8; ++i) og_attn_trace_buf[tsel][wave][kt][i] = tp[i];
 #endif
     };
-    {
+    if (ntiles > 0) {
         using B0 = std::integral_constant<int, 0>; using B1 = std::integral_constant<int, 1>;
         int kt = 0;
         for (; kt + 2 < ntiles; kt += 2) {                 // pairs of tiles that are not the last one: no mask code at all
@@ -873,6 +892,33 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(AttnArgs a, RD rd
         }
     }
 
+    if constexpr (KS == 2) {
+        // the halves walked ntiles - 1 (or 0) barriers inside their loops: the shorter one catches up, then (O, m, l) of half 1 cross LDS
+        const int mine = ntiles > 1 ? ntiles - 1 : 0, other = ntiles_other > 1 ? ntiles_other - 1 : 0;
+        for (int i = mine; i < other; ++i) __syncthreads();
+        __syncthreads();                                   // every wave is done with the K / V rings
+        float* const xch = reinterpret_cast<float*>(smem_all) + (wave * (16 * NDV + 2)) * 64 + lane;      // [wave][register][lane]
+        if (ntiles == 0) m_run = -1e30f;                   // an empty half weighs nothing in the merge
+        if (half == 1) {
+#pragma unroll
+            for (int d = 0; d < NDV; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xch[(d * 16 + r) * 64] = oacc[d][r];
+            xch[(16 * NDV) * 64] = m_run;
+            xch[(16 * NDV + 1) * 64] = l_run;
+        }
+        __syncthreads();
+        if (half == 1) return;
+        const float m1 = xch[(16 * NDV) * 64], l1 = xch[(16 * NDV + 1) * 64];
+        const float m = fmaxf(m_run, m1);
+        const float a0 = __builtin_amdgcn_exp2f(m_run - m), a1 = __builtin_amdgcn_exp2f(m1 - m);
+#pragma unroll
+        for (int d = 0; d < NDV; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[d][r] = oacc[d][r] * a0 + xch[(d * 16 + r) * 64] * a1;
+        l_run = l_run * a0 + l1 * a1;
+        m_run = m;
+    }
     // ---- normalise and store O[q][h*DH + dv] ----
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.f / l_tot;
@@ -930,6 +976,20 @@ int og_launch_attention(const AttnArgs& a, hipStream_t stream) {
     const bool dma = dma_on && (a.dh == 64 || a.dh == 32);       // head rows of one or half a 128-byte line: the LDS-DMA kernel
     const int groups8 = (a.nz * a.num_heads + 7) / 8 * 8;
     dim3 grid(groups8 * a2.qtiles), block(256);
+    // Few workgroups (at most one per CU) and enough keys: the key range of a query tile is split over the two halves of an 8-wave
+    // workgroup (attention_dma_kernel<64, ., 2>).  OG_ATTN_KSPLIT=0 / 1 forces.
+    static const int ks_mode = [] { const char* e = getenv("OG_ATTN_KSPLIT"); return e ? atoi(e) : -1; }();
+    int nkmin = 1 << 30;
+    for (int g = 0; g < 2; ++g) {
+        const bool used = g == 0 ? a.split > 0 : a.split < a.nz;
+        if (used && a.nk[g] < nkmin) nkmin = a.nk[g];
+    }
+    const bool ksplit = dma && a.dh == 64 && (ks_mode >= 0 ? ks_mode != 0 : ((int)grid.x <= 256 && (a.rag || nkmin >= 4 * KV_TILE)));
+    if (ksplit) {
+        if (a.rag) hipLaunchKernelGGL((attention_dma_kernel<64, RaggedDesc, 2>), grid, dim3(512), 0, stream, a2, rd);
+        else hipLaunchKernelGGL((attention_dma_kernel<64, RaggedNone, 2>), grid, dim3(512), 0, stream, a2, RaggedNone{});
+        return og_launch_status();
+    }
     if (a.rag) {
         switch (a.dh) {
             case 16: hipLaunchKernelGGL((attention_kernel<16, RaggedDesc>), grid, block, 0, stream, a2, rd); break;
