@@ -11,7 +11,7 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OPENGLUE_AMD_LIB") or os.path.join(HERE, "lib", "libopenglue_amd.so")   # override: A/B builds
 
-OG_ABI_VERSION = 6
+OG_ABI_VERSION = 7
 OG_FLAG_RESIDUAL, OG_FLAG_USE_OFFSET, OG_FLAG_NO_DESCRIPTORS, OG_FLAG_SIREN_ENCODER, OG_FLAG_LINEAR_ATTENTION = 1, 2, 4, 8, 16
 OG_FLAG_FAVOR_RELU = 32
 OG_MAX_HIDDEN = 8
@@ -68,7 +68,7 @@ class og_packed_layout_t(C.Structure):
     _fields_ = [("n_enc", C.c_int32), ("enc_k", C.c_int32 * (OG_MAX_HIDDEN + 1)), ("enc_out", C.c_int32 * (OG_MAX_HIDDEN + 1)),
                 ("enc_w", C.c_int64 * (OG_MAX_HIDDEN + 1)), ("enc_b", C.c_int64 * (OG_MAX_HIDDEN + 1))] + \
                [(k, C.c_int64) for k in ("layer0", "layer_stride", "o_wqkv", "o_bqkv", "o_w0", "o_b0", "o_w3", "o_b3",
-                                         "wp", "bp", "alpha", "dustbin", "total", "o_scale", "scales", "o_wmlp")]
+                                         "wp", "bp", "alpha", "dustbin", "total", "o_scale", "scales", "o_wmlp", "o_wqkvs")]
 
 
 # every symbol include/openglue_amd.h declares: name -> (restype, argtypes)
@@ -101,6 +101,9 @@ SYMBOLS = {
                                    _vp, _vp, _i64, _i32, _vp]),
     "og_gemm_nt_f16x3_reshl": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _f, _vp, _i32, _vp, _i64, _vp, _i64,
                                          _vp, _vp, _i64, _i32, _vp]),
+    "og_proj_block_stream_bytes": (_sz, [_i32, _i32]),
+    "og_proj_block_pack": (C.c_int, [_i32, _i32, _vp, _vp]),
+    "og_proj_block": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
     "og_mlp_block_stream_bytes": (_sz, [_i32]),
     "og_mlp_block_pack": (C.c_int, [_i32, _vp, _vp, _vp]),
     "og_mlp_block": (C.c_int, [_i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),

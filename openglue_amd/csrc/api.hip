@@ -191,7 +191,7 @@ extern "C" int og_packed_layout(const og_shape* shape, og_packed_layout_t* o) {
     o->layer0 = L.layer0; o->layer_stride = L.layer_stride;
     o->o_wqkv = L.o_wqkv; o->o_bqkv = L.o_bqkv;
     o->o_w0 = L.o_w0; o->o_b0 = L.o_b0;
-    o->o_w3 = L.o_w3; o->o_b3 = L.o_b3; o->o_wmlp = L.o_wmlp; o->o_scale = L.o_scale; o->scales = L.scales;
+    o->o_w3 = L.o_w3; o->o_b3 = L.o_b3; o->o_wmlp = L.o_wmlp; o->o_wqkvs = L.o_wqkvs; o->o_scale = L.o_scale; o->scales = L.scales;
     o->wp = L.wp; o->bp = L.bp; o->alpha = L.alpha; o->dustbin = L.dustbin; o->total = L.total;
     return 0;
 }

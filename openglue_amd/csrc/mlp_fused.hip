@@ -1062,3 +1062,24 @@ int og_launch_proj_small(const _Float16* X, int64_t ld, int M, const char* wstre
     hipLaunchKernelGGL(proj_small_kernel, dim3((M + SM_T - 1) / SM_T), dim3(512), 0, stream, g);
     return og_launch_status();
 }
+
+extern "C" size_t og_proj_block_stream_bytes(int32_t N, int32_t K) { return og_proj_stream_bytes(N, K); }
+
+extern "C" int og_proj_block_pack(int32_t N, int32_t K, const float* W, void* stream_host) {
+    if (!W || !stream_host) return OG_E_INVALID;
+    if (!og_proj_stream_bytes(N, K)) return OG_E_SHAPE;
+    double* w = (double*)malloc(sizeof(double) * (size_t)N * K);
+    if (!w) return OG_E_INVALID;
+    for (int64_t i = 0; i < (int64_t)N * K; ++i) w[i] = W[i];
+    const bool ok = og_pack_proj_stream(N, K, w, stream_host, OG_W_SCALE);
+    free(w);
+    return ok ? 0 : OG_E_RANGE;
+}
+
+extern "C" int og_proj_block(const void* x_rows, int64_t ld, int32_t M, const void* stream_dev, const float* bias, const float* inv_scale_dev,
+                             void* yh, void* yl, int64_t ldy, int32_t split_row, int32_t a0, int32_t a1, int32_t b0, int32_t b1, void* stream) {
+    og_clear_status();
+    if (a0 < 0 || b0 < 0 || a1 < a0 || b1 < b0 || ldy < 32 * (int64_t)(a1 > b1 ? a1 : b1)) return OG_E_SHAPE;
+    return og_launch_proj_small((const _Float16*)x_rows, ld, M, (const char*)stream_dev, bias, inv_scale_dev, (_Float16*)yh, (_Float16*)yl, ldy,
+                                split_row, a0, a1, b0, b1, (hipStream_t)stream);
+}

@@ -161,6 +161,32 @@ def mlp_block(x: torch.Tensor, o: torch.Tensor, w0: torch.Tensor, b0: torch.Tens
     return (out, rows) if return_rows else out
 
 
+def proj_block(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, split_row: int = 0, cols_a=None, cols_b=None):
+    """The small-batch projection kernel (og_proj_block): y = x @ w.T + bias on token-major fp32 x [M, 256], w [N, 256], N a multiple of 32.
+    Rows below split_row get the output columns cols_a = (c0, c1), the others cols_b (multiples of 32; default: all N); columns outside a
+    row's range come back as zeros."""
+    lib = _lib.load()
+    x = _req(x, "x")
+    M, K = x.shape
+    N = w.shape[0]
+    nbytes = lib.og_proj_block_stream_bytes(N, K)
+    if nbytes == 0:
+        raise RuntimeError(f"og_proj_block: no kernel for N = {N}, K = {K}")
+    wh = w.detach().float().cpu().contiguous()
+    stream_host = torch.empty(nbytes, dtype=torch.uint8)
+    _lib.check(lib.og_proj_block_pack(N, K, wh.data_ptr(), stream_host.data_ptr()), "og_proj_block_pack")
+    stream_dev = stream_host.to(x.device)
+    rows = split_f16_hl(x)                                       # [M][2K halves]
+    bias = _req(bias, "bias")
+    inv = torch.full((1,), 1.0 / 256.0, device=x.device, dtype=torch.float32)
+    yh = torch.zeros(M, N, device=x.device, dtype=torch.float16)
+    yl = torch.zeros_like(yh)
+    a, b = cols_a or (0, N), cols_b or (0, N)
+    _lib.check(lib.og_proj_block(rows.data_ptr(), 2 * K, M, stream_dev.data_ptr(), bias.data_ptr(), inv.data_ptr(), yh.data_ptr(), yl.data_ptr(), N,
+                                 split_row, a[0] // 32, a[1] // 32, b[0] // 32, b[1] // 32, _stream()), "og_proj_block")
+    return merge_f16(yh, yl)
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int, return_lse: bool = False):
     """Multi-head softmax attention on token-major fp32 tensors q [Z,nq,D], k,v [Z,nk,D]; head h owns
     channels h*d..(h+1)*d-1.  q must already carry the d^-1/2 scale (the log2(e) factor of the kernel's

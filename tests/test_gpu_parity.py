@@ -138,6 +138,31 @@ def test_mlp_block_fused_vs_float64(gpu_device, M):
     assert (two - out).abs().max().item() < 2e-5 + 1e-6 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("M,split,cols_a,cols_b", [(2048, 0, None, None), (1, 0, None, None), (33, 0, None, None), (8192, 0, None, (256, 768)),
+                                                   (1000, 512, (0, 256), (0, 768)), (96, 64, (0, 256), (0, 768)), (777, 0, None, (0, 256))])
+def test_proj_block_small_batch_vs_float64(gpu_device, M, split, cols_a, cols_b):
+    """og_proj_block (csrc/mlp_fused.hip: proj_small_kernel), the q / k / v projection kernel og_forward uses for launches of <= 8192 token
+    rows (attention_gnn.py:43-47): against float64 on the (hi, lo) operands the kernel is given.  Partial tiles, one / two / three output
+    blocks per wave, the cross layer's row split (rows of image 0: the q columns only); columns outside a row's range stay untouched."""
+    D, N = 256, 768
+    g = torch.Generator().manual_seed(2000 + M)
+    x, w, b = _rand(g, M, D, scale=2.0), _rand(g, N, D, scale=0.06), _rand(g, N, scale=0.3)
+    dev = lambda t: t.to(gpu_device)
+    out = ops.proj_block(dev(x), dev(w), dev(b), split_row=split, cols_a=cols_a, cols_b=cols_b).cpu()
+    x_in = ops.merge_f16_hl(ops.split_f16_hl(dev(x))).cpu()
+    ref = x_in.double() @ w.double().T + b.double()
+    fp32_err = ((x_in @ w.T + b).double() - ref).abs().max().item()
+    ca, cb = cols_a or (0, N), cols_b or (0, N)
+    mask = torch.zeros(M, N, dtype=torch.bool)
+    mask[:split, ca[0]:ca[1]] = True
+    mask[split:, cb[0]:cb[1]] = True
+    err = ((out.double() - ref).abs() * mask).max().item()
+    print(f"[proj_block M={M} split={split}] err {err:.2e} (fp32 CPU err {fp32_err:.2e})")
+    assert torch.isfinite(out).all()
+    assert err < max(2.0 * fp32_err, 2e-6) + 2e-6 * ref.abs().max().item()
+    assert (out[~mask] == 0).all()                 # nothing written outside the requested ranges
+
+
 def test_mlp_block_rows_past_m_untouched(gpu_device):
     from openglue_amd import _lib
     lib = _lib.load()

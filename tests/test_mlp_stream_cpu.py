@@ -101,3 +101,24 @@ def test_mlp_stream_range_error():
     w0[3, 5] = 300.0                                  # 256 * 300 > 65504
     st = torch.empty(lib.og_mlp_block_stream_bytes(D), dtype=torch.uint8)
     assert lib.og_mlp_block_pack(D, w0.data_ptr(), w3.data_ptr(), st.data_ptr()) == -5
+
+
+def test_proj_stream_layout():
+    """og_proj_block_pack (the small-batch projection kernel's weight stream): fragment ((i * 16 + ks) * 2 + part) of 1 KiB, lane l =
+    (rho = l & 31, h = l >> 5), element e = 256 w[32 i + rho][16 ks + 8 h + e] as (hi, lo) halves -- re-read here with numpy."""
+    lib = _lib.load()
+    N, K = 96, 256
+    assert lib.og_proj_block_stream_bytes(N, K) == N * K * 4
+    assert lib.og_proj_block_stream_bytes(100, K) == 0 and lib.og_proj_block_stream_bytes(N, 128) == 0
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(N, K, generator=g) * 0.05
+    st = torch.empty(N * K * 4, dtype=torch.uint8)
+    assert lib.og_proj_block_pack(N, K, w.data_ptr(), st.data_ptr()) == 0
+    h = st.numpy().view(np.float16).reshape(N // 32, K // 16, 2, 64, 8).astype(np.float64)       # [i][ks][part][lane][e]
+    back = np.zeros((N, K))
+    for l in range(64):
+        rho, hh = l & 31, l >> 5
+        for e in range(8):
+            back[rho::32, 8 * hh + e::16] = (h[:, :, 0, l, e] + h[:, :, 1, l, e])
+    assert np.abs(back / 256.0 - w.double().numpy()).max() < 2e-8
+    assert lib.og_proj_block_pack(N, K, (w * 1e4).contiguous().data_ptr(), st.data_ptr()) == -5      # OG_E_RANGE: 256 w leaves binary16
