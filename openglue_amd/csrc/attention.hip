@@ -477,7 +477,10 @@ __device__ __forceinline__ f32x16 og_attn_mfma(f16x8 a, f16x8 b, f32x16 c) {
 // range of the same 128 queries, each with its own K/V ring, and merge their (O, m, l) through LDS at the end -- a workgroup is alone on
 // its CU then, and its latency is the number of key tiles a wave walks through (16 at 1024 keys: 26 us per launch at any small batch).
 template <int DH, class RD, int KS = 1>
-__global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void attention_dma_kernel(AttnArgs a, RD rd) {      // (dh = 32 would fit three workgroups per CU: measured 4 % slower)
+#ifndef OG_ATTN_WG32
+#define OG_ATTN_WG32 2        // workgroups per CU the dh = 32 instantiation is compiled for (experiment: 3)
+#endif
+__global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2) void attention_dma_kernel(AttnArgs a, RD rd) {      // (dh = 32 would fit three workgroups per CU: measured 4 % slower)
     static_assert(DH == 64 || DH == 32, "head rows of 128 or 64 bytes");
     constexpr int NDV = DH / 32, NCH = DH / 16;
     constexpr int ROWB = DH * 2;                    // bytes of a head row of one plane: a full 128-byte line (dh = 64) or half of one

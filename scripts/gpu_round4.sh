@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-4 reference measurement: smoke, the bench line of the driver (defaults: 50 steps / 10 warm-up, CPU baseline), C1/C3/C4/C5 lines WITH
 # their CPU baselines, B=1 / B=4 / B=64 lines at the C2 shape, rocprofv3 kernel stats of C2..C5, optionally ("pmc") the SQ counter and
-# traffic passes.   usage: OG_COMMIT=<hash> gpu_round4.sh <tag> [pmc] [tests]
+# traffic passes; kernel stats of B=1 / B=4 steps; the granted shader clock per kernel.   usage: OG_COMMIT=<hash> gpu_round4.sh <tag> [pmc] [tests]
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
@@ -33,6 +33,14 @@ for c in C2 C3 C4 C5; do
   f=$(find /tmp/prof_${TAG}_$c -name "*kernel_stats.csv" | head -1)
   if [ -n "$f" ]; then cp $f $OUT/${TAG}_kernel_stats_$c.csv; echo "== $c"; head -9 $OUT/${TAG}_kernel_stats_$c.csv | cut -c1-150; else tail -5 /tmp/prof_${TAG}_$c.log; fi
 done
+# the small-batch kernels (mlp_small_kernel, proj_small_kernel, the key-split attention): kernel stats of a single-pair and a four-pair step
+for b in 1 4; do
+  ( cd /tmp && rm -rf /tmp/prof_${TAG}_B$b && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG}_B$b -o run -- python $GRAFT_REPO_ROOT/bench.py --batch $b --steps 20 --warmup 5 --no-cpu-baseline > /tmp/prof_${TAG}_B$b.log 2>&1 )
+  f=$(find /tmp/prof_${TAG}_B$b -name "*kernel_stats.csv" | head -1)
+  if [ -n "$f" ]; then cp $f $OUT/${TAG}_kernel_stats_B$b.csv; echo "== B=$b"; head -7 $OUT/${TAG}_kernel_stats_B$b.csv | cut -c1-150; fi
+done
+# the shader clock the chip grants each hot kernel and the whole C2 step (power cap)
+timeout 300 python scripts/clock_under_load.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_clock_under_load.log; tail -3 $OUT/${TAG}_clock_under_load.log | cut -c1-200
 if [[ " $* " == *" pmc "* ]]; then
   bash scripts/gpu_pmc.sh > $OUT/${TAG}_pmc.log 2>&1; tail -3 $OUT/${TAG}_pmc.log
   bash scripts/gpu_traffic.sh > $OUT/${TAG}_traffic.log 2>&1
