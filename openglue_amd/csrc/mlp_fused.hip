@@ -988,7 +988,7 @@ int og_launch_mlp_fused(const MlpFusedArgs& a, int D, hipStream_t stream) {
     if (((uintptr_t)a.XO & 15) || ((uintptr_t)a.wstream & 15) || (a.ld & 7) || a.ld < 4 * (int64_t)D) return OG_E_ALIGN;
     if ((int64_t)MT * a.ld * 2 >= (int64_t)1 << 31) return OG_E_SHAPE;              // 32-bit lane offsets are relative to the TILE's first row (baseX is 64-bit)
     if (!(a.scale != 0.f) || !std::isfinite(a.scale)) return OG_E_INVALID;
-    if (og_mlp_small_wanted(a.M)) {
+    if (og_mlp_small_wanted(a.M) && !(((uintptr_t)a.b0 | (uintptr_t)a.b3) & 15)) {      // (mlp_small_kernel reads the biases as 16-byte vectors)
         hipLaunchKernelGGL(mlp_small_kernel<256>, dim3((a.M + SM_T - 1) / SM_T), dim3(512), 0, stream, a);
         return og_launch_status();
     }
@@ -1056,7 +1056,8 @@ bool og_pack_proj_stream(int N, int K, const double* W, void* out, double S) {
 int og_launch_proj_small(const _Float16* X, int64_t ld, int M, const char* wstream, const float* bias, const float* scale_dev,
                          _Float16* Ch, _Float16* Cl, int64_t ldc, int split_row, int a0, int a1, int b0, int b1, hipStream_t stream) {
     if (!X || !wstream || !bias || !scale_dev || !Ch || !Cl || M <= 0) return OG_E_INVALID;
-    if (((uintptr_t)X & 15) || ((uintptr_t)wstream & 15) || (ld & 7) || (ldc & 3) || ((uintptr_t)Ch & 7) || ((uintptr_t)Cl & 7)) return OG_E_ALIGN;
+    if (((uintptr_t)X & 15) || ((uintptr_t)wstream & 15) || ((uintptr_t)bias & 15) || (ld & 7) || (ldc & 3) || ((uintptr_t)Ch & 7) || ((uintptr_t)Cl & 7)) return OG_E_ALIGN;
+    if (a0 < 0 || b0 < 0 || a1 < a0 || b1 < b0 || ld < 2 * 256) return OG_E_SHAPE;
     if (split_row > 0 && split_row < M && (split_row % SM_T)) return OG_E_SHAPE;
     ProjSmallArgs g{X, ld, M, wstream, bias, scale_dev, Ch, Cl, ldc, split_row, a0, a1, b0, b1};
     hipLaunchKernelGGL(proj_small_kernel, dim3((M + SM_T - 1) / SM_T), dim3(512), 0, stream, g);
