@@ -83,7 +83,7 @@ PackedLayout packed_layout(const og_shape& s) {
 
 struct WorkspaceLayout {
     // float offsets; f16 planes take half a float per element, hl32 rows one float per element
-    int64_t x32, xo, qkvh, qkvl, h, g, ei, ea, eb, sbuf, sink, match, total;
+    int64_t x32, xo, qkvh, qkvl, h, g, ei, ea, eb, sbuf, sink, match, attn, total;      // attn: key-split scratch of attention.hip (counters, then partial results)
     int64_t lds;
 };
 
@@ -107,6 +107,7 @@ WorkspaceLayout workspace_layout(const og_shape& s) {
     W.sbuf = off; off = al64(off + (int64_t)s.batch * s.m * W.lds);
     W.sink = off; off = al64(off + (int64_t)(og_sinkhorn_workspace_bytes(s.batch, s.m, s.n) + 3) / 4);
     W.match = off; off = al64(off + (int64_t)(og_matches_workspace_bytes(s.batch, s.m, s.n) + 3) / 4);
+    W.attn = off; off = al64(off + OG_ATTN_COUNTERS + OG_ATTN_PARTIAL_FLOATS);       // 8.9 MB; used by launches of one or two pairs only
     W.total = off;
     return W;
 }
@@ -523,6 +524,8 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
 
     // ---- 2. attentional GNN (attention_gnn.py:84-93) ----
     const int dh = D / s.num_heads;
+    // the arrival counters of the key-split attention launches (one or two pairs) start at zero; the kernels re-arm them themselves
+    if (hipMemsetAsync(ws + W.attn, 0, OG_ATTN_COUNTERS * sizeof(int), st) != hipSuccess) return OG_E_INVALID;
     auto attention = [&](int nz, int split, int64_t qb0, int64_t qs0, int nq0, int64_t kb0, int64_t ks0, int nk0,
                          int64_t qb1, int64_t qs1, int nq1, int64_t kb1, int64_t ks1, int nk1, int rag_mode) -> int {
         AttnArgs a{};
@@ -532,6 +535,7 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
         a.feat = favor ? WQ : 0;
         a.oh = XO + D2; a.ol = XO + D2 + 32; a.ldo = D4; a.o_hl = 1;        // O = channels D..2D-1 of the [x | O] rows
         a.nz = nz; a.num_heads = s.num_heads; a.dh = dh; a.split = split;
+        a.counters = reinterpret_cast<int*>(ws + W.attn); a.partial = ws + W.attn + OG_ATTN_COUNTERS;
         a.q_base[0] = qb0; a.q_step[0] = qs0; a.nq[0] = nq0; a.kv_base[0] = kb0; a.kv_step[0] = ks0; a.nk[0] = nk0;
         a.q_base[1] = qb1; a.q_step[1] = qs1; a.nq[1] = nq1; a.kv_base[1] = kb1; a.kv_step[1] = ks1; a.nk[1] = nk1;
         Scope sc(prof, OG_STAGE_ATTENTION);

@@ -476,7 +476,10 @@ __device__ __forceinline__ f32x16 og_attn_mfma(f16x8 a, f16x8 b, f32x16 c) {
 // KS = 2 (few workgroups: one or a few image pairs, og_launch_attention): an 8-wave workgroup whose two halves take the two halves of the KEY
 // range of the same 128 queries, each with its own K/V ring, and merge their (O, m, l) through LDS at the end -- a workgroup is alone on
 // its CU then, and its latency is the number of key tiles a wave walks through (16 at 1024 keys: 26 us per launch at any small batch).
-template <int DH, class RD, int KS = 1>
+// GS = 2 / 4 (ONE or two pairs: fewer workgroups than a quarter / half of the CUs): the key tiles of a query tile are dealt to GS WORKGROUPS
+// (same XCD); each writes its unnormalised (O, m, l) to scratch, and the workgroup that arrives last (one counter per query tile) merges the
+// GS partial results in index order -- deterministic -- and runs the normal epilogue.
+template <int DH, class RD, int KS = 1, int GS = 1>
 #ifndef OG_ATTN_WG32
 #define OG_ATTN_WG32 2        // workgroups per CU the dh = 32 instantiation is compiled for (experiment: 3)
 #endif
@@ -492,10 +495,12 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
     static_assert(KS == 1 || KS == 2, "key split");
     __shared__ __attribute__((aligned(1024))) char smem_all[KS * 2 * BUFB];
 
+    static_assert(GS == 1 || (KS == 1 && DH == 64), "the workgroup-level key split is built for dh = 64, 4-wave workgroups");
     const int id = blockIdx.x;
     const int xcd = id & 7, local = id >> 3;
-    const int grp = (local / a.qtiles) * 8 + xcd;          // (problem, head) group: all its query tiles on one XCD
+    const int grp = (local / (a.qtiles * GS)) * 8 + xcd;   // (problem, head) group: all its query tiles (and key parts) on one XCD
     if (grp >= a.nz * a.num_heads) return;
+    const int qt_part = local % (a.qtiles * GS), qt = qt_part / GS, part = qt_part % GS;
     const int z = grp / a.num_heads, h = grp - z * a.num_heads;
     const int gsel = z < a.split ? 0 : 1;
     const int zz = gsel ? z - a.split : z;
@@ -512,7 +517,7 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
         q_row0 = q_is0 ? r0 : r1; nq = q_is0 ? m_b : n_b;
         kv_row0 = kv_is0 ? r0 : r1; nk = kv_is0 ? m_b : n_b;
     }
-    const int q0 = (local % a.qtiles) * Q_TILE;
+    const int q0 = qt * Q_TILE;
     if (q0 >= nq) return;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -524,6 +529,14 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
     // key tiles of this half: [t_begin, t_begin + ntiles) of the problem's ceil(nk / 64); everything below sees only "its" keys
     const int nk_all = nk;
     int ntiles_other = 0;                                 // KS = 2: tiles of the other half (the halves must meet at the same barriers)
+    if constexpr (GS > 1) {
+        const int nt_all = (nk_all + KV_TILE - 1) / KV_TILE, per = (nt_all + GS - 1) / GS;
+        const int t_begin = part * per < nt_all ? part * per : nt_all, t_end = t_begin + per < nt_all ? t_begin + per : nt_all;
+        kv_row0 += (int64_t)t_begin * KV_TILE;
+        const int k_end = t_end * KV_TILE < nk_all ? t_end * KV_TILE : nk_all;
+        nk = k_end - t_begin * KV_TILE;                   // 0: a part past the last tile
+        if (nk < 0) nk = 0;
+    }
     if constexpr (KS == 2) {
         const int nt_all = (nk_all + KV_TILE - 1) / KV_TILE, t_half = (nt_all + 1) / 2;
         const int t_begin = half ? t_half : 0, t_end = half ? nt_all : t_half;
@@ -922,6 +935,53 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
         l_run = l_run * a0 + l1 * a1;
         m_run = m;
     }
+    if constexpr (GS > 1) {
+        constexpr int PSTRIDE = (16 * NDV + 2) * 64;      // floats per wave: [register][lane]
+        float* const tile_base = a.partial + ((int64_t)(grp * a.qtiles + qt) * GS * 4) * PSTRIDE;
+        float* const mine = tile_base + (part * 4 + wave) * PSTRIDE + lane;
+        // Agent-scope (sc1) accesses one by one, no fence: a device-scope release fence writes the WHOLE L2 back on this part (the first
+        // version, with __threadfence(): attention 0.72 -> 1.16 ms per single-pair step); the stores are complete when vmcnt reaches 0.
+        auto st = [](float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+#pragma unroll
+        for (int d = 0; d < NDV; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st(mine + (d * 16 + r) * 64, oacc[d][r]);
+        st(mine + (16 * NDV) * 64, ntiles == 0 ? -1e30f : m_run);      // an empty part weighs nothing in the merge
+        st(mine + (16 * NDV + 1) * 64, l_run);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my partial result has reached the coherence point ...
+        __syncthreads();                                   // ... and so has everybody's of this workgroup (and nobody reads the rings any more)
+        int* const s_last = reinterpret_cast<int*>(smem_all);
+        if (tid == 0) {
+            int* const cnt = a.counters + grp * a.qtiles + qt;
+            const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == GS - 1) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // the last arriver re-arms the counter for the next launch
+            *s_last = old == GS - 1;
+        }
+        __syncthreads();
+        if (!*s_last) return;
+        // merge the GS partial results in index order (the same order whoever arrives last): m = max, O and l rescaled to it
+        auto ld = [](const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+        const float* const src = tile_base + wave * PSTRIDE + lane;
+        float mp[GS], m = -1e30f;
+#pragma unroll
+        for (int p = 0; p < GS; ++p) { mp[p] = ld(src + (int64_t)p * 4 * PSTRIDE + (16 * NDV) * 64); m = fmaxf(m, mp[p]); }
+        l_run = 0.f;
+#pragma unroll
+        for (int d = 0; d < NDV; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+#pragma unroll
+        for (int p = 0; p < GS; ++p) {
+            const float w = __builtin_amdgcn_exp2f(mp[p] - m);
+            const float* const sp = src + (int64_t)p * 4 * PSTRIDE;
+            l_run += ld(sp + (16 * NDV + 1) * 64) * w;
+#pragma unroll
+            for (int d = 0; d < NDV; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[d][r] += ld(sp + (d * 16 + r) * 64) * w;
+        }
+        m_run = m;
+    }
     // ---- normalise and store O[q][h*DH + dv] ----
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.f / l_tot;
@@ -955,6 +1015,39 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
 
 }  // namespace
 
+namespace {
+__global__ void xcc_probe_kernel(unsigned* out) {
+    if (threadIdx.x == 0) out[blockIdx.x] = __builtin_amdgcn_s_getreg(20 | (31 << 11)) & 0x00F0000Fu;      // HW_REG_XCC_ID: XCC_ID [3:0], DIE_ID [23:20]
+}
+}  // namespace
+
+// The workgroup-level key split lets the parts of a query tile meet through one L2: plain agent-scope accesses, no device-wide fence.  That is only
+// right if workgroup i of a 1-D grid really runs on XCD i mod 8 (what the blockIdx -> (problem, head) mapping of every kernel here assumes for
+// SPEED).  Checked once per process with a probe launch on a private stream; any failure or another dispatch order switches the split off.
+static bool og_xcd_round_robin_ok() {
+    static const bool ok = [] {
+        constexpr int N = 1024;
+        unsigned* dev = nullptr;
+        hipStream_t st = nullptr;
+        bool good = false;
+        if (hipMalloc((void**)&dev, N * sizeof(unsigned)) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess) {
+            unsigned host[N];
+            hipLaunchKernelGGL(xcc_probe_kernel, dim3(N), dim3(64), 0, st, dev);
+            if (hipMemcpyAsync(host, dev, sizeof(host), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess) {
+                good = true;
+                for (int i = 8; i < N; ++i) good &= host[i] == host[i & 7];
+                for (int i = 1; i < 8; ++i)
+                    for (int j = 0; j < i; ++j) good &= host[i] != host[j];          // eight distinct XCDs, each seeing every eighth workgroup
+            }
+        }
+        if (st) (void)hipStreamDestroy(st);
+        if (dev) (void)hipFree(dev);
+        (void)hipGetLastError();
+        return good;
+    }();
+    return ok;
+}
+
 int og_launch_attention(const AttnArgs& a, hipStream_t stream) {
     if (!a.qh || !a.ql || !a.kh || !a.kl || !a.vh || !a.vl || !a.oh || !a.ol || a.nz <= 0 || a.num_heads <= 0) return OG_E_INVALID;
     if ((a.ldq & 7) || (a.ldk & 7) || (a.ldv & 7) || (a.ldo & 3)) return OG_E_ALIGN;
@@ -986,6 +1079,29 @@ int og_launch_attention(const AttnArgs& a, hipStream_t stream) {
     for (int g = 0; g < 2; ++g) {
         const bool used = g == 0 ? a.split > 0 : a.split < a.nz;
         if (used && a.nk[g] < nkmin) nkmin = a.nk[g];
+    }
+    // One or two pairs (the grid covers at most half of the CUs) and scratch at hand: the key tiles of a query tile go to 2 or 4 workgroups
+    // (attention_dma_kernel<64, ., 1, GS>).  OG_ATTN_GSPLIT=0 / 2 / 4 forces.
+    static const int gs_mode = [] { const char* e = getenv("OG_ATTN_GSPLIT"); return e ? atoi(e) : -1; }();
+    int gs = 1;
+    if (dma && a.dh == 64 && a.partial && a.counters && (int)grid.x <= OG_ATTN_COUNTERS) {
+        if (gs_mode >= 0) gs = gs_mode == 2 || gs_mode == 4 ? gs_mode : 1;
+        else if ((int)grid.x * 4 <= 256 && (a.rag || nkmin >= 16 * KV_TILE)) gs = 4;
+        else if ((int)grid.x * 2 <= 256 && (a.rag || nkmin >= 8 * KV_TILE)) gs = 2;
+        if ((int)grid.x * gs > 256 && gs_mode < 0) gs = 1;
+        if ((int64_t)grid.x * gs * 4 * 34 * 64 > OG_ATTN_PARTIAL_FLOATS) gs = 1;
+        if (gs > 1 && !og_xcd_round_robin_ok()) gs = 1;
+    }
+    if (gs > 1) {
+        dim3 g2(grid.x * gs);
+        if (a.rag) {
+            if (gs == 4) hipLaunchKernelGGL((attention_dma_kernel<64, RaggedDesc, 1, 4>), g2, block, 0, stream, a2, rd);
+            else hipLaunchKernelGGL((attention_dma_kernel<64, RaggedDesc, 1, 2>), g2, block, 0, stream, a2, rd);
+        } else {
+            if (gs == 4) hipLaunchKernelGGL((attention_dma_kernel<64, RaggedNone, 1, 4>), g2, block, 0, stream, a2, RaggedNone{});
+            else hipLaunchKernelGGL((attention_dma_kernel<64, RaggedNone, 1, 2>), g2, block, 0, stream, a2, RaggedNone{});
+        }
+        return og_launch_status();
     }
     const bool ksplit = dma && a.dh == 64 && (ks_mode >= 0 ? ks_mode != 0 : ((int)grid.x <= 256 && (a.rag || nkmin >= 4 * KV_TILE)));
     if (ksplit) {

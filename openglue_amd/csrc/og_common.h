@@ -189,6 +189,8 @@ bool og_pack_proj_stream(int N, int K, const double* W, void* out, double S);
 int og_launch_proj_small(const _Float16* X, int64_t ld, int M, const char* wstream, const float* bias, const float* scale_dev,
                          _Float16* Ch, _Float16* Cl, int64_t ldc, int split_row, int a0, int a1, int b0, int b1, hipStream_t stream);
 
+constexpr int OG_ATTN_COUNTERS = 256;                                   // (problem, head, query tile) triples of a key-split launch
+constexpr int64_t OG_ATTN_PARTIAL_FLOATS = (int64_t)256 * 4 * 34 * 64;     // 256 workgroups x 4 waves x (32 O registers + m + l) x 64 lanes
 struct AttnArgs {
     const _Float16* qh; const _Float16* ql; int64_t ldq;     // leading dimensions in halves
     const _Float16* kh; const _Float16* kl; int64_t ldk;
@@ -205,6 +207,8 @@ struct AttnArgs {
     int rag_mode;             // 2 = cross, queries of image 0 attend image 1, 3 = cross, image 1 attends image 0
     int feat;                 // og_launch_favor_attention only: random features per head (columns of q and k; v / out have dh columns)
     float* lse;               // optional (uniform single-geometry calls): [nz][num_heads][nq] row log-sum-exp of the scaled scores, natural units
+    float* partial;           // optional scratch of OG_ATTN_PARTIAL_FLOATS floats + int* counters of OG_ATTN_COUNTERS zeroed ints: with both set, launches of
+    int* counters;            // very few workgroups split the KEY range of a query tile over 2 or 4 workgroups (attention.hip: GS)
 };
 int og_launch_attention(const AttnArgs& a, hipStream_t stream);
 int og_launch_linear_attention(const AttnArgs& a, hipStream_t stream);   // attention = 'linear' (elu+1 feature map)
