@@ -26,6 +26,7 @@
 //   * 3-slot weight ring + 3-slot token ring in LDS, LDS-DMA two stages ahead, one s_barrier per stage; waits counted by hand.
 //
 // Per 128-token tile: 9216 MFMAs (73.7k matrix-pipe cycles per SIMD); traffic per tile 1.5 MB of weights (L2) + 2 x 256 KB of tokens.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <cmath>
@@ -802,6 +803,7 @@ struct ProjSmallArgs {
     const float* scale_dev;                    // DEVICE: 1 / pre-scale of the matrix
     _Float16* Ch; _Float16* Cl; int64_t ldc;   // output planes [M][ldc]
     int split_row, a0, a1, b0, b1;             // block ranges (units of 32 output channels)
+    int parts, bpp;                            // very few rows: the block range of a token tile dealt to `parts` workgroups, bpp blocks each
 };
 
 template <int NB>
@@ -899,8 +901,14 @@ __global__ __launch_bounds__(512) void proj_small_kernel(ProjSmallArgs g) {
     __shared__ __attribute__((aligned(16))) char smem[SM_T * PS_ROW];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int t0 = blockIdx.x * SM_T;
-    const int cb0 = t0 < g.split_row ? g.a0 : g.b0, cb1 = t0 < g.split_row ? g.a1 : g.b1;
+    // (the division runs on the vector ALU: back to SGPRs at once -- the fragment loads below take their base address in SGPRs through inline asm,
+    //  and a v_readfirstlane right in front of such a load is a VALU-writes-SGPR -> VMEM hazard the compiler does not see: the first version of
+    //  this split faulted on a stale base)
+    const int tile = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / g.parts));
+    const int t0 = tile * SM_T, part = (int)blockIdx.x - tile * g.parts;
+    const int r0 = t0 < g.split_row ? g.a0 : g.b0, r1 = t0 < g.split_row ? g.a1 : g.b1;
+    const int cb0 = __builtin_amdgcn_readfirstlane(r0 + part * g.bpp);
+    const int cb1 = __builtin_amdgcn_readfirstlane(cb0 + g.bpp < r1 ? cb0 + g.bpp : r1);
     if (cb1 <= cb0) return;
     // ---- x halves of the token rows -> LDS: thread (row tid >> 4, 16-byte column tid & 15 + 16 j), 1 KiB per row ----
     {
@@ -1059,8 +1067,14 @@ int og_launch_proj_small(const _Float16* X, int64_t ld, int M, const char* wstre
     if (((uintptr_t)X & 15) || ((uintptr_t)wstream & 15) || ((uintptr_t)bias & 15) || (ld & 7) || (ldc & 3) || ((uintptr_t)Ch & 7) || ((uintptr_t)Cl & 7)) return OG_E_ALIGN;
     if (a0 < 0 || b0 < 0 || a1 < a0 || b1 < b0 || ld < 2 * 256) return OG_E_SHAPE;
     if (split_row > 0 && split_row < M && (split_row % SM_T)) return OG_E_SHAPE;
-    ProjSmallArgs g{X, ld, M, wstream, bias, scale_dev, Ch, Cl, ldc, split_row, a0, a1, b0, b1};
-    hipLaunchKernelGGL(proj_small_kernel, dim3((M + SM_T - 1) / SM_T), dim3(512), 0, stream, g);
+    // One or two pairs: a token tile's output blocks go to several workgroups, 8 blocks (one per wave) each -- nothing to reduce, and a workgroup
+    // streams 256 KB of weights instead of the whole matrix (the per-CU weight stream is what bounds these kernels).
+    const int tiles = (M + SM_T - 1) / SM_T, nblk = (a1 - a0) > (b1 - b0) ? (a1 - a0) : (b1 - b0);
+    int parts = 1, bpp = nblk > 0 ? nblk : 1;
+    static const bool split_on = [] { const char* e = getenv("OG_PROJ_PARTS"); return !(e && e[0] == '0'); }();      // OG_PROJ_PARTS=0: one workgroup per token tile
+    if (split_on && nblk > 8 && tiles * ((nblk + 7) / 8) <= 256) { parts = (nblk + 7) / 8; bpp = 8; }
+    ProjSmallArgs g{X, ld, M, wstream, bias, scale_dev, Ch, Cl, ldc, split_row, a0, a1, b0, b1, parts, bpp};
+    hipLaunchKernelGGL(proj_small_kernel, dim3(tiles * parts), dim3(512), 0, stream, g);
     return og_launch_status();
 }
 
