@@ -110,18 +110,21 @@ def roofline_block(counts_per_step, stages, launches, num_iters, measured_on_thi
     # kernel -> (profiler stage, algorithmic work per step, peak, PMC / traffic key, description)
     kernels = {
         "attention_dma_kernel": ("attention", counts_per_step["attention_flops"], PEAK_F16_MFMA_TFLOPS, "attention",
-                                 "split-f16 flash attention (dh = 64, 32: K/V tiles by LDS-DMA; dh = 16: attention_kernel); executes 3x the algorithmic flops"),
+                                 "split-f16 flash attention (dh = 64, 32: K/V tiles by LDS-DMA; dh = 16: attention_kernel; one to four pairs: the key-split forms of the "
+                                 "same kernel); executes 3x the algorithmic flops"),
         "gemm_nt_f16x3 (stand-alone)": ("gemm_f16x3", counts_per_step["gemm_f16x3_flops"] - (counts_per_step["mlp_flops"] if mlp_ms > 0 else 0.0),
                                         PEAK_F16_MFMA_TFLOPS, "gemm_f16x3_standalone",
                                         "gemm_nt_f16x3_big2_kernel (256x256 tiles: q/k/v projections) / gemm_nt_f16x3_kernel (128-token tiles: last encoder "
-                                        "conv, final projection; the message MLP when it is not fused) / gemm_nt_f16x3_big_kernel (batched score matrix); "
+                                        "conv, final projection; the message MLP when it is not fused) / gemm_nt_f16x3_big_kernel (batched score matrix) / "
+                                        "proj_small_kernel (q/k/v projections of launches of <= 8192 rows); "
                                         "split-f16 3-pass MFMA: executes 3x the algorithmic flops"),
         "gemm_nt_f32_kernel": ("gemm_f32", counts_per_step["gemm_f32_flops"], PEAK_F32_MFMA_TFLOPS, "gemm_f32",
                                "keypoint-encoder MLP without its last conv; exact fp32 MFMA"),
     }
     if mlp_ms > 0:
         kernels["mlp_fused_kernel"] = ("mlp_fused", counts_per_step["mlp_flops"], PEAK_F16_MFMA_TFLOPS, "mlp_fused",
-                                       "message MLP of a GNN layer (fc.0 -> ReLU -> fc.3 + residual) in one launch, hidden activation in registers; "
+                                       "message MLP of a GNN layer (fc.0 -> ReLU -> fc.3 + residual) in one launch, hidden activation in registers "
+                                       "(launches of <= 8192 rows: mlp_small_kernel, 32-token workgroups); "
                                        "split-f16 3-pass MFMA: executes 3x the algorithmic flops")
     roofs, ms_of = {}, {}
     for name, (stage, work, peak, key, desc) in kernels.items():
