@@ -22,10 +22,15 @@
 //                               each.  (The k order inside an MFMA is free as long as A and B agree.)
 // Q is expected PRE-SCALED by d^-1/2 * log2(e) (folded into the packed q-projection weights): the
 // softmax then runs in the base-2 domain, p = 2^(s - m) is one v_exp_f32 with no extra multiply.
-// The running max is only advanced (and O, l rescaled) when some row's max grew by more than 2^11
-// in the current tile ("deferred rescale"): p stays <= 2^11, well inside f16 range, and the rescale of O
-// leaves the common path.  The QKᵀ accumulator is initialised with -m_run, so in the common path the
-// exponent arguments s - m_run come straight from the matrix pipe (no per-element subtract).
+// The running max is only advanced (and O, l rescaled) when it has to ("deferred rescale"): the QKᵀ accumulator is initialised with
+// -m_run, so in the common path the exponent arguments s - m_run come straight from the matrix pipe (no per-element subtract) and the
+// rescale of O leaves the common path.  attention_kernel (register-staged, dh = 16) computes the tile maximum and advances when a row's
+// max grew by more than 2^11; attention_dma_kernel (dh = 64 / 32, the hot one) does not even compute the maximum per tile: it reads the
+// need off the row sum it forms anyway (a lane whose 32 exponentials add up to <= 2^15 holds no p above 2^15: inside f16 range).
+// This file is compiled WITHOUT packed-fp32 instructions (openglue_amd/build.py: a v_pk_*_f32 does not issue while the other wave of
+// the SIMD keeps the matrix pipe busy).  Launch forms of attention_dma_kernel: 4 waves / two workgroups per CU (batches); KS = 2, an
+// 8-wave workgroup whose halves split the key range (<= one workgroup per CU); GS = 2 / 4, the key range of a query tile split over
+// workgroups that meet in scratch (one or two pairs) -- og_launch_attention picks.
 // I/O: q, k, v arrive as f16 (hi, lo) PLANES written by the producing GEMM's epilogue and O leaves as planes
 // (it is the A operand of the fc.0 GEMM), so no conversion sits on the load path of either kernel.
 #include <cstdlib>

@@ -26,6 +26,10 @@
 //   * 3-slot weight ring + 3-slot token ring in LDS, LDS-DMA two stages ahead, one s_barrier per stage; waits counted by hand.
 //
 // Per 128-token tile: 9216 MFMAs (73.7k matrix-pipe cycles per SIMD); traffic per tile 1.5 MB of weights (L2) + 2 x 256 KB of tokens.
+//
+// Kernels in this file: mlp_fused_kernel (the above, 128-token tiles: batches); mlp_small_kernel (32-token workgroups whose waves split the
+// hidden dimension, weights straight from the same stream: launches of <= 8192 rows, i.e. one to four pairs); proj_small_kernel (the q / k / v
+// projections of such launches, 32-token workgroups whose waves split the OUTPUT blocks, its own fragment-major stream).
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
