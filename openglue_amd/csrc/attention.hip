@@ -33,6 +33,7 @@
 // workgroups that meet in scratch (one or two pairs) -- og_launch_attention picks.
 // I/O: q, k, v arrive as f16 (hi, lo) PLANES written by the producing GEMM's epilogue and O leaves as planes
 // (it is the A operand of the fc.0 GEMM), so no conversion sits on the load path of either kernel.
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -1029,28 +1030,33 @@ __global__ void xcc_probe_kernel(unsigned* out) {
 // The workgroup-level key split lets the parts of a query tile meet through one L2: plain agent-scope accesses, no device-wide fence.  That is only
 // right if workgroup i of a 1-D grid really runs on XCD i mod 8 (what the blockIdx -> (problem, head) mapping of every kernel here assumes for
 // SPEED).  Checked once per process with a probe launch on a private stream; any failure or another dispatch order switches the split off.
-static bool og_xcd_round_robin_ok() {
-    static const bool ok = [] {
-        constexpr int N = 1024;
-        unsigned* dev = nullptr;
-        hipStream_t st = nullptr;
-        bool good = false;
-        if (hipMalloc((void**)&dev, N * sizeof(unsigned)) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess) {
-            unsigned host[N];
-            hipLaunchKernelGGL(xcc_probe_kernel, dim3(N), dim3(64), 0, st, dev);
-            if (hipMemcpyAsync(host, dev, sizeof(host), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess) {
-                good = true;
-                for (int i = 8; i < N; ++i) good &= host[i] == host[i & 7];
-                for (int i = 1; i < 8; ++i)
-                    for (int j = 0; j < i; ++j) good &= host[i] != host[j];          // eight distinct XCDs, each seeing every eighth workgroup
-            }
+static bool og_xcd_round_robin_ok(hipStream_t caller) {
+    static std::atomic<int> state{0};                      // 0: not probed yet, 1: round robin verified, 2: anything else
+    const int s0 = state.load(std::memory_order_acquire);
+    if (s0) return s0 == 1;
+    // the probe allocates and synchronises: never while the caller's stream is being captured into a graph (the launch then takes the unsplit
+    // kernel; an eager call probes later)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(caller, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return false; }
+    constexpr int N = 1024;
+    unsigned* dev = nullptr;
+    hipStream_t st = nullptr;
+    bool good = false;
+    if (hipMalloc((void**)&dev, N * sizeof(unsigned)) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess) {
+        unsigned host[N];
+        hipLaunchKernelGGL(xcc_probe_kernel, dim3(N), dim3(64), 0, st, dev);
+        if (hipMemcpyAsync(host, dev, sizeof(host), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess) {
+            good = true;
+            for (int i = 8; i < N; ++i) good &= host[i] == host[i & 7];
+            for (int i = 1; i < 8; ++i)
+                for (int j = 0; j < i; ++j) good &= host[i] != host[j];          // eight distinct XCDs, each seeing every eighth workgroup
         }
-        if (st) (void)hipStreamDestroy(st);
-        if (dev) (void)hipFree(dev);
-        (void)hipGetLastError();
-        return good;
-    }();
-    return ok;
+    }
+    if (st) (void)hipStreamDestroy(st);
+    if (dev) (void)hipFree(dev);
+    (void)hipGetLastError();
+    state.store(good ? 1 : 2, std::memory_order_release);
+    return good;
 }
 
 int og_launch_attention(const AttnArgs& a, hipStream_t stream) {
@@ -1095,7 +1101,7 @@ int og_launch_attention(const AttnArgs& a, hipStream_t stream) {
         else if ((int)grid.x * 2 <= 256 && (a.rag || nkmin >= 8 * KV_TILE)) gs = 2;
         if ((int)grid.x * gs > 256 && gs_mode < 0) gs = 1;
         if ((int64_t)grid.x * gs * 4 * 34 * 64 > OG_ATTN_PARTIAL_FLOATS) gs = 1;
-        if (gs > 1 && !og_xcd_round_robin_ok()) gs = 1;
+        if (gs > 1 && !og_xcd_round_robin_ok(stream)) gs = 1;
     }
     if (gs > 1) {
         dim3 g2(grid.x * gs);
