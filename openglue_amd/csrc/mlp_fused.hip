@@ -1077,6 +1077,7 @@ int og_launch_proj_small(const _Float16* X, int64_t ld, int M, const char* wstre
     int parts = 1, bpp = nblk > 0 ? nblk : 1;
     static const bool split_on = [] { const char* e = getenv("OG_PROJ_PARTS"); return !(e && e[0] == '0'); }();      // OG_PROJ_PARTS=0: one workgroup per token tile
     if (split_on && nblk > 8 && tiles * ((nblk + 7) / 8) <= 256) { parts = (nblk + 7) / 8; bpp = 8; }
+    if (nblk > 24) { parts = (nblk + 7) / 8; bpp = 8; }          // a workgroup covers at most 3 blocks per wave: wider ranges are always dealt out
     ProjSmallArgs g{X, ld, M, wstream, bias, scale_dev, Ch, Cl, ldc, split_row, a0, a1, b0, b1, parts, bpp};
     hipLaunchKernelGGL(proj_small_kernel, dim3(tiles * parts), dim3(512), 0, stream, g);
     return og_launch_status();

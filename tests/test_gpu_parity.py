@@ -138,6 +138,17 @@ def test_mlp_block_fused_vs_float64(gpu_device, M):
     assert (two - out).abs().max().item() < 2e-5 + 1e-6 * ref.abs().max().item()
 
 
+def test_proj_block_wide_matrix(gpu_device):
+    """N = 1024 output channels (32 blocks): more than the 3 blocks per wave one workgroup covers -- the launcher must deal the range out."""
+    D, N, M = 256, 1024, 4000
+    g = torch.Generator().manual_seed(77)
+    x, w, b = _rand(g, M, D, scale=2.0), _rand(g, N, D, scale=0.06), _rand(g, N, scale=0.3)
+    out = ops.proj_block(x.to(gpu_device), w.to(gpu_device), b.to(gpu_device)).cpu()
+    x_in = ops.merge_f16_hl(ops.split_f16_hl(x.to(gpu_device))).cpu()
+    ref = x_in.double() @ w.double().T + b.double()
+    assert (out.double() - ref).abs().max().item() < 1e-5 + 2e-6 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("M,split,cols_a,cols_b", [(2048, 0, None, None), (1, 0, None, None), (33, 0, None, None), (8192, 0, None, (256, 768)),
                                                    (1000, 512, (0, 256), (0, 768)), (96, 64, (0, 256), (0, 768)), (777, 0, None, (0, 256))])
 def test_proj_block_small_batch_vs_float64(gpu_device, M, split, cols_a, cols_b):
