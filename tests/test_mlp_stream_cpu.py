@@ -94,6 +94,69 @@ def test_mlp_stream_numpy_emulation_of_the_kernel():
     assert err < 2e-5          # fp32 rounding of the hidden activation + the dropped lo*lo terms
 
 
+def test_mlp_small_kernel_addresses_the_same_stream():
+    """mlp_small_kernel (few token rows: 32-token workgroups, wave w owns hidden blocks 2w, 2w+1 in fc.0 and OUTPUT block w in fc.3) reads its weight
+    fragments straight from the big kernel's stream with per-wave address formulas (csrc/mlp_fused.hip: frag0 / frag3).  Emulated here with numpy,
+    fragment by fragment at exactly those byte offsets: it must reproduce x + W3 relu(W0 [x ; O] + b0) + b3."""
+    lib = _lib.load()
+    D = 256
+    g = torch.Generator().manual_seed(12)
+    w0 = (torch.randn(2 * D, 2 * D, generator=g) * 0.04).contiguous()
+    w3 = (torch.randn(D, 2 * D, generator=g) * 0.05).contiguous()
+    b0 = (torch.randn(2 * D, generator=g) * 0.3).double().numpy()
+    b3 = (torch.randn(D, generator=g) * 0.3).double().numpy()
+    st = torch.empty(lib.og_mlp_block_stream_bytes(D), dtype=torch.uint8)
+    assert lib.og_mlp_block_pack(D, w0.data_ptr(), w3.data_ptr(), st.data_ptr()) == 0
+    flat = st.numpy().view(np.float16).astype(np.float64)                     # the stream as halves
+    WSTAGE = 32768
+
+    def frag(byte_off):                                                        # one fragment: 1 KiB = [lane][8 halves]
+        assert byte_off % 1024 == 0
+        return flat[byte_off // 2:byte_off // 2 + 512].reshape(64, 8)
+
+    xo = (torch.randn(32, 2 * D, generator=g) * 1.5).double().numpy()
+    xh, xl = _split(xo)
+    xo_rep = xh + xl
+    lanes = np.arange(64)
+    tok, hh = lanes & 31, lanes >> 5
+    hid_h = np.zeros((16, 2, 64, 8)); hid_l = np.zeros((16, 2, 64, 8))       # the LDS hand-over: [hidden block][t][lane][e]
+    for w in range(8):                                                         # fc.0: wave w, hidden blocks 2w + j
+        a, q, i0 = w >> 2, (w >> 1) & 1, 2 * (w & 1)
+        for j in range(2):
+            hb = 2 * w + j
+            acc = np.zeros((64, 16))
+            for l in range(64):
+                for r in range(16):
+                    acc[l, r] = 256.0 * b0[32 * hb + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)]
+            for ks in range(32):
+                kg, t = ks >> 1, ks & 1
+                cols = (32 * kg + 16 * t + 8 * hh)[:, None] + np.arange(8)[None, :]
+                bh, bl = xh[tok[:, None], cols], xl[tok[:, None], cols]
+                base = (24 * q + kg) * WSTAGE + ((((a * 2 + t) * 4 + i0 + j) * 2) << 10)          # frag0(dst, j, kg, t, part)
+                wh, wl = frag(base), frag(base + 1024)
+                _mfma_32x32x16(wl, bh, acc); _mfma_32x32x16(wh, bl, acc); _mfma_32x32x16(wh, bh, acc)
+            v = np.maximum(acc.astype(np.float32) * np.float32(1.0 / 256.0), 0).astype(np.float64)
+            vh, vl = _split(v)
+            for t in range(2):
+                hid_h[hb, t], hid_l[hb, t] = vh[:, 8 * t:8 * t + 8], vl[:, 8 * t:8 * t + 8]      # element e of k-step t = accumulator register 8 t + e
+    out = np.zeros((32, D))
+    for w in range(8):                                                         # fc.3: wave w, output block w over all 16 hidden blocks
+        acc = np.zeros((64, 16))
+        for hb in range(16):
+            for t in range(2):
+                base = (24 * ((hb >> 2) & 1) + 16 + 2 * (hb & 3) + t) * WSTAGE + ((((hb >> 3) * 8 + w) * 2) << 10)      # frag3(dst, hb, t, part)
+                wh, wl = frag(base), frag(base + 1024)
+                _mfma_32x32x16(wl, hid_h[hb, t], acc); _mfma_32x32x16(wh, hid_l[hb, t], acc); _mfma_32x32x16(wh, hid_h[hb, t], acc)
+        for l in range(64):
+            for r in range(16):
+                ch = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
+                out[l & 31, ch] = acc[l, r] / 256.0 + b3[ch] + xo_rep[l & 31, ch]
+    ref = xo_rep[:, :D] + np.maximum(xo_rep @ w0.double().numpy().T + b0, 0) @ w3.double().numpy().T + b3
+    err = np.abs(out - ref).max()
+    print(f"emulated small kernel vs float64: {err:.2e}")
+    assert err < 2e-5
+
+
 def test_mlp_stream_range_error():
     lib = _lib.load()
     D = 256
