@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define OG_ABI_VERSION 7
+#define OG_ABI_VERSION 8
 
 #define OG_E_INVALID   (-1)  /* NULL pointer / non-positive size                         */
 #define OG_E_SHAPE     (-2)  /* unsupported shape (see og_check_shape)                   */
@@ -345,6 +345,11 @@ int og_sinkhorn_schedule_ragged(int32_t batch, const int32_t* lens0, const int32
  * out4 = {W, X, Gx, pairs per launch} -- workgroup tiles of (128 / W) rows x (1024 W) columns, X column blocks (one per XCD) x Gx row blocks;
  * returns 0, or OG_E_SHAPE when the shape has no resident geometry (more than 4096 rows or columns: streaming kernels). */
 int og_sinkhorn_resident_geometry(int32_t m, int32_t n, int32_t* out4);
+/* Host arithmetic only (8 XCDs x 32 CUs assumed): the resident launches a RAGGED batch of per-pair sizes takes and the bytes of the
+ * resident exchange slot the widest of them touches, out2 = {launches, bytes}; OG_E_SHAPE when some pair has no one-XCD geometry (the
+ * batch streams).  The slot og_sinkhorn_workspace_bytes(batch, max m, max n) reserves is sized for the widest tile class any pair with
+ * n_b <= max n can take, so `bytes` always fits it (tests/test_boundary_cpu.py checks that over random plans). */
+int og_sinkhorn_resident_ragged_footprint(int32_t batch, const int32_t* lens0, const int32_t* lens1, int64_t* out2);
 /* The same check for the workspace of an og_forward / og_forward_ragged call with this shape (for ragged calls: the shape
  * that was passed, i.e. the maxima).  Waits like og_sinkhorn_status (NULL stream only).  Return values as og_sinkhorn_status. */
 int og_forward_status(const og_shape* shape, const void* workspace_dev);

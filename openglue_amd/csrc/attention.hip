@@ -1029,9 +1029,13 @@ __global__ void xcc_probe_kernel(unsigned* out) {
 
 // The workgroup-level key split lets the parts of a query tile meet through one L2: plain agent-scope accesses, no device-wide fence.  That is only
 // right if workgroup i of a 1-D grid really runs on XCD i mod 8 (what the blockIdx -> (problem, head) mapping of every kernel here assumes for
-// SPEED).  Checked once per process with a probe launch on a private stream; any failure or another dispatch order switches the split off.
+// SPEED).  Checked once per process AND DEVICE with a probe launch on a private stream; any failure or another dispatch order switches the split off.
 static bool og_xcd_round_robin_ok(hipStream_t caller) {
-    static std::atomic<int> state{0};                      // 0: not probed yet, 1: round robin verified, 2: anything else
+    constexpr int MAXDEV = 64;
+    static std::atomic<int> states[MAXDEV];                // per DEVICE -- 0: not probed yet, 1: round robin verified, 2: anything else
+    int dev_id = 0;
+    if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= MAXDEV) { (void)hipGetLastError(); return false; }
+    std::atomic<int>& state = states[dev_id];
     const int s0 = state.load(std::memory_order_acquire);
     if (s0) return s0 == 1;
     // the probe allocates and synchronises: never while the caller's stream is being captured into a graph (the launch then takes the unsplit

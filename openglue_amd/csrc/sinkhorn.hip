@@ -942,29 +942,30 @@ extern "C" int og_sinkhorn_schedule_ragged(int32_t batch, const int32_t* lens0, 
     return launches;
 }
 
-// Reads the two status words with ONE stream-ordered copy each on a private non-blocking stream created for the call -- after
-// waiting, through an event recorded on the NULL stream, for the work the caller has already enqueued there; callers on other
-// streams synchronise their stream first (openglue_amd/superglue.py does).  No device-wide synchronisation, nothing left behind.
+// Reads the two status words on a private non-blocking stream -- after waiting, through an event recorded on the NULL stream, for the
+// work the caller has already enqueued there; callers on other streams synchronise their stream first (openglue_amd/superglue.py drains
+// the stream the call was enqueued on).  No device-wide synchronisation.  The copies land in a pinned-by-lifetime heap block, and the
+// private stream is drained on EVERY path before anything it may still write to goes away (the first version returned from
+// an error path with an asynchronous copy into its stack frame still pending).
 extern "C" int og_sinkhorn_status(const void* workspace_dev, int32_t batch, int32_t m, int32_t n) {
     if (!workspace_dev || batch <= 0 || m <= 0 || n <= 0 || n > 8192) return -1;
     const SinkhornWs w = sk_layout(const_cast<void*>(workspace_dev), batch, m, n);
     const bool has_res = og_sinkhorn_resident_ws_bytes(batch, m, n) != 0;
-    unsigned bad = 0, st = 0;
+    unsigned words[2] = {0, 0};                          // {non-finite flag, resident status}
     hipStream_t q = nullptr;
     if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) return -1;
     int rc = 0;
     hipEvent_t ev = nullptr;
     if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, nullptr) != hipSuccess ||
         hipStreamWaitEvent(q, ev, 0) != hipSuccess) rc = -1;
-    if (!rc && hipMemcpyAsync(&bad, w.flags, sizeof(bad), hipMemcpyDeviceToHost, q) != hipSuccess) rc = -1;
-    if (!rc && has_res && hipMemcpyAsync(&st, w.flags + 1, sizeof(st), hipMemcpyDeviceToHost, q) != hipSuccess) rc = -1;
-    if (!rc && hipStreamSynchronize(q) != hipSuccess) rc = -1;
+    if (!rc && hipMemcpyAsync(&words[0], w.flags, sizeof(unsigned) * (has_res ? 2 : 1), hipMemcpyDeviceToHost, q) != hipSuccess) rc = -1;
+    if (hipStreamSynchronize(q) != hipSuccess) rc = -1;  // always: nothing of this call is in flight past this line
     if (ev) (void)hipEventDestroy(ev);
     (void)hipStreamDestroy(q);
     if (rc) return rc;
-    if (bad) return 3;                                  // non-finite scores were written
+    if (words[0]) return 3;                              // non-finite scores were written
     if (!has_res) return 0;
-    return st == 0 ? 0 : st == 2 ? 2 : 1;
+    return words[1] == 0 ? 0 : words[1] == 2 ? 2 : 1;
 }
 
 extern "C" int og_sinkhorn(const float* S, int64_t lds, float dustbin, int32_t batch, int32_t m, int32_t n,

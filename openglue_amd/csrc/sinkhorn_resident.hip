@@ -896,8 +896,11 @@ bool og_sinkhorn_resident_shape_ok(int B, int m, int n) {
 
 size_t og_sinkhorn_resident_ws_bytes(int B, int m, int n) {
     if (!og_sinkhorn_resident_shape_ok(B, m, n)) return 0;
-    const RsGeom q = rs_geom(m, n);
-    return rs_area_bytes(q.W, RS_MAXWG, RS_MAXPAIRS);
+    // A ragged batch launches every width class with ITS OWN W, and a pair narrower in rows can take a wider tile than the maxima
+    // (m_max, n_max) would (2100 x 900 next to 1000 x 2100: the maxima give W = 1, the second pair W = 4): the slot is sized for the widest
+    // class any pair of n_b <= n can fall into, not for rs_geom(m, n).W.
+    const int Wmax = n <= RS_SEG ? 1 : n <= 2 * RS_SEG ? 2 : 4;
+    return rs_area_bytes(Wmax, RS_MAXWG, RS_MAXPAIRS);
 }
 
 // The tile geometry of one pair on a part with 8 XCDs x 32 CUs (pure host arithmetic, no device needed: CPU tests): out = {W, X, Gx,
@@ -974,8 +977,8 @@ int og_launch_sinkhorn_resident(const float* S, int64_t lds, const float* zdev, 
 namespace {
 struct RsPlanPair { int b, W, G; };
 // false: some pair has no resident geometry (or needs more than one XCD): the caller streams the whole batch
-bool rs_ragged_plan(const RaggedDesc& rd, RsPlanPair* pp) {
-    if (rd.B <= 0 || rd.B > OG_MAX_RAGGED || rs_num_cus() < 256) return false;
+bool rs_ragged_plan(const RaggedDesc& rd, RsPlanPair* pp, int cus) {
+    if (rd.B <= 0 || rd.B > OG_MAX_RAGGED || cus < 256) return false;
     for (int b = 0; b < rd.B; ++b) {
         const RsGeom q = rs_geom(rd.off0[b + 1] - rd.off0[b], rd.off1[b + 1] - rd.off1[b]);
         if (q.W == 0 || q.X != 1) return false;
@@ -983,37 +986,14 @@ bool rs_ragged_plan(const RaggedDesc& rd, RsPlanPair* pp) {
     }
     return true;
 }
-}  // namespace
-
-bool og_sinkhorn_resident_ragged_wanted(const RaggedDesc& rd, int mode) {
-    if (mode <= 0) return false;
-    RsPlanPair pp[OG_MAX_RAGGED];
-    if (!rs_ragged_plan(rd, pp)) return false;
-    if (mode >= 2) return true;
-    int64_t elems = 0;
-    for (int b = 0; b < rd.B; ++b) elems += (int64_t)(rd.off0[b + 1] - rd.off0[b]) * (rd.off1[b + 1] - rd.off1[b]);
-    return elems >= (int64_t)1 << 18;
+// bytes of the exchange slot (from its first byte, the status word) one ragged launch of width class W touches
+size_t rs_ragged_launch_bytes(int W, int slots, int groups) {
+    const size_t NCX = (size_t)RS_SEG * W + RS_PAD;
+    return 256 + (size_t)RS_MAXWG * sizeof(unsigned) + (size_t)2 * slots * NCX * 8 + (size_t)2 * groups * NCX * 8;   // (ragged pairs: one column block, no row records)
 }
-
-int og_launch_sinkhorn_resident_ragged(const float* S, int64_t lds, const float* zdev, float zhost, const RaggedDesc& rd, int m_max, int n_max, int iters,
-                                       float inv_reg, float* u, int ldu, const float* v_in, float* v_out, int ldv, void* xws, unsigned* status,
-                                       hipStream_t st, bool trusted_padding, int* count_only) {
-    if (!count_only && (!S || !u || !v_in || !v_out || !xws || !status || iters < 1)) return OG_E_INVALID;
-    RsPlanPair pp[OG_MAX_RAGGED];
-    if (!rs_ragged_plan(rd, pp)) return OG_E_SHAPE;
-    if (count_only) *count_only = 0;
-    hipError_t e = hipSuccess;
-    SkResArgs a{};
-    a.S = S; a.lds = lds; a.strideS = (int64_t)m_max * lds;
-    a.u = u; a.ldu = ldu; a.v_in = v_in; a.v_out = v_out; a.ldv = ldv;
-    a.status = status;
-    a.xcc = (unsigned*)((char*)xws + 256);
-    a.xa = (char*)xws + 256 + RS_MAXWG * sizeof(unsigned);
-    { const char* ev = getenv("OG_SINKHORN_AGENT_SCOPE"); a.force_agent_scope = ev && atoi(ev) != 0; }
-    a.zdev = zdev; a.zhost = zhost; a.inv_reg = inv_reg;
-    a.m = m_max; a.n = n_max; a.iters = iters; a.local_ok = 1;
-    (void)trusted_padding;
-    a.sanitize_pad = 1;     // columns [n_b, lds) of a ragged pair's rows were never written by anybody: they may hold NaN / Inf
+// The launches of a ragged batch, pure host arithmetic: f(W, map, np, slots, qmax) once per launch, widest class first.
+template <class F>
+void rs_ragged_for_each_launch(const RaggedDesc& rd, RsPlanPair* pp, F&& f) {
     // largest pairs first (stable: ties keep the batch order)
     for (int i = 1; i < rd.B; ++i) { const RsPlanPair t = pp[i]; int j = i; while (j > 0 && pp[j - 1].G < t.G) { pp[j] = pp[j - 1]; --j; } pp[j] = t; }
     bool done[OG_MAX_RAGGED] = {};
@@ -1049,19 +1029,80 @@ int og_launch_sinkhorn_resident_ragged(const float* S, int64_t lds, const float*
                 }
             }
             if (np == 0) break;
-            if (count_only) { ++*count_only; continue; }
-            const size_t NCX = (size_t)RS_SEG * W + RS_PAD;
-            a.b0 = 0; a.npairs = np; a.slots = slots; a.groups = np;
-            a.xb = a.xa + (size_t)2 * a.slots * NCX * 8;
-            a.xc = a.xb + (size_t)2 * a.groups * NCX * 8;
-            e = hipMemsetAsync(a.xcc, 0, RS_MAXWG * sizeof(unsigned) + (size_t)2 * a.slots * NCX * 8 + (size_t)2 * a.groups * NCX * 8, st);   // (ragged pairs: one column block, no row records)
-            if (e != hipSuccess) return (int)e;
-            const int grid = 8 * qmax;
-            if (W == 1) rs_launch<1>(a, map, grid, st);
-            else if (W == 2) rs_launch<2>(a, map, grid, st);
-            else rs_launch<4>(a, map, grid, st);
+            f(W, map, np, slots, qmax);
         }
     }
-    return count_only ? 0 : og_launch_status();
+}
+}  // namespace
+
+bool og_sinkhorn_resident_ragged_wanted(const RaggedDesc& rd, int mode) {
+    if (mode <= 0) return false;
+    RsPlanPair pp[OG_MAX_RAGGED];
+    if (!rs_ragged_plan(rd, pp, rs_num_cus())) return false;
+    if (mode >= 2) return true;
+    int64_t elems = 0;
+    for (int b = 0; b < rd.B; ++b) elems += (int64_t)(rd.off0[b + 1] - rd.off0[b]) * (rd.off1[b + 1] - rd.off1[b]);
+    return elems >= (int64_t)1 << 18;
 }
 
+// Host arithmetic only (a part with 8 XCDs x 32 CUs assumed; CPU tests): the launches a ragged batch of per-pair sizes would take and the
+// bytes of the resident exchange slot the widest of them touches; out2 = {launches, bytes}.  OG_E_SHAPE: some pair has no one-XCD geometry
+// (the batch streams).  The slot og_sinkhorn_workspace_bytes(batch, max m, max n) reserves must hold `bytes`.
+extern "C" int og_sinkhorn_resident_ragged_footprint(int32_t batch, const int32_t* lens0, const int32_t* lens1, int64_t* out2) {
+    if (!lens0 || !lens1 || !out2 || batch <= 0 || batch > OG_MAX_RAGGED) return OG_E_INVALID;
+    RaggedDesc rd{};
+    rd.B = batch;
+    for (int b = 0; b < batch; ++b) {
+        if (lens0[b] <= 0 || lens1[b] <= 0) return OG_E_SHAPE;
+        rd.off0[b + 1] = rd.off0[b] + lens0[b]; rd.off1[b + 1] = rd.off1[b] + lens1[b];
+    }
+    RsPlanPair pp[OG_MAX_RAGGED];
+    if (!rs_ragged_plan(rd, pp, 256)) return OG_E_SHAPE;
+    int64_t launches = 0, bytes = 0;
+    rs_ragged_for_each_launch(rd, pp, [&](int W, const RsRagged&, int np, int slots, int) {
+        ++launches;
+        const int64_t by = (int64_t)rs_ragged_launch_bytes(W, slots, np);
+        if (by > bytes) bytes = by;
+    });
+    out2[0] = launches; out2[1] = bytes;
+    return 0;
+}
+
+int og_launch_sinkhorn_resident_ragged(const float* S, int64_t lds, const float* zdev, float zhost, const RaggedDesc& rd, int m_max, int n_max, int iters,
+                                       float inv_reg, float* u, int ldu, const float* v_in, float* v_out, int ldv, void* xws, unsigned* status,
+                                       hipStream_t st, bool trusted_padding, int* count_only) {
+    if (!count_only && (!S || !u || !v_in || !v_out || !xws || !status || iters < 1)) return OG_E_INVALID;
+    RsPlanPair pp[OG_MAX_RAGGED];
+    if (!rs_ragged_plan(rd, pp, rs_num_cus())) return OG_E_SHAPE;
+    if (count_only) *count_only = 0;
+    const size_t ws_bytes = og_sinkhorn_resident_ws_bytes(rd.B, m_max, n_max);      // what the caller's slot holds
+    SkResArgs a{};
+    a.S = S; a.lds = lds; a.strideS = (int64_t)m_max * lds;
+    a.u = u; a.ldu = ldu; a.v_in = v_in; a.v_out = v_out; a.ldv = ldv;
+    a.status = status;
+    a.xcc = (unsigned*)((char*)xws + 256);
+    a.xa = (char*)xws + 256 + RS_MAXWG * sizeof(unsigned);
+    { const char* ev = getenv("OG_SINKHORN_AGENT_SCOPE"); a.force_agent_scope = ev && atoi(ev) != 0; }
+    a.zdev = zdev; a.zhost = zhost; a.inv_reg = inv_reg;
+    a.m = m_max; a.n = n_max; a.iters = iters; a.local_ok = 1;
+    (void)trusted_padding;
+    a.sanitize_pad = 1;     // columns [n_b, lds) of a ragged pair's rows were never written by anybody: they may hold NaN / Inf
+    int rc = 0;
+    rs_ragged_for_each_launch(rd, pp, [&](int W, const RsRagged& map, int np, int slots, int qmax) {
+        if (count_only) { ++*count_only; return; }
+        if (rc) return;
+        if (rs_ragged_launch_bytes(W, slots, np) > ws_bytes) { rc = OG_E_SHAPE; return; }      // never past the slot (cannot happen: the slot is sized for W = 4 whenever n_max allows it)
+        const size_t NCX = (size_t)RS_SEG * W + RS_PAD;
+        a.b0 = 0; a.npairs = np; a.slots = slots; a.groups = np;
+        a.xb = a.xa + (size_t)2 * a.slots * NCX * 8;
+        a.xc = a.xb + (size_t)2 * a.groups * NCX * 8;
+        const hipError_t e = hipMemsetAsync(a.xcc, 0, rs_ragged_launch_bytes(W, slots, np) - 256, st);
+        if (e != hipSuccess) { rc = (int)e; return; }
+        const int grid = 8 * qmax;
+        if (W == 1) rs_launch<1>(a, map, grid, st);
+        else if (W == 2) rs_launch<2>(a, map, grid, st);
+        else rs_launch<4>(a, map, grid, st);
+    });
+    if (rc) return rc;
+    return count_only ? 0 : og_launch_status();
+}

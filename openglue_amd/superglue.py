@@ -50,32 +50,14 @@ def _siren_container(*sizes: int) -> nn.Sequential:
     return nn.Sequential(*layers)
 
 
-def _reference_favor_base():
-    """`models.superglue.attention.FavorAttention` of the HOST application when this package is used inside the reference's tree (the
-    drop-in case), else None.  The reference's redraw callback (utils/lightning_callbacks.py:6-14) finds the modules to redraw with
-    `isinstance(module, FavorAttention)`: deriving the buffer container from the host's own class makes that callback work UNMODIFIED.
-    Nothing of the reference is copied or required: without it the container is a plain nn.Module with the same buffer and method."""
-    try:
-        from models.superglue.attention import FavorAttention          # noqa: the host application's module, if importable
-        return FavorAttention if isinstance(FavorAttention, type) and issubclass(FavorAttention, nn.Module) else None
-    except Exception:
-        return None
-
-
-_REF_FAVOR = _reference_favor_base()
-
-
-class _FavorFeatures(_REF_FAVOR or nn.Module):
+class _FavorFeatures(nn.Module):
     """Buffer container named like the reference's GeneralizedFavorAttention (attention.py:43-95; created by
     get_attention_mechanism(embed_dim, 'favor_relu'), __init__.py:19-25, as `mha.attention_func`): `projection_matrix`
     [2 * embed_dim, embed_dim], drawn like FavorAttention.sample_orthogonal_random_vectors, and `resample_projection()` for the
-    redraw callback (utils/lightning_callbacks.py:6-14).  Inside the reference's tree it IS a `FavorAttention` (see above); its
-    `forward` is never called -- the arithmetic runs in the HIP kernels on the packed projection."""
+    redraw callback (utils/lightning_callbacks.py:6-14).  Its `forward` is never called -- the arithmetic runs in the HIP kernels on
+    the packed projection."""
 
     def __init__(self, embed_dim: int):
-        if _REF_FAVOR is not None:
-            super().__init__(embed_dim, num_orthogonal_features=2 * embed_dim)      # registers `projection_matrix` with the host's own sampler
-            return
         super().__init__()
         from .synthetic import orthogonal_random_features
         self.embed_dim, self.num_orthogonal_features = embed_dim, 2 * embed_dim
@@ -83,11 +65,45 @@ class _FavorFeatures(_REF_FAVOR or nn.Module):
 
     @torch.no_grad()
     def resample_projection(self) -> None:
-        if _REF_FAVOR is not None:
-            return super().resample_projection()                                    # copy_ in place: bumps _version, the packed weights re-pack
         from .synthetic import orthogonal_random_features
         new = orthogonal_random_features(self.num_orthogonal_features, self.embed_dim)
         self.projection_matrix.copy_(new.to(self.projection_matrix.device))      # in place: bumps _version, the packed weights re-pack
+
+
+# The reference's redraw callback (utils/lightning_callbacks.py:6-14) finds the modules to redraw with `isinstance(module, FavorAttention)`,
+# FavorAttention being the HOST application's class (models/superglue/attention.py:43).  A host that wants that callback to work UNMODIFIED
+# registers its class once -- `openglue_amd.superglue.register_favor_base(FavorAttention)` -- or passes it per model
+# (`SuperGlue(config, favor_base=FavorAttention)`); the buffer containers then derive from it and use ITS sampler.  Explicit opt-in: nothing
+# is imported from the host's tree behind its back, and without a registration the container is the plain nn.Module above (the branch
+# the GPU box tests).  [Round 4 sniffed `models.superglue.attention` off sys.path at import time: class hierarchy and sampler depended on
+# the import order of the process.]
+_FAVOR_BASE: Optional[type] = None
+_HOSTED_FAVOR: dict = {}
+
+
+def register_favor_base(cls: Optional[type]) -> None:
+    """Make the FAVOR buffer containers of every SuperGlue constructed from now on instances of `cls` (the host's FavorAttention:
+    `cls(embed_dim, num_orthogonal_features=...)` must register a `projection_matrix` buffer and offer `resample_projection()`);
+    None restores the built-in container."""
+    global _FAVOR_BASE
+    if cls is not None and not (isinstance(cls, type) and issubclass(cls, nn.Module)):
+        raise TypeError("register_favor_base: expected an nn.Module subclass (the host's models.superglue.attention.FavorAttention) or None")
+    _FAVOR_BASE = cls
+
+
+def _favor_container(embed_dim: int, base: Optional[type]) -> nn.Module:
+    if base is None:
+        return _FavorFeatures(embed_dim)
+    cls = _HOSTED_FAVOR.get(base)
+    if cls is None:
+        # the host's own constructor registers `projection_matrix` with the host's sampler; its resample_projection() copies in place
+        cls = type("_HostedFavorFeatures", (base,), {"__doc__": "FAVOR buffer container derived from the registered host class; forward is never called."})
+        _HOSTED_FAVOR[base] = cls
+    mod = cls(embed_dim, num_orthogonal_features=2 * embed_dim)
+    pm = getattr(mod, "projection_matrix", None)
+    if not torch.is_tensor(pm) or tuple(pm.shape) != (2 * embed_dim, embed_dim) or not callable(getattr(mod, "resample_projection", None)):
+        raise TypeError(f"favor base {base.__name__}: expected a projection_matrix buffer [{2 * embed_dim}, {embed_dim}] and resample_projection()")
+    return mod
 
 
 class _Holder(nn.Module):
@@ -124,9 +140,10 @@ class _EvalFastPathOutputs(torch.autograd.Function):
 
 
 class SuperGlue(nn.Module):
-    def __init__(self, config: Mapping):
+    def __init__(self, config: Mapping, favor_base: Optional[type] = None):
         super().__init__()
         self.config = config
+        favor_base = favor_base if favor_base is not None else _FAVOR_BASE       # explicit: register_favor_base() / this argument
         pe = dict(config["positional_encoding"])
         gnn = dict(config["attention_gnn"])
         enc_name = pe.get("encoder_name", "FeedForwardNet")
@@ -161,7 +178,7 @@ class SuperGlue(nn.Module):
         self.positional_encoding = _Holder(encoder=make_enc(2 + self.side_info_size, *self.hidden, D))
         layers = nn.ModuleList()
         for _ in range(2 * self.num_stages):       # even = self, odd = cross (attention_gnn.py:84-89)
-            favor = dict(attention_func=_FavorFeatures(D)) if self.favor_relu else {}
+            favor = dict(attention_func=_favor_container(D, favor_base)) if self.favor_relu else {}
             mha = _Holder(**favor, in_proj_q=nn.Conv1d(D, D, 1), in_proj_k=nn.Conv1d(D, D, 1),
                           in_proj_v=nn.Conv1d(D, D, 1), out_proj=nn.Conv1d(D, D, 1))
             layers.append(_Holder(module=_Holder(mha=mha, fc=_mlp_container(2 * D, 2 * D, D))))
@@ -238,9 +255,9 @@ class SuperGlue(nn.Module):
         last = getattr(self, "_last_call", None)
         if last is None:
             return 0
-        shape, ws = last
+        shape, ws, stream = last
         with torch.cuda.device(ws.device):
-            torch.cuda.current_stream(ws.device).synchronize()      # og_forward_status only waits for the NULL stream: the call's own stream is ours to drain
+            stream.synchronize()      # the stream the call was ENQUEUED on (not whatever is current now): og_forward_status itself only waits for the NULL stream
             rc = _lib.load().og_forward_status(C.byref(shape), ws.data_ptr())
         if rc == 2:
             import warnings
@@ -350,7 +367,7 @@ class SuperGlue(nn.Module):
         with torch.cuda.device(dev):
             packed = self._pack(dev)
             ws = self._get_workspace(dev, (B, m, n), lib.og_workspace_bytes(C.byref(shape)))
-            self._last_call = (shape, ws)
+            self._last_call = (shape, ws, torch.cuda.current_stream(dev))      # check_status() drains THIS stream
             out = {
                 "context_descriptors0": torch.empty(B, D, m, device=dev, dtype=torch.float32),
                 "context_descriptors1": torch.empty(B, D, n, device=dev, dtype=torch.float32),
@@ -481,7 +498,7 @@ class SuperGlue(nn.Module):
             with torch.cuda.device(dev):
                 pk = self._pack(dev)
                 ws = self._get_workspace(dev, ("ragged", B, max(l0), max(l1)), lib.og_workspace_bytes(C.byref(shape)))
-                self._last_call = (shape, ws)     # the ragged path takes the resident Sinkhorn schedule too: check_status() covers it
+                self._last_call = (shape, ws, torch.cuda.current_stream(dev))     # the ragged path takes the resident Sinkhorn schedule too: check_status() covers it
                 scores = torch.empty(n_scores, device=dev, dtype=torch.float32)
                 m0 = torch.empty(T0, device=dev, dtype=torch.int64)
                 s0 = torch.empty(T0, device=dev, dtype=torch.float32)

@@ -45,9 +45,9 @@ def test_oracle_equals_live_reference(m, n, kw):
 
 def test_favor_redraw_callback_works_unmodified_inside_the_reference_tree():
     """Drop-in detail (VERDICT r3 missing 7): the reference's FavorAttentionProjectionRedrawCallback (utils/lightning_callbacks.py:6-14) finds
-    the modules to redraw with isinstance(module, FavorAttention).  With the reference's tree importable -- the drop-in case -- the buffer
-    containers of openglue_amd.SuperGlue ARE instances of the host's FavorAttention, so the callback's loop redraws them as it stands.  A
-    fresh interpreter: the base class is chosen when openglue_amd.superglue is imported."""
+    the modules to redraw with isinstance(module, FavorAttention).  Once the host registers its class (register_favor_base: explicit,
+    VERDICT r4 weak 9 -- no sys.path sniffing at import) the buffer containers of openglue_amd.SuperGlue ARE instances of the host's
+    FavorAttention, so the callback's loop redraws them as it stands; without the registration they are the built-in container."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = f"""
@@ -55,8 +55,15 @@ import sys; sys.path.insert(0, {REF!r}); sys.path.insert(0, {root!r})
 import torch
 from models.superglue.attention import FavorAttention
 from openglue_amd import synthetic as syn
+from openglue_amd import superglue as ogs
 from openglue_amd.superglue import SuperGlue
 cfg = syn.make_config(descriptor_dim=64, num_stages=1, num_heads=1, num_iters=3, attention='favor_relu')
+plain = SuperGlue(cfg)                                  # nothing registered: the built-in container, whatever sys.path holds
+assert not any(isinstance(m, FavorAttention) for m in plain.modules())
+assert len([m for m in plain.modules() if isinstance(m, ogs._FavorFeatures)]) == 2
+per_model = SuperGlue(cfg, favor_base=FavorAttention)   # per-model switch
+assert len([m for m in per_model.modules() if isinstance(m, FavorAttention)]) == 2
+ogs.register_favor_base(FavorAttention)                 # the host's one-line opt-in (INTEGRATION.md)
 model = SuperGlue(cfg)
 mods = [m for m in model.modules() if isinstance(m, FavorAttention)]
 assert len(mods) == 2, len(mods)                       # one self layer + one cross layer
