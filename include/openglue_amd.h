@@ -166,7 +166,7 @@ typedef struct og_packed_layout_t {
     int64_t o_wmlp;   /* ABI v5: per layer, the SAME folded w0 / w3 once more as the fragment-major stream og_mlp_block consumes
                          (og_mlp_block_stream_bytes(D) bytes; -1 when D has no fused message-MLP kernel)                         */
     int64_t o_wqkvs;  /* ABI v7: per layer, the q | k | v matrix once more as the fragment-major stream og_proj_block consumes (the
-                         small-batch projection kernel; og_proj_block_stream_bytes(3D, D) bytes; -1: D != 256 or favor_relu)   */
+                         small-batch projection kernel; og_proj_block_stream_bytes(3D, D) bytes; -1: D not 256 / 128, or favor_relu)   */
 } og_packed_layout_t;
 int og_packed_layout(const og_shape* shape, og_packed_layout_t* layout);
 
@@ -279,19 +279,20 @@ int og_gemm_nt_f16x3_reshl(const void* A, int64_t lda, const void* B, int64_t ld
  * og_pack_weights does) as ONE launch, in place on M token rows of hl32 rows [x | O] (4D halves used per row, row stride ld halves):
  *     x <- x + W3 relu(W0 [x ; O] + b0) + b3,     W0 [2D][2D], W3 [D][2D] row-major fp32, b0 [2D], b3 [D] (device).
  * The hidden activation lives in registers (csrc/mlp_fused.hip); the weights are consumed as a fragment-major stream of (hi, lo)
- * halves of 256 w that og_mlp_block_pack writes on the host (og_mlp_block_stream_bytes(D) bytes, 0 = D not supported: D == 256).
+ * halves of 256 w that og_mlp_block_pack writes on the host (og_mlp_block_stream_bytes(D) bytes, 0 = D not supported: D == 256, and since
+ * ABI v8 D == 128, the reference's SIFT / HardNet descriptor width).
  * Same arithmetic as og_gemm_nt_f16x3 (relu) followed by og_gemm_nt_f16x3_reshl. */
 /* ABI v7.  A 1x1 conv of the residual stream for FEW token rows (the q / k / v projections of attention_gnn.py:43-47 when one or a few
  * image pairs are matched: og_forward uses it for launches of <= 8192 rows): y[M][N] = x W^T + bias on the x halves of M hl32 rows
- * (the first 2K halves of a row, row stride ld halves), W [N][K] row-major fp32, K = 256, N a multiple of 32; the result leaves as
+ * (the first 2K halves of a row, row stride ld halves), W [N][K] row-major fp32, K = 256 or (ABI v8) 128, N a multiple of 32; the result leaves as
  * (hi, lo) f16 planes yh / yl [M][ldy].  32-token workgroups whose 8 waves split the output blocks (csrc/mlp_fused.hip:
  * proj_small_kernel); the weights are consumed as a fragment-major stream of (hi, lo) halves of 256 w that og_proj_block_pack writes on
  * the host (og_proj_block_stream_bytes(N, K) bytes, 0 = shape not supported).  Rows below split_row get the output columns
  * [32 a0, 32 a1), the others [32 b0, 32 b1) (split_row a multiple of 32, or 0 / >= M for one range).  inv_scale_dev: DEVICE float,
- * 1 / 256 for streams packed here.  Same arithmetic as og_gemm_nt_f16x3. */
+ * 1 / 256 for streams packed here.  Same arithmetic as og_gemm_nt_f16x3.  ABI v8: og_proj_block takes K. */
 size_t og_proj_block_stream_bytes(int32_t N, int32_t K);
 int og_proj_block_pack(int32_t N, int32_t K, const float* W, void* stream_host);
-int og_proj_block(const void* x_rows, int64_t ld, int32_t M, const void* stream_dev, const float* bias, const float* inv_scale_dev,
+int og_proj_block(const void* x_rows, int64_t ld, int32_t M, int32_t K, const void* stream_dev, const float* bias, const float* inv_scale_dev,
                   void* yh, void* yl, int64_t ldy, int32_t split_row, int32_t a0, int32_t a1, int32_t b0, int32_t b1, void* stream);
 
 size_t og_mlp_block_stream_bytes(int32_t D);

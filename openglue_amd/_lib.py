@@ -103,7 +103,7 @@ SYMBOLS = {
                                          _vp, _vp, _i64, _i32, _vp]),
     "og_proj_block_stream_bytes": (_sz, [_i32, _i32]),
     "og_proj_block_pack": (C.c_int, [_i32, _i32, _vp, _vp]),
-    "og_proj_block": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "og_proj_block": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
     "og_mlp_block_stream_bytes": (_sz, [_i32]),
     "og_mlp_block_pack": (C.c_int, [_i32, _vp, _vp, _vp]),
     "og_mlp_block": (C.c_int, [_i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),

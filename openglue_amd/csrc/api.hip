@@ -553,7 +553,7 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
     };
     auto proj_small = [&](const float* lw, int64_t r0, int64_t R, int split_row, int a0, int a1, int b0, int b1) -> int {
         Scope sc(prof, OG_STAGE_GEMM_F16X3);
-        return og_launch_proj_small(XO + r0 * D4, D4, (int)R, (const char*)(lw + L.o_wqkvs), lw + L.o_bqkv, lw + L.o_scale,
+        return og_launch_proj_small(XO + r0 * D4, D4, (int)R, D, (const char*)(lw + L.o_wqkvs), lw + L.o_bqkv, lw + L.o_scale,
                                     QKVh + r0 * QW, QKVl + r0 * QW, QW, split_row, a0, a1, b0, b1, st);
     };
     auto qkv_proj = [&](const float* lw, int64_t r0, int64_t R, int c0, int c1) -> int {

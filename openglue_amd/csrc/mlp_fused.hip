@@ -83,10 +83,14 @@ __device__ unsigned og_mlp_trace_buf[OG_MT_BLOCKS][8][4][64];
 
 template <int D>
 __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpFusedArgs g) {
-    static_assert(D == 256, "instantiated for 256-d descriptors (8 output blocks, 2 halves x 2 quarters x 4 hidden blocks, 16 k-groups)");
-    constexpr int G0 = 2 * D / 32;            // k-groups of fc.0 (K = 2D)
-    constexpr int NJT = 8;                    // fc.3 stages per quarter: 4 hidden blocks x 2 k-steps
-    constexpr int NPASS = 2;                  // quarters per hidden half
+    static_assert(D == 256 || D == 128, "256-d: 8 output blocks, 2 hidden halves x 2 quarters x 4 hidden blocks, 16 k-groups; 128-d: 4 output blocks, 2 halves x 4 hidden blocks, 8 k-groups");
+    constexpr int G0 = 2 * D / 32;            // k-groups of fc.0 (K = 2D) = hidden blocks
+    constexpr int NOB = D / 32;               // output blocks
+    constexpr int NOBH = NOB / 2;             // ... each wave of a token block finishes
+    constexpr int HB2 = G0 / 2;               // hidden blocks per hidden half
+    constexpr int NPASS = HB2 / 4;            // passes of 4 hidden blocks per hidden half (256-d: the two quarters; 128-d: one)
+    // fc.3 stages per pass, 16 fragments per wave each.  256-d: (hidden block j, k-step t) x 8 output blocks; 128-d: hidden block j, BOTH k-steps x 4 output blocks
+    constexpr int NJT = D == 256 ? 8 : 4;
     constexpr int STAGES = NPASS * (G0 + NJT);
     constexpr int XSTAGES = NPASS * G0;
     constexpr int SMEM = BOFF + (2 * D + D) * 4;
@@ -197,11 +201,10 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpFusedArgs g) {
 
     // ---- prologue: the bias loads first (inline asm: the compiler must not drain the DMA pieces issued behind them), then W(0), X(0),
     //      W(1), X(1); the biases * 256 go to LDS in their shadow ----
-    static_assert(D == 256, "one b0 value per thread, one b3 value per thread pair");
-    float bv0, bv3;
+    float bv0, bv3;                           // (512 threads cover the 2D + D values at least once; duplicates write the same LDS word)
     {
-        const float* p0 = g.b0 + tid;
-        const float* p3 = g.b3 + (tid & 255);
+        const float* p0 = g.b0 + (tid & (2 * D - 1));
+        const float* p3 = g.b3 + (tid & (D - 1));
         asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off" : "=&v"(bv0), "=&v"(bv3) : "v"(p0), "v"(p3) : "memory");
     }
     issue_w4(0, 0); issue_x2(0, 0);
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpFusedArgs g) {
     const float sc0 = g.scales_dev ? g.scales_dev[0] : g.scale, sc3 = g.scales_dev ? g.scales_dev[1] : g.scale;
     {
         const float is0 = 1.f / sc0, is3 = 1.f / sc3;
-        const unsigned ba0 = lds0 + BOFF + (unsigned)tid * 4u, ba3 = lds0 + BOFF + (unsigned)(2 * D + (tid & 255)) * 4u;
+        const unsigned ba0 = lds0 + BOFF + (unsigned)(tid & (2 * D - 1)) * 4u, ba3 = lds0 + BOFF + (unsigned)(2 * D + (tid & (D - 1))) * 4u;
         asm volatile("s_waitcnt vmcnt(12)\n\t"          // the two bias loads are older than the 12 pieces
                      "v_mul_f32 %0, %0, %4\n\t"
                      "v_mul_f32 %1, %1, %5\n\t"
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpFusedArgs g) {
                      : "+v"(bv0), "+v"(bv3) : "v"(ba0), "v"(ba3), "s"(is0), "s"(is3) : "memory");
     }
 
-    f32x16 acc0[4], acc3[8];
+    f32x16 acc0[4], acc3[NOB];
     f16x8 wh[2], wl[2], xh[2], xl[2];
     auto lds_read = [&](f16x8& dst, unsigned addr, int imm) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm)); };
     // this wave's fragment (block b, part) of the current weight stage: (b * 2 + part) KiB behind the base of its hidden half
@@ -268,13 +271,18 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpFusedArgs g) {
 
     asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");       // my pieces of W(0), X(0) landed (W(1), X(1) may still fly), my bias stores too
     __builtin_amdgcn_s_barrier();                                     // ... everybody's
-    // fc.3 partial sums: the output blocks this wave finishes (4 ha .. 4 ha + 3) start from the bias, the ones it hands to its partner from 0
+    // fc.3 partial sums: the output blocks this wave finishes (NOBH ha .. NOBH ha + NOBH - 1) start from the bias, the ones it hands to its partner from 0
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < NOB; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc3[i][r] = 0.f;
-    if (ha == 0) { init_acc2(acc3[0], acc3[1], 2 * D); init_acc2(acc3[2], acc3[3], 2 * D + 64); }
-    else { init_acc2(acc3[4], acc3[5], 2 * D + 128); init_acc2(acc3[6], acc3[7], 2 * D + 192); }
+    if constexpr (D == 256) {
+        if (ha == 0) { init_acc2(acc3[0], acc3[1], 2 * D); init_acc2(acc3[2], acc3[3], 2 * D + 64); }
+        else { init_acc2(acc3[4], acc3[5], 2 * D + 128); init_acc2(acc3[6], acc3[7], 2 * D + 192); }
+    } else {
+        if (ha == 0) init_acc2(acc3[0], acc3[1], 2 * D);
+        else init_acc2(acc3[2], acc3[3], 2 * D + 64);
+    }
 
     int s = 0, wslot = 0;           // weight stage being consumed and its ring slot
     int xs = 0, xslot = 0;          // token stage being consumed (fc.0 stages only) and its ring slot
@@ -373,8 +381,8 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpFusedArgs g) {
 
 #pragma unroll 1
     for (int pass = 0; pass < NPASS; ++pass) {
-        init_acc2(acc0[0], acc0[1], (8 * ha + 4 * pass) * 32);
-        init_acc2(acc0[2], acc0[3], (8 * ha + 4 * pass + 2) * 32);
+        init_acc2(acc0[0], acc0[1], (HB2 * ha + 4 * pass) * 32);
+        init_acc2(acc0[2], acc0[3], (HB2 * ha + 4 * pass + 2) * 32);
 
         // ================= fc.0: acc0[i] += W0'[hidden block 8 ha + 4 pass + i][k-group] · [x ; O][k-group], 16 stages =================
         auto fc0_stage = [&](int kg, auto RB) {
@@ -401,12 +409,14 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpFusedArgs g) {
         };
         using NoRes = std::integral_constant<int, -1>;
         int kg0 = 0;
-        if (pass == NPASS - 1) {        // the x half of [x ; O] (k-groups 0..7) in the last quarter: unrolled, every stage knows its output block
+        if (pass == NPASS - 1) {        // the x half of [x ; O] (k-groups 0..NOB-1) in the last pass: unrolled, every stage knows its output block
             fc0_stage(0, std::integral_constant<int, 0>{}); fc0_stage(1, std::integral_constant<int, 1>{});
             fc0_stage(2, std::integral_constant<int, 2>{}); fc0_stage(3, std::integral_constant<int, 3>{});
-            fc0_stage(4, std::integral_constant<int, 4>{}); fc0_stage(5, std::integral_constant<int, 5>{});
-            fc0_stage(6, std::integral_constant<int, 6>{}); fc0_stage(7, std::integral_constant<int, 7>{});
-            kg0 = 8;
+            if constexpr (NOB == 8) {
+                fc0_stage(4, std::integral_constant<int, 4>{}); fc0_stage(5, std::integral_constant<int, 5>{});
+                fc0_stage(6, std::integral_constant<int, 6>{}); fc0_stage(7, std::integral_constant<int, 7>{});
+            }
+            kg0 = NOB;
         }
 #pragma unroll 1
         for (int kg = kg0; kg < G0; ++kg) fc0_stage(kg, NoRes{});
@@ -427,28 +437,59 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpFusedArgs g) {
         };
 #pragma unroll
         for (int st = 0; st < 4; ++st) convert_step(acc0[0], 0, st, 0);
+        if constexpr (D == 256) {
 #pragma unroll
-        for (int jt = 0; jt < NJT; ++jt) {
-            const bool iw = s + 2 < STAGES;
-            const int wslot2 = prev3(wslot);
-            const bool next_exists = s + 1 < STAGES;
-            const bool next_x = jt + 1 == NJT && pass + 1 < NPASS;      // the next stage is the first fc.0 stage of the next quarter
-            const int hb = jt & 1;
-            const f16x8 bh = __builtin_bit_cast(f16x8, og_u32x4{hh[hb][0], hh[hb][1], hh[hb][2], hh[hb][3]});
-            const f16x8 bl = __builtin_bit_cast(f16x8, og_u32x4{hl[hb][0], hl[hb][1], hl[hb][2], hl[hb][3]});
-            constexpr int NXT = 0;
-            (void)NXT;
-            // the next stage's B fragments: hidden block (jt + 1) / 2, k-step (jt + 1) & 1
-            auto conv = [&](int step) { if (jt + 1 < NJT) convert_step(acc0[(jt + 1 < NJT ? jt + 1 : jt) >> 1], (jt + 1) & 1, step, hb ^ 1); };
+            for (int jt = 0; jt < NJT; ++jt) {
+                const bool iw = s + 2 < STAGES;
+                const int wslot2 = prev3(wslot);
+                const bool next_exists = s + 1 < STAGES;
+                const bool next_x = jt + 1 == NJT && pass + 1 < NPASS;      // the next stage is the first fc.0 stage of the next quarter
+                const int hb = jt & 1;
+                const f16x8 bh = __builtin_bit_cast(f16x8, og_u32x4{hh[hb][0], hh[hb][1], hh[hb][2], hh[hb][3]});
+                const f16x8 bl = __builtin_bit_cast(f16x8, og_u32x4{hl[hb][0], hl[hb][1], hl[hb][2], hl[hb][3]});
+                constexpr int NXT = 0;
+                (void)NXT;
+                // the next stage's B fragments: hidden block (jt + 1) / 2, k-step (jt + 1) & 1
+                auto conv = [&](int step) { if (jt + 1 < NJT) convert_step(acc0[(jt + 1 < NJT ? jt + 1 : jt) >> 1], (jt + 1) & 1, step, hb ^ 1); };
 #define OG_SLOT_P0(k) { if ((k) == 2 && iw && !(OG_MLP_ABL & 8)) issue_w4(s + 2, wslot2); }
 #define OG_SLOT_P1(k) {}
 #define OG_SLOT_C2(k) conv((k) - 2)
 #define OG_SLOT_C3(k) conv((k))
-            OG_GROUP(acc3[0], acc3[1], bh, bl, 0, 3, 3, 3, 2, OG_SLOT_P0)
-            OG_GROUP(acc3[2], acc3[3], bh, bl, 1, 3, 3, 3, 2, OG_SLOT_P1)
-            OG_GROUP(acc3[4], acc3[5], bh, bl, 2, 3, 3, 3, 2, OG_SLOT_C2)
-            OG_GROUP_LAST(acc3[6], acc3[7], bh, bl, OG_SLOT_C3, hand_over(next_exists, next_x, xslot, iw ? 4 : 0), next_exists, next_x)
-            ++s; wslot = next3(wslot);
+                OG_GROUP(acc3[0], acc3[1], bh, bl, 0, 3, 3, 3, 2, OG_SLOT_P0)
+                OG_GROUP(acc3[2], acc3[3], bh, bl, 1, 3, 3, 3, 2, OG_SLOT_P1)
+                OG_GROUP(acc3[4], acc3[5], bh, bl, 2, 3, 3, 3, 2, OG_SLOT_C2)
+                OG_GROUP_LAST(acc3[6], acc3[7], bh, bl, OG_SLOT_C3, hand_over(next_exists, next_x, xslot, iw ? 4 : 0), next_exists, next_x)
+                ++s; wslot = next3(wslot);
+            }
+        } else {
+            // 128-d: stage j = hidden block j with BOTH k-steps over the 4 output blocks: groups 0, 1 take k-step 0 (B fragments in buffer 0), groups
+            // 2, 3 k-step 1 (buffer 1).  Conversions ride behind the MFMAs as above: k-step 1 of block j (into buffer 1) during groups 0, 1,
+            // k-step 0 of block j + 1 (into buffer 0, free once group 1 has issued) during groups 2, 3.
+#pragma unroll
+            for (int j = 0; j < NJT; ++j) {
+                const bool iw = s + 2 < STAGES;
+                const int wslot2 = prev3(wslot);
+                const bool next_exists = s + 1 < STAGES;
+                auto conv1 = [&](int step) { convert_step(acc0[j], 1, step, 1); };
+                auto conv0n = [&](int step) { if (j + 1 < NJT) convert_step(acc0[j + 1 < NJT ? j + 1 : j], 0, step, 0); };
+#define OG_SLOT_Q0(k) { if ((k) == 2 && iw && !(OG_MLP_ABL & 8)) issue_w4(s + 2, wslot2); conv1((k) - 2); }
+#define OG_SLOT_Q1(k) conv1((k))
+#define OG_SLOT_Q2(k) conv0n((k) - 2)
+#define OG_SLOT_Q3(k) conv0n((k))
+                {
+                    const f16x8 bh = __builtin_bit_cast(f16x8, og_u32x4{hh[0][0], hh[0][1], hh[0][2], hh[0][3]});
+                    const f16x8 bl = __builtin_bit_cast(f16x8, og_u32x4{hl[0][0], hl[0][1], hl[0][2], hl[0][3]});
+                    OG_GROUP(acc3[0], acc3[1], bh, bl, 0, 3, 3, 3, 2, OG_SLOT_Q0)
+                    OG_GROUP(acc3[2], acc3[3], bh, bl, 1, 3, 3, 3, 2, OG_SLOT_Q1)
+                }
+                {
+                    const f16x8 bh = __builtin_bit_cast(f16x8, og_u32x4{hh[1][0], hh[1][1], hh[1][2], hh[1][3]});
+                    const f16x8 bl = __builtin_bit_cast(f16x8, og_u32x4{hl[1][0], hl[1][1], hl[1][2], hl[1][3]});
+                    OG_GROUP(acc3[0], acc3[1], bh, bl, 2, 3, 3, 3, 2, OG_SLOT_Q2)
+                    OG_GROUP_LAST(acc3[2], acc3[3], bh, bl, OG_SLOT_Q3, hand_over(next_exists, false, xslot, iw ? 4 : 0), next_exists, false)
+                }
+                ++s; wslot = next3(wslot);
+            }
         }
     }
 #undef OG_GROUP
@@ -466,36 +507,36 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpFusedArgs g) {
     for (int it = 0; it < 4; ++it) {
         int r = tok0 + it * 8 + (lane >> 3);
         if (r > g.M - 1) r = g.M - 1;
-        rowb[it] = (int64_t)r * g.ld * 2 + (lane & 7) * 16 + 4 * ha * 128;
+        rowb[it] = (int64_t)r * g.ld * 2 + (lane & 7) * 16 + NOBH * ha * 128;
     }
     __syncthreads();          // every wave is past its last fragment reads, no DMA in flight: the rings are free
 
     // ================= the two waves of a token block exchange half of their partial sums =================
-    // Wave (tb, a) finishes output blocks 4a .. 4a+3 and hands its partial sums of the other four to its partner: 16 KiB per wave,
+    // Wave (tb, a) finishes output blocks NOBH a .. NOBH a + NOBH - 1 and hands its partial sums of the other NOBH to its partner: 16 KiB per wave at 256-d,
     // [block][register group][lane] x 16 B (conflict-free), region `wave`; afterwards the region a wave has READ belongs to it alone
     // (epilogue slabs).
-    f32x16 accf[4];
+    f32x16 accf[NOBH];
     {
         char* const mine = smem + wave * 16384;
         char* const theirs = smem + (wave ^ 1) * 16384;
         const bool lowhalf = ha == 0;                          // wave-uniform; element-wise selects keep the accumulators in registers
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NOBH; ++i)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = lowhalf ? acc3[4 + i][4 * q + e] : acc3[i][4 * q + e];
+                for (int e = 0; e < 4; ++e) v[e] = lowhalf ? acc3[NOBH + i][4 * q + e] : acc3[i][4 * q + e];
                 *reinterpret_cast<f32x4*>(mine + ((i * 4 + q) * 64 + lane) * 16) = v;
             }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NOBH; ++i) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(theirs + ((i * 4 + q) * 64 + lane) * 16);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) accf[i][4 * q + e] = (lowhalf ? acc3[i][4 * q + e] : acc3[4 + i][4 * q + e]) + v[e];
+                for (int e = 0; e < 4; ++e) accf[i][4 * q + e] = (lowhalf ? acc3[i][4 * q + e] : acc3[NOBH + i][4 * q + e]) + v[e];
             }
         }
     }
@@ -511,7 +552,7 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpFusedArgs g) {
         const unsigned rd_off = (unsigned)((lane >> 3) * ROWB + (lane & 7) * 16);
         const bool full = t0 + MT <= g.M;                    // block-uniform
 #pragma unroll
-        for (int ip = 0; ip < 2; ++ip) {
+        for (int ip = 0; ip < NOBH / 2; ++ip) {
             f32x16 a[2];
             a[0] = accf[2 * ip]; a[1] = accf[2 * ip + 1];
             // v = acc / S3 (bias and residual are inside the accumulator); pinned: og_split4 must see ONE rounded product
@@ -575,13 +616,21 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpFusedArgs g) {
 //     16 bytes sit at fragment base + 16 lane: one coalesced global_load_dwordx4 per fragment, no LDS staging -- no two waves share
 //     a fragment), a few k-steps ahead of their MFMAs.
 // Bound: the 1.5 MB weight stream every workgroup pulls from L2 (~64 B/clk per CU).
+// 128-d (the reference's SIFT / HardNet descriptor family): 8 hidden blocks = one per wave; the 4 output blocks x 2 halves of the hidden
+// dimension = 8 waves, the two partial sums of an output block meet in LDS (16 KB).  384 KB of weights per workgroup instead of 1.5 MB.
 constexpr int SM_T = 32;                       // tokens per workgroup
-constexpr int SM_ROW = 4 * 256 * 2 + 16;       // bytes of one padded LDS row: 4D halves + 16
 
 template <int D>
 __global__ __launch_bounds__(512) void mlp_small_kernel(MlpFusedArgs g) {
-    static_assert(D == 256, "8 waves x 2 hidden blocks of 32 = 2D; 8 output blocks");
-    __shared__ __attribute__((aligned(16))) char smem[SM_T * SM_ROW + 16 * 2 * 2 * 1024];      // the token tile (66 KB) + the hidden activation as B fragments (64 KB)
+    static_assert(D == 256 || D == 128, "256-d: 8 waves x 2 hidden blocks, 8 output blocks; 128-d: 8 waves x 1 hidden block, 4 output blocks x 2 hidden halves");
+    constexpr int SM_ROW = 4 * D * 2 + 16;     // bytes of one padded LDS row: 4D halves + 16
+    constexpr int G0 = 2 * D / 32;             // k-groups of fc.0 = hidden blocks (16 / 8)
+    constexpr int NJ = G0 / 8;                 // hidden blocks per wave in fc.0 (2 / 1)
+    constexpr int NOB = D / 32;                // output blocks (8 / 4)
+    constexpr int HB2 = G0 / 2, SPP = G0 + (D == 256 ? 8 : 4);      // hidden blocks per half, stages per pass of the big kernel's stream
+    constexpr int KS0 = 2 * G0;                // k-steps of fc.0 (32 / 16)
+    constexpr int NS3 = G0 * NOB / 8;          // fc.3 steps per wave (one hidden block, both k-steps, each): 16 / 4
+    __shared__ __attribute__((aligned(16))) char smem[SM_T * SM_ROW + G0 * 2 * 2 * 1024];      // the token tile (66 / 33 KB) + the hidden activation as B fragments (64 / 32 KB)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
@@ -596,8 +645,7 @@ __global__ __launch_bounds__(512) void mlp_small_kernel(MlpFusedArgs g) {
 #endif
     OG_ST(0);
 
-    // fragment addresses in the big kernel's stream (og_pack_mlp_stream): hidden block hb = 8 a + 4 q + i
-    const int a = wave >> 2, q = (wave >> 1) & 1, i0 = 2 * (wave & 1);
+    // fragment addresses in the big kernel's stream (og_pack_mlp_stream): hidden block hb = HB2 a + 4 q + i; this wave's are NJ wave + j
     // Weight fragments: inline-asm loads (scalar base + 16 lane) counted by hand -- left to the compiler every load sank down to its
     // use and each k-step waited for a full L2 round trip.  All asm statements carry a memory clobber, so no compiler-issued
     // vector-memory operation moves across them; the compiler's own loads (token rows, bias) are all issued AFTER the first fragments
@@ -610,8 +658,9 @@ __global__ __launch_bounds__(512) void mlp_small_kernel(MlpFusedArgs g) {
         return reinterpret_cast<const char*>((uintptr_t)(((uint64_t)hi32 << 32) | lo));
     };
     auto ldfrag = [&](f16x8& dst, const char* base) { asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(lane16), "s"(base) : "memory"); };
-    auto frag0 = [&](f16x8& dst, int j, int kg, int t, int part) {       // W0' rows of hidden block 2 wave + j, k-step (kg, t)
-        ldfrag(dst, sbase(g.wstream + (int64_t)(24 * q + kg) * WSTAGE + ((((a * 2 + t) * 4 + i0 + j) * 2 + part) << 10)));
+    auto frag0 = [&](f16x8& dst, int j, int kg, int t, int part) {       // W0' rows of hidden block NJ wave + j, k-step (kg, t)
+        const int hb = NJ * wave + j, a = hb / HB2, q = (hb % HB2) >> 2, i = hb & 3;
+        ldfrag(dst, sbase(g.wstream + (int64_t)(SPP * q + kg) * WSTAGE + ((((a * 2 + t) * 4 + i) * 2 + part) << 10)));
     };
     // "all but the n youngest loads have landed" (n a multiple of 4); the operands tie the wait to the registers it releases
     auto wait4 = [](int n, f16x8& r0, f16x8& r1, f16x8& r2, f16x8& r3) {
@@ -621,12 +670,25 @@ __global__ __launch_bounds__(512) void mlp_small_kernel(MlpFusedArgs g) {
         else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) :: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) :: "memory");
     };
-    constexpr int PF = 5;                      // k-steps of W0' fragments in flight (4 fragments each): 20 KB per wave
-    f16x8 wf[PF][4];
+    auto wait2 = [](int n, f16x8& r0, f16x8& r1) {      // n in {0, 2, .. 14}
+        switch (n) {
+            case 14: asm volatile("s_waitcnt vmcnt(14)" : "+v"(r0), "+v"(r1) :: "memory"); break;
+            case 12: asm volatile("s_waitcnt vmcnt(12)" : "+v"(r0), "+v"(r1) :: "memory"); break;
+            case 10: asm volatile("s_waitcnt vmcnt(10)" : "+v"(r0), "+v"(r1) :: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" : "+v"(r0), "+v"(r1) :: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" : "+v"(r0), "+v"(r1) :: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" : "+v"(r0), "+v"(r1) :: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" : "+v"(r0), "+v"(r1) :: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1) :: "memory"); break;
+        }
+    };
+    constexpr int FPK = 2 * NJ;                // fragments per k-step
+    constexpr int PF = D == 256 ? 5 : 8;       // k-steps of W0' fragments in flight: 20 / 16 KB per wave
+    f16x8 wf[PF][FPK];
 #pragma unroll
     for (int ks = 0; ks < PF; ++ks)
 #pragma unroll
-        for (int f = 0; f < 4; ++f) frag0(wf[ks][f], f >> 1, ks >> 1, ks & 1, f & 1);
+        for (int f = 0; f < FPK; ++f) frag0(wf[ks][f], f >> 1, ks >> 1, ks & 1, f & 1);
 
     // ---- token tile -> LDS: thread (row tid >> 4, 16-byte column tid & 15 + 16 j) ----
     {
@@ -634,22 +696,22 @@ __global__ __launch_bounds__(512) void mlp_small_kernel(MlpFusedArgs g) {
         if (r > g.M - 1) r = g.M - 1;          // rows past the matrix are clamped (computed, never stored)
         const char* src = rows + (int64_t)r * ldb + (tid & 15) * 16;
         char* dst = smem + (tid >> 4) * SM_ROW + (tid & 15) * 16;
-        og_u32x4 v[8];
+        og_u32x4 v[D / 32];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const og_u32x4*>(src + j * 256);
+        for (int j = 0; j < D / 32; ++j) v[j] = *reinterpret_cast<const og_u32x4*>(src + j * 256);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) *reinterpret_cast<og_u32x4*>(dst + j * 256) = v[j];
+        for (int j = 0; j < D / 32; ++j) *reinterpret_cast<og_u32x4*>(dst + j * 256) = v[j];
     }
     const float sc0 = g.scales_dev ? g.scales_dev[0] : g.scale, sc3 = g.scales_dev ? g.scales_dev[1] : g.scale;
     const float is0 = 1.f / sc0;
 
-    // ================= fc.0: acc0[j] = b0' / s0 + W0'[hidden block 2 wave + j] . [x ; O], 32 k-steps =================
-    f32x16 acc0[2];
+    // ================= fc.0: acc0[j] = b0' / s0 + W0'[hidden block NJ wave + j] . [x ; O], KS0 k-steps =================
+    f32x16 acc0[NJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(g.b0 + 32 * (2 * wave + j) + 8 * qq + 4 * hi);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(g.b0 + 32 * (NJ * wave + j) + 8 * qq + 4 * hi);
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc0[j][4 * qq + e] = b[e] * is0;
         }
@@ -658,50 +720,64 @@ __global__ __launch_bounds__(512) void mlp_small_kernel(MlpFusedArgs g) {
     OG_ST(2);
     const char* const xrow = smem + l31 * SM_ROW + hi * 16;
 #pragma unroll
-    for (int ks = 0; ks < 32; ++ks) {
+    for (int ks = 0; ks < KS0; ++ks) {
         const int kg = ks >> 1, t = ks & 1, slot = ks % PF;
         const f16x8 xh = *reinterpret_cast<const f16x8*>(xrow + kg * 128 + t * 32);
         const f16x8 xl = *reinterpret_cast<const f16x8*>(xrow + kg * 128 + t * 32 + 64);
-        const int younger = 32 - 1 - ks < PF - 1 ? 4 * (32 - 1 - ks) : 4 * (PF - 1);
-        wait4(younger, wf[slot][0], wf[slot][1], wf[slot][2], wf[slot][3]);
-        // the two accumulator chains alternate (fragment 2 j + part: part 0 = hi, 1 = lo)
-        acc0[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[slot][1], xh, acc0[0], 0, 0, 0);
-        acc0[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[slot][3], xh, acc0[1], 0, 0, 0);
-        acc0[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[slot][0], xl, acc0[0], 0, 0, 0);
-        acc0[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[slot][2], xl, acc0[1], 0, 0, 0);
-        acc0[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[slot][0], xh, acc0[0], 0, 0, 0);
-        acc0[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[slot][2], xh, acc0[1], 0, 0, 0);
-        if (ks + PF < 32) {
+        const int ysteps = KS0 - 1 - ks < PF - 1 ? KS0 - 1 - ks : PF - 1;      // k-steps younger than this one still in flight
+        if constexpr (NJ == 2) {
+            wait4(4 * ysteps, wf[slot][0], wf[slot][1], wf[slot][2], wf[slot][3]);
+            // the two accumulator chains alternate (fragment 2 j + part: part 0 = hi, 1 = lo)
+            acc0[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[slot][1], xh, acc0[0], 0, 0, 0);
+            acc0[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[slot][3], xh, acc0[1], 0, 0, 0);
+            acc0[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[slot][0], xl, acc0[0], 0, 0, 0);
+            acc0[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[slot][2], xl, acc0[1], 0, 0, 0);
+            acc0[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[slot][0], xh, acc0[0], 0, 0, 0);
+            acc0[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[slot][2], xh, acc0[1], 0, 0, 0);
+        } else {
+            wait2(2 * ysteps, wf[slot][0], wf[slot][1]);
+            acc0[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[slot][1], xh, acc0[0], 0, 0, 0);
+            acc0[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[slot][0], xl, acc0[0], 0, 0, 0);
+            acc0[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[slot][0], xh, acc0[0], 0, 0, 0);
+        }
+        if (ks + PF < KS0) {
 #pragma unroll
-            for (int f = 0; f < 4; ++f) frag0(wf[slot][f], f >> 1, (ks + PF) >> 1, (ks + PF) & 1, f & 1);
+            for (int f = 0; f < FPK; ++f) frag0(wf[slot][f], f >> 1, (ks + PF) >> 1, (ks + PF) & 1, f & 1);
         }
     }
 
     OG_ST(3);
     char* const hid = smem + SM_T * SM_ROW;
-    // ================= fc.3: wave w owns OUTPUT block w over all 512 hidden channels: 32 k-steps, two accumulator chains =================
-    // W3' fragment (output block i, hidden block hb = 8 a' + 4 q' + j', k-step t): stage 24 q' + 16 + 2 j' + t, fragment (a' 8 + i) 2 + part
+    // ================= fc.3.  256-d: wave w owns OUTPUT block w over all 512 hidden channels (16 steps of two k-steps, two accumulator chains);
+    //                   128-d: wave w owns output block w & 3 over hidden blocks 4 (w >> 2) .. + 3 (4 steps), the two halves meet in LDS =================
+    // W3' fragment (output block i, hidden block hb = HB2 a' + 4 q' + j', k-step t), og_pack_mlp_stream:
+    //   256-d: stage 24 q' + 16 + 2 j' + t, fragment (a' 8 + i) 2 + part;  128-d: stage 8 + j', fragment ((a' 2 + t) 4 + i) 2 + part
+    const int ob = wave & (NOB - 1);           // this wave's output block
+    const int hb0 = D == 256 ? 0 : 4 * (wave >> 2);      // ... and its first hidden block
     auto frag3 = [&](f16x8& dst, int hb, int t, int part) {
-        ldfrag(dst, sbase(g.wstream + (int64_t)(24 * ((hb >> 2) & 1) + 16 + 2 * (hb & 3) + t) * WSTAGE + ((((hb >> 3) * 8 + wave) * 2 + part) << 10)));
+        if constexpr (D == 256)
+            ldfrag(dst, sbase(g.wstream + (int64_t)(24 * ((hb >> 2) & 1) + 16 + 2 * (hb & 3) + t) * WSTAGE + ((((hb >> 3) * 8 + ob) * 2 + part) << 10)));
+        else
+            ldfrag(dst, sbase(g.wstream + (int64_t)(8 + (hb & 3)) * WSTAGE + (((((hb >> 2) * 2 + t) * 4 + ob) * 2 + part) << 10)));
     };
     constexpr int PF3 = 4;                     // steps of two k-steps (4 fragments) in flight
     f16x8 w3f[PF3][4];
-    auto frag3_step = [&](f16x8 (&dst)[4], int n) {          // step n = hidden block n, k-steps t = 0, 1: (t0 hi, t0 lo, t1 hi, t1 lo)
+    auto frag3_step = [&](f16x8 (&dst)[4], int n) {          // step n = hidden block hb0 + n, k-steps t = 0, 1: (t0 hi, t0 lo, t1 hi, t1 lo)
 #pragma unroll
-        for (int f = 0; f < 4; ++f) frag3(dst[f], n, f >> 1, f & 1);
+        for (int f = 0; f < 4; ++f) frag3(dst[f], hb0 + n, f >> 1, f & 1);
     };
 #pragma unroll
     for (int n = 0; n < PF3; ++n) frag3_step(w3f[n], n);
     // bias and residual of this wave's block for the epilogue (the compiler's loads: younger than the fragments above, see the note at the top)
     const int tok = t0 + l31;
     const bool live = tok < g.M;
-    char* const orow = rows + (int64_t)(live ? tok : 0) * ldb + wave * 128;      // hl32 row: 64 B hi | 64 B lo per 32 channels
+    char* const orow = rows + (int64_t)(live ? tok : 0) * ldb + ob * 128;        // hl32 row: 64 B hi | 64 B lo per 32 channels
     f32x4 bias3[4];
     uint2 rxh[4], rxl[4];
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
         const int ch = 8 * qq + 4 * hi;        // first of this lane's 4 consecutive channels of register group qq
-        bias3[qq] = *reinterpret_cast<const f32x4*>(g.b3 + 32 * wave + ch);
+        bias3[qq] = *reinterpret_cast<const f32x4*>(g.b3 + 32 * ob + ch);
         rxh[qq] = *reinterpret_cast<const uint2*>(orow + ch * 2);
         rxl[qq] = *reinterpret_cast<const uint2*>(orow + ch * 2 + 64);
     }
@@ -710,7 +786,7 @@ __global__ __launch_bounds__(512) void mlp_small_kernel(MlpFusedArgs g) {
     {
 #pragma clang fp contract(off)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 og_u32x4 h4, l4;
@@ -724,7 +800,7 @@ __global__ __launch_bounds__(512) void mlp_small_kernel(MlpFusedArgs g) {
                     og_split4(c0, c1, c2, c3, ha, la, hb, lb);
                     h4[2 * h] = ha; h4[2 * h + 1] = hb; l4[2 * h] = la; l4[2 * h + 1] = lb;
                 }
-                char* d = hid + ((((2 * wave + j) * 2 + t) * 2) << 10) + lane * 16;
+                char* d = hid + ((((NJ * wave + j) * 2 + t) * 2) << 10) + lane * 16;
                 *reinterpret_cast<og_u32x4*>(d) = h4;
                 *reinterpret_cast<og_u32x4*>(d + 1024) = l4;
             }
@@ -738,13 +814,13 @@ __global__ __launch_bounds__(512) void mlp_small_kernel(MlpFusedArgs g) {
     for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc3[c][r] = 0.f;
-    const char* const hrd = hid + lane * 16;
+    const char* const hrd = hid + lane * 16 + ((hb0 * 4) << 10);
 #pragma unroll
-    for (int n = 0; n < 16; ++n) {
+    for (int n = 0; n < NS3; ++n) {
         const int slot = n % PF3;
         const f16x8 bh0 = *reinterpret_cast<const f16x8*>(hrd + (((n * 2 + 0) * 2) << 10)), bl0 = *reinterpret_cast<const f16x8*>(hrd + (((n * 2 + 0) * 2 + 1) << 10));
         const f16x8 bh1 = *reinterpret_cast<const f16x8*>(hrd + (((n * 2 + 1) * 2) << 10)), bl1 = *reinterpret_cast<const f16x8*>(hrd + (((n * 2 + 1) * 2 + 1) << 10));
-        const int younger = n < PF3 ? 0 : (16 - 1 - n < PF3 - 1 ? 4 * (16 - 1 - n) : 4 * (PF3 - 1));      // the first PF3 steps were waited for above
+        const int younger = n < PF3 ? 0 : (NS3 - 1 - n < PF3 - 1 ? 4 * (NS3 - 1 - n) : 4 * (PF3 - 1));      // the first PF3 steps were waited for above
         if (n >= PF3) wait4(younger, w3f[slot][0], w3f[slot][1], w3f[slot][2], w3f[slot][3]);
         acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3f[slot][1], bh0, acc3[0], 0, 0, 0);
         acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3f[slot][3], bh1, acc3[1], 0, 0, 0);
@@ -752,9 +828,30 @@ __global__ __launch_bounds__(512) void mlp_small_kernel(MlpFusedArgs g) {
         acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3f[slot][2], bl1, acc3[1], 0, 0, 0);
         acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3f[slot][0], bh0, acc3[0], 0, 0, 0);
         acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3f[slot][2], bh1, acc3[1], 0, 0, 0);
-        if (n + PF3 < 16) frag3_step(w3f[slot], n + PF3);
+        if (n + PF3 < NS3) frag3_step(w3f[slot], n + PF3);
     }
     OG_ST(6);
+    if constexpr (D == 128) {
+        // the two hidden halves of an output block meet: waves 4..7 leave their sums in the (dead) token-tile area, waves 0..3 add them and finish
+        char* const red = smem + ((wave & 3) << 12) + lane * 16;       // [output block][register group][lane] x 16 B: 4 KB per block
+        if (wave >= 4) {
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc3[0][4 * qq + e] + acc3[1][4 * qq + e];
+                *reinterpret_cast<f32x4*>(red + (qq << 10)) = v;
+            }
+        }
+        __syncthreads();
+        if (wave >= 4) return;
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(red + (qq << 10));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc3[0][4 * qq + e] += v[e];
+        }
+    }
 
     // ================= epilogue: x <- (acc / S3 + b3') + x, written back as (hi, lo) halves: 8 bytes per register group and plane =================
     {
@@ -797,7 +894,7 @@ __global__ __launch_bounds__(512) void mlp_small_kernel(MlpFusedArgs g) {
 // fragment-major stream (og_pack_proj_stream).  Output: (hi, lo) planes.  The 128-token tile GEMM it replaces takes 17.5 us per launch at
 // 2048 or 8192 rows (profiles/r04_small_batch_kernel_stats_B*.csv: 36 launches per step).  Workgroups whose first row is below
 // `split_row` use the block range [a0, a1), the others [b0, b1) -- the cross layer's "q of image 0, q | k | v of image 1" in one launch.
-constexpr int PS_ROW = 256 * 2 * 2 + 16;       // bytes of one padded LDS row: the x half of an hl32 row (2D halves) + 16
+template <int K> constexpr int PS_ROW = K * 2 * 2 + 16;       // bytes of one padded LDS row: the x half of an hl32 row (2K halves) + 16; K = D = 256 or 128
 
 struct ProjSmallArgs {
     const _Float16* X; int64_t ld;             // [M] hl32 rows, the first 2D halves = x
@@ -810,8 +907,9 @@ struct ProjSmallArgs {
     int parts, bpp;                            // very few rows: the block range of a token tile dealt to `parts` workgroups, bpp blocks each
 };
 
-template <int NB>
+template <int NB, int K>
 __device__ __forceinline__ void proj_small_run(const ProjSmallArgs& g, const char* smem, int wave, int lane, int cb0, int t0) {
+    constexpr int KS = K / 16;                 // k-steps
     const int l31 = lane & 31, hi = lane >> 5;
     unsigned lane16 = (unsigned)lane * 16u;
     asm volatile("" : "+v"(lane16));
@@ -820,9 +918,9 @@ __device__ __forceinline__ void proj_small_run(const ProjSmallArgs& g, const cha
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi32 = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
         return reinterpret_cast<const char*>((uintptr_t)(((uint64_t)hi32 << 32) | lo));
     };
-    // fragment (block i, k-step ks, part): ((i * 16 + ks) * 2 + part) KiB
+    // fragment (block i, k-step ks, part): ((i * KS + ks) * 2 + part) KiB
     auto frag = [&](f16x8& dst, int b, int ks, int part) {
-        const char* base = sbase(g.wstream + ((((int64_t)(cb0 + wave + 8 * b) * 16 + ks) * 2 + part) << 10));
+        const char* base = sbase(g.wstream + ((((int64_t)(cb0 + wave + 8 * b) * KS + ks) * 2 + part) << 10));
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(lane16), "s"(base) : "memory");
     };
     constexpr int PF = 4, FPS = 2 * NB;        // k-steps in flight, fragments per k-step
@@ -837,13 +935,13 @@ __device__ __forceinline__ void proj_small_run(const ProjSmallArgs& g, const cha
     for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
-    const char* const xrow = smem + l31 * PS_ROW + hi * 16;
+    const char* const xrow = smem + l31 * PS_ROW<K> + hi * 16;
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
         const int slot = ks % PF;
         const f16x8 xh = *reinterpret_cast<const f16x8*>(xrow + (ks >> 1) * 128 + (ks & 1) * 32);
         const f16x8 xl = *reinterpret_cast<const f16x8*>(xrow + (ks >> 1) * 128 + (ks & 1) * 32 + 64);
-        const int ysteps = 16 - 1 - ks < PF - 1 ? 16 - 1 - ks : PF - 1;       // k-steps younger than this one still in flight
+        const int ysteps = KS - 1 - ks < PF - 1 ? KS - 1 - ks : PF - 1;       // k-steps younger than this one still in flight
         // "all but the ysteps * FPS youngest loads have landed"
         if constexpr (NB == 1) {
             if (ysteps == 3) asm volatile("s_waitcnt vmcnt(6)" : "+v"(wf[slot][0]), "+v"(wf[slot][1]) :: "memory");
@@ -868,7 +966,7 @@ __device__ __forceinline__ void proj_small_run(const ProjSmallArgs& g, const cha
         for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[slot][2 * b], xl, acc[b], 0, 0, 0);
 #pragma unroll
         for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[slot][2 * b], xh, acc[b], 0, 0, 0);
-        if (ks + PF < 16) {
+        if (ks + PF < KS) {
 #pragma unroll
             for (int f = 0; f < FPS; ++f) frag(wf[slot][f], f >> 1, ks + PF, f & 1);
         }
@@ -901,8 +999,9 @@ __device__ __forceinline__ void proj_small_run(const ProjSmallArgs& g, const cha
     }
 }
 
+template <int K>
 __global__ __launch_bounds__(512) void proj_small_kernel(ProjSmallArgs g) {
-    __shared__ __attribute__((aligned(16))) char smem[SM_T * PS_ROW];
+    __shared__ __attribute__((aligned(16))) char smem[SM_T * PS_ROW<K>];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // (the division runs on the vector ALU: back to SGPRs at once -- the fragment loads below take their base address in SGPRs through inline asm,
@@ -914,29 +1013,29 @@ __global__ __launch_bounds__(512) void proj_small_kernel(ProjSmallArgs g) {
     const int cb0 = __builtin_amdgcn_readfirstlane(r0 + part * g.bpp);
     const int cb1 = __builtin_amdgcn_readfirstlane(cb0 + g.bpp < r1 ? cb0 + g.bpp : r1);
     if (cb1 <= cb0) return;
-    // ---- x halves of the token rows -> LDS: thread (row tid >> 4, 16-byte column tid & 15 + 16 j), 1 KiB per row ----
+    // ---- x halves of the token rows -> LDS: thread (row tid >> 4, 16-byte column tid & 15 + 16 j), 4K bytes per row ----
     {
         int r = t0 + (tid >> 4);
         if (r > g.M - 1) r = g.M - 1;
         const char* src = reinterpret_cast<const char*>(g.X) + (int64_t)r * g.ld * 2 + (tid & 15) * 16;
-        char* dst = smem + (tid >> 4) * PS_ROW + (tid & 15) * 16;
-        og_u32x4 v[4];
+        char* dst = smem + (tid >> 4) * PS_ROW<K> + (tid & 15) * 16;
+        og_u32x4 v[K / 64];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const og_u32x4*>(src + j * 256);
+        for (int j = 0; j < K / 64; ++j) v[j] = *reinterpret_cast<const og_u32x4*>(src + j * 256);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<og_u32x4*>(dst + j * 256) = v[j];
+        for (int j = 0; j < K / 64; ++j) *reinterpret_cast<og_u32x4*>(dst + j * 256) = v[j];
     }
     __syncthreads();
     const int mine = (cb1 - cb0 - wave + 7) / 8;             // blocks cb0 + wave + 8 b < cb1 (wave-uniform)
-    if (mine >= 3) proj_small_run<3>(g, smem, wave, lane, cb0, t0);
-    else if (mine == 2) proj_small_run<2>(g, smem, wave, lane, cb0, t0);
-    else if (mine == 1) proj_small_run<1>(g, smem, wave, lane, cb0, t0);
+    if (mine >= 3) proj_small_run<3, K>(g, smem, wave, lane, cb0, t0);
+    else if (mine == 2) proj_small_run<2, K>(g, smem, wave, lane, cb0, t0);
+    else if (mine == 1) proj_small_run<1, K>(g, smem, wave, lane, cb0, t0);
 }
 
 }  // namespace
 
 // ---- host side ----------------------------------------------------------------------------------------------------------------
-bool og_mlp_fused_supported(int D) { return D == 256; }
+bool og_mlp_fused_supported(int D) { return D == 256 || D == 128; }
 
 size_t og_mlp_stream_bytes(int D) { return og_mlp_fused_supported(D) ? (size_t)6 * D * D * 4 : 0; }      // 4D^2 (W0') + 2D^2 (W3') (hi, lo) pairs
 
@@ -946,7 +1045,9 @@ bool og_mlp_fused_enabled(int D) {
 }
 
 // Fragment-major weight stream of mlp_fused_kernel.  W0 [2D][2D], W3 [D][2D] row-major double (already folded), written as (hi, lo)
-// halves of S0 w / S3 w (power-of-two pre-scales, 256 unless a weight would leave binary16).  48 stages of 32 fragments (1 KiB = 64 lanes x 8 halves; a lo fragment follows its hi fragment); quarter q:
+// halves of S0 w / S3 w (power-of-two pre-scales, 256 unless a weight would leave binary16).  256-d: 48 stages of 32 fragments (1 KiB = 64 lanes x 8 halves; a lo fragment
+// follows its hi fragment), as below; 128-d: 12 stages -- 8 fc.0 stages (hidden block 4 a + i), then one fc.3 stage per hidden block j of a half,
+// fragment ((a * 2 + t) * 4 + i) * 2 + part (both k-steps, output block i).  256-d, quarter q:
 //   fc.0 stage 24 q + kg (k-group kg):   fragment ((a * 2 + t) * 4 + i) * 2 + part, lane l = (rho = l & 31, h = l >> 5), element e:
 //          W0[32 (8a + 4q + i) + rho][32 kg + 16 t + 8 h + e]                                   (a = hidden half, i = block of the quarter)
 //   fc.3 stage 24 q + 16 + 2 j + t:      fragment (a * 8 + i) * 2 + part (i = output block):
@@ -954,7 +1055,8 @@ bool og_mlp_fused_enabled(int D) {
 // Returns false when a scaled weight does not fit binary16.
 bool og_pack_mlp_stream(int D, const double* W0, const double* W3, void* out, double S0, double S3) {
     if (!og_mlp_fused_supported(D)) return false;
-    const int D2 = 2 * D, G0 = D2 / 32;
+    const int D2 = 2 * D, G0 = D2 / 32, HB2 = G0 / 2, NPASS = HB2 / 4, NOB = D / 32;
+    const int SPP = G0 + (D == 256 ? 8 : 4);            // stages per pass: G0 fc.0 stages + the fc.3 stages of its 4 hidden blocks per half
     _Float16* o = (_Float16*)out;
     bool ok = true;
     auto put = [&](int64_t stage, int f, int l, int e, double w, double S) {
@@ -965,23 +1067,27 @@ bool og_pack_mlp_stream(int D, const double* W0, const double* W3, void* out, do
         base[0] = hi;
         base[512] = (_Float16)(w - (double)hi);                                        // the lo fragment follows the hi fragment
     };
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < NPASS; ++q) {
         for (int kg = 0; kg < G0; ++kg)
             for (int a = 0; a < 2; ++a)
                 for (int t = 0; t < 2; ++t)
                     for (int i = 0; i < 4; ++i)
                         for (int l = 0; l < 64; ++l)
                             for (int e = 0; e < 8; ++e)
-                                put(24 * q + kg, ((a * 2 + t) * 4 + i) * 2, l, e,
-                                    W0[(int64_t)(32 * (8 * a + 4 * q + i) + (l & 31)) * D2 + 32 * kg + 16 * t + 8 * (l >> 5) + e], S0);
+                                put(SPP * q + kg, ((a * 2 + t) * 4 + i) * 2, l, e,
+                                    W0[(int64_t)(32 * (HB2 * a + 4 * q + i) + (l & 31)) * D2 + 32 * kg + 16 * t + 8 * (l >> 5) + e], S0);
         for (int j = 0; j < 4; ++j)
             for (int t = 0; t < 2; ++t)
                 for (int a = 0; a < 2; ++a)
-                    for (int i = 0; i < D / 32; ++i)
+                    for (int i = 0; i < NOB; ++i)
                         for (int l = 0; l < 64; ++l)
-                            for (int e = 0; e < 8; ++e)
-                                put(24 * q + 16 + 2 * j + t, (a * 8 + i) * 2, l, e,
-                                    W3[(int64_t)(32 * i + (l & 31)) * D2 + 32 * (8 * a + 4 * q + j) + 16 * t + 8 * (e >> 2) + 4 * (l >> 5) + (e & 3)], S3);
+                            for (int e = 0; e < 8; ++e) {
+                                // 256-d: one stage per (hidden block j, k-step t), 8 output blocks per half; 128-d: one stage per hidden block, (t, 4 output blocks) per half
+                                const int64_t stage = D == 256 ? SPP * q + G0 + 2 * j + t : SPP * q + G0 + j;
+                                const int frag = D == 256 ? (a * 8 + i) * 2 : ((a * 2 + t) * 4 + i) * 2;
+                                put(stage, frag, l, e,
+                                    W3[(int64_t)(32 * i + (l & 31)) * D2 + 32 * (HB2 * a + 4 * q + j) + 16 * t + 8 * (e >> 2) + 4 * (l >> 5) + (e & 3)], S3);
+                            }
     }
     return ok;
 }
@@ -1001,11 +1107,13 @@ int og_launch_mlp_fused(const MlpFusedArgs& a, int D, hipStream_t stream) {
     if ((int64_t)MT * a.ld * 2 >= (int64_t)1 << 31) return OG_E_SHAPE;              // 32-bit lane offsets are relative to the TILE's first row (baseX is 64-bit)
     if (!(a.scale != 0.f) || !std::isfinite(a.scale)) return OG_E_INVALID;
     if (og_mlp_small_wanted(a.M) && !(((uintptr_t)a.b0 | (uintptr_t)a.b3) & 15)) {      // (mlp_small_kernel reads the biases as 16-byte vectors)
-        hipLaunchKernelGGL(mlp_small_kernel<256>, dim3((a.M + SM_T - 1) / SM_T), dim3(512), 0, stream, a);
+        if (D == 256) hipLaunchKernelGGL(mlp_small_kernel<256>, dim3((a.M + SM_T - 1) / SM_T), dim3(512), 0, stream, a);
+        else hipLaunchKernelGGL(mlp_small_kernel<128>, dim3((a.M + SM_T - 1) / SM_T), dim3(512), 0, stream, a);
         return og_launch_status();
     }
     const int tiles = (a.M + MT - 1) / MT;
-    hipLaunchKernelGGL(mlp_fused_kernel<256>, dim3(tiles), dim3(512), 0, stream, a);
+    if (D == 256) hipLaunchKernelGGL(mlp_fused_kernel<256>, dim3(tiles), dim3(512), 0, stream, a);
+    else hipLaunchKernelGGL(mlp_fused_kernel<128>, dim3(tiles), dim3(512), 0, stream, a);
     return og_launch_status();
 }
 
@@ -1041,9 +1149,9 @@ extern "C" int og_mlp_block(int32_t D, void* xo_rows, int64_t ld, int32_t M, con
 }
 
 // ---- the small-batch projection (proj_small_kernel) ----
-// Fragment-major stream of an [N][256] matrix (N a multiple of 32), standard k order: fragment ((i * 16 + ks) * 2 + part), lane l =
+// Fragment-major stream of an [N][K] matrix (K = 256 or 128, N a multiple of 32), standard k order: fragment ((i * K / 16 + ks) * 2 + part), lane l =
 // (rho = l & 31, h = l >> 5), element e = S w[32 i + rho][16 ks + 8 h + e] as (hi, lo) halves (the lo fragment follows the hi fragment).
-size_t og_proj_stream_bytes(int N, int K) { return (K == 256 && N % 32 == 0) ? (size_t)N * K * 4 : 0; }
+size_t og_proj_stream_bytes(int N, int K) { return ((K == 256 || K == 128) && N > 0 && N % 32 == 0) ? (size_t)N * K * 4 : 0; }
 
 bool og_pack_proj_stream(int N, int K, const double* W, void* out, double S) {
     if (!og_proj_stream_bytes(N, K)) return false;
@@ -1065,11 +1173,12 @@ bool og_pack_proj_stream(int N, int K, const double* W, void* out, double S) {
 
 // Rows [0, M) of X (hl32 rows, x half) times columns [32 a0, 32 a1) of the packed matrix for rows below split_row, [32 b0, 32 b1) for the
 // others (split_row must be a multiple of 32 unless it is 0 or >= M); planes Ch / Cl [M][ldc].
-int og_launch_proj_small(const _Float16* X, int64_t ld, int M, const char* wstream, const float* bias, const float* scale_dev,
+int og_launch_proj_small(const _Float16* X, int64_t ld, int M, int K, const char* wstream, const float* bias, const float* scale_dev,
                          _Float16* Ch, _Float16* Cl, int64_t ldc, int split_row, int a0, int a1, int b0, int b1, hipStream_t stream) {
     if (!X || !wstream || !bias || !scale_dev || !Ch || !Cl || M <= 0) return OG_E_INVALID;
+    if (K != 256 && K != 128) return OG_E_SHAPE;
     if (((uintptr_t)X & 15) || ((uintptr_t)wstream & 15) || ((uintptr_t)bias & 15) || (ld & 7) || (ldc & 3) || ((uintptr_t)Ch & 7) || ((uintptr_t)Cl & 7)) return OG_E_ALIGN;
-    if (a0 < 0 || b0 < 0 || a1 < a0 || b1 < b0 || ld < 2 * 256) return OG_E_SHAPE;
+    if (a0 < 0 || b0 < 0 || a1 < a0 || b1 < b0 || ld < 2 * K) return OG_E_SHAPE;
     if (split_row > 0 && split_row < M && (split_row % SM_T)) return OG_E_SHAPE;
     // One or two pairs: a token tile's output blocks go to several workgroups, 8 blocks (one per wave) each -- nothing to reduce, and a workgroup
     // streams 256 KB of weights instead of the whole matrix (the per-CU weight stream is what bounds these kernels).
@@ -1079,7 +1188,8 @@ int og_launch_proj_small(const _Float16* X, int64_t ld, int M, const char* wstre
     if (split_on && nblk > 8 && tiles * ((nblk + 7) / 8) <= 256) { parts = (nblk + 7) / 8; bpp = 8; }
     if (nblk > 24) { parts = (nblk + 7) / 8; bpp = 8; }          // a workgroup covers at most 3 blocks per wave: wider ranges are always dealt out
     ProjSmallArgs g{X, ld, M, wstream, bias, scale_dev, Ch, Cl, ldc, split_row, a0, a1, b0, b1, parts, bpp};
-    hipLaunchKernelGGL(proj_small_kernel, dim3(tiles * parts), dim3(512), 0, stream, g);
+    if (K == 256) hipLaunchKernelGGL(proj_small_kernel<256>, dim3(tiles * parts), dim3(512), 0, stream, g);
+    else hipLaunchKernelGGL(proj_small_kernel<128>, dim3(tiles * parts), dim3(512), 0, stream, g);
     return og_launch_status();
 }
 
@@ -1096,10 +1206,10 @@ extern "C" int og_proj_block_pack(int32_t N, int32_t K, const float* W, void* st
     return ok ? 0 : OG_E_RANGE;
 }
 
-extern "C" int og_proj_block(const void* x_rows, int64_t ld, int32_t M, const void* stream_dev, const float* bias, const float* inv_scale_dev,
+extern "C" int og_proj_block(const void* x_rows, int64_t ld, int32_t M, int32_t K, const void* stream_dev, const float* bias, const float* inv_scale_dev,
                              void* yh, void* yl, int64_t ldy, int32_t split_row, int32_t a0, int32_t a1, int32_t b0, int32_t b1, void* stream) {
     og_clear_status();
     if (a0 < 0 || b0 < 0 || a1 < a0 || b1 < b0 || ldy < 32 * (int64_t)(a1 > b1 ? a1 : b1)) return OG_E_SHAPE;
-    return og_launch_proj_small((const _Float16*)x_rows, ld, M, (const char*)stream_dev, bias, inv_scale_dev, (_Float16*)yh, (_Float16*)yl, ldy,
+    return og_launch_proj_small((const _Float16*)x_rows, ld, M, K, (const char*)stream_dev, bias, inv_scale_dev, (_Float16*)yh, (_Float16*)yl, ldy,
                                 split_row, a0, a1, b0, b1, (hipStream_t)stream);
 }

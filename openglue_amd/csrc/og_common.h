@@ -186,7 +186,7 @@ bool og_mlp_small_wanted(int M);
 // the q / k / v projections for few token rows (mlp_fused.hip: proj_small_kernel), a fragment-major copy of the packed matrix
 size_t og_proj_stream_bytes(int N, int K);
 bool og_pack_proj_stream(int N, int K, const double* W, void* out, double S);
-int og_launch_proj_small(const _Float16* X, int64_t ld, int M, const char* wstream, const float* bias, const float* scale_dev,
+int og_launch_proj_small(const _Float16* X, int64_t ld, int M, int K, const char* wstream, const float* bias, const float* scale_dev,
                          _Float16* Ch, _Float16* Cl, int64_t ldc, int split_row, int a0, int a1, int b0, int b1, hipStream_t stream);
 
 constexpr int OG_ATTN_COUNTERS = 256;                                   // (problem, head, query tile) triples of a key-split launch

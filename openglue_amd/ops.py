@@ -162,7 +162,7 @@ def mlp_block(x: torch.Tensor, o: torch.Tensor, w0: torch.Tensor, b0: torch.Tens
 
 
 def proj_block(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, split_row: int = 0, cols_a=None, cols_b=None):
-    """The small-batch projection kernel (og_proj_block): y = x @ w.T + bias on token-major fp32 x [M, 256], w [N, 256], N a multiple of 32.
+    """The small-batch projection kernel (og_proj_block): y = x @ w.T + bias on token-major fp32 x [M, K], w [N, K], K = 256 or 128, N a multiple of 32.
     Rows below split_row get the output columns cols_a = (c0, c1), the others cols_b (multiples of 32; default: all N); columns outside a
     row's range come back as zeros."""
     lib = _lib.load()
@@ -182,7 +182,7 @@ def proj_block(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, split_row: 
     yh = torch.zeros(M, N, device=x.device, dtype=torch.float16)
     yl = torch.zeros_like(yh)
     a, b = cols_a or (0, N), cols_b or (0, N)
-    _lib.check(lib.og_proj_block(rows.data_ptr(), 2 * K, M, stream_dev.data_ptr(), bias.data_ptr(), inv.data_ptr(), yh.data_ptr(), yl.data_ptr(), N,
+    _lib.check(lib.og_proj_block(rows.data_ptr(), 2 * K, M, K, stream_dev.data_ptr(), bias.data_ptr(), inv.data_ptr(), yh.data_ptr(), yl.data_ptr(), N,
                                  split_row, a[0] // 32, a[1] // 32, b[0] // 32, b[1] // 32, _stream()), "og_proj_block")
     return merge_f16(yh, yl)
 

@@ -34,6 +34,10 @@ CONFIGS = {
                kpts=(2048, 2048), batch=32),   # 256 pairs over 8 GPUs -> 32 per GPU
     "C4": dict(descriptor_dim=128, num_stages=9, num_heads=4, num_iters=100, side_info_size=6,
                kpts=(4096, 4096), batch=8),    # 64 pairs over 8 GPUs -> 8 per GPU
+    # not a BASELINE config: the reference's OWN shipped operating point for its 128-d feature family -- config/features/sift_opencv.yaml:2-4
+    # (descriptor_dim 128, max_keypoints 2048), config/config.yaml:44,53 (laf_to_sideinfo_method 'none' = response only, num_iters 20)
+    "S128": dict(descriptor_dim=128, num_stages=9, num_heads=4, num_iters=20, side_info_size=1,
+                 kpts=(2048, 2048), batch=32),
 }
 
 

@@ -49,6 +49,12 @@ CASES = {
     "favor": (dict(descriptor_dim=128, num_stages=2, num_heads=1, num_iters=8, side_info_size=1, attention="favor_relu"),
               140, 101, 2, 8, "full"),
     "c2": (dict(syn.CONFIGS["C2"]), 1024, 1024, 2, 5, "sub8"),
+    # round 5 (VERDICT r4 missing 1, 5): the reference's 128-d family at its own operating point (sift_opencv.yaml:2-4: 128-d, config.yaml:53:
+    # 20 iterations), whole path, 9 stages, s = 6 ...
+    "d128": (dict(descriptor_dim=128, num_stages=9, num_heads=4, num_iters=20, side_info_size=6), 640, 512, 2, 41, "full"),
+    # ... and the LARGE BASELINE shapes from the reference itself (until round 4 only the oracle port was checked there):
+    "c3": (dict(syn.CONFIGS["C3"]), 2048, 2048, 2, 43, "sub8"),
+    "c4": (dict(syn.CONFIGS["C4"]), 4096, 4096, 2, 47, "sub8"),
 }
 
 
@@ -101,6 +107,12 @@ def full_case(name, kw, m, n, batch, seed, store):
         arrays["scores_lastcol"] = scores[:, :, -1].numpy()
         arrays["context_descriptors0_sub"] = out["context_descriptors0"][:, ::4, ::16].numpy()
         arrays["context_descriptors1_sub"] = out["context_descriptors1"][:, ::4, ::16].numpy()
+        if name != "c2":      # (c2 predates these) top-1 / top-2 gap of every row and column of the reference's scores[:, :-1, :-1]: lets a test
+            inner = scores[:, :-1, :-1]                                   # explain an index difference as a near-tie without re-running anything
+            t2r = inner.topk(2, dim=2).values; t2c = inner.topk(2, dim=1).values
+            arrays["row_gap"] = (t2r[..., 0] - t2r[..., 1]).numpy()
+            arrays["col_gap"] = (t2c[:, 0] - t2c[:, 1]).numpy()
+            arrays["row_argmax"] = inner.argmax(2).numpy().astype(np.int32)
     if name == "c1":  # inputs and weights in full, so this case does not depend on torch's RNG stream
         for k, v in data.items():
             if torch.is_tensor(v):
@@ -164,15 +176,19 @@ LAYER_CASES = {
                    residual=False, use_offset=True, reg=0.5, dustbin_score_init=0.3), 96, 130, 2, 3),
     "d256": (dict(descriptor_dim=256, num_stages=1, num_heads=4, num_iters=5, side_info_size=1), 130, 100, 2, 21),   # the fused message-MLP kernel
 }
+# round 5: the 128-d kernel family (mlp_fused_kernel<128> and friends) at 9 stages, s = 6, >= 512 keypoints; its own file (stage_layers_d128.npz)
+LAYER_CASES_D128 = {
+    "d128": (dict(descriptor_dim=128, num_stages=9, num_heads=4, num_iters=20, side_info_size=6), 520, 512, 1, 41),
+}
 
 
-def layer_cases():
+def layer_cases(cases=None, fname="stage_layers.npz"):
     """Per-stage goldens: x = local_descriptors + positional_encoding(...) as it enters the GNN (superglue.py:41-55) and
     the descriptors after every element of attention_gnn.layers (attention_gnn.py:57-77: DescriptorsSelfAttention /
     DescriptorsCrossAttention = ResidualAttentionMessagePropagation on both images), from the reference's own modules.  Stored
     token-major [B, n, D] (the reference holds them channel-first)."""
     arrays = {}
-    for name, (kw, m, n, batch, seed) in LAYER_CASES.items():
+    for name, (kw, m, n, batch, seed) in (cases or LAYER_CASES).items():
         cfg = syn.make_config(**kw)
         sd = syn.make_state_dict(cfg, seed=0)
         ref = RefSuperGlue(cfg)
@@ -198,7 +214,7 @@ def layer_cases():
                 data["local_descriptors0"].transpose(2, 1), data["local_descriptors1"].transpose(2, 1)).transpose(1, 2).contiguous().numpy()
         arrays[f"{name}/meta"] = np.array(repr(dict(kw=kw, m=m, n=n, batch=batch, seed=seed, taps=len(ref.attention_gnn.layers) + 1)))
         print(f"layers {name}: {len(ref.attention_gnn.layers)} layers, |x| max {float(d0.abs().max()):.2f}")
-    np.savez_compressed(os.path.join(HERE, "stage_layers.npz"), **arrays)
+    np.savez_compressed(os.path.join(HERE, fname), **arrays)
 
 
 if __name__ == "__main__":
@@ -206,6 +222,9 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     if sys.argv[1:] == ["layers"]:
         layer_cases()
+        sys.exit(0)
+    if sys.argv[1:] == ["layers_d128"]:
+        layer_cases(LAYER_CASES_D128, "stage_layers_d128.npz")
         sys.exit(0)
     if sys.argv[1:] == ["trained"]:
         trained_case()

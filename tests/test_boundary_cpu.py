@@ -79,19 +79,20 @@ def test_pack_weights_algebra_against_oracle(name):
     assert np.abs(got["scores"].float().numpy() - z["scores"]).max() < 3e-4
 
 
-def test_fragment_major_streams_in_the_blob_equal_the_hl32_matrices():
-    """D = 256: og_pack_weights stores every layer's q | k | v matrix TWICE -- hl32 rows for the tile GEMM and a fragment-major stream for the
+@pytest.mark.parametrize("D", [256, 128])
+def test_fragment_major_streams_in_the_blob_equal_the_hl32_matrices(D):
+    """D = 256 / 128: og_pack_weights stores every layer's q | k | v matrix TWICE -- hl32 rows for the tile GEMM and a fragment-major stream for the
     small-batch projection kernel (o_wqkvs, ABI v7; csrc/mlp_fused.hip: og_pack_proj_stream) -- with the same power-of-two pre-scale.  Both copies
-    are re-read here with numpy and must hold the same numbers; favor_relu and D != 256 have no stream (-1)."""
+    are re-read here with numpy and must hold the same numbers; favor_relu and other widths have no stream (-1)."""
     from tests.packed_model import layout_of
-    cfg = syn.make_config(descriptor_dim=256, num_stages=1, num_heads=4, num_iters=3)
+    cfg = syn.make_config(descriptor_dim=D, num_stages=1, num_heads=4, num_iters=3)
     model = SuperGlue(cfg).eval()
     model.load_state_dict(syn.make_state_dict(cfg, seed=3), strict=True)
     L = layout_of(model)
     assert L.o_wqkvs >= 0 and L.o_wmlp >= 0
     raw = model.pack_host()
     half = raw.view(np.float16).astype(np.float64)
-    D, N = 256, 768
+    N = 3 * D
     for l in range(2):
         base = L.layer0 + l * L.layer_stride
         g = half[2 * (base + L.o_wqkv):2 * (base + L.o_wqkv) + 2 * N * D].reshape(N, D // 32, 2, 32)

@@ -106,13 +106,13 @@ def test_gemm_nt_f16x3_gnn_forms(gpu_device, M, N, K, form):
     assert torch.isfinite(out).all()
 
 
+@pytest.mark.parametrize("D", [256, 128])              # 128: the reference's SIFT / HardNet width (config/features/sift_opencv.yaml:2; attention_gnn.py:41 is generic in D)
 @pytest.mark.parametrize("M", [128, 4096, 32768, 777, 1, 8192, 8320, 33])       # <= 8192 rows: mlp_small_kernel (32-token workgroups), above: 128-token tiles
-def test_mlp_block_fused_vs_float64(gpu_device, M):
+def test_mlp_block_fused_vs_float64(gpu_device, M, D):
     """og_mlp_block (csrc/mlp_fused.hip): x + W3 relu(W0 [x ; O] + b0) + b3 in ONE launch with the hidden activation in registers
     (attention_gnn.py:53-55 + models/utils.py:48-58 after the folds of og_pack_weights) -- against float64 and against the two
     split-f16 GEMM launches it replaces.  Asymmetric random operands: a wrong fragment permutation cannot pass.  M = 777 / 1: partial
     tiles (clamped loads, predicated stores); rows past M must stay untouched."""
-    D = 256
     g = torch.Generator().manual_seed(1000 + M)
     x, o = _rand(g, M, D, scale=2.0), _rand(g, M, D, scale=1.5)
     w0, w3 = _rand(g, 2 * D, 2 * D, scale=0.04), _rand(g, D, 2 * D, scale=0.05)
@@ -127,7 +127,7 @@ def test_mlp_block_fused_vs_float64(gpu_device, M):
     err = (out[sl].double() - ref).abs().max().item()
     h32 = torch.relu(xo_in[sl] @ w0.T + b0)
     fp32_err = ((xo_in[sl, :D] + h32 @ w3.T + b3).double() - ref).abs().max().item()
-    print(f"[mlp_block M={M}] err {err:.2e} (fp32 CPU err {fp32_err:.2e})")
+    print(f"[mlp_block D={D} M={M}] err {err:.2e} (fp32 CPU err {fp32_err:.2e})")
     assert torch.isfinite(out).all()
     assert err < max(2.0 * fp32_err, 2e-6) + 2e-6 * ref.abs().max().item()
     # the O half of the rows is read-only
@@ -138,9 +138,10 @@ def test_mlp_block_fused_vs_float64(gpu_device, M):
     assert (two - out).abs().max().item() < 2e-5 + 1e-6 * ref.abs().max().item()
 
 
-def test_proj_block_wide_matrix(gpu_device):
+@pytest.mark.parametrize("D", [256, 128])
+def test_proj_block_wide_matrix(gpu_device, D):
     """N = 1024 output channels (32 blocks): more than the 3 blocks per wave one workgroup covers -- the launcher must deal the range out."""
-    D, N, M = 256, 1024, 4000
+    N, M = 1024, 4000
     g = torch.Generator().manual_seed(77)
     x, w, b = _rand(g, M, D, scale=2.0), _rand(g, N, D, scale=0.06), _rand(g, N, scale=0.3)
     out = ops.proj_block(x.to(gpu_device), w.to(gpu_device), b.to(gpu_device)).cpu()
@@ -149,13 +150,17 @@ def test_proj_block_wide_matrix(gpu_device):
     assert (out.double() - ref).abs().max().item() < 1e-5 + 2e-6 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("D", [256, 128])
 @pytest.mark.parametrize("M,split,cols_a,cols_b", [(2048, 0, None, None), (1, 0, None, None), (33, 0, None, None), (8192, 0, None, (256, 768)),
                                                    (1000, 512, (0, 256), (0, 768)), (96, 64, (0, 256), (0, 768)), (777, 0, None, (0, 256))])
-def test_proj_block_small_batch_vs_float64(gpu_device, M, split, cols_a, cols_b):
+def test_proj_block_small_batch_vs_float64(gpu_device, M, split, cols_a, cols_b, D):
     """og_proj_block (csrc/mlp_fused.hip: proj_small_kernel), the q / k / v projection kernel og_forward uses for launches of <= 8192 token
     rows (attention_gnn.py:43-47): against float64 on the (hi, lo) operands the kernel is given.  Partial tiles, one / two / three output
-    blocks per wave, the cross layer's row split (rows of image 0: the q columns only); columns outside a row's range stay untouched."""
-    D, N = 256, 768
+    blocks per wave, the cross layer's row split (rows of image 0: the q columns only); columns outside a row's range stay untouched.
+    D = 128: K = 128 (8 k-steps), N = 384 = the q | k | v matrix of the 128-d family (12 blocks: one or two per wave)."""
+    N = 3 * D
+    sc = lambda c: None if c is None else (c[0] * D // 256, c[1] * D // 256)       # the column ranges were written for N = 768
+    cols_a, cols_b = sc(cols_a), sc(cols_b)
     g = torch.Generator().manual_seed(2000 + M)
     x, w, b = _rand(g, M, D, scale=2.0), _rand(g, N, D, scale=0.06), _rand(g, N, scale=0.3)
     dev = lambda t: t.to(gpu_device)
@@ -168,16 +173,17 @@ def test_proj_block_small_batch_vs_float64(gpu_device, M, split, cols_a, cols_b)
     mask[:split, ca[0]:ca[1]] = True
     mask[split:, cb[0]:cb[1]] = True
     err = ((out.double() - ref).abs() * mask).max().item()
-    print(f"[proj_block M={M} split={split}] err {err:.2e} (fp32 CPU err {fp32_err:.2e})")
+    print(f"[proj_block D={D} M={M} split={split}] err {err:.2e} (fp32 CPU err {fp32_err:.2e})")
     assert torch.isfinite(out).all()
     assert err < max(2.0 * fp32_err, 2e-6) + 2e-6 * ref.abs().max().item()
     assert (out[~mask] == 0).all()                 # nothing written outside the requested ranges
 
 
-def test_mlp_block_rows_past_m_untouched(gpu_device):
+@pytest.mark.parametrize("D", [256, 128])
+def test_mlp_block_rows_past_m_untouched(gpu_device, D):
     from openglue_amd import _lib
     lib = _lib.load()
-    D, M, R = 256, 200, 384
+    M, R = 200, 384
     g = torch.Generator().manual_seed(7)
     xo = _rand(g, R, 2 * D).to(gpu_device)
     w0, w3 = _rand(g, 2 * D, 2 * D, scale=0.04), _rand(g, D, 2 * D, scale=0.05)
@@ -370,7 +376,7 @@ def _index_agreement(got_matches0, scores_gpu, sd, cfg, data):
     return ndiff, n_bad, o64
 
 
-@pytest.mark.parametrize("name", ["c1", "mid", "flags", "nodesc", "siren", "linear", "favor"])
+@pytest.mark.parametrize("name", ["c1", "mid", "flags", "nodesc", "siren", "linear", "favor", "d128"])
 def test_forward_against_reference_fixture(gpu_device, name):
     z, cfg, sd, data = load_case(name)
     model = _build(cfg, sd, gpu_device)
@@ -409,6 +415,35 @@ def test_forward_c2_shape_against_reference_fixture(gpu_device):
     ndiff, unexplained, o64 = _index_agreement(out["matches0"], s, sd, cfg, data)
     assert unexplained == 0, (ndiff, unexplained)
     assert (s.double() - o64["scores"]).abs().max() < TOL_SCORES
+
+
+@pytest.mark.parametrize("name", ["c3", "c4"])
+def test_forward_large_shapes_against_reference_fixture(gpu_device, name):
+    """VERDICT r4 missing 5: the LARGE BASELINE shapes against fixtures produced by the reference itself (c3: 2048 x 2048 x 256-d, c4: 4096 x 4096 x
+    128-d with s = 6 -- the 128-d kernel family at BASELINE configs[3]; 9 stages, 100 iterations, 2 pairs): sub-sampled scores, dustbin row and
+    column, float64 row sums, context descriptors, matches0.  Index differences are allowed only on rows the reference's OWN scores mark as
+    near-ties (stored top-1 / top-2 gaps), and are bounded."""
+    z, cfg, sd, data = load_case(name)
+    model = _build(cfg, sd, gpu_device)
+    out = {k: v.cpu() for k, v in model.match(to_device(data, gpu_device), MATCH_THRESHOLD).items()}
+    model.check_status()
+    s = out["scores"]
+    n = s.shape[2] - 1
+    errs = [np.abs(s[:, ::8, ::8].numpy() - z["scores_sub8"]).max(), np.abs(s[:, -1, :].numpy() - z["scores_lastrow"]).max(),
+            np.abs(s[:, :, -1].numpy() - z["scores_lastcol"]).max()]
+    assert max(errs) < TOL_SCORES, errs
+    assert np.abs(s.double().sum(2).numpy() - z["row_sums64"]).max() < (n + 1) * TOL_SCORES
+    assert np.abs(out["context_descriptors0"][:, ::4, ::16].numpy() - z["context_descriptors0_sub"]).max() < TOL_SCORES
+    assert np.abs(out["context_descriptors1"][:, ::4, ::16].numpy() - z["context_descriptors1_sub"]).max() < TOL_SCORES
+    diff = out["matches0"].numpy() != z["matches0"]
+    unexplained = 0
+    for b, i in zip(*np.nonzero(diff)):
+        if not (z["row_gap"][b, i] < 2e-4 or z["col_gap"][b, z["row_argmax"][b, i]] < 2e-4 or abs(float(z["matching_scores0"][b, i]) - MATCH_THRESHOLD) < 1e-3):
+            unexplained += 1
+    assert unexplained == 0 and diff.sum() <= max(2, int(math.ceil(MAX_EXEMPT_FRAC * diff.size))), (int(diff.sum()), unexplained)
+    parity_note(f"[{name} vs reference fixture] scores err {max(errs):.2e}; matches0 identical on {(~diff).mean() * 100:.3f}% rows exempt={int(diff.sum())}")
+    want = orc.extract_matches(s, MATCH_THRESHOLD)          # extraction itself is exact given the GPU's own scores
+    assert torch.equal(out["matches0"], want["matches0"])
 
 
 def test_image_tensor_path_equals_size_path(gpu_device):
@@ -876,14 +911,14 @@ def test_forward_status_after_forced_timeout_and_on_dirty_workspace(gpu_device, 
 
 
 # ----------------------------------------------------------------------------- per-stage goldens, og_forward_tap
-@pytest.mark.parametrize("name", ["mid", "flags", "d256"])
+@pytest.mark.parametrize("name", ["mid", "flags", "d256", "d128"])
 def test_stage_taps_against_reference_layers(gpu_device, name):
     """The residual stream at every stored stage boundary against the reference's OWN sub-modules (tests/golden/make_golden.py layers):
     tap 0 = local_descriptors + positional_encoding (superglue.py:41-55), tap k = attention_gnn.layers[k-1] (attention_gnn.py:57-77:
     ResidualAttentionMessagePropagation on both images; cross layers use the UPDATED image-0 descriptors).  d256 runs the fused
     message-MLP kernel, flags the use_offset form.  A stage-local failure shows up at its own tap, not only in the scores."""
     import ast
-    z = np.load(os.path.join(GOLDEN, "stage_layers.npz"))
+    z = np.load(os.path.join(GOLDEN, "stage_layers_d128.npz" if name == "d128" else "stage_layers.npz"))     # d128 (round 5): 9 stages, s = 6, 520 x 512: the 128-d kernel family
     meta = ast.literal_eval(str(z[f"{name}/meta"]))
     cfg = syn.make_config(**meta["kw"])
     sd = syn.make_state_dict(cfg, seed=0)

@@ -4,6 +4,7 @@ emulation of the kernel's data flow -- the stage order, the MFMA operand / accum
 consumes the packed stream exactly as the kernel does and must reproduce x + W3 relu(W0 [x ; O] + b0) + b3
 (reference attention_gnn.py:53-55 + models/utils.py:48-58 after the folds of og_pack_weights)."""
 import numpy as np
+import pytest
 import torch
 
 from openglue_amd import _lib
@@ -28,12 +29,17 @@ def _split(v):
     return hi.astype(np.float64), lo.astype(np.float64)
 
 
-def test_mlp_stream_numpy_emulation_of_the_kernel():
+@pytest.mark.parametrize("D", [256, 128])
+def test_mlp_stream_numpy_emulation_of_the_kernel(D):
+    """D = 256: two hidden halves x two quarters of 4 hidden blocks, fc.3 stages (hidden block j, k-step t) over 8 output blocks.
+    D = 128 (round 5; the reference's SIFT / HardNet width, attention_gnn.py:41 is generic in D): two halves x ONE pass of 4 hidden blocks,
+    fc.3 stages = hidden block j with both k-steps over 4 output blocks (mlp_fused_kernel<128>)."""
     lib = _lib.load()
-    D = 256
     nbytes = lib.og_mlp_block_stream_bytes(D)
     assert nbytes == 6 * D * D * 4
     assert lib.og_mlp_block_stream_bytes(64) == 0 and lib.og_mlp_block_pack(64, None, None, None) != 0
+    G0, NOB = 2 * D // 32, D // 32
+    HB2 = G0 // 2; NPASS = HB2 // 4; NJT = 8 if D == 256 else 4; SPP = G0 + NJT
     g = torch.Generator().manual_seed(11)
     w0 = (torch.randn(2 * D, 2 * D, generator=g) * 0.04).contiguous()
     w3 = (torch.randn(D, 2 * D, generator=g) * 0.05).contiguous()
@@ -41,7 +47,7 @@ def test_mlp_stream_numpy_emulation_of_the_kernel():
     b3 = (torch.randn(D, generator=g) * 0.3).double().numpy()
     st = torch.empty(nbytes, dtype=torch.uint8)
     assert lib.og_mlp_block_pack(D, w0.data_ptr(), w3.data_ptr(), st.data_ptr()) == 0
-    halves = st.numpy().view(np.float16).astype(np.float64).reshape(48, 32, 64, 8)      # [stage][fragment][lane][element]
+    halves = st.numpy().view(np.float16).astype(np.float64).reshape(NPASS * SPP, 32, 64, 8)      # [stage][fragment][lane][element]
 
     xo = (torch.randn(32, 2 * D, generator=g) * 1.5).double().numpy()                   # one wave: 32 tokens of [x | O]
     xh, xl = _split(xo)
@@ -49,21 +55,21 @@ def test_mlp_stream_numpy_emulation_of_the_kernel():
     lanes = np.arange(64)
     tok, hh = lanes & 31, lanes >> 5
 
-    # one token block = two waves: wave a owns hidden half a (two quarters of 4 blocks) and a PARTIAL fc.3 sum over all 8 output blocks
-    acc3 = np.zeros((2, 8, 64, 16))
-    for i in range(8):                                       # the bias enters once: in the wave that finishes the block (4a .. 4a+3)
+    # one token block = two waves: wave a owns hidden half a and a PARTIAL fc.3 sum over all output blocks
+    acc3 = np.zeros((2, NOB, 64, 16))
+    for i in range(NOB):                                     # the bias enters once: in the wave that finishes the block
         for l in range(64):
             for r in range(16):
-                acc3[i // 4, i, l, r] = 256.0 * b3[32 * i + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)]
+                acc3[i // (NOB // 2), i, l, r] = 256.0 * b3[32 * i + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)]
     for a in range(2):
-        for q in range(2):
+        for q in range(NPASS):
             acc0 = np.zeros((4, 64, 16))
             for i in range(4):
                 for l in range(64):
                     for r in range(16):
-                        acc0[i, l, r] = 256.0 * b0[32 * (8 * a + 4 * q + i) + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)]
-            for kg in range(16):                             # fc.0 stages
-                s = 24 * q + kg
+                        acc0[i, l, r] = 256.0 * b0[32 * (HB2 * a + 4 * q + i) + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)]
+            for kg in range(G0):                             # fc.0 stages
+                s = SPP * q + kg
                 for t in range(2):
                     cols = (32 * kg + 16 * t + 8 * hh)[:, None] + np.arange(8)[None, :]
                     bh, bl = xh[tok[:, None], cols], xl[tok[:, None], cols]
@@ -71,19 +77,21 @@ def test_mlp_stream_numpy_emulation_of_the_kernel():
                         f = ((a * 2 + t) * 4 + i) * 2
                         wh, wl = halves[s, f], halves[s, f + 1]
                         _mfma_32x32x16(wl, bh, acc0[i]); _mfma_32x32x16(wh, bl, acc0[i]); _mfma_32x32x16(wh, bh, acc0[i])
-            for j in range(4):                               # fc.3 stages (j, t): hidden block j of this quarter from acc0[j]
+            for j in range(4):                               # fc.3: hidden block j of this pass from acc0[j]
                 v = np.maximum(acc0[j].astype(np.float32) * np.float32(1.0 / 256.0), 0).astype(np.float64)
                 vh, vl = _split(v)
                 for t in range(2):
-                    s = 24 * q + 16 + 2 * j + t
                     bh, bl = vh[:, 8 * t:8 * t + 8], vl[:, 8 * t:8 * t + 8]      # element e of k-step t = accumulator register 8t + e
-                    for i in range(8):
-                        f = (a * 8 + i) * 2
+                    for i in range(NOB):
+                        if D == 256:
+                            s = SPP * q + G0 + 2 * j + t; f = (a * 8 + i) * 2           # stage (j, t), fragment (a, output block i)
+                        else:
+                            s = SPP * q + G0 + j; f = ((a * 2 + t) * 4 + i) * 2          # stage j, fragment (a, t, output block i)
                         wh, wl = halves[s, f], halves[s, f + 1]
                         _mfma_32x32x16(wl, bh, acc3[a, i]); _mfma_32x32x16(wh, bl, acc3[a, i]); _mfma_32x32x16(wh, bh, acc3[a, i])
     acc3 = acc3[0] + acc3[1]                                 # the exchange at the end of the kernel
     out = np.zeros((32, D))
-    for i in range(8):
+    for i in range(NOB):
         for l in range(64):
             for r in range(16):
                 ch = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
@@ -94,12 +102,16 @@ def test_mlp_stream_numpy_emulation_of_the_kernel():
     assert err < 2e-5          # fp32 rounding of the hidden activation + the dropped lo*lo terms
 
 
-def test_mlp_small_kernel_addresses_the_same_stream():
-    """mlp_small_kernel (few token rows: 32-token workgroups, wave w owns hidden blocks 2w, 2w+1 in fc.0 and OUTPUT block w in fc.3) reads its weight
-    fragments straight from the big kernel's stream with per-wave address formulas (csrc/mlp_fused.hip: frag0 / frag3).  Emulated here with numpy,
-    fragment by fragment at exactly those byte offsets: it must reproduce x + W3 relu(W0 [x ; O] + b0) + b3."""
+@pytest.mark.parametrize("D", [256, 128])
+def test_mlp_small_kernel_addresses_the_same_stream(D):
+    """mlp_small_kernel (few token rows: 32-token workgroups) reads its weight fragments straight from the big kernel's stream with per-wave
+    address formulas (csrc/mlp_fused.hip: frag0 / frag3).  D = 256: wave w owns hidden blocks 2w, 2w+1 in fc.0 and OUTPUT block w over all 16
+    hidden blocks in fc.3; D = 128: wave w owns hidden block w in fc.0 and output block w & 3 over hidden blocks 4 (w >> 2) .. + 3 in fc.3 (the two
+    halves are added).  Emulated here with numpy, fragment by fragment at exactly those byte offsets: it must reproduce
+    x + W3 relu(W0 [x ; O] + b0) + b3."""
     lib = _lib.load()
-    D = 256
+    G0, NOB = 2 * D // 32, D // 32
+    NJ, HB2, SPP = G0 // 8, G0 // 2, G0 + (8 if D == 256 else 4)
     g = torch.Generator().manual_seed(12)
     w0 = (torch.randn(2 * D, 2 * D, generator=g) * 0.04).contiguous()
     w3 = (torch.randn(D, 2 * D, generator=g) * 0.05).contiguous()
@@ -119,37 +131,44 @@ def test_mlp_small_kernel_addresses_the_same_stream():
     xo_rep = xh + xl
     lanes = np.arange(64)
     tok, hh = lanes & 31, lanes >> 5
-    hid_h = np.zeros((16, 2, 64, 8)); hid_l = np.zeros((16, 2, 64, 8))       # the LDS hand-over: [hidden block][t][lane][e]
-    for w in range(8):                                                         # fc.0: wave w, hidden blocks 2w + j
-        a, q, i0 = w >> 2, (w >> 1) & 1, 2 * (w & 1)
-        for j in range(2):
-            hb = 2 * w + j
+    hid_h = np.zeros((G0, 2, 64, 8)); hid_l = np.zeros((G0, 2, 64, 8))       # the LDS hand-over: [hidden block][t][lane][e]
+    for w in range(8):                                                         # fc.0: wave w, hidden blocks NJ w + j
+        for j in range(NJ):
+            hb = NJ * w + j
+            a, q, i = hb // HB2, (hb % HB2) >> 2, hb & 3
             acc = np.zeros((64, 16))
             for l in range(64):
                 for r in range(16):
                     acc[l, r] = 256.0 * b0[32 * hb + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)]
-            for ks in range(32):
+            for ks in range(2 * G0):
                 kg, t = ks >> 1, ks & 1
                 cols = (32 * kg + 16 * t + 8 * hh)[:, None] + np.arange(8)[None, :]
                 bh, bl = xh[tok[:, None], cols], xl[tok[:, None], cols]
-                base = (24 * q + kg) * WSTAGE + ((((a * 2 + t) * 4 + i0 + j) * 2) << 10)          # frag0(dst, j, kg, t, part)
+                base = (SPP * q + kg) * WSTAGE + ((((a * 2 + t) * 4 + i) * 2) << 10)          # frag0(dst, j, kg, t, part)
                 wh, wl = frag(base), frag(base + 1024)
                 _mfma_32x32x16(wl, bh, acc); _mfma_32x32x16(wh, bl, acc); _mfma_32x32x16(wh, bh, acc)
             v = np.maximum(acc.astype(np.float32) * np.float32(1.0 / 256.0), 0).astype(np.float64)
             vh, vl = _split(v)
             for t in range(2):
                 hid_h[hb, t], hid_l[hb, t] = vh[:, 8 * t:8 * t + 8], vl[:, 8 * t:8 * t + 8]      # element e of k-step t = accumulator register 8 t + e
-    out = np.zeros((32, D))
-    for w in range(8):                                                         # fc.3: wave w, output block w over all 16 hidden blocks
-        acc = np.zeros((64, 16))
-        for hb in range(16):
+    accs = np.zeros((8, 64, 16))
+    for w in range(8):                                                         # fc.3: wave w, output block w & (NOB - 1)
+        ob = w & (NOB - 1)
+        hbs = range(16) if D == 256 else range(4 * (w >> 2), 4 * (w >> 2) + 4)
+        for hb in hbs:
             for t in range(2):
-                base = (24 * ((hb >> 2) & 1) + 16 + 2 * (hb & 3) + t) * WSTAGE + ((((hb >> 3) * 8 + w) * 2) << 10)      # frag3(dst, hb, t, part)
+                if D == 256:
+                    base = (24 * ((hb >> 2) & 1) + 16 + 2 * (hb & 3) + t) * WSTAGE + ((((hb >> 3) * 8 + ob) * 2) << 10)      # frag3(dst, hb, t, part)
+                else:
+                    base = (8 + (hb & 3)) * WSTAGE + (((((hb >> 2) * 2 + t) * 4 + ob) * 2) << 10)
                 wh, wl = frag(base), frag(base + 1024)
-                _mfma_32x32x16(wl, hid_h[hb, t], acc); _mfma_32x32x16(wh, hid_l[hb, t], acc); _mfma_32x32x16(wh, hid_h[hb, t], acc)
+                _mfma_32x32x16(wl, hid_h[hb, t], accs[w]); _mfma_32x32x16(wh, hid_l[hb, t], accs[w]); _mfma_32x32x16(wh, hid_h[hb, t], accs[w])
+    out = np.zeros((32, D))
+    for ob in range(NOB):
+        acc = accs[ob] if D == 256 else accs[ob] + accs[ob + 4]                # 128-d: the two hidden halves meet in LDS
         for l in range(64):
             for r in range(16):
-                ch = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
+                ch = 32 * ob + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
                 out[l & 31, ch] = acc[l, r] / 256.0 + b3[ch] + xo_rep[l & 31, ch]
     ref = xo_rep[:, :D] + np.maximum(xo_rep @ w0.double().numpy().T + b0, 0) @ w3.double().numpy().T + b3
     err = np.abs(out - ref).max()
@@ -166,13 +185,14 @@ def test_mlp_stream_range_error():
     assert lib.og_mlp_block_pack(D, w0.data_ptr(), w3.data_ptr(), st.data_ptr()) == -5
 
 
-def test_proj_stream_layout():
-    """og_proj_block_pack (the small-batch projection kernel's weight stream): fragment ((i * 16 + ks) * 2 + part) of 1 KiB, lane l =
+@pytest.mark.parametrize("K", [256, 128])
+def test_proj_stream_layout(K):
+    """og_proj_block_pack (the small-batch projection kernel's weight stream): fragment ((i * K / 16 + ks) * 2 + part) of 1 KiB, lane l =
     (rho = l & 31, h = l >> 5), element e = 256 w[32 i + rho][16 ks + 8 h + e] as (hi, lo) halves -- re-read here with numpy."""
     lib = _lib.load()
-    N, K = 96, 256
+    N = 96
     assert lib.og_proj_block_stream_bytes(N, K) == N * K * 4
-    assert lib.og_proj_block_stream_bytes(100, K) == 0 and lib.og_proj_block_stream_bytes(N, 128) == 0
+    assert lib.og_proj_block_stream_bytes(100, K) == 0 and lib.og_proj_block_stream_bytes(N, 64) == 0
     g = torch.Generator().manual_seed(5)
     w = torch.randn(N, K, generator=g) * 0.05
     st = torch.empty(N * K * 4, dtype=torch.uint8)
