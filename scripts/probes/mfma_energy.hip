@@ -8,6 +8,9 @@
 //   R32   V32 with ONE A and ONE B register set for every MFMA (operand fetch of identical registers)
 //   B32   v_mfma_f32_32x32x16_bf16, C/D in VGPRs
 //   W1    V32 with one wave per SIMD
+//   M8    (round 5) v_mfma_scale_f32_32x32x64_f8f6f4 with e4m3 operands (N(0,1) values) and unit E8M0 block scales: 4x the flops
+//         of a 32x32x16 f16 MFMA per instruction -- does the block-scaled fp8 path sustain >= 1.7x the f16 rate under the power cap?
+//   I8    v_mfma_i32_32x32x32_i8 (2x the flops per instruction), operands uniform in [-127, 127]
 // Reports the clock the chip settles at and the TFLOP/s; higher = less energy per flop.
 //   hipcc --offload-arch=gfx950 -O3 scripts/probes/mfma_energy.hip -o mfma_energy && ./mfma_energy
 #include <hip/hip_runtime.h>
@@ -21,7 +24,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum { V32, A32, V16, A16, R32, B32, W1 };
+enum { V32, A32, V16, A16, R32, B32, W1, M8, I8 };
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
 
 template <int VAR>
 __global__ __launch_bounds__(512) void k(const f16x8* in, float* out, unsigned long long* res, int iters) {
@@ -32,7 +38,45 @@ __global__ __launch_bounds__(512) void k(const f16x8* in, float* out, unsigned l
     float s = 0.f;
     __syncthreads();
     unsigned long long t0, r0, t1, r1;
-    if constexpr (VAR == V32 || VAR == R32 || VAR == W1 || VAR == A32 || VAR == B32) {
+    if constexpr (VAR == M8) {
+        // operands: 8 dwords = 32 fp8 bytes per lane (the same random bytes reinterpreted: the host filled `in` with e4m3 encodings for this variant)
+        i32x8 a8[2], b8[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            a8[i] = i32x8{__builtin_bit_cast(i32x4, a[2 * i])[0], __builtin_bit_cast(i32x4, a[2 * i])[1], __builtin_bit_cast(i32x4, a[2 * i])[2], __builtin_bit_cast(i32x4, a[2 * i])[3],
+                          __builtin_bit_cast(i32x4, a[2 * i + 1])[0], __builtin_bit_cast(i32x4, a[2 * i + 1])[1], __builtin_bit_cast(i32x4, a[2 * i + 1])[2], __builtin_bit_cast(i32x4, a[2 * i + 1])[3]};
+            b8[i] = i32x8{__builtin_bit_cast(i32x4, b[2 * i])[0], __builtin_bit_cast(i32x4, b[2 * i])[1], __builtin_bit_cast(i32x4, b[2 * i])[2], __builtin_bit_cast(i32x4, b[2 * i])[3],
+                          __builtin_bit_cast(i32x4, b[2 * i + 1])[0], __builtin_bit_cast(i32x4, b[2 * i + 1])[1], __builtin_bit_cast(i32x4, b[2 * i + 1])[2], __builtin_bit_cast(i32x4, b[2 * i + 1])[3]};
+        }
+        f32x16 acc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+        t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime();
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i)      // 12 x 4 = the flops of 48 32x32x16 f16 MFMAs
+                acc[i & 7] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i & 1], b8[(i >> 1) & 1], acc[i & 7], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+        }
+        t1 = __builtin_amdgcn_s_memtime(); r1 = __builtin_amdgcn_s_memrealtime();
+#pragma unroll
+        for (int c = 0; c < 8; ++c) for (int r = 0; r < 16; ++r) s += acc[c][r];
+    } else if constexpr (VAR == I8) {
+        i32x4 a8[4], b8[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a8[i] = __builtin_bit_cast(i32x4, a[i]); b8[i] = __builtin_bit_cast(i32x4, b[i]); }
+        i32x16 acc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) for (int r = 0; r < 16; ++r) acc[c][r] = 0;
+        t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime();
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 24; ++i)      // 24 x 2 = the flops of 48 32x32x16 f16 MFMAs
+                acc[i & 7] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a8[(i >> 1) & 3], b8[(i >> 3) & 3], acc[i & 7], 0, 0, 0);
+        }
+        t1 = __builtin_amdgcn_s_memtime(); r1 = __builtin_amdgcn_s_memrealtime();
+#pragma unroll
+        for (int c = 0; c < 8; ++c) for (int r = 0; r < 16; ++r) s += (float)acc[c][r];
+    } else if constexpr (VAR == V32 || VAR == R32 || VAR == W1 || VAR == A32 || VAR == B32) {
         f32x16 acc[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
@@ -105,5 +149,26 @@ int main() {
     CHECK(hipMemcpy(in, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
     run<B32>("B32  32x32x16 bf16, C/D in VGPRs", in, out, res);
     run<B32>("B32  32x32x16 bf16, C/D in VGPRs", in, out, res);
+    // fp8 e4m3 encodings of N(0,1) values (OCP e4m3fn: bias 7, 3 mantissa bits), unit block scales
+    std::vector<unsigned char> h8(64 * 64 * 16);
+    for (size_t i = 0; i < h8.size(); ++i) {
+        float v = gauss(); const unsigned sgn = v < 0 ? 0x80u : 0u; v = fabsf(v);
+        int e; float m = frexpf(v, &e);                 // v = m 2^e, m in [0.5, 1)
+        unsigned code = 0;
+        if (v >= 0.015625f) {                           // normal range 2^-6 ..
+            int E = e - 1 + 7; int M = (int)lrintf((m * 2.f - 1.f) * 8.f); if (M == 8) { M = 0; ++E; }
+            if (E > 15) { E = 15; M = 6; }
+            code = (unsigned)(E << 3 | M);
+        } else code = (unsigned)lrintf(v * 512.f);      // subnormals: multiples of 2^-9
+        h8[i] = (unsigned char)(sgn | code);
+    }
+    CHECK(hipMemcpy(in, h8.data(), h8.size(), hipMemcpyHostToDevice));
+    run<M8>("M8   32x32x64 MX fp8 e4m3 (v_mfma_scale_f32_32x32x64_f8f6f4), unit scales", in, out, res);
+    run<M8>("M8   32x32x64 MX fp8 e4m3 (v_mfma_scale_f32_32x32x64_f8f6f4), unit scales", in, out, res);
+    for (size_t i = 0; i < h8.size(); ++i) h8[i] = (unsigned char)(rand() & 0xFF);
+    CHECK(hipMemcpy(in, h8.data(), h8.size(), hipMemcpyHostToDevice));
+    run<I8>("I8   32x32x32 i8 (v_mfma_i32_32x32x32_i8), uniform bytes", in, out, res);
+    run<I8>("I8   32x32x32 i8 (v_mfma_i32_32x32x32_i8), uniform bytes", in, out, res);
+    run<V32>("V32  32x32x16 f16 again (operands now random bytes)", in, out, res);
     return 0;
 }

@@ -9,6 +9,10 @@ per row, or "drop" (plain f16 operands), everything accumulated in float64, and 
 
     python tests/emulate_cross_term_precision.py [case ...]
     python tests/emulate_cross_term_precision.py --attention-only [case ...]     # round 4: only the attention kernel's cross products in 8 bits
+    python tests/emulate_cross_term_precision.py --mx [case ...]                 # round 5: the HARDWARE block-scaled fp8 MFMA
+        (v_mfma_scale_f32_32x32x64_f8f6f4: e4m3 elements, one E8M0 scale per 32 elements along k applied by the matrix pipe itself, fp32 accumulation into
+        the same accumulator as the f16 hi.hi product) for the two cross products of Q K^T K-concatenated ([Qh | Ql] . [Kl | Kh]^T), P V left at f16 x 3
+        ("mxqk"), and for both contractions ("mxboth").  Kill criterion: worst case over all fixtures + `trained` <= 5e-4.
 """
 import os
 import sys
@@ -81,6 +85,16 @@ def q_rows(x, mode):
     return (x / scale).to(torch.float32).to(torch.float8_e4m3fn).to(torch.float64) * scale
 
 
+def mx(x):
+    """e4m3 elements with one power-of-two scale per 32 elements along the contraction (the last axis), as the block-scaled MFMA applies them."""
+    global MODE
+    keep, MODE = MODE, "fp8"
+    try:
+        return q8(x)
+    finally:
+        MODE = keep
+
+
 def mm_attn(a, b, tile=None):
     """a [..., M, K] @ b [..., N, K]^T as the flash kernel would run it with 8-bit correction products: the hi.hi product in f16, the two
     cross products with 8-bit operands; tile = the key-tile length of P V (scales per (row, key tile): every tile is its own integer
@@ -90,8 +104,10 @@ def mm_attn(a, b, tile=None):
     out = ah @ bh.transpose(-1, -2)
     if MODE == "drop":
         return out
-    if MODE == "exact":
+    if MODE == "exact" or (MODE == "mxqk" and tile is not None):
         return out + ah @ bl.transpose(-1, -2) + al @ bh.transpose(-1, -2)
+    if MODE in ("mxqk", "mxboth"):       # block scales vary along k: no per-tile accumulation needed, the pipe applies them
+        return out + mx(ah) @ mx(bl).transpose(-1, -2) + mx(al) @ mx(bh).transpose(-1, -2)
     if tile is None:
         return out + q_rows(ah, MODE) @ q_rows(bl, MODE).transpose(-1, -2) + q_rows(al, MODE) @ q_rows(bh, MODE).transpose(-1, -2)
     K = a.shape[-1]
@@ -121,20 +137,33 @@ def softmax_attention(q, k, v, num_heads, operand_dtype=None):
 def main():
     global MODE, ATTN_ONLY
     args = sys.argv[1:]
-    if args and args[0] == "--attention-only":
+    modes = ("exact", "fp8", "int8", "drop")
+    if args and args[0] == "--mx":
+        ATTN_ONLY = True
+        modes = ("exact", "mxqk", "mxboth")
+        args = args[1:]
+        print("block-scaled fp8 (MX e4m3, E8M0 scale per 32 along k) for the cross products of the ATTENTION kernel: mxqk = Q K^T only (P V f16 x 3), mxboth = both; "
+              "kill criterion: worst case <= 5e-4")
+    elif args and args[0] == "--attention-only":
         ATTN_ONLY = True
         args = args[1:]
         print("correction products of the ATTENTION kernel only (Qh.Kl + Ql.Kh per head, Ph.Vl + Pl.Vh per 64-key tile), convs split-f16 x3; kill criterion: flags <= 5e-4")
     cases = args or ["c1", "flags", "mid"]
     torch.set_num_threads(os.cpu_count() or 8)
     for name in cases:
-        z, cfg, sd, data = load_case(name)
+        if name.startswith("trained"):       # tests/golden/trained.npz: dead BatchNorm channels, large weights; unit-norm ("unit") or x4 descriptors
+            from openglue_amd import synthetic as syn
+            cfg = syn.make_config(descriptor_dim=256, num_stages=2, num_heads=4, num_iters=20, side_info_size=1)
+            sd = syn.make_trained_like_state_dict(cfg, seed=0)
+            data = syn.make_batch(2, 140, 120, 256, 1, seed=31, desc_scale=4.0 if name.endswith("x4") else 1.0)
+        else:
+            z, cfg, sd, data = load_case(name)
         with torch.no_grad():
             ref = orc.superglue_forward(sd, cfg, data, dtype=torch.float64)["scores"]
             keep = orc.conv1x1, orc.softmax_attention
             orc.conv1x1, orc.softmax_attention = conv1x1, softmax_attention
             try:
-                for MODE in ("exact", "fp8", "int8", "drop"):
+                for MODE in modes:
                     got = orc.superglue_forward(sd, cfg, data, dtype=torch.float64)["scores"]
                     err = (got - ref).abs().max().item()
                     m_ref = orc.extract_matches(ref.float(), 0.2)["matches0"]
