@@ -166,7 +166,9 @@ typedef struct og_packed_layout_t {
     int64_t o_wmlp;   /* ABI v5: per layer, the SAME folded w0 / w3 once more as the fragment-major stream og_mlp_block consumes
                          (og_mlp_block_stream_bytes(D) bytes; -1 when D has no fused message-MLP kernel)                         */
     int64_t o_wqkvs;  /* ABI v7: per layer, the q | k | v matrix once more as the fragment-major stream og_proj_block consumes (the
-                         small-batch projection kernel; og_proj_block_stream_bytes(3D, D) bytes; -1: D not 256 / 128, or favor_relu)   */
+                         small-batch projection kernel; N K 4 bytes; -1: D not 256 / 128, or favor_relu)   */
+    int64_t o_wqkvb;  /* ABI v8: ... and a third time as the stream of the BATCH projection kernel (proj_stream_kernel: launches of more than
+                         8192 token rows; N K 4 bytes; -1 as above).  og_proj_block_stream_bytes(N, K) = both streams, the small one first  */
 } og_packed_layout_t;
 int og_packed_layout(const og_shape* shape, og_packed_layout_t* layout);
 
@@ -289,7 +291,10 @@ int og_gemm_nt_f16x3_reshl(const void* A, int64_t lda, const void* B, int64_t ld
  * proj_small_kernel); the weights are consumed as a fragment-major stream of (hi, lo) halves of 256 w that og_proj_block_pack writes on
  * the host (og_proj_block_stream_bytes(N, K) bytes, 0 = shape not supported).  Rows below split_row get the output columns
  * [32 a0, 32 a1), the others [32 b0, 32 b1) (split_row a multiple of 32, or 0 / >= M for one range).  inv_scale_dev: DEVICE float,
- * 1 / 256 for streams packed here.  Same arithmetic as og_gemm_nt_f16x3.  ABI v8: og_proj_block takes K. */
+ * 1 / 256 for streams packed here.  Same arithmetic as og_gemm_nt_f16x3.  ABI v8: og_proj_block takes K; launches of more than 8192 rows whose column
+ * ranges are whole groups of 128 channels (and split_row a multiple of 128, yh / yl 128-byte aligned) take the batch kernel (proj_stream_kernel:
+ * 128-token workgroups, the x fragments in registers, weights through an LDS ring) -- og_proj_block_pack writes its stream behind the small-batch
+ * one, ldy must then equal N.  OG_PROJ_STREAM=0 / 1 forces either kernel. */
 size_t og_proj_block_stream_bytes(int32_t N, int32_t K);
 int og_proj_block_pack(int32_t N, int32_t K, const float* W, void* stream_host);
 int og_proj_block(const void* x_rows, int64_t ld, int32_t M, int32_t K, const void* stream_dev, const float* bias, const float* inv_scale_dev,

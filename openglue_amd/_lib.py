@@ -68,7 +68,7 @@ class og_packed_layout_t(C.Structure):
     _fields_ = [("n_enc", C.c_int32), ("enc_k", C.c_int32 * (OG_MAX_HIDDEN + 1)), ("enc_out", C.c_int32 * (OG_MAX_HIDDEN + 1)),
                 ("enc_w", C.c_int64 * (OG_MAX_HIDDEN + 1)), ("enc_b", C.c_int64 * (OG_MAX_HIDDEN + 1))] + \
                [(k, C.c_int64) for k in ("layer0", "layer_stride", "o_wqkv", "o_bqkv", "o_w0", "o_b0", "o_w3", "o_b3",
-                                         "wp", "bp", "alpha", "dustbin", "total", "o_scale", "scales", "o_wmlp", "o_wqkvs")]
+                                         "wp", "bp", "alpha", "dustbin", "total", "o_scale", "scales", "o_wmlp", "o_wqkvs", "o_wqkvb")]
 
 
 # every symbol include/openglue_amd.h declares: name -> (restype, argtypes)

@@ -23,6 +23,7 @@ struct PackedLayout {
     int64_t o_wqkv, o_bqkv, o_w0, o_b0, o_w3, o_b3;
     int64_t o_wmlp;                             // fragment-major stream of mlp_fused.hip (W0' then W3' per hidden half), -1: none
     int64_t o_wqkvs;                            // fragment-major copy of the q | k | v matrix for proj_small_kernel (few token rows), -1: none
+    int64_t o_wqkvb;                            // ... and for proj_stream_kernel (batches), -1: none
     int64_t o_scale;                            // per layer: accumulator multipliers {1 / S_qkv, 1 / S_0, 1 / S_3, 0} of its three split-f16 matrices
     int64_t scales;                             // {1 / S_wp, 1 / S_enc_whl}: final projection, last encoder conv
     int64_t wp, bp, alpha, dustbin;
@@ -69,6 +70,10 @@ PackedLayout packed_layout(const og_shape& s) {
     L.o_wqkvs = -1;
     if (!(s.flags & OG_FLAG_FAVOR_RELU) && og_proj_stream_bytes(qkv_width(s), (int)D)) {
         L.o_wqkvs = lo; lo = al64(lo + (int64_t)(og_proj_stream_bytes(qkv_width(s), (int)D) / 4));
+    }
+    L.o_wqkvb = -1;
+    if (!(s.flags & OG_FLAG_FAVOR_RELU) && og_proj_stream_big_bytes(qkv_width(s), (int)D)) {
+        L.o_wqkvb = lo; lo = al64(lo + (int64_t)(og_proj_stream_big_bytes(qkv_width(s), (int)D) / 4));
     }
     L.layer_stride = lo;
     L.layer0 = off; off += lo * 2 * s.num_stages;
@@ -192,7 +197,7 @@ extern "C" int og_packed_layout(const og_shape* shape, og_packed_layout_t* o) {
     o->layer0 = L.layer0; o->layer_stride = L.layer_stride;
     o->o_wqkv = L.o_wqkv; o->o_bqkv = L.o_bqkv;
     o->o_w0 = L.o_w0; o->o_b0 = L.o_b0;
-    o->o_w3 = L.o_w3; o->o_b3 = L.o_b3; o->o_wmlp = L.o_wmlp; o->o_wqkvs = L.o_wqkvs; o->o_scale = L.o_scale; o->scales = L.scales;
+    o->o_w3 = L.o_w3; o->o_b3 = L.o_b3; o->o_wmlp = L.o_wmlp; o->o_wqkvs = L.o_wqkvs; o->o_wqkvb = L.o_wqkvb; o->o_scale = L.o_scale; o->scales = L.scales;
     o->wp = L.wp; o->bp = L.bp; o->alpha = L.alpha; o->dustbin = L.dustbin; o->total = L.total;
     return 0;
 }
@@ -313,6 +318,7 @@ extern "C" int og_pack_weights(const og_shape* shape, const og_params* P, void* 
         double Sq = OG_W_SCALE;
         ok &= put_matrix(Wqkv, Wqd.data(), qkv_width(s), D, scl + 0, &Sq);
         if (L.o_wqkvs >= 0) ok &= og_pack_proj_stream(qkv_width(s), D, Wqd.data(), base + L.o_wqkvs, Sq);
+        if (L.o_wqkvb >= 0) ok &= og_pack_proj_stream_big(qkv_width(s), D, Wqd.data(), base + L.o_wqkvb, Sq);
         // fc.0 on y = [x ; msg] (or [x - msg ; msg] with use_offset, attention_gnn.py:51-54), msg = Wo O + bo:
         //   W0 y = W0a x + Wm (Wo O + bo),  Wm = W0b (- W0a)   ->  [W0a | Wm Wo] [x ; O] + (b0 + Wm bo)
         if (!lp.fc0.weight || !lp.fc0.bias || !lp.out_proj.weight || !lp.out_proj.bias || !lp.fc3.weight || !lp.fc3.bias)
@@ -556,8 +562,22 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
         return og_launch_proj_small(XO + r0 * D4, D4, (int)R, D, (const char*)(lw + L.o_wqkvs), lw + L.o_bqkv, lw + L.o_scale,
                                     QKVh + r0 * QW, QKVl + r0 * QW, QW, split_row, a0, a1, b0, b1, st);
     };
+    // Batches (more than 8192 rows per launch) of the 128-d family: proj_stream_kernel, 128-token workgroups with the x fragments in registers and the
+    // weights through an LDS ring (mlp_fused.hip).  At D = 128 the q | k | v matrix (N = 384) has no 256-tile form and the 128-token tile GEMM runs 4
+    // k-stages per tile; at D = 256 the 256-tile GEMM stays faster in the whole step (og_proj_stream_wanted).  OG_PROJ_STREAM=0 / 1 forces.
+    // The plane rows (QW halves) are whole 128-byte lines: QW = 3D, D a multiple of 64.
+    auto proj_stream_ok = [&](int64_t R) {
+        return L.o_wqkvb >= 0 && !favor && og_proj_stream_wanted((int)(R < ((int64_t)1 << 30) ? R : 0), D) && R < ((int64_t)1 << 30) && QW % 64 == 0 &&
+               !(((uintptr_t)QKVh | (uintptr_t)QKVl) & 127);
+    };
+    auto proj_stream = [&](const float* lw, int64_t r0, int64_t R, int split_row, int a0, int a1, int b0, int b1) -> int {      // ranges in channels
+        Scope sc(prof, OG_STAGE_GEMM_F16X3);
+        return og_launch_proj_stream(XO + r0 * D4, D4, (int)R, D, (const char*)(lw + L.o_wqkvb), lw + L.o_bqkv, lw + L.o_scale,
+                                     QKVh + r0 * QW, QKVl + r0 * QW, QW, split_row, a0 / 128, a1 / 128, b0 / 128, b1 / 128, st);
+    };
     auto qkv_proj = [&](const float* lw, int64_t r0, int64_t R, int c0, int c1) -> int {
         if (proj_small_ok(R) && c0 % 32 == 0 && c1 % 32 == 0) return proj_small(lw, r0, R, 0, 0, 0, c0 / 32, c1 / 32);
+        if (proj_stream_ok(R) && c0 % 128 == 0 && c1 % 128 == 0 && ((r0 * QW * 2) % 128 == 0)) return proj_stream(lw, r0, R, 0, 0, 0, c0, c1);
         const int cut = favor ? 2 * WQ : c1;
         const int ca[2] = {c0, c0 < cut && cut < c1 ? cut : c1}, cb[2] = {ca[1], c1};
         for (int part = 0; part < 2; ++part) {
@@ -607,6 +627,8 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
                 g.split_row = (int)T0; g.split_n = WQ;
                 if (proj_small_ok(T) && T0 % 32 == 0 && WQ % 32 == 0) {      // rows of image 0: the q blocks only
                     if ((rc = proj_small(lw, 0, T, (int)T0, 0, WQ / 32, 0, QW / 32))) return rc;
+                } else if (proj_stream_ok(T) && T0 % 128 == 0 && WQ % 128 == 0) {
+                    if ((rc = proj_stream(lw, 0, T, (int)T0, 0, WQ, 0, QW))) return rc;
                 } else if (!favor && !rag && T < (int64_t)1 << 30 && og_gemm_f16x3_row_split_ok(g)) {
                     Scope sc(prof, OG_STAGE_GEMM_F16X3);
                     if ((rc = og_launch_gemm_f16x3(g, st))) return rc;

@@ -492,12 +492,9 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpFusedArgs g) {
             }
         }
     }
-#undef OG_GROUP
-#undef OG_GROUP_LAST
 #undef OG_RESID
 #undef OG_RES1
-#undef OG_MM
-#undef OG_RD
+      // (OG_GROUP / OG_GROUP_LAST / OG_MM / OG_RD / OG_SB stay defined: proj_stream_kernel below is built from the same stage groups)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     OG_MT(3, 1);
     const int tok0 = t0 + tb * 32;
@@ -597,6 +594,282 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpFusedArgs g) {
         for (int k = 0; k < 4; ++k) og_mlp_trace_buf[blockIdx.x][wave][k][lane] = (unsigned)mt_v[k];
 #endif
 }
+
+
+// =================================================================================================================================
+// proj_stream_kernel -- the q / k / v projections of a BATCH (launches of more than 8192 token rows) in the style of mlp_fused_kernel.
+// The 256 x 256-tile GEMM it replaces spends a quarter of a tile's life in prologue + epilogue (K = 256 is 8 k-stages), moves BOTH
+// operands through LDS and reaches 0.097 of the f16 peak at C2; at D = 128 (N = 384: no 256-tile form) the 128-token
+// tile kernel runs 4 k-stages per tile.  Here:
+//   * a workgroup = 128 tokens, 8 waves, wave (tb, a) = token block tb x half a of every 128-channel group of the output ("super-pair":
+//     4 blocks of 32 channels, wave a owns blocks 2a, 2a + 1 -- one full 128-byte line of each output plane per token);
+//   * the x rows of the tile are NOT staged in LDS: every wave loads the B fragments of its 32 tokens -- all K channels, (hi, lo) --
+//     straight from the hl32 rows into registers ONCE (K / 16 x 2 fragments: 128 VGPRs at K = 256) and keeps them for all output blocks;
+//   * only the weights stream through LDS: the fragment-major stream of og_pack_proj_stream_big, 32 KiB stages (4 blocks x 4 k-steps x
+//     (hi, lo)), 3-slot ring, LDS-DMA two stages ahead, one barrier per stage -- the stage groups, counted waits and hand-over of
+//     mlp_fused_kernel;
+//   * after the K / 64 stages of a super-pair the wave scales, splits and writes its 32 x 64 outputs as whole 128-byte lines of the two
+//     planes (through a private LDS slab), then starts the next super-pair from the bias.
+// Workgroups whose first row is below split_row take the super-pairs [a0, a1), the others [b0, b1) (the cross layer's launch).
+struct ProjStreamArgs {
+    const _Float16* X; int64_t ld; int M;      // [M] hl32 rows, the first 2K halves = x
+    const char* wstream;                       // og_pack_proj_stream_big
+    const float* bias;                         // [N]
+    const float* scale_dev;                    // DEVICE: 1 / pre-scale of the matrix
+    _Float16* Ch; _Float16* Cl; int64_t ldc;   // output planes [M][ldc]
+    int split_row, a0, a1, b0, b1;             // super-pair ranges (units of 128 output channels)
+};
+
+template <int K>
+__global__ __launch_bounds__(512) void proj_stream_kernel(ProjStreamArgs g) {
+    static_assert(K == 256 || K == 128, "K = the descriptor width");
+    constexpr int KS = K / 16, SPS = KS / 4;   // k-steps; stages per super-pair
+    constexpr int PBOFF = 3 * WSTAGE;          // bias / scale of the columns of this workgroup: up to 1024 floats
+    constexpr int PSLAB = PBOFF + 4096;        // per-wave epilogue slabs: 32 rows x (128 + 16) B
+    constexpr int ROWB = 128 + 16;
+    __shared__ __attribute__((aligned(16))) char smem[PSLAB + 8 * EPI_SLAB];
+    static_assert(PSLAB + 8 * EPI_SLAB <= 163840, "LDS budget");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tb = wave >> 1, ha = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int t0 = blockIdx.x * MT;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const int sp0 = __builtin_amdgcn_readfirstlane(t0 < g.split_row ? g.a0 : g.b0), sp1 = __builtin_amdgcn_readfirstlane(t0 < g.split_row ? g.a1 : g.b1);
+    if (sp1 <= sp0) return;
+#if OG_MLP_TRACE
+    int mt_v[4] = {0, 0, 0, 0};      // experiment builds: [0..2][stage] hand-over stamps as in mlp_fused_kernel; [3]: 0 entry, 1 prologue done, 8 + 2 i / 9 + 2 i epilogue i, 30 end
+    OG_MT(3, 0);
+#endif
+    const int nst = (sp1 - sp0) * SPS;         // weight stages of this workgroup
+
+    auto scalar_ptr = [](const char* p) {
+        const uint64_t v = (uint64_t)(uintptr_t)p;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi32 = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        return reinterpret_cast<const char*>((uintptr_t)(((uint64_t)hi32 << 32) | lo));
+    };
+    unsigned lane16 = (unsigned)lane * 16u;
+    asm volatile("" : "+v"(lane16));
+    const char* const baseW = g.wstream + (int64_t)sp0 * SPS * WSTAGE + wave * 4 * 1024;
+    auto issue_w4 = [&](int st, int slot) {               // the 4 pieces of this wave of weight stage st (relative to sp0) into ring slot `slot`
+        const char* src = scalar_ptr(baseW + (int64_t)st * WSTAGE);
+        const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + slot * WSTAGE + wave * 4096);
+        asm volatile("s_mov_b32 m0, %2\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dwordx4 %0, %1\n\t"
+                     "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %0, %1 offset:2048\n\t"
+                     "global_load_lds_dwordx4 %0, %1 offset:3072"
+                     :: "v"(lane16), "s"(src), "s"(m0v) : "memory");
+    };
+    // ---- this wave's B fragments: token l31 of its block, k-step ks = channels 16 ks + 8 hi .. + 7, (hi, lo).  A lane needs 16-byte pieces of ITS
+    //      token's row: loaded straight from memory that is 32 row segments of 32 bytes per instruction -- 21k cycles of a 86k-cycle tile
+    //      (profiles/r05_d_proj_stream_trace_v1.log).  So the tile's x rows are staged through LDS like the token stages of mlp_fused_kernel: LDS-DMA
+    //      of whole 128-byte lines (k-group kg of 8 rows per piece, XOR swizzle on the source), fragment reads with the matching swizzle -- the
+    //      staging area is the (still empty) weight ring and what lies behind it. ----
+    f16x8 xh[KS], xl[KS];
+    {
+        constexpr int KG = K / 32;                         // k-groups: one 128-byte line per row each
+        static_assert(KG * XSTAGE <= PSLAB + 8 * EPI_SLAB, "the staging area fits the kernel's LDS");
+        unsigned xoff[2];
+        const char* const baseX = reinterpret_cast<const char*>(g.X) + (int64_t)t0 * g.ld * 2;
+        {
+            const int rl = lane >> 3, pc = lane & 7;
+            const int last = g.M - 1 - t0;                 // rows past the matrix are clamped (computed, never stored)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int rt = wave * 16 + h * 8 + rl;
+                xoff[h] = (unsigned)((rt < last ? rt : last) * (int)g.ld * 2) + (unsigned)(pc ^ ((rt >> 1) & 7)) * 16u;
+            }
+        }
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) {
+            const char* src = scalar_ptr(baseX + kg * 128);
+            const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + kg * XSTAGE + wave * 2048);
+            asm volatile("s_mov_b32 m0, %3\n\t"
+                         "s_nop 0\n\t"
+                         "global_load_lds_dwordx4 %0, %2\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\t"
+                         "s_nop 0\n\t"
+                         "global_load_lds_dwordx4 %1, %2"
+                         :: "v"(xoff[0]), "v"(xoff[1]), "s"(src), "s"(m0v) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // every wave's rows are in LDS
+        const int swz = (l31 >> 1) & 7;
+        const unsigned rb = lds0 + (unsigned)((tb * 32 + l31) * 128);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const unsigned ah = rb + (unsigned)((ks >> 1) * XSTAGE) + (unsigned)(((2 * (ks & 1) + hi) ^ swz) * 16);
+            asm volatile("ds_read_b128 %0, %1" : "=v"(xh[ks]) : "v"(ah) : "memory");
+            asm volatile("ds_read_b128 %0, %1" : "=v"(xl[ks]) : "v"(ah ^ 64u) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(xh[ks]), "+v"(xl[ks]));
+        __builtin_amdgcn_s_barrier();                      // everybody has its fragments: the staging area becomes the weight ring
+    }
+    issue_w4(0, 0);
+    if (nst > 1) issue_w4(1, 1);
+    const float sc = g.scale_dev[0];
+    {   // bias / scale of this workgroup's columns -> LDS (the accumulators start from it)
+        const float isc = 1.f / sc;
+        const int ncol = 128 * (sp1 - sp0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = tid + 512 * j;
+            if (c < ncol) *reinterpret_cast<float*>(smem + PBOFF + c * 4) = g.bias[128 * sp0 + c] * isc;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // W(0), W(1), the bias: all here
+    __builtin_amdgcn_s_barrier();
+
+    f32x16 acc[2];
+    f16x8 wh[2], wl[2];
+    unsigned wa = 0;
+    auto lds_read = [&](f16x8& dst, unsigned addr, int imm) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm)); };
+    auto set_w = [&](int slot) { wa = lds0 + slot * WSTAGE + ha * 16384 + lane16; };
+    auto wait1 = [&](int newer, f16x8& r) {
+        if (newer == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r));
+        else if (newer == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(r));
+        else if (newer == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(r));
+        else if (newer == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(r));
+        else asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(r));
+    };
+    auto read_x = [&](int) {};                             // (the stage groups' hook for token fragments: they live in registers here)
+    auto init_acc2 = [&](f32x16& a0, f32x16& a1, int off) {          // as in mlp_fused_kernel: own asm reads, own full wait
+        const unsigned ad = lds0 + PBOFF + (unsigned)(off + 4 * hi) * 4u;
+        f32x4 b[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b[i][q]) : "v"(ad), "i"((i * 32 + 8 * q) * 4));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[0][3]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2]), "+v"(b[1][3]));
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a0[4 * q + e] = b[0][q][e]; a1[4 * q + e] = b[1][q][e]; }
+    };
+    auto next3 = [](int v) { return v == 2 ? 0 : v + 1; };
+    auto prev3 = [](int v) { return v == 0 ? 2 : v - 1; };
+    int s = 0, wslot = 0;
+    auto hand_over = [&](bool next_exists, int younger) {      // younger: vector-memory operations issued after the pieces of stage s + 1
+        OG_MT(0, s);
+        if (younger >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (younger == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        OG_MT(1, s);
+        if (next_exists) {
+            __builtin_amdgcn_s_barrier();
+            OG_MT(2, s);
+            set_w(next3(wslot));
+        }
+    };
+
+    // epilogue addresses: store instruction `it` writes rows tok0 + 8 it + (lane >> 3), 16-byte chunk lane & 7 of a 128-byte line
+    const int tok0 = t0 + tb * 32;
+    int64_t rowoff[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        int r = tok0 + it * 8 + (lane >> 3);
+        if (r > g.M - 1) r = g.M - 1;
+        rowoff[it] = (int64_t)r * g.ldc * 2 + (lane & 7) * 16 + ha * 128;
+    }
+    const bool full = t0 + MT <= g.M;
+    const unsigned slab = lds0 + PSLAB + wave * EPI_SLAB;
+    const unsigned swr = slab + (unsigned)(l31 * ROWB + 8 * hi), srd = slab + (unsigned)((lane >> 3) * ROWB + (lane & 7) * 16);
+
+    OG_MT(3, 1);
+    set_w(0);
+    OG_RD(0, 0); OG_RD(0, 1); OG_RD(0, 2); OG_RD(0, 3);
+    // The epilogue of a super-pair, at the boundary: acc / S -> (hi, lo) halves (VALU), then one plane at a time -- 8 LDS writes, 4 LDS reads, 4
+    // stores of whole 128-byte lines -- and the accumulators restart from the next bias: 2.3k cycles with an idle matrix pipe per super-pair (all
+    // eight waves at once).  [Measured alternative (profiles/r05_e_proj_stream_trace_v2.log): only the conversion at the boundary (0.7k), the planes
+    // deferred into the first stage of the next super-pair behind its MFMAs, at different groups for the two waves of a SIMD -- that stage then takes
+    // 5.2k cycles instead of 1.9k: 3.3k per super-pair against 2.5k.  The LDS round trips of a plane drain the wave's fragment pipeline, and the
+    // other wave of the SIMD does not fill the gap.]  Every part starts and ends with a full LDS wait, so the counted waits of the fragment
+    // pipeline around it stay valid (they become stricter, never weaker).
+    unsigned ph[2][4][2], pl[2][4][2];
+    int esp = 0;                                           // the super-pair the pending planes belong to
+    auto epi_convert = [&](int sp) {
+#pragma clang fp contract(off)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v0 = acc[i][4 * q] * sc, v1 = acc[i][4 * q + 1] * sc, v2 = acc[i][4 * q + 2] * sc, v3 = acc[i][4 * q + 3] * sc;
+                asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));      // og_split4 must see ONE rounded product
+                og_split4(v0, v1, v2, v3, ph[i][q][0], pl[i][q][0], ph[i][q][1], pl[i][q][1]);
+            }
+        esp = sp;
+    };
+    auto epi_plane = [&](int pln) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wl[0]), "+v"(wl[1]), "+v"(wh[0]), "+v"(wh[1]) :: "memory");     // fragment reads in flight land first
+        // a lane's 4 consecutive channels of block i, register group q: bytes i * 64 + (8 q + 4 hi) * 2 of its token's line
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint2 v = pln ? make_uint2(pl[i][q][0], pl[i][q][1]) : make_uint2(ph[i][q][0], ph[i][q][1]);
+                asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(swr), "v"(v), "i"(i * 64 + q * 16) : "memory");
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        f16x8 tt[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(tt[it]) : "v"(srd), "i"(it * 8 * ROWB) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tt[0]), "+v"(tt[1]), "+v"(tt[2]), "+v"(tt[3]) :: "memory");
+        char* const base = reinterpret_cast<char*>(pln ? g.Cl : g.Ch) + (int64_t)esp * 256;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            if (OG_MLP_ABL & 1) continue;
+            // (a full tile issues exactly 4 store instructions per plane: the hand-over of the stage counts them; a partial tile's predicated
+            //  stores may be skipped, so its hand-over does not count them and waits for whatever was issued)
+            if (full || tok0 + it * 8 + (lane >> 3) < g.M) *reinterpret_cast<f16x8*>(base + rowoff[it]) = tt[it];
+        }
+    };
+#define OG_SLOT_PW(k) { if ((k) == 2 && iw && !(OG_MLP_ABL & 8)) issue_w4(s + 2, wslot2); }
+#define OG_SLOT_E1(k) {}
+#define OG_SLOT_E2(k) {}
+#define OG_SLOT_E3(k) {}
+#pragma unroll 1
+    for (int sp = sp0; sp < sp1; ++sp) {
+        init_acc2(acc[0], acc[1], 128 * (sp - sp0) + 64 * ha);
+#pragma unroll
+        for (int kq = 0; kq < SPS; ++kq) {
+            const bool iw = s + 2 < nst;
+            const int wslot2 = prev3(wslot);
+            const bool next_exists = s + 1 < nst;
+            const bool pend = kq == 0 && sp > sp0;         // the planes of the previous super-pair went out just before this stage
+            const int younger = (iw ? 4 : 0) + ((pend && full && !(OG_MLP_ABL & 1)) ? 8 : 0);      // + their 8 stores (issued after the pieces of stage s + 1)
+            OG_GROUP(acc[0], acc[1], xh[4 * kq], xl[4 * kq], 0, 3, 3, 3, 2, OG_SLOT_PW)
+            OG_GROUP(acc[0], acc[1], xh[4 * kq + 1], xl[4 * kq + 1], 1, 3, 3, 3, 2, OG_SLOT_E1)
+            OG_GROUP(acc[0], acc[1], xh[4 * kq + 2], xl[4 * kq + 2], 2, 3, 3, 3, 2, OG_SLOT_E2)
+            OG_GROUP_LAST(acc[0], acc[1], xh[4 * kq + 3], xl[4 * kq + 3], OG_SLOT_E3, hand_over(next_exists, younger), next_exists, false)
+            ++s; wslot = next3(wslot);
+        }
+        OG_MT(3, 8 + 2 * (sp - sp0));
+        epi_convert(sp);
+        epi_plane(0);
+        epi_plane(1);
+        OG_MT(3, 9 + 2 * (sp - sp0));
+    }
+#if OG_MLP_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    OG_MT(3, 30);
+    if (blockIdx.x < OG_MT_BLOCKS)
+        for (int k = 0; k < 4; ++k) og_mlp_trace_buf[blockIdx.x][wave][k][lane] = (unsigned)mt_v[k];
+#endif
+#undef OG_SLOT_E1
+#undef OG_SLOT_E2
+#undef OG_SLOT_E3
+#undef OG_SLOT_PW
+#undef OG_SLOT_PN
+}
+#undef OG_GROUP
+#undef OG_GROUP_LAST
+#undef OG_MM
+#undef OG_RD
 
 
 // =================================================================================================================================
@@ -1193,7 +1466,63 @@ int og_launch_proj_small(const _Float16* X, int64_t ld, int M, int K, const char
     return og_launch_status();
 }
 
-extern "C" size_t og_proj_block_stream_bytes(int32_t N, int32_t K) { return og_proj_stream_bytes(N, K); }
+// ---- the batch projection (proj_stream_kernel) ----
+// Fragment-major stream of an [N][K] matrix, N a multiple of 128: stage (sp, kq) = sp * (K / 64) + kq covers the 4 output blocks of super-pair sp
+// and the k-steps 4 kq .. 4 kq + 3; fragment a * 16 + (g * 2 + j) * 2 + part (wave half a owns blocks 2a + j of the super-pair, g = k-step of the
+// stage), lane l = (rho = l & 31, h = l >> 5), element e = S w[32 (4 sp + 2 a + j) + rho][16 (4 kq + g) + 8 h + e] as (hi, lo) halves.
+size_t og_proj_stream_big_bytes(int N, int K) { return ((K == 256 || K == 128) && N > 0 && N % 128 == 0) ? (size_t)N * K * 4 : 0; }
+
+bool og_pack_proj_stream_big(int N, int K, const double* W, void* out, double S) {
+    if (!og_proj_stream_big_bytes(N, K)) return false;
+    _Float16* o = (_Float16*)out;
+    const int SPS = K / 64;
+    bool ok = true;
+    for (int sp = 0; sp < N / 128; ++sp)
+        for (int kq = 0; kq < SPS; ++kq)
+            for (int a = 0; a < 2; ++a)
+                for (int gq = 0; gq < 4; ++gq)
+                    for (int j = 0; j < 2; ++j)
+                        for (int l = 0; l < 64; ++l)
+                            for (int e = 0; e < 8; ++e) {
+                                double w = W[(int64_t)(32 * (4 * sp + 2 * a + j) + (l & 31)) * K + 16 * (4 * kq + gq) + 8 * (l >> 5) + e] * S;
+                                if (!(fabs(w) <= 65504.0)) { ok = false; w = 0.0; }
+                                const _Float16 hi = (_Float16)w;
+                                _Float16* base = o + (int64_t)(sp * SPS + kq) * (WSTAGE / 2) + (int64_t)(a * 16 + (gq * 2 + j) * 2) * 512 + l * 8 + e;
+                                base[0] = hi;
+                                base[512] = (_Float16)(w - (double)hi);
+                            }
+    return ok;
+}
+
+// og_forward: launches of more than 8192 rows take proj_stream_kernel at K = 128 (OG_PROJ_STREAM=0 / 1 forces for both widths).  Measured in one
+// gpurun call (profiles/r05_c_proj_micro.log, r05_b_bench_proj_stream_ab.jsonl): K = 128 -- self 37.8 us against 52.6 for the 128-token tile GEMM,
+// cross 29.2 / 40.7, kv 16.8 / 21.3; C4 13.29 -> 13.12 ms, S128 12.27 -> 12.12 ms per step.  K = 256 -- self 102 us against 104.5 for the 256-tile
+// GEMM, but kv 42.6 / 33.5 and the cross launch 87.6 / ~56: C2 8.92 -> 8.99 ms, so the tile GEMMs keep the 256-d batches.
+bool og_proj_stream_wanted(int M, int K) {
+    static const int mode = [] { const char* e = getenv("OG_PROJ_STREAM"); return e ? atoi(e) : -1; }();
+    if (mode >= 0) return mode != 0 && M > 0;
+    return M > 8192 && K == 128;
+}
+
+// Rows [0, M) of X (hl32 rows, x half) times columns [128 a0, 128 a1) of the packed matrix for rows below split_row, [128 b0, 128 b1) for the
+// others (split_row a multiple of 128 unless it is 0 or >= M); planes Ch / Cl [M][ldc].
+int og_launch_proj_stream(const _Float16* X, int64_t ld, int M, int K, const char* wstream, const float* bias, const float* scale_dev,
+                          _Float16* Ch, _Float16* Cl, int64_t ldc, int split_row, int a0, int a1, int b0, int b1, hipStream_t stream) {
+    if (!X || !wstream || !bias || !scale_dev || !Ch || !Cl || M <= 0) return OG_E_INVALID;
+    if (K != 256 && K != 128) return OG_E_SHAPE;
+    if (((uintptr_t)X & 15) || ((uintptr_t)wstream & 15) || (ld & 7) || (ldc & 63) || ((uintptr_t)Ch & 127) || ((uintptr_t)Cl & 127)) return OG_E_ALIGN;
+    if (a0 < 0 || b0 < 0 || a1 < a0 || b1 < b0 || a1 - a0 > 8 || b1 - b0 > 8 || ld < 2 * K) return OG_E_SHAPE;      // (the bias area holds 1024 columns)
+    if (split_row > 0 && split_row < M && (split_row % MT)) return OG_E_SHAPE;
+    if ((int64_t)M * ld * 2 >= (int64_t)1 << 40) return OG_E_SHAPE;
+    ProjStreamArgs g{X, ld, M, wstream, bias, scale_dev, Ch, Cl, ldc, split_row, a0, a1, b0, b1};
+    const int tiles = (M + MT - 1) / MT;
+    if (K == 256) hipLaunchKernelGGL(proj_stream_kernel<256>, dim3(tiles), dim3(512), 0, stream, g);
+    else hipLaunchKernelGGL(proj_stream_kernel<128>, dim3(tiles), dim3(512), 0, stream, g);
+    return og_launch_status();
+}
+
+// og_proj_block_pack writes the small-batch stream and, when N is a multiple of 128, the batch stream right behind it
+extern "C" size_t og_proj_block_stream_bytes(int32_t N, int32_t K) { return og_proj_stream_bytes(N, K) ? og_proj_stream_bytes(N, K) + og_proj_stream_big_bytes(N, K) : 0; }
 
 extern "C" int og_proj_block_pack(int32_t N, int32_t K, const float* W, void* stream_host) {
     if (!W || !stream_host) return OG_E_INVALID;
@@ -1201,7 +1530,8 @@ extern "C" int og_proj_block_pack(int32_t N, int32_t K, const float* W, void* st
     double* w = (double*)malloc(sizeof(double) * (size_t)N * K);
     if (!w) return OG_E_INVALID;
     for (int64_t i = 0; i < (int64_t)N * K; ++i) w[i] = W[i];
-    const bool ok = og_pack_proj_stream(N, K, w, stream_host, OG_W_SCALE);
+    bool ok = og_pack_proj_stream(N, K, w, stream_host, OG_W_SCALE);
+    if (og_proj_stream_big_bytes(N, K)) ok &= og_pack_proj_stream_big(N, K, w, (char*)stream_host + og_proj_stream_bytes(N, K), OG_W_SCALE);
     free(w);
     return ok ? 0 : OG_E_RANGE;
 }
@@ -1210,6 +1540,13 @@ extern "C" int og_proj_block(const void* x_rows, int64_t ld, int32_t M, int32_t 
                              void* yh, void* yl, int64_t ldy, int32_t split_row, int32_t a0, int32_t a1, int32_t b0, int32_t b1, void* stream) {
     og_clear_status();
     if (a0 < 0 || b0 < 0 || a1 < a0 || b1 < b0 || ldy < 32 * (int64_t)(a1 > b1 ? a1 : b1)) return OG_E_SHAPE;
+    // batches: the 128-token kernel (its stream sits behind the small one) when the ranges are whole 128-channel groups; N = ldy here
+    // (the stage entry of BOTH kernels: above 8192 rows it runs proj_stream_kernel at either width, whatever og_forward prefers)
+    static const int ps_mode = [] { const char* e = getenv("OG_PROJ_STREAM"); return e ? atoi(e) : -1; }();
+    if ((ps_mode >= 0 ? ps_mode != 0 : M > 8192) && og_proj_stream_big_bytes((int)ldy, K) && !(a0 % 4) && !(a1 % 4) && !(b0 % 4) && !(b1 % 4) && a1 - a0 <= 32 && b1 - b0 <= 32 &&
+        !(split_row > 0 && split_row < M && (split_row % MT)) && !((uintptr_t)yh & 127) && !((uintptr_t)yl & 127))
+        return og_launch_proj_stream((const _Float16*)x_rows, ld, M, K, (const char*)stream_dev + og_proj_stream_bytes((int)ldy, K), bias, inv_scale_dev,
+                                     (_Float16*)yh, (_Float16*)yl, ldy, split_row, a0 / 4, a1 / 4, b0 / 4, b1 / 4, (hipStream_t)stream);
     return og_launch_proj_small((const _Float16*)x_rows, ld, M, K, (const char*)stream_dev, bias, inv_scale_dev, (_Float16*)yh, (_Float16*)yl, ldy,
                                 split_row, a0, a1, b0, b1, (hipStream_t)stream);
 }

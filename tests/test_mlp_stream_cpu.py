@@ -191,7 +191,7 @@ def test_proj_stream_layout(K):
     (rho = l & 31, h = l >> 5), element e = 256 w[32 i + rho][16 ks + 8 h + e] as (hi, lo) halves -- re-read here with numpy."""
     lib = _lib.load()
     N = 96
-    assert lib.og_proj_block_stream_bytes(N, K) == N * K * 4
+    assert lib.og_proj_block_stream_bytes(N, K) == N * K * 4          # (N not a multiple of 128: the small-batch stream only)
     assert lib.og_proj_block_stream_bytes(100, K) == 0 and lib.og_proj_block_stream_bytes(N, 64) == 0
     g = torch.Generator().manual_seed(5)
     w = torch.randn(N, K, generator=g) * 0.05
@@ -205,3 +205,46 @@ def test_proj_stream_layout(K):
             back[rho::32, 8 * hh + e::16] = (h[:, :, 0, l, e] + h[:, :, 1, l, e])
     assert np.abs(back / 256.0 - w.double().numpy()).max() < 2e-8
     assert lib.og_proj_block_pack(N, K, (w * 1e4).contiguous().data_ptr(), st.data_ptr()) == -5      # OG_E_RANGE: 256 w leaves binary16
+
+
+@pytest.mark.parametrize("K", [256, 128])
+def test_proj_stream_big_layout_and_kernel_emulation(K):
+    """The BATCH projection kernel's stream (csrc/mlp_fused.hip: og_pack_proj_stream_big, behind the small-batch stream in og_proj_block_pack's
+    output when N is a multiple of 128) consumed exactly as proj_stream_kernel does: stage (sp, kq) = sp K/64 + kq, wave half a reads fragments
+    [16 a, 16 a + 16), group g = k-step 4 kq + g, blocks 2a + j of super-pair sp; B fragments = the token's (hi, lo) halves in standard k order.
+    Must reproduce x W^T (q / k / v projections, attention_gnn.py:43-47)."""
+    lib = _lib.load()
+    N = 3 * K
+    small = N * K * 4
+    assert lib.og_proj_block_stream_bytes(N, K) == 2 * small
+    g = torch.Generator().manual_seed(9)
+    w = (torch.randn(N, K, generator=g) * 0.05).contiguous()
+    st = torch.empty(2 * small, dtype=torch.uint8)
+    assert lib.og_proj_block_pack(N, K, w.data_ptr(), st.data_ptr()) == 0
+    SPS = K // 64
+    halves = st.numpy()[small:].view(np.float16).astype(np.float64).reshape(N // 128 * SPS, 32, 64, 8)     # [stage][fragment][lane][element]
+    x = (torch.randn(32, K, generator=g) * 1.5).double().numpy()            # one wave: 32 tokens
+    xh, xl = _split(x)
+    lanes = np.arange(64)
+    tok, hh = lanes & 31, lanes >> 5
+    out = np.zeros((32, N))
+    for sp in range(N // 128):
+        for a in range(2):
+            acc = np.zeros((2, 64, 16))
+            for kq in range(SPS):
+                for gq in range(4):
+                    ks = 4 * kq + gq
+                    cols = (16 * ks + 8 * hh)[:, None] + np.arange(8)[None, :]
+                    bh, bl = xh[tok[:, None], cols], xl[tok[:, None], cols]
+                    for j in range(2):
+                        f = a * 16 + (gq * 2 + j) * 2
+                        wh, wl = halves[sp * SPS + kq, f], halves[sp * SPS + kq, f + 1]
+                        _mfma_32x32x16(wl, bh, acc[j]); _mfma_32x32x16(wh, bl, acc[j]); _mfma_32x32x16(wh, bh, acc[j])
+            for j in range(2):
+                for l in range(64):
+                    for r in range(16):
+                        out[l & 31, 32 * (4 * sp + 2 * a + j) + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)] = acc[j, l, r] / 256.0
+    ref = (xh + xl) @ w.double().numpy().T
+    err = np.abs(out - ref).max()
+    print(f"emulated proj_stream_kernel vs float64: {err:.2e}")
+    assert err < 1e-5
