@@ -257,8 +257,16 @@ __device__ __forceinline__ float rs_uniform(float v) {      // a value every lan
 
 // The 12 register-resident rows of a wave are an ordinary array of 192 floats (fully unrolled, static indices only).
 // Audit after every edit: no scratch traffic inside the iteration loop (hipcc -Rpass-analysis=kernel-resource-usage).
-template <int W, class MAP>
+// RW = row slots per wave: 16 (12 rows in registers + 4 in LDS: the chip holds 128 MB of plan entries), or 4 -- the FEW-PAIRS geometry
+// (round 5): a launch of one to eight pairs of <= 1024 x 1024 keypoints occupies 8 .. 64 of the 256 CUs with 16-row waves and spends 4.9k of its
+// 12.7k cycles per iteration in the two passes over its 128 x 1024 tile (profiles/r04_e_sinkhorn_lazy_trace.log); with 4 rows per wave a pair is
+// 32 workgroup tiles of 32 x 1024 (all rows in registers, a quarter of the arithmetic per workgroup, the exchange unchanged: Gx = 32 row blocks
+// on one XCD, as the 2048 x 2048 pairs have them).
+template <int W, class MAP, int RW = 16>
 __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP map) {
+    static_assert(RW == 16 || RW == 4, "row slots per wave");
+    constexpr int RS_RW = RW, RS_RR = RW == 16 ? 12 : RW, RS_LR = RS_RW - RS_RR;      // (shadow the namespace-scope defaults inside this kernel)
+    constexpr int NHALF = (RS_RW + 7) / 8; // batches of eight rows in the row reductions
     constexpr int NC = RS_SEG * W;         // columns on chip
     constexpr int NCX = NC + RS_PAD;       // granules per row of the exchange areas
     constexpr int WC = W, WR = RS_NW / W;  // wave tiles of the workgroup: WR rows x WC columns
@@ -488,9 +496,9 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
                 f32x4 xr[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) xr[k] = *reinterpret_cast<const f32x4*>(Xl + 256 * k);
-                float zA, zB;
+                float zA = 0.f, zB = 0.f;
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
+                for (int half = 0; half < NHALF; ++half) {
                     float ps[8];                               // this lane's partial sums of eight rows
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
@@ -503,7 +511,7 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
                                 for (int e = 0; e < 4; e += 2) {
                                     sum2 += rs_f32x2{er[s < RS_RR ? s : 0][k][e], er[s < RS_RR ? s : 0][k][e + 1]} * rs_f32x2{xr[k][e], xr[k][e + 1]};
                                 }
-                        } else if (s < nvalid) {
+                        } else if (s < RS_RW && s < nvalid) {
                             const int sl = s - RS_RR;
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
@@ -517,7 +525,7 @@ __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP
                     const float z = rs_reduce8(ps, lane);
                     if (half == 0) zA = z; else zB = z;
                 }
-                rsv = (lane & 8) ? zB : zA;
+                rsv = (NHALF == 2 && (lane & 8)) ? zB : zA;
             }
             RS_TP(1);
             if constexpr (WC > 1) {                        // the rows cross WC waves: partial sums through LDS, fixed order
@@ -858,10 +866,10 @@ int rs_num_cus() {
 // geometry of one pair: W = wave tiles per row of a workgroup tile (tile = 128 / W rows x 1024 W columns; 0 = not resident-capable),
 // X column blocks of Gx row blocks each (G = X Gx workgroups).  One column block per XCD: Gx <= 32.
 struct RsGeom { int W, G, Gx, X; };
-RsGeom rs_geom(int m, int n) {
+RsGeom rs_geom(int m, int n, int rw = RS_RW) {
     RsGeom q{0, 0, 0, 1};
     if (m <= 0 || n <= 0 || n > 4 * RS_SEG) return q;
-    auto rows = [&](int W) { const int RB = RS_RW * RS_NW / W; int g = (m + RB - 1) / RB; return g < 2 * W ? 2 * W : g; };   // an owner sums <= 512 columns
+    auto rows = [&](int W) { const int RB = rw * RS_NW / W; int g = (m + RB - 1) / RB; return g < 2 * W ? 2 * W : g; };   // an owner sums <= 512 columns
     // the widest tile whose row blocks still fit one XCD; narrower tiles = more column blocks = a row hop per iteration
     if (n <= RS_SEG) { q.W = 1; q.X = 1; }
     else if (n <= 2 * RS_SEG) { if (rows(2) <= 32) { q.W = 2; q.X = 1; } else { q.W = 1; q.X = 2; } }
@@ -886,6 +894,18 @@ size_t rs_area_bytes(int W, int slots, int groups) {    // status + xcc table, t
 template <int W, class MAP>
 void rs_launch(const SkResArgs& a, const MAP& map, int grid, hipStream_t st) {
     hipLaunchKernelGGL((sinkhorn_resident_kernel<W, MAP>), dim3(grid), dim3(512), 0, st, a, map);
+}
+
+// Few pairs (round 5): 4 rows per wave instead of 16 when the 16-row geometry would leave three quarters of the CUs idle and the pair fits one
+// XCD as 32 x 1024 tiles (n <= 1024, m <= 1024).  OG_SINKHORN_FEW=0 / 1 forces (1: whenever the geometry exists).  -> rows per wave (16 or 4)
+int rs_rows_per_wave(int B, int m, int n, int cus) {
+    if (cus < 256 || n > RS_SEG) return RS_RW;
+    const RsGeom q4 = rs_geom(m, n, 4), q16 = rs_geom(m, n);
+    if (q4.W != 1 || q4.X != 1 || q16.W == 0) return RS_RW;
+    if ((int64_t)B * q4.G > 256) return RS_RW;                       // one launch
+    const char* e = getenv("OG_SINKHORN_FEW");                       // read per call: the tests switch it
+    if (e) return atoi(e) != 0 ? 4 : RS_RW;
+    return (int64_t)B * q16.G <= 64 ? 4 : RS_RW;
 }
 
 }  // namespace
@@ -916,7 +936,7 @@ extern "C" int og_sinkhorn_resident_geometry(int32_t m, int32_t n, int32_t* out4
 // launches the resident kernel would need for this uniform batch on this device (0 = not possible)
 int og_sinkhorn_resident_rounds(int B, int m, int n) {
     if (!og_sinkhorn_resident_shape_ok(B, m, n)) return 0;
-    const int ppr = rs_pairs_per_round(rs_geom(m, n), rs_num_cus());
+    const int ppr = rs_pairs_per_round(rs_geom(m, n, rs_rows_per_wave(B, m, n, rs_num_cus())), rs_num_cus());
     return ppr > 0 ? (B + ppr - 1) / ppr : 0;
 }
 
@@ -933,7 +953,8 @@ int og_launch_sinkhorn_resident(const float* S, int64_t lds, const float* zdev, 
                                 float inv_reg, float la, float la_bin, float lb, float lb_bin, float* u, int ldu, const float* v_in,
                                 float* v_out, int ldv, void* xws, unsigned* status, hipStream_t st, bool trusted_padding) {
     if (!S || !u || !v_in || !v_out || !xws || !status || iters < 1 || !og_sinkhorn_resident_shape_ok(B, m, n)) return OG_E_INVALID;
-    const RsGeom q = rs_geom(m, n);
+    const int rw = rs_rows_per_wave(B, m, n, rs_num_cus());
+    const RsGeom q = rs_geom(m, n, rw);
     const int ppr = rs_pairs_per_round(q, rs_num_cus());
     if (ppr <= 0) return OG_E_SHAPE;
     const int rounds = (B + ppr - 1) / ppr, per = (B + rounds - 1) / rounds;      // balanced rounds
@@ -965,7 +986,8 @@ int og_launch_sinkhorn_resident(const float* S, int64_t lds, const float* zdev, 
             const int ppl = 8 / q.X;                       // pairs per layer
             map.layers = (np + ppl - 1) / ppl; grid = 8 * map.layers * q.Gx; a.local_ok = 1;
         }
-        if (q.W == 1) rs_launch<1>(a, map, grid, st);
+        if (rw == 4) hipLaunchKernelGGL((sinkhorn_resident_kernel<1, RsUniform, 4>), dim3(grid), dim3(512), 0, st, a, map);
+        else if (q.W == 1) rs_launch<1>(a, map, grid, st);
         else if (q.W == 2) rs_launch<2>(a, map, grid, st);
         else rs_launch<4>(a, map, grid, st);
     }

@@ -9,7 +9,7 @@ from openglue_amd import _lib, ops
 lib = _lib.load(); dev = torch.device("cuda:0")
 lib.og_debug_mlp_trace.restype = C.c_int
 lib.og_debug_mlp_trace.argtypes = [C.c_void_p, C.c_size_t]
-D = 256
+D = int(os.environ.get("OG_TRACE_D", "256"))      # 256 or 128
 g = torch.Generator().manual_seed(0)
 w0 = torch.randn(2 * D, 2 * D, generator=g) * 0.04; w3 = torch.randn(D, 2 * D, generator=g) * 0.05
 b0 = (torch.randn(2 * D, generator=g) * 0.3).to(dev); b3 = (torch.randn(D, generator=g) * 0.3).to(dev)
@@ -17,7 +17,7 @@ sh = torch.empty(lib.og_mlp_block_stream_bytes(D), dtype=torch.uint8)
 _lib.check(lib.og_mlp_block_pack(D, w0.data_ptr(), w3.data_ptr(), sh.data_ptr()), "pack")
 ws = sh.to(dev)
 st = torch.cuda.current_stream().cuda_stream
-for M in (int(a) for a in (sys.argv[1:] or ["65536", "32768", "4096"])):
+for M in (int(a) for a in (sys.argv[1:] or ["65536", "32768", "16384"])):
     rows0 = ops.split_f16_hl((torch.randn(M, 2 * D, generator=g) * 1.5).to(dev)); rows = rows0.clone()
     def run():
         assert lib.og_mlp_block(D, rows.data_ptr(), 4 * D, M, ws.data_ptr(), b0.data_ptr(), b3.data_ptr(), st) == 0
@@ -33,7 +33,7 @@ for M in (int(a) for a in (sys.argv[1:] or ["65536", "32768", "4096"])):
     nblk = min(512, M // 128)
     t = buf[:nblk].astype(np.int64)
     d = lambda x, y: (x - y) & 0xFFFFFFFF
-    S = 48
+    S = 48 if D == 256 else 12
     pre, post, bar = t[:, :, 0, :S], t[:, :, 1, :S], t[:, :, 2, :S]
     entry, loop_end, st_iss, st_ack = t[:, :, 3, 0], t[:, :, 3, 1], t[:, :, 3, 2], t[:, :, 3, 3]
     f = lambda x: f"{np.median(x):8.0f} (p10 {np.percentile(x, 10):7.0f} p90 {np.percentile(x, 90):7.0f})"
