@@ -121,7 +121,8 @@ def roofline_block(counts_per_step, stages, launches, num_iters, measured_on_thi
                                         PEAK_F16_MFMA_TFLOPS, "gemm_f16x3_standalone",
                                         "gemm_nt_f16x3_big2_kernel (256x256 tiles: q/k/v projections) / gemm_nt_f16x3_kernel (128-token tiles: last encoder "
                                         "conv, final projection; the message MLP when it is not fused) / gemm_nt_f16x3_big_kernel (batched score matrix) / "
-                                        "proj_small_kernel (q/k/v projections of launches of <= 8192 rows); "
+                                        "proj_small_kernel (q/k/v projections of launches of <= 8192 rows) / proj_stream_kernel (q/k/v projections of 128-d batches: x fragments in "
+                                        "registers, weights through an LDS ring); "
                                         "split-f16 3-pass MFMA: executes 3x the algorithmic flops"),
         "gemm_nt_f32_kernel": ("gemm_f32", counts_per_step["gemm_f32_flops"], PEAK_F32_MFMA_TFLOPS, "gemm_f32",
                                "keypoint-encoder MLP without its last conv; exact fp32 MFMA"),

@@ -257,14 +257,14 @@ __device__ __forceinline__ float rs_uniform(float v) {      // a value every lan
 
 // The 12 register-resident rows of a wave are an ordinary array of 192 floats (fully unrolled, static indices only).
 // Audit after every edit: no scratch traffic inside the iteration loop (hipcc -Rpass-analysis=kernel-resource-usage).
-// RW = row slots per wave: 16 (12 rows in registers + 4 in LDS: the chip holds 128 MB of plan entries), or 4 -- the FEW-PAIRS geometry
+// RW = row slots per wave: 16 (12 rows in registers + 4 in LDS: the chip holds 128 MB of plan entries), or 4 / 8 -- the FEW-PAIRS geometries
 // (round 5): a launch of one to eight pairs of <= 1024 x 1024 keypoints occupies 8 .. 64 of the 256 CUs with 16-row waves and spends 4.9k of its
 // 12.7k cycles per iteration in the two passes over its 128 x 1024 tile (profiles/r04_e_sinkhorn_lazy_trace.log); with 4 rows per wave a pair is
 // 32 workgroup tiles of 32 x 1024 (all rows in registers, a quarter of the arithmetic per workgroup, the exchange unchanged: Gx = 32 row blocks
 // on one XCD, as the 2048 x 2048 pairs have them).
 template <int W, class MAP, int RW = 16>
 __global__ __launch_bounds__(512) void sinkhorn_resident_kernel(SkResArgs a, MAP map) {
-    static_assert(RW == 16 || RW == 4, "row slots per wave");
+    static_assert(RW == 16 || RW == 8 || RW == 4, "row slots per wave");
     constexpr int RS_RW = RW, RS_RR = RW == 16 ? 12 : RW, RS_LR = RS_RW - RS_RR;      // (shadow the namespace-scope defaults inside this kernel)
     constexpr int NHALF = (RS_RW + 7) / 8; // batches of eight rows in the row reductions
     constexpr int NC = RS_SEG * W;         // columns on chip
@@ -900,12 +900,19 @@ void rs_launch(const SkResArgs& a, const MAP& map, int grid, hipStream_t st) {
 // XCD as 32 x 1024 tiles (n <= 1024, m <= 1024).  OG_SINKHORN_FEW=0 / 1 forces (1: whenever the geometry exists).  -> rows per wave (16 or 4)
 int rs_rows_per_wave(int B, int m, int n, int cus) {
     if (cus < 256 || n > RS_SEG) return RS_RW;
-    const RsGeom q4 = rs_geom(m, n, 4), q16 = rs_geom(m, n);
-    if (q4.W != 1 || q4.X != 1 || q16.W == 0) return RS_RW;
-    if ((int64_t)B * q4.G > 256) return RS_RW;                       // one launch
-    const char* e = getenv("OG_SINKHORN_FEW");                       // read per call: the tests switch it
-    if (e) return atoi(e) != 0 ? 4 : RS_RW;
-    return (int64_t)B * q16.G <= 64 ? 4 : RS_RW;
+    const RsGeom q16 = rs_geom(m, n);
+    if (q16.W == 0) return RS_RW;
+    const char* e = getenv("OG_SINKHORN_FEW");                       // read per call: the tests switch it; 0 = never, 4 / 8 = that geometry when it exists, 1 = the finest
+    const int want = e ? atoi(e) : -1;
+    if (want == 0) return RS_RW;
+    for (int rw = 4; rw <= 8; rw *= 2) {                             // the finest geometry that still fits ONE launch (and, by default, fills <= all CUs from <= half of them)
+        if (want > 1 && want != rw) continue;
+        const RsGeom q = rs_geom(m, n, rw);
+        if (q.W != 1 || q.X != 1 || (int64_t)B * q.G > 256) continue;
+        if (want < 0 && (int64_t)B * rs_geom(m, n, 2 * rw).G > 128) continue;      // the next coarser geometry already uses more than half the chip: stay there
+        return rw;
+    }
+    return RS_RW;
 }
 
 }  // namespace
@@ -987,6 +994,7 @@ int og_launch_sinkhorn_resident(const float* S, int64_t lds, const float* zdev, 
             map.layers = (np + ppl - 1) / ppl; grid = 8 * map.layers * q.Gx; a.local_ok = 1;
         }
         if (rw == 4) hipLaunchKernelGGL((sinkhorn_resident_kernel<1, RsUniform, 4>), dim3(grid), dim3(512), 0, st, a, map);
+        else if (rw == 8) hipLaunchKernelGGL((sinkhorn_resident_kernel<1, RsUniform, 8>), dim3(grid), dim3(512), 0, st, a, map);
         else if (q.W == 1) rs_launch<1>(a, map, grid, st);
         else if (q.W == 2) rs_launch<2>(a, map, grid, st);
         else rs_launch<4>(a, map, grid, st);

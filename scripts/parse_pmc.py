@@ -15,7 +15,7 @@ root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
 out = sys.argv[2] if len(sys.argv) > 2 else "profiles/r03_pmc_summary.json"
 # gemm_f16x3 = the whole split-f16 GEMM class (stand-alone GEMM launches AND the fused message-MLP kernel, like bench.py's class);
 # mlp_fused / gemm_f16x3_standalone = its two parts
-CLASSES = [("gemm_f16x3", ("gemm_nt_f16x3", "mlp_fused_kernel")), ("mlp_fused", ("mlp_fused_kernel",)), ("gemm_f16x3_standalone", ("gemm_nt_f16x3",)),
+CLASSES = [("gemm_f16x3", ("gemm_nt_f16x3", "mlp_fused_kernel", "proj_stream_kernel", "proj_small_kernel", "mlp_small_kernel")), ("mlp_fused", ("mlp_fused_kernel", "mlp_small_kernel")), ("gemm_f16x3_standalone", ("gemm_nt_f16x3", "proj_stream_kernel", "proj_small_kernel")),
            ("attention", ("attention",)), ("sinkhorn_resident", ("sinkhorn_resident_kernel",)), ("sinkhorn_sweep", ("sinkhorn_sweep",)),
            ("gemm_f32", ("gemm_nt_f32",))]
 N_SIMD = 256 * 4

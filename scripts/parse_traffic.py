@@ -6,7 +6,7 @@ import collections, csv, json, os, sys
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/traffic"
 out = sys.argv[2] if len(sys.argv) > 2 else "profiles/r03_traffic_c2.json"
-CLASSES = [("gemm_f16x3", ("gemm_nt_f16x3", "mlp_fused_kernel")), ("mlp_fused", ("mlp_fused_kernel",)), ("gemm_f16x3_standalone", ("gemm_nt_f16x3",)),
+CLASSES = [("gemm_f16x3", ("gemm_nt_f16x3", "mlp_fused_kernel", "proj_stream_kernel", "proj_small_kernel", "mlp_small_kernel")), ("mlp_fused", ("mlp_fused_kernel", "mlp_small_kernel")), ("gemm_f16x3_standalone", ("gemm_nt_f16x3", "proj_stream_kernel", "proj_small_kernel")),
            ("attention", ("attention",)), ("sinkhorn_resident", ("sinkhorn_resident_kernel",)), ("sinkhorn_sweep", ("sinkhorn_sweep",)),
            ("sinkhorn_combine", ("sinkhorn_combine",)), ("gemm_f32", ("gemm_nt_f32",))]
 vals = {c: collections.defaultdict(list) for c, _ in CLASSES}

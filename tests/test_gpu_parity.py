@@ -825,26 +825,26 @@ def test_sinkhorn_resident_vs_oracle(gpu_device, monkeypatch, B, m, n, iters, re
 
 
 @pytest.mark.parametrize("B,m,n,iters,reg", [(1, 1024, 1024, 100, 1.0), (8, 1024, 1024, 30, 1.0), (3, 777, 1000, 25, 0.8), (2, 50, 1024, 12, 1.0), (1, 1000, 513, 20, 1.0),
-                                             (1, 1, 1, 3, 1.0), (4, 33, 7, 6, 2.0), (1, 1023, 1, 5, 1.0), (5, 640, 333, 25, 1.0)])
+                                             (1, 1, 1, 3, 1.0), (4, 33, 7, 6, 2.0), (1, 1023, 1, 5, 1.0), (5, 640, 333, 25, 1.0), (12, 1024, 1024, 20, 1.0), (16, 1000, 700, 15, 1.0)])
 def test_sinkhorn_resident_few_pairs_geometry(gpu_device, monkeypatch, B, m, n, iters, reg):
     """Round 5: launches of few pairs of <= 1024 x 1024 keypoints (the reference's inference.py regime: ONE pair per call) take 4 rows per wave
-    instead of 16 -- a pair is 32 workgroup tiles of 32 x 1024 instead of 8 of 128 x 1024 (sinkhorn_resident_kernel<1, ., 4>).  Both geometries
-    (OG_SINKHORN_FEW = 1 / 0) against the float64 oracle and against each other; partial last row blocks, single rows / columns, 8 pairs = 256
+    instead of 16 -- a pair is 32 workgroup tiles of 32 x 1024 instead of 8 of 128 x 1024 (sinkhorn_resident_kernel<1, ., 4>); 9 to 16 pairs take 8 rows
+    per wave (16 tiles of 64 x 1024).  All three geometries (OG_SINKHORN_FEW = 1 / 8 / 0) against the float64 oracle and against each other; partial last row blocks, single rows / columns, 8 pairs = 256
     workgroups."""
     g = torch.Generator().manual_seed(m * 37 + n + B)
     S = _rand(g, B, m, n, scale=4.0)
     ref = _sinkhorn_ref(S, 0.7, iters, reg)
     monkeypatch.setenv("OG_SINKHORN_RESIDENT", "2")
     outs = {}
-    for few in ("1", "0"):
+    for few in ("1", "8", "0"):                        # the finest geometry that exists (4, else 8 rows per wave), 8 rows per wave, 16
         monkeypatch.setenv("OG_SINKHORN_FEW", few)
         out, status = ops.sinkhorn(S.to(gpu_device), 0.7, iters, reg, return_status=True)
         assert status == 0, f"few={few}: a cross-workgroup wait timed out"
         outs[few] = out.cpu()
         err = (outs[few].double() - ref).abs().max().item()
         assert err < 1e-4, (few, err)
-    d = (outs["1"] - outs["0"]).abs().max().item()
-    print(f"[sinkhorn few-pairs geometry {B}x{m}x{n} it={iters}] 4 rows per wave vs 16: {d:.2e}")
+    d = max((outs["1"] - outs["0"]).abs().max().item(), (outs["8"] - outs["0"]).abs().max().item())
+    print(f"[sinkhorn few-pairs geometry {B}x{m}x{n} it={iters}] 4 / 8 rows per wave vs 16: {d:.2e}")
     assert d < 5e-5, d
     monkeypatch.setenv("OG_SINKHORN_FEW", "1")
     again = ops.sinkhorn(S.to(gpu_device), 0.7, iters, reg).cpu()
