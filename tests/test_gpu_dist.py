@@ -67,6 +67,11 @@ def test_bench_with_the_collective_forced(gpu_device):
     assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
     line = json.loads(lines[0])
     assert line["n_gpus"] == 1 and line["value"] > 0 and "roofline" in line
+    # round 5: the rccl block explains a scaling line by itself -- every rank's step time with and without the collective, the gather's own time
+    rc = line["rccl"]
+    assert rc["backend"] == "nccl" and rc["world_size"] == 1
+    assert len(rc["per_rank_ms_compute_only"]) == 1 and len(rc["per_rank_ms_with_gather"]) == 1 and rc["per_rank_ms_compute_only"][0] > 0
+    assert abs(rc["gather_ms_rank0"] - (rc["per_rank_ms_with_gather"][0] - rc["per_rank_ms_compute_only"][0])) < 1e-2
     print("forced-collective bench:", line["value"], line["unit"], line["ms_per_step"], "ms/step")
 
 
