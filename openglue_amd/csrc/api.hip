@@ -112,7 +112,7 @@ WorkspaceLayout workspace_layout(const og_shape& s) {
     W.sbuf = off; off = al64(off + (int64_t)s.batch * s.m * W.lds);
     W.sink = off; off = al64(off + (int64_t)(og_sinkhorn_workspace_bytes(s.batch, s.m, s.n) + 3) / 4);
     W.match = off; off = al64(off + (int64_t)(og_matches_workspace_bytes(s.batch, s.m, s.n) + 3) / 4);
-    W.attn = off; off = al64(off + OG_ATTN_COUNTERS + OG_ATTN_PARTIAL_FLOATS);       // 8.9 MB; used by launches of one or two pairs only
+    W.attn = off; off = al64(off + OG_ATTN_COUNTERS + OG_ATTN_PARTIAL_FLOATS);       // 17.8 MB; used by launches of one or two pairs only
     W.total = off;
     return W;
 }

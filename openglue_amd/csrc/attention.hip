@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
     static_assert(KS == 1 || KS == 2, "key split");
     __shared__ __attribute__((aligned(1024))) char smem_all[KS * 2 * BUFB];
 
-    static_assert(GS == 1 || (KS == 1 && DH == 64), "the workgroup-level key split is built for dh = 64, 4-wave workgroups");
+    static_assert(GS == 1 || KS == 1, "the workgroup-level key split is built for 4-wave workgroups (dh = 64 and, round 5, dh = 32: the 128-d family's single pairs)");
     const int id = blockIdx.x;
     const int xcd = id & 7, local = id >> 3;
     const int grp = (local / (a.qtiles * GS)) * 8 + xcd;   // (problem, head) group: all its query tiles (and key parts) on one XCD
@@ -1099,22 +1099,38 @@ int og_launch_attention(const AttnArgs& a, hipStream_t stream) {
     // (attention_dma_kernel<64, ., 1, GS>).  OG_ATTN_GSPLIT=0 / 2 / 4 forces.
     static const int gs_mode = [] { const char* e = getenv("OG_ATTN_GSPLIT"); return e ? atoi(e) : -1; }();
     int gs = 1;
-    if (dma && a.dh == 64 && a.partial && a.counters && (int)grid.x <= OG_ATTN_COUNTERS) {
+    if (dma && (a.dh == 64 || a.dh == 32) && a.partial && a.counters && (int)grid.x <= OG_ATTN_COUNTERS) {
+        // The split launch may hold up to two workgroups per CU at dh = 32 (they do not wait for each other: the last arriver of a query tile merges),
+        // one at dh = 64 -- measured in one call (profiles/r05_j_bench_attn_gsplit_maxwg_ab.jsonl): dh = 32, 512 against 256 workgroups: a single
+        // 2048-keypoint pair 1.428 -> 1.394 ms per step, two pairs 1.703 -> 1.640, one 4096-keypoint pair 3.47 -> 3.24; dh = 64: one pair +-0, two pairs
+        // 1.962 -> 1.997, four 2.385 -> 2.427 (slower).  OG_ATTN_GS_MAXWG overrides (experiments).
+        static const int maxwg_env = [] { const char* e = getenv("OG_ATTN_GS_MAXWG"); return e ? atoi(e) : 0; }();
+        const int maxwg = maxwg_env > 0 ? maxwg_env : (a.dh == 32 ? 512 : 256);
         if (gs_mode >= 0) gs = gs_mode == 2 || gs_mode == 4 ? gs_mode : 1;
-        else if ((int)grid.x * 4 <= 256 && (a.rag || nkmin >= 16 * KV_TILE)) gs = 4;
-        else if ((int)grid.x * 2 <= 256 && (a.rag || nkmin >= 8 * KV_TILE)) gs = 2;
-        if ((int)grid.x * gs > 256 && gs_mode < 0) gs = 1;
+        else if ((int)grid.x * 4 <= maxwg && (a.rag || nkmin >= 16 * KV_TILE)) gs = 4;
+        else if ((int)grid.x * 2 <= maxwg && (a.rag || nkmin >= 8 * KV_TILE)) gs = 2;
+        if ((int)grid.x * gs > maxwg && gs_mode < 0) gs = 1;
         if ((int64_t)grid.x * gs * 4 * 34 * 64 > OG_ATTN_PARTIAL_FLOATS) gs = 1;
         if (gs > 1 && !og_xcd_round_robin_ok(stream)) gs = 1;
     }
     if (gs > 1) {
         dim3 g2(grid.x * gs);
-        if (a.rag) {
-            if (gs == 4) hipLaunchKernelGGL((attention_dma_kernel<64, RaggedDesc, 1, 4>), g2, block, 0, stream, a2, rd);
-            else hipLaunchKernelGGL((attention_dma_kernel<64, RaggedDesc, 1, 2>), g2, block, 0, stream, a2, rd);
-        } else {
-            if (gs == 4) hipLaunchKernelGGL((attention_dma_kernel<64, RaggedNone, 1, 4>), g2, block, 0, stream, a2, RaggedNone{});
-            else hipLaunchKernelGGL((attention_dma_kernel<64, RaggedNone, 1, 2>), g2, block, 0, stream, a2, RaggedNone{});
+        if (a.dh == 64) {
+            if (a.rag) {
+                if (gs == 4) hipLaunchKernelGGL((attention_dma_kernel<64, RaggedDesc, 1, 4>), g2, block, 0, stream, a2, rd);
+                else hipLaunchKernelGGL((attention_dma_kernel<64, RaggedDesc, 1, 2>), g2, block, 0, stream, a2, rd);
+            } else {
+                if (gs == 4) hipLaunchKernelGGL((attention_dma_kernel<64, RaggedNone, 1, 4>), g2, block, 0, stream, a2, RaggedNone{});
+                else hipLaunchKernelGGL((attention_dma_kernel<64, RaggedNone, 1, 2>), g2, block, 0, stream, a2, RaggedNone{});
+            }
+        } else {          // dh = 32 (round 5): a single 2048-keypoint pair of the 128-d family = 128 workgroups of 32 key tiles each without the split
+            if (a.rag) {
+                if (gs == 4) hipLaunchKernelGGL((attention_dma_kernel<32, RaggedDesc, 1, 4>), g2, block, 0, stream, a2, rd);
+                else hipLaunchKernelGGL((attention_dma_kernel<32, RaggedDesc, 1, 2>), g2, block, 0, stream, a2, rd);
+            } else {
+                if (gs == 4) hipLaunchKernelGGL((attention_dma_kernel<32, RaggedNone, 1, 4>), g2, block, 0, stream, a2, RaggedNone{});
+                else hipLaunchKernelGGL((attention_dma_kernel<32, RaggedNone, 1, 2>), g2, block, 0, stream, a2, RaggedNone{});
+            }
         }
         return og_launch_status();
     }

@@ -196,7 +196,7 @@ int og_launch_proj_small(const _Float16* X, int64_t ld, int M, int K, const char
                          _Float16* Ch, _Float16* Cl, int64_t ldc, int split_row, int a0, int a1, int b0, int b1, hipStream_t stream);
 
 constexpr int OG_ATTN_COUNTERS = 256;                                   // (problem, head, query tile) triples of a key-split launch
-constexpr int64_t OG_ATTN_PARTIAL_FLOATS = (int64_t)256 * 4 * 34 * 64;     // 256 workgroups x 4 waves x (32 O registers + m + l) x 64 lanes
+constexpr int64_t OG_ATTN_PARTIAL_FLOATS = (int64_t)512 * 4 * 34 * 64;     // 512 workgroups (two per CU) x 4 waves x (32 O registers + m + l) x 64 lanes
 struct AttnArgs {
     const _Float16* qh; const _Float16* ql; int64_t ldq;     // leading dimensions in halves
     const _Float16* kh; const _Float16* kl; int64_t ldk;

@@ -122,6 +122,33 @@ def test_c3_c4_at_baseline_batch(gpu_device, cfg_name, B):
     parity_note(f"[{cfg_name} B={B}] all {B} pairs vs the CPU oracle: worst scores err {worst:.2e} exempt={exempt} of {B * m} rows")
 
 
+@pytest.mark.parametrize("D,n,B,iters", [(128, 2048, 1, 20), (128, 1024, 1, 20), (128, 2048, 2, 20), (256, 1024, 1, 100), (128, 700, 3, 10)])
+def test_single_pair_regime_of_inference_py(gpu_device, D, n, B, iters):
+    """The reference matches ONE pair per call (inference.py:214-235), with 128-d SIFT features at up to 2048 keypoints and 20 iterations
+    (config/features/sift_opencv.yaml:2-4, config/config.yaml:53) or 256-d SuperPoint.  Such calls take the 32-token message-MLP / projection kernels
+    (mlp_small_kernel<D>, proj_small_kernel<D>), the key range of a query tile split over 2 or 4 workgroups that meet in scratch (round 5: at dh = 32
+    too) and the few-pairs geometry of the resident Sinkhorn -- all of them against the per-pair CPU oracle, 4 stages, every pair."""
+    cfg = syn.make_config(descriptor_dim=D, num_stages=4, num_heads=4, num_iters=iters, side_info_size=1)
+    sd = syn.make_state_dict(cfg, seed=0)
+    model = _build(cfg, sd, gpu_device)
+    data = syn.make_batch(B, n, n - 37, D, 1, seed=77)
+    out = model.match(to_device(data, gpu_device), MATCH_THRESHOLD)
+    assert model.check_status() == 0
+    with torch.no_grad():
+        ref = orc.match_pairs(sd, cfg, data, MATCH_THRESHOLD)
+        o64 = orc.superglue_forward(sd, cfg, data, dtype=torch.float64)
+    err = (out["scores"].cpu() - ref["scores"]).abs().max().item()
+    diff = out["matches0"].cpu() != ref["matches0"]
+    amb_r, amb_c = orc.ambiguous_rows(o64["scores"], 1e-4)
+    bad = 0
+    for b, i in torch.nonzero(diff).tolist():
+        if not (bool(amb_r[b, i]) or bool(amb_c[b, int(ref["_row_argmax"][b, i])]) or abs(float(ref["matching_scores0"][b, i]) - MATCH_THRESHOLD) < 1e-3):
+            bad += 1
+    parity_note(f"[single-pair regime D={D} {n}x{n - 37} B={B}] scores err {err:.2e} exempt={int(diff.sum())}")
+    assert err < TOL_SCORES, err
+    assert bad == 0 and int(diff.sum()) <= 2, (int(diff.sum()), bad)
+
+
 def test_dustbin_dominated_regime_unit_norm_descriptors(gpu_device):
     """Unit-norm descriptors with random-init weights: every keypoint goes to the dustbin, 0 valid matches, top-1/top-2 gaps
     of a few 1e-6 -- the regime real SuperPoint/SIFT inputs are in before training.  Scores must
