@@ -88,6 +88,35 @@ def test_c5_ragged_at_baseline_shape_equals_per_pair_oracle(gpu_device):
                 f"of {sum(a for a, _ in lens)} rows")
 
 
+@pytest.mark.parametrize("npairs,lo,hi", [(8, 512, 2048), (2, 300, 900)])
+def test_ragged_pairs_of_the_128d_family(gpu_device, npairs, lo, hi):
+    """Ragged (token-packed) batches through the 128-d kernel family (round 5): `mlp_fused_kernel<128>` / `proj_stream_kernel<128>` when the packed
+    token matrix has more than 8192 rows (8 pairs of 512..2048 keypoints; the image-0 / image-1 boundary is NOT a multiple of 128, so the cross
+    layer's projections run as separate row ranges with arbitrary row offsets), the 32-token kernels below that (2 small pairs) -- every pair against
+    the per-pair oracle (128-d, s = 6, 3 stages, 20 iterations: the reference's SIFT / LAF family, config/features/sift_opencv.yaml:2-4)."""
+    cfg = syn.make_config(descriptor_dim=128, num_stages=3, num_heads=4, num_iters=20, side_info_size=6)
+    sd = syn.make_state_dict(cfg, seed=0)
+    model = _build(cfg, sd, gpu_device)
+    lens = syn.ragged_lengths(npairs, lo, hi, seed=5)
+    pairs_cpu = []
+    for i, (m, n) in enumerate(lens):
+        p = syn.make_pair(m, n, 128, 6, seed=900 + i)
+        p["image0_size"] = list(syn.IMAGE_WH); p["image1_size"] = list(syn.IMAGE_WH)
+        pairs_cpu.append(p)
+    res = model.match_ragged([to_device(p, gpu_device) for p in pairs_cpu], MATCH_THRESHOLD, both_sides=True, context_descriptors=True)
+    torch.cuda.synchronize()
+    worst, exempt = 0.0, 0
+    for p, r, (m, n) in zip(pairs_cpu, res, lens):
+        one = {k: (v[None] if torch.is_tensor(v) else v) for k, v in p.items()}
+        ndiff, bad, ref = _unexplained(r["matches0"], sd, cfg, one)
+        err = (r["scores"].cpu() - ref["scores"][0]).abs().max().item()
+        worst = max(worst, err); exempt += ndiff
+        assert err < TOL_SCORES, (m, n, err)
+        assert bad == 0, f"pair {m}x{n}: {ndiff} rows differ, {bad} not explained by float64 near-ties"
+        assert (r["context_descriptors0"].cpu() - ref["context_descriptors0"][0]).abs().max() < TOL_SCORES
+    parity_note(f"[ragged 128-d, {npairs} pairs {lo}..{hi} kpts] worst scores err {worst:.2e} exempt={exempt} of {sum(a for a, _ in lens)} rows")
+
+
 @pytest.mark.parametrize("cfg_name,B", [("C3", 32), ("C4", 8)])
 def test_c3_c4_at_baseline_batch(gpu_device, cfg_name, B):
     """BASELINE configs[2] (2048 kpts, 256-d, 32 pairs per GPU) and configs[3] (4096 kpts, 128-d, 6 side-info channels,
