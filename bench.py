@@ -435,7 +435,9 @@ def bench_ragged(args, world, rank, dev, dist_on=False):
         return match_mine(mine)
 
     dt, _ = _timed_steps(step, args, dist_on, dev)
-    rccl = _rccl_block(dist_on, lambda: match_mine(mine), step, dev)       # collective inside: every rank calls it
+    # `step` contains the collective when N > 1: EVERY rank runs these, never rank 0 alone (a rank-0-only step() would wait for peers that have moved on)
+    spread = _step_spread(step, args.steps, dev)
+    rccl = _rccl_block(dist_on, lambda: match_mine(mine), step, dev)
     if rank == 0:
         res = match_mine(mine)
         my_lens = [lens[i] for i in mine]
@@ -451,7 +453,7 @@ def bench_ragged(args, world, rank, dev, dist_on=False):
         roof, roof2 = roofline_block(counts, stages, launches, kw["num_iters"], False, sk_launches)
         line = {"metric": "image-pairs/sec (C5 ragged 512-2048 kpts)", "value": round(total * args.steps / dt, 2), "unit": "image-pairs/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-                "step_ms_spread": _step_spread(step, args.steps, dev),
+                "step_ms_spread": spread,
                 "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": f"BASELINE configs[4]: {total} ragged pairs ({per_gpu}/GPU), 512-2048 kpts/image, 256-dim, 9 stages, "
                                        "100 Sinkhorn iters, token-packed ragged kernels (og_forward_ragged), LPT cost-balanced over ranks",
@@ -575,7 +577,9 @@ def main():
 
     dt, out = _timed_steps(step, args, dist_on, dev)
     model.check_status()          # outside the timed region: the resident Sinkhorn kernel of the last step completed (no time-out)
-    rccl = _rccl_block(dist_on, lambda: model.match(data, MATCH_THRESHOLD, both_sides=True), step, dev)       # collective inside: every rank calls it
+    # `step` contains the collective when N > 1: EVERY rank runs these, never rank 0 alone (a rank-0-only step() would wait for peers that have moved on)
+    spread = _step_spread(step, args.steps, dev)
+    rccl = _rccl_block(dist_on, lambda: model.match(data, MATCH_THRESHOLD, both_sides=True), step, dev)
 
     if rank == 0:
         c1 = algorithmic_counts(kw, m, n)
@@ -595,7 +599,7 @@ def main():
         line = {
             "metric": "image-pairs/sec (1024 kpts, 256-dim, 9 GNN layers)" if args.config == "C2" else f"image-pairs/sec ({args.config})",
             "value": round(value, 2), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "step_ms_spread": _step_spread(step, args.steps, dev),
+            "ms_per_step": round(ms_per_step, 3), "step_ms_spread": spread,
             "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("the reference's shipped 128-d operating point (config/features/sift_opencv.yaml:2-4, config/config.yaml:53), not a BASELINE config: "

@@ -188,3 +188,27 @@ def test_pair_cost_orders_pairs_like_the_measured_classes():
     assert 2e-4 < c1 < 5e-4                      # the measured C2 step: 9.9 ms / 32 pairs = 0.31 ms per pair
     assert 2.0 * c1 < c2 < 8.0 * c1
     assert sharding.pair_cost(512, 2048) < sharding.pair_cost(2048, 2048)
+
+
+def test_bench_never_runs_a_step_with_the_collective_on_rank_0_alone():
+    """bench.py's `step` closures contain the RCCL gather when N > 1.  Anything that calls them must run on EVERY rank: round 4 computed `step_ms_spread`
+    inside `if rank == 0:` -- with more than one rank, rank 0 would have waited in the gather for peers that had already moved on to the final barrier (never
+    seen: no multi-GPU box was ever available, and the world-size-1 tests cannot show it).  Static check of the control flow."""
+    import ast
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read()
+    tree = ast.parse(src)
+
+    def is_rank0_test(node):
+        return (isinstance(node, ast.If) and isinstance(node.test, ast.Compare) and isinstance(node.test.left, ast.Name) and node.test.left.id == "rank"
+                and len(node.test.comparators) == 1 and isinstance(node.test.comparators[0], ast.Constant) and node.test.comparators[0].value == 0)
+
+    offenders = []
+    for node in ast.walk(tree):
+        if is_rank0_test(node):
+            for sub in ast.walk(ast.Module(body=node.body, type_ignores=[])):
+                if isinstance(sub, ast.Call):
+                    names = [a.id for a in sub.args if isinstance(a, ast.Name)] + ([sub.func.id] if isinstance(sub.func, ast.Name) else [])
+                    if "step" in names:
+                        offenders.append(sub.lineno)
+    assert not offenders, f"bench.py: step (which holds the collective) is used inside `if rank == 0:` at lines {offenders}"
+    assert src.count("spread = _step_spread(step, args.steps, dev)") == 2      # both the uniform and the ragged bench compute it on every rank
