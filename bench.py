@@ -339,17 +339,22 @@ def _median_stages(run_profiled, n=3):
     return stages, launches
 
 
+def _sync(dev):
+    if dev.type == "cuda":            # (the dry run drives the same control flow on the CPU under gloo)
+        torch.cuda.synchronize()
+
+
 def _timed_steps(step, args, dist_on, dev):
     for _ in range(args.warmup):
         step()
     if dist_on:
         torch.distributed.barrier()
-    torch.cuda.synchronize()
+    _sync(dev)
     t0 = time.perf_counter()
     out = None
     for _ in range(args.steps):
         out = step()
-    torch.cuda.synchronize()
+    _sync(dev)
     if dist_on:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
@@ -364,6 +369,12 @@ def _step_spread(step, steps, dev):
     """min / median / max of the per-step times of `steps` further steps: one HIP event pair per step on the launch stream (torch's
     current stream = the stream every kernel of the step is enqueued on), read after ONE synchronisation at the end -- the steps run
     back to back exactly like the timed region that defines `value`."""
+    if dev.type != "cuda":            # dry run: host clock
+        ms = []
+        for _ in range(steps):
+            t0 = time.perf_counter(); step(); ms.append((time.perf_counter() - t0) * 1e3)
+        ms.sort()
+        return {"min": round(ms[0], 3), "median": round(ms[len(ms) // 2], 3), "max": round(ms[-1], 3), "steps": steps, "how": "host clock (dry run)"}
     st = torch.cuda.current_stream(dev)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     ev[0].record(st)
@@ -387,6 +398,12 @@ def _rccl_block(dist_on, step_compute=None, step_full=None, dev=None, reps=10):
         return blk
 
     def timed(fn):
+        if dev.type != "cuda":        # dry run: host clock
+            fn(); dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            return (time.perf_counter() - t0) / reps * 1e3
         st = torch.cuda.current_stream(dev)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         fn(); torch.cuda.synchronize(); dist.barrier()
@@ -403,6 +420,17 @@ def _rccl_block(dist_on, step_compute=None, step_full=None, dev=None, reps=10):
                gather_ms_rank0=round(float(allr[0][1] - allr[0][0]), 3),
                how=f"{reps} steps each after the timed region, HIP events on the launch stream; gather = (step with the collective) - (step without) on rank 0")
     return blk
+
+
+def _measure(step, step_compute, args, dist_on, dev):
+    """The part of a bench run EVERY rank executes, in this order: the timed region, the per-step spread, the per-rank times of the rccl block.
+    `step` holds the collective when N > 1, so nothing here may run on rank 0 alone (round 4 computed the spread inside `if rank == 0`: with more
+    than one rank it would have waited in the gather for ever).  The gloo dry run (tests/test_sharding_cpu.py, 2 and 8 ranks) drives this very
+    function with a stub matcher."""
+    dt, out = _timed_steps(step, args, dist_on, dev)
+    spread = _step_spread(step, args.steps, dev)
+    rccl = _rccl_block(dist_on, step_compute, step, dev)
+    return dt, out, spread, rccl
 
 
 def bench_ragged(args, world, rank, dev, dist_on=False):
@@ -434,10 +462,7 @@ def bench_ragged(args, world, rank, dev, dist_on=False):
             return sharding.match_sharded_ragged(match_mine, lens, costs, dst=0, always_collective=True, device=dev)
         return match_mine(mine)
 
-    dt, _ = _timed_steps(step, args, dist_on, dev)
-    # `step` contains the collective when N > 1: EVERY rank runs these, never rank 0 alone (a rank-0-only step() would wait for peers that have moved on)
-    spread = _step_spread(step, args.steps, dev)
-    rccl = _rccl_block(dist_on, lambda: match_mine(mine), step, dev)
+    dt, _, spread, rccl = _measure(step, lambda: match_mine(mine), args, dist_on, dev)
     if rank == 0:
         res = match_mine(mine)
         my_lens = [lens[i] for i in mine]
@@ -505,14 +530,18 @@ def _dry_run(args, world, rank):
     def stub(ids):
         return [{"matches0": torch.full((lens[i][0],), i, dtype=torch.int64), "matching_scores0": torch.full((lens[i][0],), 0.5)}
                 for i in ids]
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        got = sharding.match_sharded_ragged(stub, lens, always_collective=world > 1)
-    dt = time.perf_counter() - t0
+    costs = [sharding.pair_cost(m, n) for m, n in lens]
+    mine = sharding.shard_pairs(len(lens), world, costs)[rank]
+    dev = torch.device("cpu")
+
+    def step():
+        return sharding.match_sharded_ragged(stub, lens, costs, always_collective=world > 1)
+    # the SAME control flow as the real bench (timed region -> spread -> per-rank block, every rank; then rank 0 reports; then the barrier)
+    dt, got, spread, rccl = _measure(step, lambda: stub(mine), args, world > 1, dev)
     if rank == 0:
         ok = all(bool((got["matches0"][i, :lens[i][0]] == i).all()) for i in range(len(lens)))
         print(json.dumps({"metric": "dry run (no GPU, gloo, stub matcher)", "dry_run": True, "n_gpus": world, "steps": args.steps, "global_batch": len(lens),
-                          "scaling": "strong" if args.global_batch else "weak",
+                          "scaling": "strong" if args.global_batch else "weak", "step_ms_spread": spread, "rccl": rccl,
                           "gather_ok": ok, "value": round(len(lens) * args.steps / dt, 1), "unit": "stub-pairs/s"}), flush=True)
     if world > 1:
         dist.barrier()
@@ -575,11 +604,8 @@ def main():
             sharding.gather_matches(out, pair_ids, world * B, dst=0, always_collective=True, cap=B)
         return out
 
-    dt, out = _timed_steps(step, args, dist_on, dev)
+    dt, out, spread, rccl = _measure(step, lambda: model.match(data, MATCH_THRESHOLD, both_sides=True), args, dist_on, dev)
     model.check_status()          # outside the timed region: the resident Sinkhorn kernel of the last step completed (no time-out)
-    # `step` contains the collective when N > 1: EVERY rank runs these, never rank 0 alone (a rank-0-only step() would wait for peers that have moved on)
-    spread = _step_spread(step, args.steps, dev)
-    rccl = _rccl_block(dist_on, lambda: model.match(data, MATCH_THRESHOLD, both_sides=True), step, dev)
 
     if rank == 0:
         c1 = algorithmic_counts(kw, m, n)

@@ -171,6 +171,10 @@ def test_eight_rank_dry_run_of_the_bench_plumbing():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["dry_run"] is True and d["n_gpus"] == 8 and d["gather_ok"] is True
+    # the dry run drives bench.py's own _measure(): timed region -> per-step spread -> per-rank block, on EVERY rank (steps hold the collective).  With
+    # round 4's rank-0-only spread these eight ranks would have dead-locked here instead of printing a line.
+    assert d["step_ms_spread"]["steps"] == 2 and d["rccl"]["backend"] == "gloo" and d["rccl"]["world_size"] == 8
+    assert len(d["rccl"]["per_rank_ms_with_gather"]) == 8 and len(d["rccl"]["per_rank_ms_compute_only"]) == 8
     # --global-batch: the BASELINE batch of a config split over the ranks (C3: 256 over 8), fixed job size = strong scaling
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--global-batch", "10"],
                        env=env, capture_output=True, text=True, timeout=600)
@@ -211,4 +215,5 @@ def test_bench_never_runs_a_step_with_the_collective_on_rank_0_alone():
                     if "step" in names:
                         offenders.append(sub.lineno)
     assert not offenders, f"bench.py: step (which holds the collective) is used inside `if rank == 0:` at lines {offenders}"
-    assert src.count("spread = _step_spread(step, args.steps, dev)") == 2      # both the uniform and the ragged bench compute it on every rank
+    # the uniform bench, the ragged bench and the dry run all go through _measure(), which every rank executes
+    assert src.count("= _measure(step, ") == 3 and src.count("spread = _step_spread(step, args.steps, dev)") == 1
