@@ -339,6 +339,13 @@ def _median_stages(run_profiled, n=3):
     return stages, launches
 
 
+def _flush_c_stdio():
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def _sync(dev):
     if dev.type == "cuda":            # (the dry run drives the same control flow on the CPU under gloo)
         torch.cuda.synchronize()
@@ -495,6 +502,7 @@ def bench_ragged(args, world, rank, dev, dist_on=False):
             line["cpu_baseline"]["sample"] += f" [one {mm}x{nn_}-keypoint pair = the mean size of the ragged job]"
         else:
             line["cpu_baseline"] = None
+        _flush_c_stdio()              # RCCL's version banner sits in the C library's stdout buffer: get it out BEFORE the line, which stays the last one
         print(json.dumps(line), flush=True)
     if dist_on:
         torch.distributed.barrier()
@@ -675,6 +683,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(cfg, sd, kw, m, n)
         else:
             line["cpu_baseline"] = None
+        _flush_c_stdio()              # RCCL's version banner sits in the C library's stdout buffer: get it out BEFORE the line, which stays the last one
         print(json.dumps(line), flush=True)
     if dist_on:
         torch.distributed.barrier()
