@@ -351,6 +351,11 @@ int og_sinkhorn_schedule_ragged(int32_t batch, const int32_t* lens0, const int32
  * out4 = {W, X, Gx, pairs per launch} -- workgroup tiles of (128 / W) rows x (1024 W) columns, X column blocks (one per XCD) x Gx row blocks;
  * returns 0, or OG_E_SHAPE when the shape has no resident geometry (more than 4096 rows or columns: streaming kernels). */
 int og_sinkhorn_resident_geometry(int32_t m, int32_t n, int32_t* out4);
+/* Host arithmetic only (8 XCDs x 32 CUs assumed): the row slots per WAVE a uniform launch of `batch` pairs takes in the resident kernel: 16 (workgroup
+ * tiles of 128 / W rows), or -- launches of few pairs of <= 1024 x 1024 keypoints, the reference's one-pair-per-call regime (inference.py:214-235) --
+ * 4 (a pair = 32 tiles of 32 x 1024: up to 8 pairs) or 8 (16 tiles of 64 x 1024: 9 to 16 pairs); 0 = no resident geometry.  OG_SINKHORN_FEW=0 / 1 / 4 / 8
+ * overrides. */
+int og_sinkhorn_resident_rows_per_wave(int32_t batch, int32_t m, int32_t n);
 /* Host arithmetic only (8 XCDs x 32 CUs assumed): the resident launches a RAGGED batch of per-pair sizes takes and the bytes of the
  * resident exchange slot the widest of them touches, out2 = {launches, bytes}; OG_E_SHAPE when some pair has no one-XCD geometry (the
  * batch streams).  The slot og_sinkhorn_workspace_bytes(batch, max m, max n) reserves is sized for the widest tile class any pair with

@@ -117,6 +117,7 @@ SYMBOLS = {
     "og_sinkhorn_schedule_ragged": (C.c_int, [_i32, _vp, _vp, _i32]),
     "og_sinkhorn_resident_geometry": (C.c_int, [_i32, _i32, _vp]),
     "og_sinkhorn_resident_ragged_footprint": (C.c_int, [_i32, _vp, _vp, _vp]),
+    "og_sinkhorn_resident_rows_per_wave": (C.c_int, [_i32, _i32, _i32]),
     "og_forward_status": (C.c_int, [_vp, _vp]),
     "og_sinkhorn_train_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "og_sinkhorn_train_forward": (C.c_int, [_vp, _i64, _f, _vp, _i32, _i32, _i32, _i32, _f, _vp, _vp, _vp]),

@@ -940,6 +940,13 @@ extern "C" int og_sinkhorn_resident_geometry(int32_t m, int32_t n, int32_t* out4
     return 0;
 }
 
+// Host arithmetic only (8 XCDs x 32 CUs assumed; CPU tests): the row slots per wave a uniform launch of B pairs of m x n keypoints takes -- 16, or the
+// few-pairs geometries 4 / 8 (OG_SINKHORN_FEW overrides as at run time); 0 when the shape has no resident geometry.
+extern "C" int og_sinkhorn_resident_rows_per_wave(int32_t batch, int32_t m, int32_t n) {
+    if (batch <= 0 || rs_geom(m, n).W == 0) return 0;
+    return rs_rows_per_wave(batch, m, n, 256);
+}
+
 // launches the resident kernel would need for this uniform batch on this device (0 = not possible)
 int og_sinkhorn_resident_rounds(int B, int m, int n) {
     if (!og_sinkhorn_resident_shape_ok(B, m, n)) return 0;

@@ -366,3 +366,27 @@ def test_favor_base_is_an_explicit_switch():
             ogs.SuperGlue(cfg, favor_base=Bad)
     finally:
         ogs.register_favor_base(None)
+
+
+def test_resident_sinkhorn_few_pairs_geometry_selection(monkeypatch):
+    """Host arithmetic of the few-pairs geometries (csrc/sinkhorn_resident.hip: rs_rows_per_wave, round 5): launches of one to eight pairs of
+    <= 1024 x 1024 keypoints take 4 rows per wave (a pair = 32 tiles on one XCD), 9 to 16 pairs take 8, anything that fills the chip -- or is wider
+    than one wave tile, or has more than 1024 rows -- keeps 16."""
+    lib = _lib.load()
+    monkeypatch.delenv("OG_SINKHORN_FEW", raising=False)
+    rpw = lib.og_sinkhorn_resident_rows_per_wave
+    assert [rpw(B, 1024, 1024) for B in (1, 2, 4, 8, 9, 12, 16, 17, 32)] == [4, 4, 4, 4, 8, 8, 8, 16, 16]
+    assert rpw(1, 2048, 2048) == 16 and rpw(1, 1024, 1025) == 16 and rpw(1, 1025, 1024) == 8 and rpw(1, 2049, 1024) == 16
+    assert rpw(1, 1, 1) == 4 and rpw(64, 100, 100) == 4 and rpw(65, 100, 100) == 16       # tiny pairs: at least two tiles each; the coarser geometry must leave half the chip idle
+    assert rpw(1, 5000, 100) == 0 and rpw(0, 10, 10) == 0                                   # no resident geometry at all
+    # every selected geometry fits ONE launch of 256 workgroups with one XCD (<= 32 tiles) per pair
+    for B in range(1, 40):
+        for m in (1, 31, 32, 33, 500, 1000, 1024):
+            r = rpw(B, m, 700)
+            if r in (4, 8):
+                tiles = max(2, -(-m // (r * 8)))
+                assert tiles <= 32 and B * tiles <= 256, (B, m, r)
+    monkeypatch.setenv("OG_SINKHORN_FEW", "0")
+    assert rpw(1, 1024, 1024) == 16
+    monkeypatch.setenv("OG_SINKHORN_FEW", "8")
+    assert rpw(1, 1024, 1024) == 8 and rpw(32, 1024, 1024) == 16                             # 8 rows per wave x 32 pairs would need 512 workgroups
