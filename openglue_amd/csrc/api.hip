@@ -566,8 +566,8 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
     // weights through an LDS ring (mlp_fused.hip).  At D = 128 the q | k | v matrix (N = 384) has no 256-tile form and the 128-token tile GEMM runs 4
     // k-stages per tile; at D = 256 the 256-tile GEMM stays faster in the whole step (og_proj_stream_wanted).  OG_PROJ_STREAM=0 / 1 forces.
     // The plane rows (QW halves) are whole 128-byte lines: QW = 3D, D a multiple of 64.
-    auto proj_stream_ok = [&](int64_t R) {
-        return L.o_wqkvb >= 0 && !favor && og_proj_stream_wanted((int)(R < ((int64_t)1 << 30) ? R : 0), D) && R < ((int64_t)1 << 30) && QW % 64 == 0 &&
+    auto proj_stream_ok = [&](int64_t R, bool full = false) {
+        return L.o_wqkvb >= 0 && !favor && og_proj_stream_wanted((int)(R < ((int64_t)1 << 30) ? R : 0), D, full) && R < ((int64_t)1 << 30) && QW % 64 == 0 &&
                !(((uintptr_t)QKVh | (uintptr_t)QKVl) & 127);
     };
     auto proj_stream = [&](const float* lw, int64_t r0, int64_t R, int split_row, int a0, int a1, int b0, int b1) -> int {      // ranges in channels
@@ -577,7 +577,7 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
     };
     auto qkv_proj = [&](const float* lw, int64_t r0, int64_t R, int c0, int c1) -> int {
         if (proj_small_ok(R) && c0 % 32 == 0 && c1 % 32 == 0) return proj_small(lw, r0, R, 0, 0, 0, c0 / 32, c1 / 32);
-        if (proj_stream_ok(R) && c0 % 128 == 0 && c1 % 128 == 0 && ((r0 * QW * 2) % 128 == 0)) return proj_stream(lw, r0, R, 0, 0, 0, c0, c1);
+        if (proj_stream_ok(R, c0 == 0 && c1 == QW) && c0 % 128 == 0 && c1 % 128 == 0 && ((r0 * QW * 2) % 128 == 0)) return proj_stream(lw, r0, R, 0, 0, 0, c0, c1);
         const int cut = favor ? 2 * WQ : c1;
         const int ca[2] = {c0, c0 < cut && cut < c1 ? cut : c1}, cb[2] = {ca[1], c1};
         for (int part = 0; part < 2; ++part) {

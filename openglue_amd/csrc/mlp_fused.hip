@@ -1498,8 +1498,11 @@ bool og_pack_proj_stream_big(int N, int K, const double* W, void* out, double S)
 // gpurun call (profiles/r05_c_proj_micro.log, r05_b_bench_proj_stream_ab.jsonl): K = 128 -- self 37.8 us against 52.6 for the 128-token tile GEMM,
 // cross 29.2 / 40.7, kv 16.8 / 21.3; C4 13.29 -> 13.12 ms, S128 12.27 -> 12.12 ms per step.  K = 256 -- self 102 us against 104.5 for the 256-tile
 // GEMM, but kv 42.6 / 33.5 and the cross launch 87.6 / ~56: C2 8.92 -> 8.99 ms, so the tile GEMMs keep the 256-d batches.
-bool og_proj_stream_wanted(int M, int K) {
+// `full`: the launch produces every column of the matrix for all its rows (a self layer's q | k | v).  OG_PROJ_STREAM=2 (experiment): at K = 256 the stream
+// kernel takes those launches only (95 against 104.5 us in the micro-benchmark), the tile GEMMs the cross / kv forms.
+bool og_proj_stream_wanted(int M, int K, bool full) {
     static const int mode = [] { const char* e = getenv("OG_PROJ_STREAM"); return e ? atoi(e) : -1; }();
+    if (mode == 2) return M > 8192 && (K == 128 || full);
     if (mode >= 0) return mode != 0 && M > 0;
     return M > 8192 && K == 128;
 }

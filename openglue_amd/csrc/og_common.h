@@ -189,7 +189,7 @@ bool og_pack_proj_stream(int N, int K, const double* W, void* out, double S);
 // ... and for batches (mlp_fused.hip: proj_stream_kernel, 128-token workgroups, x fragments in registers, the weights through an LDS ring)
 size_t og_proj_stream_big_bytes(int N, int K);
 bool og_pack_proj_stream_big(int N, int K, const double* W, void* out, double S);
-bool og_proj_stream_wanted(int M, int K);      // og_forward's choice: K = 128 batches (OG_PROJ_STREAM forces)
+bool og_proj_stream_wanted(int M, int K, bool full);      // og_forward's choice: K = 128 batches (OG_PROJ_STREAM forces)
 int og_launch_proj_stream(const _Float16* X, int64_t ld, int M, int K, const char* wstream, const float* bias, const float* scale_dev,
                           _Float16* Ch, _Float16* Cl, int64_t ldc, int split_row, int a0, int a1, int b0, int b1, hipStream_t stream);   // ranges in units of 128 channels
 int og_launch_proj_small(const _Float16* X, int64_t ld, int M, int K, const char* wstream, const float* bias, const float* scale_dev,
