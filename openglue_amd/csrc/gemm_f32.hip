@@ -241,24 +241,31 @@ int og_launch_gemm(const GemmArgs& a, hipStream_t stream) {
     const int tiles_m = (a.M + BM - 1) / BM;
     const int tiles_m8 = (tiles_m + 7) / 8 * 8;
     const int64_t vtiles8 = ((int64_t)tiles_m * a.batch + 7) / 8 * 8;      // uniform batches: see the kernel
-    if (vtiles8 * ((a.N + 127) / 128) > 0x7fffffffLL) return OG_E_SHAPE;
+    if (vtiles8 * ((a.N + 63) / 64) > 0x7fffffffLL) return OG_E_SHAPE;
     GemmArgs k = a;
     k.rag = nullptr;
+    // Tile width: 128 x 64 unless OG_GEMM_F32_BN=128 asks for the 128 x 128 form (experiments).  A workgroup is four waves = ONE per SIMD, and
+    // the k loop has two barriers per 32-deep tile with nothing else to run between them -- what hides them is a second and third workgroup on the
+    // CU, and the narrow tile is what provides those: the training step's convs are 8192 token rows x 256 ... 768 channels = 128 ... 384 wide
+    // workgroups on 256 CUs (half the chip idle at 256 channels, a second round on half the CUs at 768).  The narrow form reads 1.5x the operand
+    // bytes per flop (L2 hits) and was faster or equal wherever it was measured (profiles/r05_v_*): training step 39.3 -> 32.3 ms at 4 pairs,
+    // 81.4 -> 75.0 ms at 16 pairs (512 ... 1536 wide workgroups per launch), the encoder convs of the inference path 0.093 -> 0.068 ms at C2.
+    static const int force_bn = [] { const char* e = getenv("OG_GEMM_F32_BN"); return e ? atoi(e) : 0; }();
+    const bool narrow = a.N <= 64 || force_bn != 128;
+    const int tiles_n = narrow ? (a.N + 63) / 64 : (a.N + 127) / 128;
     auto launch = [&](auto rd) -> int {       // the per-pair descriptor is a kernel argument only for ragged launches (og_common.h)
         using RD = decltype(rd);
         constexpr bool uniform = std::is_same<RD, RaggedNone>::value;
-        const int tiles_n = a.N > 64 ? (a.N + 127) / 128 : 1;
         const dim3 grid = uniform ? dim3((unsigned)(vtiles8 * tiles_n)) : dim3(tiles_m8 * tiles_n, a.batch);
-        if (a.N > 64) hipLaunchKernelGGL((gemm_nt_f32_kernel<128, false, false, RD>), grid, dim3(256), 0, stream, k, tiles_m, tiles_n, rd);
-        else hipLaunchKernelGGL((gemm_nt_f32_kernel<64, false, false, RD>), grid, dim3(256), 0, stream, k, tiles_m, 1, rd);
+        if (!narrow) hipLaunchKernelGGL((gemm_nt_f32_kernel<128, false, false, RD>), grid, dim3(256), 0, stream, k, tiles_m, tiles_n, rd);
+        else hipLaunchKernelGGL((gemm_nt_f32_kernel<64, false, false, RD>), grid, dim3(256), 0, stream, k, tiles_m, tiles_n, rd);
         return og_launch_status();
     };
     auto launch_t = [&](auto ta, auto tb) -> int {
         constexpr bool TA_ = decltype(ta)::value, TB_ = decltype(tb)::value;
-        const int tiles_n = a.N > 64 ? (a.N + 127) / 128 : 1;
         const dim3 grid((unsigned)(vtiles8 * tiles_n));
-        if (a.N > 64) hipLaunchKernelGGL((gemm_nt_f32_kernel<128, TA_, TB_, RaggedNone>), grid, dim3(256), 0, stream, k, tiles_m, tiles_n, RaggedNone{});
-        else hipLaunchKernelGGL((gemm_nt_f32_kernel<64, TA_, TB_, RaggedNone>), grid, dim3(256), 0, stream, k, tiles_m, 1, RaggedNone{});
+        if (!narrow) hipLaunchKernelGGL((gemm_nt_f32_kernel<128, TA_, TB_, RaggedNone>), grid, dim3(256), 0, stream, k, tiles_m, tiles_n, RaggedNone{});
+        else hipLaunchKernelGGL((gemm_nt_f32_kernel<64, TA_, TB_, RaggedNone>), grid, dim3(256), 0, stream, k, tiles_m, tiles_n, RaggedNone{});
         return og_launch_status();
     };
     if (a.ta) return launch_t(std::true_type{}, std::true_type{});
