@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define OG_ABI_VERSION 8
+#define OG_ABI_VERSION 9
 
 #define OG_E_INVALID   (-1)  /* NULL pointer / non-positive size                         */
 #define OG_E_SHAPE     (-2)  /* unsupported shape (see og_check_shape)                   */
@@ -426,6 +426,24 @@ int og_attention_backward_parts(int32_t nk);
 int og_attention_backward(const float* q, const float* k, const float* v, const float* dout, const float* lse, const float* delta,
                           int32_t batch, int32_t nq, int32_t nk, int32_t num_heads, int32_t dh, float scale, float* dq_part, float* dk,
                           float* dv, void* stream);
+/* ABI v9 -- the same with ROW STRIDES (floats, multiples of 4, >= D) on q, k, v and on the dk, dv outputs, so that the training step hands over
+ * column ranges of its [tokens][3D] projection matrix and receives dk, dv inside the [tokens][3D] gradient matrix (no slices copied out, no
+ * concatenation); dout and dq_part rows stay D wide.  og_attention_delta: delta[row][h] = sum_c dout[row][h dh + c] out[row][h dh + c] for
+ * contiguous [rows][num_heads * dh] tensors (what og_attention_backward wants as `delta`), one launch. */
+int og_attention_backward_ld(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const float* dout,
+                             const float* lse, const float* delta, int32_t batch, int32_t nq, int32_t nk, int32_t num_heads, int32_t dh,
+                             float scale, float* dq_part, float* dk, int64_t lddk, float* dv, int64_t lddv, void* stream);
+int og_attention_delta(const float* dout, const float* out, int64_t rows, int32_t num_heads, int32_t dh, float* delta, void* stream);
+/* ABI v9 -- glue of the training step as single launches (openglue_amd/train.py):
+ * og_split_f16_rows: x [rows][cols] fp32 (row stride ldx) -> (hi, lo) binary16 planes (row stride ldo), columns [0, scale_cols) multiplied by
+ *   s1, then s2, first (the q columns of a q | k | v matrix: dh^-1/2, then the log2(e) of og_attention's base-2 softmax);
+ * og_merge_f16: out[i] = float(hi[i]) + float(lo[i]) (og_attention's output planes back to fp32);
+ * og_splitk_reduce: the `parts` partial products part[p][rows][ld] of a split-K weight gradient (og_gemm_kmajor with batch = parts) summed in
+ *   part order into dW [rows][cols]; db (may be NULL) [rows] = the sums of column `cols` (the a_colsum column: ld >= cols + 4 then). */
+int og_split_f16_rows(const float* x, int64_t ldx, int64_t rows, int32_t cols, int32_t scale_cols, float s1, float s2, void* hi, void* lo,
+                      int64_t ldo, void* stream);
+int og_merge_f16(const void* hi, const void* lo, int64_t n, float* out, void* stream);
+int og_splitk_reduce(const float* part, int32_t parts, int32_t rows, int64_t ld, int32_t cols, float* dW, float* db, void* stream);
 
 /* mutual-NN match extraction from a scores tensor [B][m+1][n+1] (matching_module.py:174-187;
  * matches1/matching_scores1 as inference.py:183-188, may be NULL).  First maximal index wins.

@@ -11,7 +11,7 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OPENGLUE_AMD_LIB") or os.path.join(HERE, "lib", "libopenglue_amd.so")   # override: A/B builds
 
-OG_ABI_VERSION = 8
+OG_ABI_VERSION = 9
 OG_FLAG_RESIDUAL, OG_FLAG_USE_OFFSET, OG_FLAG_NO_DESCRIPTORS, OG_FLAG_SIREN_ENCODER, OG_FLAG_LINEAR_ATTENTION = 1, 2, 4, 8, 16
 OG_FLAG_FAVOR_RELU = 32
 OG_MAX_HIDDEN = 8
@@ -95,6 +95,11 @@ SYMBOLS = {
     "og_attention_train_lse": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f, _vp, _vp]),
     "og_attention_backward_parts": (C.c_int, [_i32]),
     "og_attention_backward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f, _vp, _vp, _vp, _vp]),
+    "og_attention_backward_ld": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f, _vp, _vp, _i64, _vp, _i64, _vp]),
+    "og_attention_delta": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "og_split_f16_rows": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _f, _f, _vp, _vp, _i64, _vp]),
+    "og_merge_f16": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
+    "og_splitk_reduce": (C.c_int, [_vp, _i32, _i32, _i64, _i32, _vp, _vp, _vp]),
     "og_split_f16": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
     "og_split_f16_hl": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i64, _vp]),
     "og_gemm_nt_f16x3": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _f, _vp, _i32, _vp, _i64, _vp, _i64,

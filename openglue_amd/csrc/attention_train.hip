@@ -30,6 +30,7 @@ struct AttnTrainArgs {
     float* dq_part; float* dk; float* dv; float* lse_out;
     int B, nq, nk, H, D;
     float scale;
+    int64_t ldq, ldk, ldv, lddk, lddv;     // row strides (floats) of q, k, v and of the dk, dv outputs; dout and dq_part rows are D wide
 };
 
 __device__ __forceinline__ f32x16 zero16() {
@@ -93,14 +94,14 @@ __global__ __launch_bounds__(256) void attention_lse_kernel(AttnTrainArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qi = wave >> 1, kj = wave & 1;
     const int i0 = ib * BR;
-    const float* qz = a.q + (int64_t)b * a.nq * a.D + h * DH;
-    const float* kz = a.k + (int64_t)b * a.nk * a.D + h * DH;
+    const float* qz = a.q + (int64_t)b * a.nq * a.ldq + h * DH;
+    const float* kz = a.k + (int64_t)b * a.nk * a.ldk + h * DH;
 
 #pragma unroll
-    for (int p = 0; p < IO::PASSES; ++p) IO::store(Qs, tid, p, IO::load(qz, a.D, i0, a.nq, tid, p));
+    for (int p = 0; p < IO::PASSES; ++p) IO::store(Qs, tid, p, IO::load(qz, a.ldq, i0, a.nq, tid, p));
     f32x4 rk[IO::PASSES];
 #pragma unroll
-    for (int p = 0; p < IO::PASSES; ++p) rk[p] = IO::load(kz, a.D, 0, a.nk, tid, p);
+    for (int p = 0; p < IO::PASSES; ++p) rk[p] = IO::load(kz, a.ldk, 0, a.nk, tid, p);
 
     float m = -INFINITY, l = 0.f;
     const int nkb = (a.nk + BC - 1) / BC;
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void attention_lse_kernel(AttnTrainArgs a) {
         __syncthreads();
         if (jb + 1 < nkb) {
 #pragma unroll
-            for (int p = 0; p < IO::PASSES; ++p) rk[p] = IO::load(kz, a.D, (jb + 1) * BC, a.nk, tid, p);
+            for (int p = 0; p < IO::PASSES; ++p) rk[p] = IO::load(kz, a.ldk, (jb + 1) * BC, a.nk, tid, p);
         }
         const f32x16 st = rows_dot_rows<DHP>(Ks, 32 * kj, Qs, 32 * qi, lane);      // [key][query]: lane = query
         float mx = -INFINITY;
@@ -171,24 +172,24 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(AttnTrainArgs a) {
     const int l31 = lane & 31, hi = lane >> 5;
     const int qi = wave >> 1, kj = wave & 1;
     const int j0 = jb * BC;
-    const float* qz = a.q + (int64_t)b * a.nq * a.D + h * DH;
+    const float* qz = a.q + (int64_t)b * a.nq * a.ldq + h * DH;
     const float* doz = a.dout + (int64_t)b * a.nq * a.D + h * DH;
-    const float* kz = a.k + (int64_t)b * a.nk * a.D + h * DH;
-    const float* vz = a.v + (int64_t)b * a.nk * a.D + h * DH;
+    const float* kz = a.k + (int64_t)b * a.nk * a.ldk + h * DH;
+    const float* vz = a.v + (int64_t)b * a.nk * a.ldv + h * DH;
     const float* lz = a.lse + ((int64_t)b * a.H + h) * a.nq;
     const float* dz = a.delta + (int64_t)b * a.nq * a.H + h;            // [B][nq][H]
 
 #pragma unroll
     for (int p = 0; p < IO::PASSES; ++p) {
-        IO::store(Ks, tid, p, IO::load(kz, a.D, j0, a.nk, tid, p));
-        IO::store(Vs, tid, p, IO::load(vz, a.D, j0, a.nk, tid, p));
+        IO::store(Ks, tid, p, IO::load(kz, a.ldk, j0, a.nk, tid, p));
+        IO::store(Vs, tid, p, IO::load(vz, a.ldv, j0, a.nk, tid, p));
     }
     f32x4 rq[IO::PASSES], ro[IO::PASSES];
     float rl = 0.f, rd = 0.f;
     auto prefetch = [&](int i0) {
 #pragma unroll
         for (int p = 0; p < IO::PASSES; ++p) {
-            rq[p] = IO::load(qz, a.D, i0, a.nq, tid, p);
+            rq[p] = IO::load(qz, a.ldq, i0, a.nq, tid, p);
             ro[p] = IO::load(doz, a.D, i0, a.nq, tid, p);
         }
         if (tid < BR) {
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(AttnTrainArgs a) {
         }
     }
     // dV, dK of this key block: the two query halves add up (wave qi = 1 -> wave qi = 0)
-    auto flush = [&](f32x16 (&acc)[NB], float* dst) {
+    auto flush = [&](f32x16 (&acc)[NB], float* dst, int64_t ldd) {
         __syncthreads();
         float* R = Rs + kj * 32 * DHP;
         if (qi == 1) {
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(AttnTrainArgs a) {
         }
         __syncthreads();
         if (qi == 0) {
-            float* out = dst + (int64_t)b * a.nk * a.D + h * DH;
+            float* out = dst + (int64_t)b * a.nk * ldd + h * DH;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const int col = nb * 32 + l31;
@@ -303,14 +304,14 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(AttnTrainArgs a) {
                     for (int r = 0; r < 16; ++r) {
                         const int rr = mfma32_row(r, lane);
                         const int row = j0 + 32 * kj + rr;
-                        if (row < a.nk) out[(int64_t)row * a.D + col] = acc[nb][r] + R[rr * DHP + col];
+                        if (row < a.nk) out[(int64_t)row * ldd + col] = acc[nb][r] + R[rr * DHP + col];
                     }
                 }
             }
         }
     };
-    flush(dv, a.dv);
-    flush(dk, a.dk);
+    flush(dv, a.dv, a.lddv);
+    flush(dk, a.dk, a.lddk);
 }
 
 int check(const AttnTrainArgs& a, int dh) {
@@ -318,10 +319,37 @@ int check(const AttnTrainArgs& a, int dh) {
     if (dh != 16 && dh != 32 && dh != 64) return OG_E_SHAPE;
     if (a.D != a.H * dh) return OG_E_SHAPE;
     if (((uintptr_t)a.q & 15) || ((uintptr_t)a.k & 15)) return OG_E_ALIGN;
+    if ((a.ldq & 3) || (a.ldk & 3) || a.ldq < a.D || a.ldk < a.D) return OG_E_ALIGN;
     return 0;
 }
 
+// delta[row][h] = sum_c dout[row][h dh + c] * out[row][h dh + c]: the row term of the softmax backward (one thread per (row, head))
+__global__ __launch_bounds__(256) void attention_delta_kernel(const float* __restrict__ dout, const float* __restrict__ out, int64_t rows, int H,
+                                                              int dh, float* __restrict__ delta) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * H) return;
+    const float* a = dout + i * dh;
+    const float* b = out + i * dh;
+    float s = 0.f;
+    for (int c = 0; c < dh; c += 4) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(a + c), y = *reinterpret_cast<const f32x4*>(b + c);
+        s += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+    }
+    delta[i] = s;
+}
+
 }  // namespace
+
+extern "C" int og_attention_delta(const float* dout, const float* out, int64_t rows, int32_t num_heads, int32_t dh, float* delta, void* stream) {
+    og_clear_status();
+    if (!dout || !out || !delta || rows <= 0 || num_heads <= 0 || dh <= 0) return OG_E_INVALID;
+    if ((dh & 3) || ((uintptr_t)dout & 15) || ((uintptr_t)out & 15)) return OG_E_ALIGN;
+    const int64_t n = rows * num_heads;
+    if ((n + 255) / 256 > 0x7fffffffLL) return OG_E_SHAPE;
+    hipLaunchKernelGGL(attention_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dout, out, rows, num_heads, dh,
+                       delta);
+    return og_launch_status();
+}
 
 extern "C" int og_attention_train_lse(const float* q, const float* k, int32_t batch, int32_t nq, int32_t nk, int32_t num_heads, int32_t dh,
                                       float scale, float* lse, void* stream) {
@@ -329,6 +357,7 @@ extern "C" int og_attention_train_lse(const float* q, const float* k, int32_t ba
     AttnTrainArgs a{};
     a.q = q; a.k = k; a.lse_out = lse;
     a.B = batch; a.nq = nq; a.nk = nk; a.H = num_heads; a.D = num_heads * dh; a.scale = scale;
+    a.ldq = a.ldk = a.D;
     if (int rc = check(a, dh)) return rc;
     if (!lse) return OG_E_INVALID;
     const int64_t blocks = (int64_t)batch * num_heads * ((nq + BR - 1) / BR);
@@ -342,17 +371,18 @@ extern "C" int og_attention_train_lse(const float* q, const float* k, int32_t ba
 
 extern "C" int og_attention_backward_parts(int32_t nk) { return nk > 0 ? (nk + BC - 1) / BC : 0; }
 
-extern "C" int og_attention_backward(const float* q, const float* k, const float* v, const float* dout, const float* lse,
-                                     const float* delta, int32_t batch, int32_t nq, int32_t nk, int32_t num_heads, int32_t dh,
-                                     float scale, float* dq_part, float* dk, float* dv, void* stream) {
+extern "C" int og_attention_backward_ld(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const float* dout,
+                                        const float* lse, const float* delta, int32_t batch, int32_t nq, int32_t nk, int32_t num_heads, int32_t dh,
+                                        float scale, float* dq_part, float* dk, int64_t lddk, float* dv, int64_t lddv, void* stream) {
     og_clear_status();
     AttnTrainArgs a{};
     a.q = q; a.k = k; a.v = v; a.dout = dout; a.lse = lse; a.delta = delta;
     a.dq_part = dq_part; a.dk = dk; a.dv = dv;
     a.B = batch; a.nq = nq; a.nk = nk; a.H = num_heads; a.D = num_heads * dh; a.scale = scale;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.lddk = lddk; a.lddv = lddv;
     if (int rc = check(a, dh)) return rc;
     if (!v || !dout || !lse || !delta || !dq_part || !dk || !dv) return OG_E_INVALID;
-    if (((uintptr_t)v & 15) || ((uintptr_t)dout & 15)) return OG_E_ALIGN;
+    if (((uintptr_t)v & 15) || ((uintptr_t)dout & 15) || (ldv & 3) || ldv < a.D || lddk < a.D || lddv < a.D) return OG_E_ALIGN;
     const int64_t blocks = (int64_t)batch * num_heads * ((nk + BC - 1) / BC);
     if (blocks > 0x7fffffffLL) return OG_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
@@ -360,4 +390,11 @@ extern "C" int og_attention_backward(const float* q, const float* k, const float
     else if (dh == 32) hipLaunchKernelGGL(attention_bwd_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(attention_bwd_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, st, a);
     return og_launch_status();
+}
+
+extern "C" int og_attention_backward(const float* q, const float* k, const float* v, const float* dout, const float* lse,
+                                     const float* delta, int32_t batch, int32_t nq, int32_t nk, int32_t num_heads, int32_t dh,
+                                     float scale, float* dq_part, float* dk, float* dv, void* stream) {
+    const int64_t D = (int64_t)num_heads * dh;
+    return og_attention_backward_ld(q, D, k, D, v, D, dout, lse, delta, batch, nq, nk, num_heads, dh, scale, dq_part, dk, D, dv, D, stream);
 }

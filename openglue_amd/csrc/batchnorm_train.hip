@@ -14,47 +14,82 @@
 
 namespace {
 
-constexpr int BN_ROWS_PER_BLOCK = 256;      // rows folded by one block of pass 1
+constexpr int BN_ROWS_PER_BLOCK = 32;       // rows folded by one block of pass 1 (round 5: 256 -> 32; 8192 x 512 activations were 256 blocks whose
+                                            // threads each walked 64 rows one 4-byte load at a time: 18 us for 16 MB)
 
-// grid (ceil(rows / BN_ROWS_PER_BLOCK), ceil(C / 64)), 256 threads = 4 row groups x 64 channels
-__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int C, float* __restrict__ part) {
-    __shared__ float red[2][4][64];
-    const int c = blockIdx.y * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+// Pass 1.  grid (ceil(rows / BN_ROWS_PER_BLOCK), ceil(C / 256)), 256 threads = 4 waves; a lane owns FOUR channels (one 16-byte load per row: a wave
+// reads 1 KB of a row), wave w the rows r0 + w, r0 + w + 4, ...; the waves meet in LDS in wave order.  part[(blk * C + c) * 2 + {0, 1}].
+// F(lane's 4 values of this row, lane's 4 channels) -> the two terms to accumulate
+template <class F>
+__device__ __forceinline__ void bn_fold_rows(int64_t rows, int C, float* __restrict__ part, F term) {
+    __shared__ f32x4 red[2][3][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.y * 256 + lane * 4;
     const int64_t r0 = (int64_t)blockIdx.x * BN_ROWS_PER_BLOCK;
-    float s1 = 0.f, s2 = 0.f;
+    const int64_t r1 = r0 + BN_ROWS_PER_BLOCK < rows ? r0 + BN_ROWS_PER_BLOCK : rows;
+    f32x4 s1{0.f, 0.f, 0.f, 0.f}, s2{0.f, 0.f, 0.f, 0.f};
     if (c < C) {
-        const float k = x[c];                                   // shift: row 0 of the channel
-        const int64_t r1 = r0 + BN_ROWS_PER_BLOCK < rows ? r0 + BN_ROWS_PER_BLOCK : rows;
-        for (int64_t r = r0 + rg; r < r1; r += 4) {
-            const float d = x[r * ldx + c] - k;
-            s1 += d;
-            s2 = fmaf(d, d, s2);
-        }
+#pragma unroll 4
+        for (int64_t r = r0 + wave; r < r1; r += 4) term(r, c, s1, s2);
     }
-    red[0][rg][threadIdx.x & 63] = s1;
-    red[1][rg][threadIdx.x & 63] = s2;
+    if (wave) { red[0][wave - 1][lane] = s1; red[1][wave - 1][lane] = s2; }
     __syncthreads();
-    if (rg == 0 && c < C) {
-        const int l = threadIdx.x;
-        const float t1 = (red[0][0][l] + red[0][1][l]) + (red[0][2][l] + red[0][3][l]);
-        const float t2 = (red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l]);
-        part[((int64_t)blockIdx.x * C + c) * 2] = t1;
-        part[((int64_t)blockIdx.x * C + c) * 2 + 1] = t2;
+    if (wave || c >= C) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+        const f32x4 a = red[0][w][lane], b = red[1][w][lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s1[e] += a[e]; s2[e] += b[e]; }
     }
+    float* dst = part + ((int64_t)blockIdx.x * C + c) * 2;
+    *reinterpret_cast<f32x4*>(dst) = f32x4{s1[0], s2[0], s1[1], s2[1]};
+    *reinterpret_cast<f32x4*>(dst + 4) = f32x4{s1[2], s2[2], s1[3], s2[3]};
 }
 
-// one thread per channel
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int C, float* __restrict__ part) {
+    const int c0 = blockIdx.y * 256 + (threadIdx.x & 63) * 4;
+    const f32x4 k = c0 < C ? *reinterpret_cast<const f32x4*>(x + c0) : f32x4{0.f, 0.f, 0.f, 0.f};      // shift: row 0 of the channel
+    bn_fold_rows(rows, C, part, [&](int64_t r, int c, f32x4& s1, f32x4& s2) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = v[e] - k[e];
+            s1[e] += d;
+            s2[e] = fmaf(d, d, s2[e]);
+        }
+    });
+}
+
+// The per-channel fold of the partials, in double: 64 channels per block, the four waves take the slabs i = w, w + 4, ... and meet in LDS in wave order
+// (one thread per channel walking every slab was fine at 32 slabs; there are 256 now).  -> (s1, s2) in the threads of wave 0, others return false.
+__device__ __forceinline__ bool bn_fold_partials(const float* __restrict__ part, int nblk, int C, int c, double& s1, double& s2) {
+    __shared__ double red[2][3][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    s1 = 0.0; s2 = 0.0;
+    if (c < C) {
+#pragma unroll 4
+        for (int i = wave; i < nblk; i += 4) {
+            const float2 v = *reinterpret_cast<const float2*>(part + ((int64_t)i * C + c) * 2);
+            s1 += (double)v.x;
+            s2 += (double)v.y;
+        }
+    }
+    if (wave) { red[0][wave - 1][lane] = s1; red[1][wave - 1][lane] = s2; }
+    __syncthreads();
+    if (wave || c >= C) return false;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) { s1 += red[0][w][lane]; s2 += red[1][w][lane]; }
+    return true;
+}
+
+// grid ceil(C / 64), 256 threads
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ x, const float* __restrict__ part, int nblk, int64_t rows, int C,
                                                           const float* __restrict__ w, const float* __restrict__ b, float eps, float momentum,
                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
                                                           float* __restrict__ scale_shift, float* __restrict__ save_mean, float* __restrict__ save_invstd) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int i = 0; i < nblk; ++i) {
-        s1 += (double)part[((int64_t)i * C + c) * 2];
-        s2 += (double)part[((int64_t)i * C + c) * 2 + 1];
-    }
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    double s1, s2;
+    if (!bn_fold_partials(part, nblk, C, c, s1, s2)) return;
     const double n = (double)rows;
     const double dm = s1 / n;                                   // mean - k
     const double mean = (double)x[c] + dm;
@@ -110,8 +145,8 @@ extern "C" int og_batchnorm_train_forward(const float* x, int64_t ldx, int64_t r
     const int nblk = (int)((rows + BN_ROWS_PER_BLOCK - 1) / BN_ROWS_PER_BLOCK);
     float* part = reinterpret_cast<float*>(workspace);
     float* scale_shift = part + (int64_t)nblk * channels * 2;
-    hipLaunchKernelGGL(bn_partial_kernel, dim3(nblk, (channels + 63) / 64), dim3(256), 0, st, x, ldx, rows, channels, part);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((channels + 255) / 256), dim3(256), 0, st, x, part, nblk, rows, channels, weight, bias, eps, momentum,
+    hipLaunchKernelGGL(bn_partial_kernel, dim3(nblk, (channels + 255) / 256), dim3(256), 0, st, x, ldx, rows, channels, part);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((channels + 63) / 64), dim3(256), 0, st, x, part, nblk, rows, channels, weight, bias, eps, momentum,
                        running_mean, running_var, scale_shift, save_mean, save_invstd);
     const int64_t n4 = rows * (channels / 4);
     hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x, ldx, rows, channels / 4, scale_shift, y, ldy);
@@ -129,40 +164,27 @@ namespace {
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ dy, int64_t lddy,
                                                              int64_t rows, int C, const float* __restrict__ mean, const float* __restrict__ invstd,
                                                              float* __restrict__ part) {
-    __shared__ float red[2][4][64];
-    const int c = blockIdx.y * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
-    const int64_t r0 = (int64_t)blockIdx.x * BN_ROWS_PER_BLOCK;
-    float s1 = 0.f, s2 = 0.f;
-    if (c < C) {
-        const float mu = mean[c], is = invstd[c];
-        const int64_t r1 = r0 + BN_ROWS_PER_BLOCK < rows ? r0 + BN_ROWS_PER_BLOCK : rows;
-        for (int64_t r = r0 + rg; r < r1; r += 4) {
-            const float g = dy[r * lddy + c];
-            s1 += g;
-            s2 = fmaf(g, (a[r * lda + c] - mu) * is, s2);
+    const int c0 = blockIdx.y * 256 + (threadIdx.x & 63) * 4;
+    const f32x4 zero{0.f, 0.f, 0.f, 0.f};
+    const f32x4 mu = c0 < C ? *reinterpret_cast<const f32x4*>(mean + c0) : zero, is = c0 < C ? *reinterpret_cast<const f32x4*>(invstd + c0) : zero;
+    bn_fold_rows(rows, C, part, [&](int64_t r, int c, f32x4& s1, f32x4& s2) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(dy + r * lddy + c);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(a + r * lda + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            s1[e] += g[e];
+            s2[e] = fmaf(g[e], (v[e] - mu[e]) * is[e], s2[e]);
         }
-    }
-    red[0][rg][threadIdx.x & 63] = s1;
-    red[1][rg][threadIdx.x & 63] = s2;
-    __syncthreads();
-    if (rg == 0 && c < C) {
-        const int l = threadIdx.x;
-        part[((int64_t)blockIdx.x * C + c) * 2] = (red[0][0][l] + red[0][1][l]) + (red[0][2][l] + red[0][3][l]);
-        part[((int64_t)blockIdx.x * C + c) * 2 + 1] = (red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l]);
-    }
+    });
 }
 
-// coef[c] = w invstd, coef[C + c] = dbias / T, coef[2C + c] = dweight / T
+// coef[c] = w invstd, coef[C + c] = dbias / T, coef[2C + c] = dweight / T;  grid ceil(C / 64), 256 threads
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int64_t rows, int C, const float* __restrict__ w,
                                                               const float* __restrict__ invstd, float* __restrict__ dweight, float* __restrict__ dbias,
                                                               float* __restrict__ coef) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int i = 0; i < nblk; ++i) {
-        s1 += (double)part[((int64_t)i * C + c) * 2];
-        s2 += (double)part[((int64_t)i * C + c) * 2 + 1];
-    }
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    double s1, s2;
+    if (!bn_fold_partials(part, nblk, C, c, s1, s2)) return;
     if (dbias) dbias[c] = (float)s1;
     if (dweight) dweight[c] = (float)s2;
     coef[c] = (w ? w[c] : 1.f) * invstd[c];
@@ -253,8 +275,8 @@ extern "C" int og_batchnorm_train_backward(const float* a, int64_t lda, const fl
     const int nblk = (int)((rows + BN_ROWS_PER_BLOCK - 1) / BN_ROWS_PER_BLOCK);
     float* part = reinterpret_cast<float*>(workspace);
     float* coef = part + (int64_t)nblk * channels * 2;       // 3 * channels floats: og_batchnorm_train_workspace_bytes reserves them
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblk, (channels + 63) / 64), dim3(256), 0, st, a, lda, dy, lddy, rows, channels, save_mean, save_invstd, part);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((channels + 255) / 256), dim3(256), 0, st, part, nblk, rows, channels, weight, save_invstd, dweight,
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblk, (channels + 255) / 256), dim3(256), 0, st, a, lda, dy, lddy, rows, channels, save_mean, save_invstd, part);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((channels + 63) / 64), dim3(256), 0, st, part, nblk, rows, channels, weight, save_invstd, dweight,
                        dbias, coef);
     const int64_t n4 = rows * (channels / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, a, lda, dy, lddy, rows, channels / 4, save_mean,

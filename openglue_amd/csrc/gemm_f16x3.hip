@@ -1092,6 +1092,44 @@ __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict_
     *reinterpret_cast<f16x4*>(l + 4 * i) = vl;
 }
 
+// x [rows][cols] (row stride ldx) fp32 -> (hi, lo) planes with row stride ldo; columns [0, scale_cols) are multiplied by s1, then by s2, first
+// (two roundings, like the two tensor multiplications they replace: the attention scale dh^-1/2 and the log2(e) of the kernel's base-2 softmax).
+// The training step's q | k | v matrix goes to the attention kernel's operand format in ONE launch, no slices copied out first.
+__global__ __launch_bounds__(256) void split_f16_rows_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int cols, int scale_cols,
+                                                             float s1, float s2, _Float16* __restrict__ h, _Float16* __restrict__ l, int64_t ldo) {
+#pragma clang fp contract(off)
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int c4 = cols / 4;
+    if (i >= rows * c4) return;
+    const int64_t r = i / c4; const int c = (int)(i % c4) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + c);
+    if (c < scale_cols) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (v[e] * s1) * s2;
+    }
+    f16x4 vh, vl;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        _Float16 hh, ll;
+        og_split(v[e], hh, ll);
+        vh[e] = hh; vl[e] = ll;
+    }
+    *reinterpret_cast<f16x4*>(h + r * ldo + c) = vh;
+    *reinterpret_cast<f16x4*>(l + r * ldo + c) = vl;
+}
+
+// out = float(hi) + float(lo): the attention kernel's output planes back to fp32 in one launch
+__global__ __launch_bounds__(256) void merge_f16_kernel(const _Float16* __restrict__ h, const _Float16* __restrict__ l, int64_t n4,
+                                                        float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const f16x4 vh = *reinterpret_cast<const f16x4*>(h + 4 * i), vl = *reinterpret_cast<const f16x4*>(l + 4 * i);
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (float)vh[e] + (float)vl[e];
+    *reinterpret_cast<f32x4*>(out + 4 * i) = v;
+}
+
 // x [rows][cols] fp32 -> hl32 rows (test helper / conversions outside the GEMMs)
 __global__ __launch_bounds__(256) void split_f16_hl_kernel(const float* __restrict__ x, int64_t rows, int cols, int64_t ldx,
                                                            _Float16* __restrict__ out, int64_t ldo) {
@@ -1267,6 +1305,31 @@ extern "C" int og_debug_gemm_trace(void* host_dst, size_t bytes) {
 extern "C" int og_split_f16(const float* x, int64_t n, void* hi, void* lo, void* stream) {
     og_clear_status();
     return og_launch_split_f16(x, n, hi, lo, (hipStream_t)stream);
+}
+
+extern "C" int og_split_f16_rows(const float* x, int64_t ldx, int64_t rows, int32_t cols, int32_t scale_cols, float s1, float s2, void* hi,
+                                 void* lo, int64_t ldo, void* stream) {
+    og_clear_status();
+    if (!x || !hi || !lo || rows <= 0 || cols <= 0 || scale_cols < 0 || scale_cols > cols) return OG_E_INVALID;
+    if ((cols & 3) || (scale_cols & 3) || (ldx & 3) || (ldo & 3) || ldx < cols || ldo < cols || ((uintptr_t)x & 15) || ((uintptr_t)hi & 7) ||
+        ((uintptr_t)lo & 7))
+        return OG_E_ALIGN;
+    const int64_t n4 = rows * (cols / 4);
+    if ((n4 + 255) / 256 > 0x7fffffffLL) return OG_E_SHAPE;
+    hipLaunchKernelGGL(split_f16_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, cols, scale_cols,
+                       s1, s2, (_Float16*)hi, (_Float16*)lo, ldo);
+    return og_launch_status();
+}
+
+extern "C" int og_merge_f16(const void* hi, const void* lo, int64_t n, float* out, void* stream) {
+    og_clear_status();
+    if (!hi || !lo || !out || n <= 0) return OG_E_INVALID;
+    if ((n & 3) || ((uintptr_t)hi & 7) || ((uintptr_t)lo & 7) || ((uintptr_t)out & 15)) return OG_E_ALIGN;
+    const int64_t n4 = n / 4;
+    if ((n4 + 255) / 256 > 0x7fffffffLL) return OG_E_SHAPE;
+    hipLaunchKernelGGL(merge_f16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)hi,
+                       (const _Float16*)lo, n4, out);
+    return og_launch_status();
 }
 
 extern "C" int og_split_f16_hl(const float* x, int64_t rows, int32_t cols, int64_t ldx, void* out, int64_t ldo, void* stream) {

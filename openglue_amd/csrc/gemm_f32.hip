@@ -21,16 +21,17 @@
 
 namespace {
 
-constexpr int BM = 128;
 constexpr int BK = 32;
 constexpr int LDSW = BK + 4;   // padded LDS row, floats
 
 // TA / TB: the operand is stored K-MAJOR (A[k][m] with row stride lda, B[k][n]) -- the layouts the backward products of a 1x1 conv
 // and of attention come in (dW = dZ^T X: both operands [tokens][channels]; dX = dZ W: W [out][in]) -- so no transposed copy of a
 // token-sized tensor is ever made.  Staged into LDS k-major ([32][tile + 4], float4 along the tile), fragments by four ds_read_b32.
-template <int BN, bool TA, bool TB, class RD>
+template <int BM, int BN, bool TA, bool TB, class RD>
 __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g, int tiles_m, int tiles_n, RD rd) {
+    constexpr int TM = BM / 64;            // MFMA tiles per wave along M
     constexpr int TN = BN / 64;            // MFMA tiles per wave along N
+    constexpr int AROWS = BM / 32;         // staging passes for A
     constexpr int BROWS = BN / 32;         // staging passes for B
     constexpr int LDTA = BM + 4, LDTB = BN + 4;     // k-major LDS rows
     constexpr int AS = TA ? (BK * LDTA > BM * LDSW ? BK * LDTA : BM * LDSW) : BM * LDSW;
@@ -75,7 +76,8 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g, int tiles_
     const int lrow = tid >> 3;          // 0..31: staging row within a 32-row pass
     const int lc4 = (tid & 7) * 4;      // staging column (floats)
     // k-major staging: a k-row of the tile is BX / 4 float4; 256 threads cover 1024 / BX k-rows per pass, BX / 32 passes
-    const int ta_k = tid >> 5, ta_c4 = (tid & 31) * 4;                                  // A tile: 128 wide
+    const int ta_k = tid / (BM / 4), ta_c4 = (tid % (BM / 4)) * 4;                      // A tile: BM wide
+    constexpr int TA_KROWS = 1024 / BM;
     const int tb_k = tid / (BN / 4), tb_c4 = (tid % (BN / 4)) * 4;                      // B tile: BN wide
     constexpr int TB_KROWS = 1024 / BN;
 
@@ -91,12 +93,12 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g, int tiles_
         return v;
     };
 
-    f32x4 ra[4], rb[BROWS];
+    f32x4 ra[AROWS], rb[BROWS];
     auto load_tiles = [&](int k0) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < AROWS; ++p) {
             if constexpr (TA) {
-                ra[p] = load_kmajor(A, g.lda, k0 + ta_k + 8 * p, m0 + ta_c4, g.M);
+                ra[p] = load_kmajor(A, g.lda, k0 + ta_k + TA_KROWS * p, m0 + ta_c4, g.M);
             } else {
                 const int row = m0 + lrow + 32 * p;
                 const int kk = k0 + lc4;
@@ -118,8 +120,8 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g, int tiles_
     };
     auto store_tiles = [&]() {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            if constexpr (TA) *reinterpret_cast<f32x4*>(&As[(ta_k + 8 * p) * LDTA + ta_c4]) = ra[p];
+        for (int p = 0; p < AROWS; ++p) {
+            if constexpr (TA) *reinterpret_cast<f32x4*>(&As[(ta_k + TA_KROWS * p) * LDTA + ta_c4]) = ra[p];
             else *reinterpret_cast<f32x4*>(&As[(lrow + 32 * p) * LDSW + lc4]) = ra[p];
         }
 #pragma unroll
@@ -129,15 +131,15 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g, int tiles_
         }
     };
 
-    f32x16 acc[2][TN];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int a_off = TA ? (lane >> 5) * 4 * LDTA + wm * 64 + (lane & 31) : (wm * 64 + (lane & 31)) * LDSW + (lane >> 5) * 4;
+    const int a_off = TA ? (lane >> 5) * 4 * LDTA + wm * (BM / 2) + (lane & 31) : (wm * (BM / 2) + (lane & 31)) * LDSW + (lane >> 5) * 4;
     const int b_off = TB ? (lane >> 5) * 4 * LDTB + wn * (BN / 2) + (lane & 31) : (wn * (BN / 2) + (lane & 31)) * LDSW + (lane >> 5) * 4;
 
     const int nk = (g.K + BK - 1) / BK;
@@ -155,9 +157,9 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g, int tiles_
         }
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
-            f32x4 a[2], b[TN];
+            f32x4 a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < TM; ++i) {
                 if constexpr (TA) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) a[i][e] = As[a_off + (kk * 8 + e) * LDTA + i * 32];
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g, int tiles_
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
@@ -199,10 +201,10 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g, int tiles_
         const float bias = g.bias ? g.bias[col] : 0.f;
         const float al = g.alpha ? g.alpha[col] : 1.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + mfma32_row(r, lane);
+                const int row = m0 + wm * (BM / 2) + i * 32 + mfma32_row(r, lane);
                 if (row >= g.M) continue;
                 float v = acc[i][j][r] + bias;
                 if (g.relu == 1) v = fmaxf(v, 0.f);
@@ -226,7 +228,57 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g, int tiles_
     }
 }
 
+// The partial products of a split-K weight gradient (og_gemm_kmajor, batch = parts, a_colsum) summed: dW[r][c] = sum_p part[p][r][c] (c < cols),
+// db[r] = sum_p part[p][r][cols] -- one launch instead of a reduction plus two strided copies.  A workgroup owns 64 float4 columns; its four
+// waves take the parts p = w, w + 4, ... (four independent loads in flight per thread) and meet in LDS in wave order: the summation order is fixed.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int parts, int rows, int64_t ld, int cols,
+                                                            float* __restrict__ dW, float* __restrict__ db) {
+    __shared__ f32x4 red[3][64];
+    const int c4n = cols / 4 + (db ? 1 : 0);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    const bool live = i < (int64_t)rows * c4n;
+    const int r = live ? (int)(i / c4n) : 0, c = live ? (int)(i % c4n) * 4 : 0;
+    const float* src = part + (int64_t)r * ld + c;
+    const int64_t sp = (int64_t)rows * ld;
+    f32x4 acc{0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        int p = wave;
+        for (; p + 12 < parts; p += 16) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + (int64_t)p * sp), v1 = *reinterpret_cast<const f32x4*>(src + (int64_t)(p + 4) * sp);
+            const f32x4 v2 = *reinterpret_cast<const f32x4*>(src + (int64_t)(p + 8) * sp), v3 = *reinterpret_cast<const f32x4*>(src + (int64_t)(p + 12) * sp);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += (v0[e] + v1[e]) + (v2[e] + v3[e]);
+        }
+        for (; p < parts; p += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + (int64_t)p * sp);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += v[e];
+        }
+    }
+    if (wave) red[wave - 1][lane] = acc;
+    __syncthreads();
+    if (wave || !live) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+        const f32x4 v = red[w][lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += v[e];
+    }
+    if (c < cols) *reinterpret_cast<f32x4*>(dW + (int64_t)r * cols + c) = acc;
+    else db[r] = acc[0];
+}
+
 }  // namespace
+
+extern "C" int og_splitk_reduce(const float* part, int32_t parts, int32_t rows, int64_t ld, int32_t cols, float* dW, float* db, void* stream) {
+    og_clear_status();
+    if (!part || !dW || parts <= 0 || rows <= 0 || cols <= 0) return OG_E_INVALID;
+    if ((cols & 3) || (ld & 3) || ld < cols + (db ? 4 : 0) || ((uintptr_t)part & 15) || ((uintptr_t)dW & 15)) return OG_E_ALIGN;
+    const int64_t n = (int64_t)rows * (cols / 4 + (db ? 1 : 0));
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, part, parts, rows, ld, cols, dW, db);
+    return og_launch_status();
+}
 
 int og_launch_gemm(const GemmArgs& a, hipStream_t stream) {
     if (!a.A || !a.B || !(a.C || a.Ch) || a.M <= 0 || a.N <= 0 || a.K <= 0 || a.batch <= 0) return OG_E_INVALID;
@@ -238,34 +290,43 @@ int og_launch_gemm(const GemmArgs& a, hipStream_t stream) {
     if ((a.ta || a.tb) && (a.rag || a.Ch || a.Ct)) return OG_E_SHAPE;
     if (a.ktot > 0 && !(a.ta && a.tb)) return OG_E_SHAPE;
     if (a.a_colsum && (!a.ta || a.ldc <= a.N)) return OG_E_SHAPE;
-    const int tiles_m = (a.M + BM - 1) / BM;
+    // Tile shape: 128 x 64, or 64 x 64 where the former gives fewer than 1024 workgroups (four per CU); OG_GEMM_F32_BN=128 asks for the 128 x 128 form,
+    // OG_GEMM_F32_BM=64 / 128 forces the tile height (experiments).  A workgroup is four waves = ONE per SIMD, and the k loop has two barriers per
+    // 32-deep tile with nothing else to run between them -- what hides them is a second and third workgroup on the CU, and the smaller tiles are
+    // what provides those: the training step's convs are 4096 / 8192 token rows x 256 ... 768 channels = 64 ... 384 workgroups of 128 x 128 on 256
+    // CUs.  The 128 x 64 form reads 1.5x the operand bytes per flop (L2 hits) and was faster or equal wherever it was measured
+    // (profiles/r05_v_*): training step 39.3 -> 32.3 ms at 4 pairs, 81.4 -> 75.0 ms at 16 pairs (512 ... 1536 wide workgroups per launch), the
+    // encoder convs of the inference path 0.093 -> 0.068 ms at C2; 64 x 64 below 1024 workgroups: a 4096 x 256 x 256 launch 19.0 -> 12.3 us, the
+    // training step 28.9 -> 26.0 ms at 4 pairs, no change at 16 (profiles/r05_x_*).
+    static const int force_bn = [] { const char* e = getenv("OG_GEMM_F32_BN"); return e ? atoi(e) : 0; }();
+    static const int force_bm = [] { const char* e = getenv("OG_GEMM_F32_BM"); return e ? atoi(e) : 0; }();
+    static const int64_t short_below = [] { const char* e = getenv("OG_GEMM_F32_SHORT_BELOW"); return e ? atoll(e) : 1024LL; }();
+    const bool narrow = a.N <= 64 || force_bn != 128;
+    const int64_t wgs_tall = (int64_t)((a.M + 127) / 128) * a.batch * ((a.N + 63) / 64);
+    const bool shortt = narrow && (force_bm == 64 ? true : force_bm == 128 ? false : wgs_tall < short_below);
+    const int bm = shortt ? 64 : 128;
+    const int tiles_m = (a.M + bm - 1) / bm;
     const int tiles_m8 = (tiles_m + 7) / 8 * 8;
     const int64_t vtiles8 = ((int64_t)tiles_m * a.batch + 7) / 8 * 8;      // uniform batches: see the kernel
     if (vtiles8 * ((a.N + 63) / 64) > 0x7fffffffLL) return OG_E_SHAPE;
     GemmArgs k = a;
     k.rag = nullptr;
-    // Tile width: 128 x 64 unless OG_GEMM_F32_BN=128 asks for the 128 x 128 form (experiments).  A workgroup is four waves = ONE per SIMD, and
-    // the k loop has two barriers per 32-deep tile with nothing else to run between them -- what hides them is a second and third workgroup on the
-    // CU, and the narrow tile is what provides those: the training step's convs are 8192 token rows x 256 ... 768 channels = 128 ... 384 wide
-    // workgroups on 256 CUs (half the chip idle at 256 channels, a second round on half the CUs at 768).  The narrow form reads 1.5x the operand
-    // bytes per flop (L2 hits) and was faster or equal wherever it was measured (profiles/r05_v_*): training step 39.3 -> 32.3 ms at 4 pairs,
-    // 81.4 -> 75.0 ms at 16 pairs (512 ... 1536 wide workgroups per launch), the encoder convs of the inference path 0.093 -> 0.068 ms at C2.
-    static const int force_bn = [] { const char* e = getenv("OG_GEMM_F32_BN"); return e ? atoi(e) : 0; }();
-    const bool narrow = a.N <= 64 || force_bn != 128;
     const int tiles_n = narrow ? (a.N + 63) / 64 : (a.N + 127) / 128;
     auto launch = [&](auto rd) -> int {       // the per-pair descriptor is a kernel argument only for ragged launches (og_common.h)
         using RD = decltype(rd);
         constexpr bool uniform = std::is_same<RD, RaggedNone>::value;
         const dim3 grid = uniform ? dim3((unsigned)(vtiles8 * tiles_n)) : dim3(tiles_m8 * tiles_n, a.batch);
-        if (!narrow) hipLaunchKernelGGL((gemm_nt_f32_kernel<128, false, false, RD>), grid, dim3(256), 0, stream, k, tiles_m, tiles_n, rd);
-        else hipLaunchKernelGGL((gemm_nt_f32_kernel<64, false, false, RD>), grid, dim3(256), 0, stream, k, tiles_m, tiles_n, rd);
+        if (!narrow) hipLaunchKernelGGL((gemm_nt_f32_kernel<128, 128, false, false, RD>), grid, dim3(256), 0, stream, k, tiles_m, tiles_n, rd);
+        else if (!shortt) hipLaunchKernelGGL((gemm_nt_f32_kernel<128, 64, false, false, RD>), grid, dim3(256), 0, stream, k, tiles_m, tiles_n, rd);
+        else hipLaunchKernelGGL((gemm_nt_f32_kernel<64, 64, false, false, RD>), grid, dim3(256), 0, stream, k, tiles_m, tiles_n, rd);
         return og_launch_status();
     };
     auto launch_t = [&](auto ta, auto tb) -> int {
         constexpr bool TA_ = decltype(ta)::value, TB_ = decltype(tb)::value;
         const dim3 grid((unsigned)(vtiles8 * tiles_n));
-        if (!narrow) hipLaunchKernelGGL((gemm_nt_f32_kernel<128, TA_, TB_, RaggedNone>), grid, dim3(256), 0, stream, k, tiles_m, tiles_n, RaggedNone{});
-        else hipLaunchKernelGGL((gemm_nt_f32_kernel<64, TA_, TB_, RaggedNone>), grid, dim3(256), 0, stream, k, tiles_m, tiles_n, RaggedNone{});
+        if (!narrow) hipLaunchKernelGGL((gemm_nt_f32_kernel<128, 128, TA_, TB_, RaggedNone>), grid, dim3(256), 0, stream, k, tiles_m, tiles_n, RaggedNone{});
+        else if (!shortt) hipLaunchKernelGGL((gemm_nt_f32_kernel<128, 64, TA_, TB_, RaggedNone>), grid, dim3(256), 0, stream, k, tiles_m, tiles_n, RaggedNone{});
+        else hipLaunchKernelGGL((gemm_nt_f32_kernel<64, 64, TA_, TB_, RaggedNone>), grid, dim3(256), 0, stream, k, tiles_m, tiles_n, RaggedNone{});
         return og_launch_status();
     };
     if (a.ta) return launch_t(std::true_type{}, std::true_type{});

@@ -20,6 +20,8 @@ Siren encoder (models/utils.py:32-45) runs through `Conv1x1` + sin(30 x).
 """
 from __future__ import annotations
 
+import os as _os
+
 import torch
 from typing import Optional
 
@@ -178,6 +180,9 @@ def _gemm_fast(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = 
     return out * (1.0 / s)
 
 
+_SPLITK_WGS = int(_os.environ.get("OG_TRAIN_SPLITK_WGS", "512"))           # experiments: the workgroup count a split-K weight gradient aims at
+
+
 def _gemm_splitk(dz: torch.Tensor, x: torch.Tensor, with_colsum: bool = False):
     """dW = dz^T x for dz [T, Cout], x [T, Cin]: a [Cout, Cin] result (at most a few 128 x 128 tiles) contracted over ALL T tokens.
     As one GEMM launch that is a grid of <= 16 workgroups on a 256-CU chip (round 2: 250-310 us per launch, 72 % of the training step);
@@ -188,17 +193,30 @@ def _gemm_splitk(dz: torch.Tensor, x: torch.Tensor, with_colsum: bool = False):
     Cin = x.shape[1]
     if Cout % 4 or Cin % 4 or dz.stride(0) % 4 or x.stride(0) % 4:
         raise ValueError("_gemm_splitk: channel counts / row strides must be multiples of 4")
-    tiles = ((Cout + 127) // 128) * ((Cin + 127) // 128)
-    parts = max(1, min(T // 64, (512 + tiles - 1) // tiles))              # ~512 workgroups, at least two 32-row k-steps each
+    tiles = ((Cout + 127) // 128) * ((Cin + 63) // 64)                    # 128 x 64 tiles (csrc/gemm_f32.hip)
+    parts = max(1, min(T // 64, (_SPLITK_WGS + tiles - 1) // tiles))      # ~512 workgroups of 128 x 64 (measured best of 512 ... 1536: r05_y), at least two 32-row k-steps each
     Kc = (T + parts - 1) // parts
     ldc = Cin + 4 if with_colsum else Cin
     part = torch.empty(parts, Cout, ldc, device=dz.device, dtype=torch.float32)
     _gemm_km(dz.device, dz.data_ptr(), dz.stride(0), Kc * dz.stride(0), 1, x.data_ptr(), x.stride(0), Kc * x.stride(0),
              part.data_ptr(), ldc, Cout * ldc, Cout, Cin, Kc, parts, k_total=T, a_colsum=with_colsum)
-    if not with_colsum:
-        return part.sum(0) if parts > 1 else part[0]
-    full = part[:, :, :Cin + 1].sum(0) if parts > 1 else part[0, :, :Cin + 1]
-    return full[:, :Cin].contiguous(), full[:, Cin].contiguous()
+    # the partial products summed in part order by ONE launch that writes dW and db where they belong (round 4: a torch reduction over the
+    # padded rows plus two strided copies)
+    dW = torch.empty(Cout, Cin, device=dz.device, dtype=torch.float32)
+    db = torch.empty(Cout, device=dz.device, dtype=torch.float32) if with_colsum else None
+    with torch.cuda.device(dz.device):
+        _lib.check(_lib.load().og_splitk_reduce(part.data_ptr(), parts, Cout, ldc, Cin, dW.data_ptr(), None if db is None else db.data_ptr(),
+                                                _stream(dz)), "og_splitk_reduce")
+    return (dW, db) if with_colsum else dW
+
+
+def _rows(t: torch.Tensor) -> torch.Tensor:
+    """A 2-D fp32 tensor the GEMMs can read as it lies: unit column stride, row stride a multiple of 4 floats, 16-byte aligned base (a
+    column range of a wider matrix -- the gradient of one operand of a concatenation -- qualifies); anything else is copied."""
+    t = t.detach()
+    if t.dim() == 2 and t.dtype == torch.float32 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.stride(0) >= t.shape[1] and t.data_ptr() % 16 == 0:
+        return t
+    return t.to(torch.float32).contiguous()
 
 
 def _conv_backward(x: torch.Tensor, W: torch.Tensor, dz: torch.Tensor, need_dx: bool, need_dw: bool = True):
@@ -230,8 +248,8 @@ class Conv1x1(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, W = ctx.saved_tensors
-        dx, dW, db = _conv_backward(x.detach(), W.detach().contiguous(), dy.detach().contiguous(), ctx.needs_input_grad[0],
-                                    ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        dx, dW, db = _conv_backward(x.detach(), W.detach().contiguous(), _rows(dy) if not _use_f16x3() else dy.detach().contiguous(),
+                                    ctx.needs_input_grad[0], ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
         return dx, dW, db
 
 
@@ -289,8 +307,10 @@ class ConvReluBNTrain(torch.autograd.Function):
 class MLPBlockTrain(torch.autograd.Function):
     """The two-conv FeedForwardNet of a GNN layer in training mode (attention_gnn.py:41-44, models/utils.py:48-58) as ONE node:
     z = (BatchNorm_train(relu(x W0^T + b0))) W3^T + b3.  Same kernels as ConvReluBNTrain followed by Conv1x1, but the BatchNorm output
-    (the widest activation of the layer, 2D channels) is NOT kept for the backward: it is one fused multiply-add of the saved
-    pre-normalisation activation and is recomputed there.  splits: see ConvReluBNTrain."""
+    (the widest activation of the layer, 2D channels) was NOT kept for the backward up to round 4 (one fused multiply-add of the saved
+    pre-normalisation activation, recomputed there); it IS kept since round 5: the recomputation was four small launches per row range on
+    the critical path of a step that is bound by launch count, and the 16 MB per layer it saved (0.45 GB per step at 4 x 1024 keypoints)
+    are nothing on a 288 GB part.  OG_TRAIN_KEEP_BN=0 = the old behaviour.  splits: see ConvReluBNTrain."""
 
     @staticmethod
     def forward(ctx, x, W0, b0, gamma, beta, running_mean, running_var, momentum, eps, splits, W3, b3):
@@ -306,7 +326,8 @@ class MLPBlockTrain(torch.autograd.Function):
             stats += [mean, invstd]
             r0 += rows
         z = _gemm_fast(y, W3.detach().contiguous(), b3.detach())
-        ctx.save_for_backward(x, W0, gamma, beta, a, W3, *stats)
+        ctx.keep_y = _os.environ.get("OG_TRAIN_KEEP_BN", "1") != "0"
+        ctx.save_for_backward(x, W0, gamma, beta, a, W3, *stats, *((y,) if ctx.keep_y else ()))
         ctx.splits = splits
         return z
 
@@ -317,12 +338,15 @@ class MLPBlockTrain(torch.autograd.Function):
         T, C = a.shape
         dzo = dzo.detach().contiguous()
         g, bt = gamma.detach(), beta.detach()
-        y = torch.empty_like(a)
-        r0 = 0
-        for i, rows in enumerate(ctx.splits):                      # y = (a - mean) invstd gamma + beta, recomputed
-            sc = stats[2 * i + 1] * g
-            torch.addcmul(bt - stats[2 * i] * sc, a[r0:r0 + rows], sc, out=y[r0:r0 + rows])
-            r0 += rows
+        if ctx.keep_y:
+            y = stats.pop()
+        else:
+            y = torch.empty_like(a)
+            r0 = 0
+            for i, rows in enumerate(ctx.splits):                  # y = (a - mean) invstd gamma + beta, recomputed
+                sc = stats[2 * i + 1] * g
+                torch.addcmul(bt - stats[2 * i] * sc, a[r0:r0 + rows], sc, out=y[r0:r0 + rows])
+                r0 += rows
         dy, dW3, db3 = _conv_backward(y, W3.detach().contiguous(), dzo, True)
         del y
         dz = torch.empty_like(a)
@@ -410,6 +434,80 @@ def _heads_last(x: torch.Tensor, B: int) -> torch.Tensor:
 def _flash_backward_enabled(dh: int) -> bool:
     import os
     return os.environ.get("OG_TRAIN_FLASH_BWD", "1") != "0" and dh in (16, 32, 64)
+
+
+_LOG2E = 1.4426950408889634
+
+
+def _attention_rows(q2: torch.Tensor, k2: torch.Tensor, v2: torch.Tensor, Bz: int, nq: int, nk: int, H: int, qkv_of_one: Optional[torch.Tensor] = None):
+    """Forward flash attention (the inference kernel, og_attention) on ROW-STRIDED fp32 operands: q2 [Bz * nq, D], k2, v2 [Bz * nk, D] may be
+    column ranges of one wider matrix (the [tokens, 3D] output of the merged q | k | v projection).  The operands go to the kernel's (hi, lo)
+    binary16 planes in one launch per source matrix (og_split_f16_rows: the q columns scaled by dh^-1/2 and log2(e) on the way -- the same
+    two roundings as the tensor multiplications of ops.attention), the output planes come back as fp32 in one (og_merge_f16).
+    qkv_of_one: the matrix q2, k2 and v2 are the three column thirds of (then ONE split launch).  -> out [Bz * nq, D], lse [Bz, H, nq]."""
+    lib = _lib.load()
+    D = q2.shape[1]
+    dh = D // H
+    dev = q2.device
+    st = _stream(q2)
+    f16 = torch.float16
+
+    def split(src, scale_cols):
+        rows, cols = src.shape
+        hi = torch.empty(rows, cols, device=dev, dtype=f16)
+        lo = torch.empty(rows, cols, device=dev, dtype=f16)
+        _lib.check(lib.og_split_f16_rows(src.data_ptr(), src.stride(0), rows, cols, scale_cols, float(dh ** -0.5), _LOG2E, hi.data_ptr(), lo.data_ptr(),
+                                         cols, st), "og_split_f16_rows")
+        return hi, lo
+
+    with torch.cuda.device(dev):
+        if qkv_of_one is not None:
+            hi, lo = split(qkv_of_one, D)
+            ld = 3 * D
+            planes = [(hi.data_ptr() + 2 * D * i, lo.data_ptr() + 2 * D * i, ld) for i in range(3)]
+        else:
+            qh, ql = split(q2, D)
+            if k2.data_ptr() + 4 * D == v2.data_ptr() and k2.stride(0) == v2.stride(0) == 2 * D:      # k | v: the two halves of one matrix
+                kvh, kvl = split(torch.as_strided(k2, (k2.shape[0], 2 * D), (2 * D, 1)), 0)
+                planes = [(qh.data_ptr(), ql.data_ptr(), D), (kvh.data_ptr(), kvl.data_ptr(), 2 * D), (kvh.data_ptr() + 2 * D, kvl.data_ptr() + 2 * D, 2 * D)]
+            else:
+                kh, kl = split(k2, 0)
+                vh, vl = split(v2, 0)
+                planes = [(qh.data_ptr(), ql.data_ptr(), D), (kh.data_ptr(), kl.data_ptr(), D), (vh.data_ptr(), vl.data_ptr(), D)]
+        oh = torch.empty(Bz * nq, D, device=dev, dtype=f16)
+        ol = torch.empty_like(oh)
+        lse = torch.empty(Bz, H, nq, device=dev, dtype=torch.float32)
+        (qh_, ql_, ldq), (kh_, kl_, ldk), (vh_, vl_, ldv) = planes
+        _lib.check(lib.og_attention(qh_, ql_, ldq, kh_, kl_, ldk, vh_, vl_, ldv, oh.data_ptr(), ol.data_ptr(), D, Bz, nq, nk, H, dh, lse.data_ptr(), st),
+                   "og_attention")
+        out = torch.empty(Bz * nq, D, device=dev, dtype=torch.float32)
+        _lib.check(lib.og_merge_f16(oh.data_ptr(), ol.data_ptr(), oh.numel(), out.data_ptr(), st), "og_merge_f16")
+    return out, lse
+
+
+def _flash_backward_rows(q2, k2, v2, out, dout, lse, Bz, nq, nk, H, dq_out, dk_out, dv_out):
+    """Flash backward on row-strided operands (og_attention_backward_ld): q2 [Bz * nq, D], k2, v2 [Bz * nk, D] fp32 views with unit column
+    stride; dk_out, dv_out: views of the same kind the kernel writes into (column ranges of the [tokens, 3D] gradient matrix of the merged
+    projection: no concatenation afterwards); dq_out receives the sum of the per-key-block partials."""
+    lib = _lib.load()
+    D = q2.shape[1]
+    dh = D // H
+    dev = q2.device
+    st = _stream(q2)
+    do = dout.detach().to(torch.float32).contiguous()
+    delta = torch.empty(Bz * nq * H, device=dev, dtype=torch.float32)
+    parts = lib.og_attention_backward_parts(nk)
+    dq_part = torch.empty(parts, Bz * nq, D, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        _lib.check(lib.og_attention_delta(do.data_ptr(), out.data_ptr(), Bz * nq, H, dh, delta.data_ptr(), st), "og_attention_delta")
+        _lib.check(lib.og_attention_backward_ld(q2.data_ptr(), q2.stride(0), k2.data_ptr(), k2.stride(0), v2.data_ptr(), v2.stride(0), do.data_ptr(),
+                                                lse.data_ptr(), delta.data_ptr(), Bz, nq, nk, H, dh, dh ** -0.5, dq_part.data_ptr(),
+                                                dk_out.data_ptr(), dk_out.stride(0), dv_out.data_ptr(), dv_out.stride(0), st),
+                   "og_attention_backward_ld")
+    if parts > 1:
+        torch.sum(dq_part, 0, out=dq_out)
+    else:
+        dq_out.copy_(dq_part[0])
 
 
 def _flash_attention_backward(q32, k32, v32, out, dout, H, lse=None):
@@ -537,49 +635,73 @@ class ProjectedAttention(torch.autograd.Function):
     out = attention(xq Wq^T + bq, xkv Wk^T + bk, xkv Wv^T + bv).  Only the layer inputs and the attention output are saved (both are
     kept by their neighbours anyway); q, k, v -- three activations per layer in the reference's graph -- are RECOMPUTED in the backward
     by the same GEMM launch, then the flash backward and the conv backward run.  xkv None = self attention (one [T, 3D] projection
-    launch).  xq [Bz * nq, D], xkv [Bz * nk, D] token-major; returns [Bz * nq, D]."""
+    launch).  xq [Bz * nq, D], xkv [Bz * nk, D] token-major; returns [Bz * nq, D].
+    Round 5: q, k and v are never copied out of the projection matrix -- the attention kernels read column ranges of it (row stride 3D, or
+    2D for the k | v matrix of a cross layer) and the flash backward writes dk and dv into column ranges of the gradient matrix the conv
+    backward contracts; the stacked weights are built once in the forward and kept for the backward."""
 
     @staticmethod
-    def _project(xq, xkv, Wq, bq, Wk, bk, Wv, bv):
-        D = Wq.shape[0]
-        if xkv is None:
-            qkv = _gemm_fast(xq, torch.cat([Wq, Wk, Wv]), torch.cat([bq, bk, bv]))
-            return tuple(qkv[:, i * D:(i + 1) * D].contiguous() for i in range(3))
-        q = _gemm_fast(xq, Wq.contiguous(), bq)
-        kv = _gemm_fast(xkv, torch.cat([Wk, Wv]), torch.cat([bk, bv]))
-        return q, kv[:, :D].contiguous(), kv[:, D:].contiguous()
+    def stacked(mha, is_self: bool):
+        """The stacked projection weights of a layer -- self: (W [3D, D], b [3D]); cross: (Wq, bq, W [2D, D] of k | v, b [2D]) -- built once and kept
+        on the module until one of its six parameters changes (the optimizer's in-place update moves the parameter's version counter; a
+        parameter object that was replaced is not the one remembered): two concatenations per layer and step instead of two per call."""
+        ps = (mha.in_proj_q.weight, mha.in_proj_q.bias, mha.in_proj_k.weight, mha.in_proj_k.bias, mha.in_proj_v.weight, mha.in_proj_v.bias)
+        key = "_og_train_stack_self" if is_self else "_og_train_stack_cross"
+        hit = getattr(mha, key, None)
+        if (hit is not None and all(a is b for a, b in zip(hit[0], ps)) and hit[1] == tuple(p._version for p in ps)
+                and hit[2][0].device == ps[0].device and hit[2][0].dtype == ps[0].dtype):
+            return hit[2]
+        with torch.no_grad():
+            Wq, bq, Wk, bk, Wv, bv = (p.detach().reshape(p.shape[0], -1) if p.dim() > 1 else p.detach() for p in ps)
+            val = (torch.cat([Wq, Wk, Wv]), torch.cat([bq, bk, bv])) if is_self else (Wq.contiguous(), bq, torch.cat([Wk, Wv]), torch.cat([bk, bv]))
+        object.__setattr__(mha, key, (ps, tuple(p._version for p in ps), val))     # not a buffer / submodule: plain attribute
+        return val
 
     @staticmethod
-    def forward(ctx, xq, xkv, Wq, bq, Wk, bk, Wv, bv, Bz, nq, nk, H):
-        from . import ops
+    def forward(ctx, xq, xkv, Wq, bq, Wk, bk, Wv, bv, Bz, nq, nk, H, stack=None):
         xq = xq.detach().contiguous()
         xkv = None if xkv is None else xkv.detach().contiguous()
-        params = tuple(t.detach() for t in (Wq, bq, Wk, bk, Wv, bv))
+        Wq, bq, Wk, bk, Wv, bv = (t.detach() for t in (Wq, bq, Wk, bk, Wv, bv))
         D = Wq.shape[0]
-        q, k, v = ProjectedAttention._project(xq, xkv, *params)
-        out, lse = ops.attention(q.reshape(Bz, nq, D) * (D // H) ** -0.5, k.reshape(Bz, nk, D), v.reshape(Bz, nk, D), H, return_lse=True)
+        if xkv is None:
+            Wc, bc = stack if stack is not None else (torch.cat([Wq, Wk, Wv]), torch.cat([bq, bk, bv]))
+            qkv = _gemm_fast(xq, Wc, bc)                                                         # [T, 3D]
+            out, lse = _attention_rows(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], Bz, nq, nk, H, qkv_of_one=qkv)
+            saved = (xq, Wc, bc, out, lse)
+        else:
+            Wq_, bq, Wkv, bkv = stack if stack is not None else (Wq.contiguous(), bq, torch.cat([Wk, Wv]), torch.cat([bk, bv]))
+            q = _gemm_fast(xq, Wq_, bq)
+            kv = _gemm_fast(xkv, Wkv, bkv)                                                       # [Tk, 2D]
+            out, lse = _attention_rows(q, kv[:, :D], kv[:, D:], Bz, nq, nk, H)
+            saved = (xq, Wq_, bq, out, lse, xkv, Wkv, bkv)
         ctx.geom = (Bz, nq, nk, H, xkv is None)
-        ctx.save_for_backward(xq, *params, out, lse, *(() if xkv is None else (xkv,)))
-        return out.reshape(Bz * nq, D)
+        ctx.save_for_backward(*saved)
+        return out
 
     @staticmethod
     def backward(ctx, dout):
         Bz, nq, nk, H, is_self = ctx.geom
-        xq, Wq, bq, Wk, bk, Wv, bv, out, lse, *rest = ctx.saved_tensors
-        xkv = None if is_self else rest[0]
-        D = Wq.shape[0]
-        q, k, v = ProjectedAttention._project(xq, xkv, Wq, bq, Wk, bk, Wv, bv)
-        dq, dk, dv = _flash_attention_backward(q.reshape(Bz, nq, D), k.reshape(Bz, nk, D), v.reshape(Bz, nk, D), out,
-                                               dout.reshape(Bz, nq, D), H, lse)
-        del q, k, v
         if is_self:
-            dqkv = torch.cat([dq.reshape(-1, D), dk.reshape(-1, D), dv.reshape(-1, D)], dim=1)
-            dx, dW, db = _conv_backward(xq, torch.cat([Wq, Wk, Wv]), dqkv, ctx.needs_input_grad[0])
-            return (dx, None, dW[:D], db[:D], dW[D:2 * D], db[D:2 * D], dW[2 * D:], db[2 * D:], None, None, None, None)
-        dxq, dWq, dbq = _conv_backward(xq, Wq.contiguous(), dq.reshape(-1, D), ctx.needs_input_grad[0])
-        dkv = torch.cat([dk.reshape(-1, D), dv.reshape(-1, D)], dim=1)
-        dxkv, dWkv, dbkv = _conv_backward(xkv, torch.cat([Wk, Wv]), dkv, ctx.needs_input_grad[1])
-        return (dxq, dxkv, dWq, dbq, dWkv[:D], dbkv[:D], dWkv[D:], dbkv[D:], None, None, None, None)
+            xq, Wc, bc, out, lse = ctx.saved_tensors
+            D = Wc.shape[0] // 3
+            qkv = _gemm_fast(xq, Wc, bc)
+            dqkv = torch.empty_like(qkv)
+            _flash_backward_rows(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, dout.reshape(Bz * nq, D), lse, Bz, nq, nk, H,
+                                 dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:])
+            del qkv
+            dx, dW, db = _conv_backward(xq, Wc, dqkv, ctx.needs_input_grad[0])
+            return (dx, None, dW[:D], db[:D], dW[D:2 * D], db[D:2 * D], dW[2 * D:], db[2 * D:], None, None, None, None, None)
+        xq, Wq, bq, out, lse, xkv, Wkv, bkv = ctx.saved_tensors
+        D = Wq.shape[0]
+        q = _gemm_fast(xq, Wq, bq)
+        kv = _gemm_fast(xkv, Wkv, bkv)
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        _flash_backward_rows(q, kv[:, :D], kv[:, D:], out, dout.reshape(Bz * nq, D), lse, Bz, nq, nk, H, dq, dkv[:, :D], dkv[:, D:])
+        del q, kv
+        dxq, dWq, dbq = _conv_backward(xq, Wq, dq, ctx.needs_input_grad[0])
+        dxkv, dWkv, dbkv = _conv_backward(xkv, Wkv, dkv, ctx.needs_input_grad[1])
+        return (dxq, dxkv, dWq, dbq, dWkv[:D], dbkv[:D], dWkv[D:], dbkv[D:], None, None, None, None, None)
 
 
 def _pad_rows(x: torch.Tensor, rows: int) -> torch.Tensor:
@@ -831,7 +953,7 @@ def superglue_forward_train(model, data, frozen_bn: bool = False):
 
     def proj_attend(mha, xq, xkv, Bz, nq, nk):                                     # projections + attention, q / k / v not kept
         return ProjectedAttention.apply(xq, xkv, w2(mha.in_proj_q), mha.in_proj_q.bias, w2(mha.in_proj_k), mha.in_proj_k.bias,
-                                        w2(mha.in_proj_v), mha.in_proj_v.bias, Bz, nq, nk, H)
+                                        w2(mha.in_proj_v), mha.in_proj_v.bias, Bz, nq, nk, H, ProjectedAttention.stacked(mha, xkv is None))
 
     for li, layer in enumerate(model.attention_gnn.layers):
         mha = layer.module.mha
