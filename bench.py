@@ -429,6 +429,48 @@ def _rccl_block(dist_on, step_compute=None, step_full=None, dev=None, reps=10):
     return blk
 
 
+def _training_step(dev, B=4, N=1024, iters=20, steps=5):
+    """Informational (never `value`): one TRAINING step of the C2 model on HIP kernels -- `SuperGlue(config).train()(data)`, the reference's NLL
+    (utils/losses.py:7-53, margin None, written with masks: no data-dependent shapes), `loss.backward()` into every parameter -- at the
+    4 pairs x 1024 keypoints the round reviews quote it on (`scripts/bench_train_step.py` is the stand-alone form).  SURVEY 8 row f2."""
+    try:
+        from openglue_amd.superglue import SuperGlue
+        cfg = syn.make_config(descriptor_dim=256, num_stages=9, num_heads=4, num_iters=iters)
+        model = SuperGlue(cfg); model.load_state_dict(syn.make_state_dict(cfg, seed=0)); model = model.to(dev).train()
+        data = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in syn.make_batch(B, N, N, 256, 1, seed=1).items()}
+        g = torch.Generator().manual_seed(0)
+        gt0 = torch.full((B, N), -1, dtype=torch.long); gt1 = torch.full((B, N), -1, dtype=torch.long)
+        for b in range(B):
+            i = torch.randperm(N, generator=g)[: N // 2]; j = torch.randperm(N, generator=g)[: N // 2]
+            gt0[b, i] = j; gt1[b, j] = i
+        gt0, gt1 = gt0.to(dev), gt1.to(dev)
+        m0, u0, u1 = (gt0 >= 0).float(), (gt0 == -1).float(), (gt1 == -1).float()
+        per = lambda val, mask: (-(val * mask).sum(1) / mask.sum(1).clamp_min(1)).sum()
+
+        def step():
+            model.zero_grad(set_to_none=True)
+            scores = model(data)["scores"]
+            picked = scores[:, :-1, :-1].gather(2, gt0.clamp_min(0)[:, :, None])[:, :, 0]
+            loss = (per(picked, m0) + 0.5 * (per(scores[:, :-1, -1], u0) + per(scores[:, -1, :-1], u1))) / B
+            loss.backward()
+            return loss
+        step(); step(); torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        torch.cuda.synchronize(dev)
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        grads = sum(1 for p in model.parameters() if p.grad is not None)
+        out = {"ms_per_step": round(ms, 2), "pairs_per_s": round(B / ms * 1e3, 1), "steps": steps, "loss": round(float(loss.item()), 4),
+               "parameters_with_grad": grads, "workload": f"{B} pairs x {N}x{N} kpts, 256-dim, 9 stages, 4 heads, {iters} Sinkhorn iters, forward (train mode) + NLL + backward, "
+                                                          "exact-fp32 GEMMs, no optimizer step (the caller's)", "dtype": "f32"}
+        del model, data
+        torch.cuda.empty_cache()
+        return out
+    except Exception as e:       # informational leg: never takes the bench line down
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
 def _measure(step, step_compute, args, dist_on, dev):
     """The part of a bench run EVERY rank executes, in this order: the timed region, the per-step spread, the per-rank times of the rccl block.
     `step` holds the collective when N > 1, so nothing here may run on rank 0 alone (round 4 computed the spread inside `if rank == 0`: with more
@@ -566,6 +608,7 @@ def main():
     ap.add_argument("--global-batch", type=int, default=None,
                     help="pairs of the whole job, split evenly over the ranks (BASELINE: C3 256, C4 64, C5 128 over 8 GPUs) -- strong scaling")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-training-step", action="store_true", help="skip the informational training-step leg (C2, N = 1 only)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -679,6 +722,7 @@ def main():
             freed[i].record(torch.cuda.current_stream(dev))
         torch.cuda.synchronize()
         line["value_incl_h2d"] = round(B * args.steps / (time.perf_counter() - t0), 2)
+        line["training_step"] = _training_step(dev) if (world == 1 and args.config == "C2" and not args.no_training_step) else None
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, sd, kw, m, n)
         else:
