@@ -43,6 +43,10 @@ for b in 1 4; do
   f=$(find /tmp/prof_${TAG}_B$b -name "*kernel_stats.csv" | head -1)
   if [ -n "$f" ]; then cp $f $OUT/${TAG}_kernel_stats_B$b.csv; echo "== B=$b"; head -7 $OUT/${TAG}_kernel_stats_B$b.csv | cut -c1-150; fi
 done
+# the training step: time at 4 and 16 pairs, kernel stats of the 4-pair run
+for b in 4 16; do B=$b timeout 300 python scripts/bench_train_step.py 2>&1 | grep "training step"; done > $OUT/${TAG}_train_step.log; cat $OUT/${TAG}_train_step.log
+( cd /tmp && rm -rf /tmp/prof_${TAG}_train && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG}_train -o run -- python $GRAFT_REPO_ROOT/scripts/bench_train_step.py > /tmp/prof_${TAG}_train.log 2>&1 )
+f=$(find /tmp/prof_${TAG}_train -name "*kernel_stats.csv" | head -1); if [ -n "$f" ]; then cp $f $OUT/${TAG}_train_kernel_stats.csv; echo "== training step (4 steps)"; head -12 $OUT/${TAG}_train_kernel_stats.csv | cut -c1-150; fi
 # the shader clock the chip grants each hot kernel and the whole C2 step (power cap)
 timeout 300 python scripts/clock_under_load.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_clock_under_load.log; tail -3 $OUT/${TAG}_clock_under_load.log | cut -c1-200
 if [[ " $* " == *" pmc "* ]]; then
