@@ -722,7 +722,9 @@ def main():
             freed[i].record(torch.cuda.current_stream(dev))
         torch.cuda.synchronize()
         line["value_incl_h2d"] = round(B * args.steps / (time.perf_counter() - t0), 2)
-        line["training_step"] = _training_step(dev) if (world == 1 and args.config == "C2" and not args.no_training_step) else None
+        # only in the driver's own invocation (C2 at its default batch, one GPU): sweeps over --batch / --config and profiler runs stay what they name
+        line["training_step"] = (_training_step(dev) if (world == 1 and args.config == "C2" and args.batch is None and args.global_batch is None
+                                                         and not args.no_training_step) else None)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, sd, kw, m, n)
         else:

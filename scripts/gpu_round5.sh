@@ -22,8 +22,8 @@ PY
 : > $OUT/${TAG}_bench_configs.jsonl
 for c in C1 C3 C4 C5 S128; do timeout 900 python bench.py --config $c --steps 20 --warmup 5 2>/dev/null | tail -1 >> $OUT/${TAG}_bench_configs.jsonl; done
 # the reference's own operating point for its 128-d family, ONE pair per call (inference.py:214-235) and four; C2 shape at B = 1 / 2 / 4 / 16 / 64
-for b in 1 4; do timeout 600 python bench.py --config S128 --batch $b --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 >> $OUT/${TAG}_bench_configs.jsonl; done
-for b in 1 2 4 16 64; do timeout 600 python bench.py --batch $b --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 >> $OUT/${TAG}_bench_configs.jsonl; done
+for b in 1 4; do timeout 600 python bench.py --config S128 --batch $b --steps 30 --warmup 5 --no-cpu-baseline --no-training-step 2>/dev/null | tail -1 >> $OUT/${TAG}_bench_configs.jsonl; done
+for b in 1 2 4 16 64; do timeout 600 python bench.py --batch $b --steps 30 --warmup 5 --no-cpu-baseline --no-training-step 2>/dev/null | tail -1 >> $OUT/${TAG}_bench_configs.jsonl; done
 python - <<PY
 import json
 for l in open("gpurun_out/${TAG}_bench_configs.jsonl"):
@@ -31,15 +31,15 @@ for l in open("gpurun_out/${TAG}_bench_configs.jsonl"):
     print(d["metric"], d["config"].get("pairs_per_gpu"), d["value"], d["ms_per_step"], d["stages_ms"], "| roofline", d["roofline"]["kernel"], d["roofline"]["frac"], "| cpu", cb.get("value"), cb.get("cores"))
 PY
 for c in C2 C3 C4 C5 S128; do
-  ( cd /tmp && rm -rf /tmp/prof_${TAG}_$c && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG}_$c -o run -- python $GRAFT_REPO_ROOT/bench.py --config $c --steps 10 --warmup 3 --no-cpu-baseline > /tmp/prof_${TAG}_$c.log 2>&1 )
+  ( cd /tmp && rm -rf /tmp/prof_${TAG}_$c && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG}_$c -o run -- python $GRAFT_REPO_ROOT/bench.py --config $c --steps 10 --warmup 3 --no-cpu-baseline --no-training-step > /tmp/prof_${TAG}_$c.log 2>&1 )
   f=$(find /tmp/prof_${TAG}_$c -name "*kernel_stats.csv" | head -1)
   if [ -n "$f" ]; then cp $f $OUT/${TAG}_kernel_stats_$c.csv; echo "== $c"; head -9 $OUT/${TAG}_kernel_stats_$c.csv | cut -c1-150; else tail -5 /tmp/prof_${TAG}_$c.log; fi
 done
 # the small-batch kernels (mlp_small_kernel, proj_small_kernel, the key-split attention): kernel stats of a single-pair and a four-pair step
-( cd /tmp && rm -rf /tmp/prof_${TAG}_S128B1 && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG}_S128B1 -o run -- python $GRAFT_REPO_ROOT/bench.py --config S128 --batch 1 --steps 20 --warmup 5 --no-cpu-baseline > /tmp/prof_${TAG}_S128B1.log 2>&1 )
+( cd /tmp && rm -rf /tmp/prof_${TAG}_S128B1 && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG}_S128B1 -o run -- python $GRAFT_REPO_ROOT/bench.py --config S128 --batch 1 --steps 20 --warmup 5 --no-cpu-baseline --no-training-step > /tmp/prof_${TAG}_S128B1.log 2>&1 )
 f=$(find /tmp/prof_${TAG}_S128B1 -name "*kernel_stats.csv" | head -1); if [ -n "$f" ]; then cp $f $OUT/${TAG}_kernel_stats_S128_B1.csv; echo "== S128 B=1"; head -7 $OUT/${TAG}_kernel_stats_S128_B1.csv | cut -c1-150; fi
 for b in 1 4; do
-  ( cd /tmp && rm -rf /tmp/prof_${TAG}_B$b && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG}_B$b -o run -- python $GRAFT_REPO_ROOT/bench.py --batch $b --steps 20 --warmup 5 --no-cpu-baseline > /tmp/prof_${TAG}_B$b.log 2>&1 )
+  ( cd /tmp && rm -rf /tmp/prof_${TAG}_B$b && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG}_B$b -o run -- python $GRAFT_REPO_ROOT/bench.py --batch $b --steps 20 --warmup 5 --no-cpu-baseline --no-training-step > /tmp/prof_${TAG}_B$b.log 2>&1 )
   f=$(find /tmp/prof_${TAG}_B$b -name "*kernel_stats.csv" | head -1)
   if [ -n "$f" ]; then cp $f $OUT/${TAG}_kernel_stats_B$b.csv; echo "== B=$b"; head -7 $OUT/${TAG}_kernel_stats_B$b.csv | cut -c1-150; fi
 done
