@@ -124,10 +124,21 @@ __global__ __launch_bounds__(256) void sk_bwd_iter_kernel(const float* __restric
             }
         }
     }
+    // the four waves of the workgroup meet in LDS first (wave order), then ONE atomic per column and workgroup: the row grid grew from 64 to 128
+    // workgroups per pair (a wave walks two rows instead of four to five) with half the atomics per workgroup-row it had: backward of
+    // 4 x 1024 x 1024 x 20 iterations 1.23 -> 0.93 ms
+    __shared__ float red[3][CH * 64];
+    if (wave) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) red[wave - 1][c * 64 + lane] = colacc[c];
+    }
+    __syncthreads();
+    if (wave) return;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
         const int j = lane + 64 * c;
-        if (j <= N && colacc[c] != 0.f) atomicAdd(dv_prev + (int64_t)b * ldv + j, colacc[c]);
+        const float sum = ((colacc[c] + red[0][c * 64 + lane]) + red[1][c * 64 + lane]) + red[2][c * 64 + lane];
+        if (j <= N && sum != 0.f) atomicAdd(dv_prev + (int64_t)b * ldv + j, sum);
     }
 }
 
@@ -183,7 +194,8 @@ extern "C" int og_sinkhorn_backward(const float* S, int64_t lds, float dustbin, 
     if (d_dustbin && (e = hipMemsetAsync(d_dustbin, 0, sizeof(float), st)) != hipSuccess) return (int)e;
     hipLaunchKernelGGL(sk_bwd_init_kernel, dim3((m + 1 + 3) / 4, B), dim3(256), 0, st, S, lds, dustbin_dev, dustbin, inv_reg, m, n, grad_scores, w.Za,
                        w.dZ, w.lda, w.du, w.ldu, w.dv[0], w.ldv);
-    const int rows_grid = (m + 1 + 3) / 4 < 64 ? (m + 1 + 3) / 4 : 64;       // waves stride over the rows
+    static const int rows_cap = [] { const char* e = getenv("OG_SK_BWD_ROWS_GRID"); return e && atoi(e) > 0 ? atoi(e) : 128; }();   // experiments (64 ... 512 measured: profiles/r05_ab_*)
+    const int rows_grid = (m + 1 + 3) / 4 < rows_cap ? (m + 1 + 3) / 4 : rows_cap;       // waves stride over the rows
     int cur = 0;
     for (int t = T; t >= 1; --t) {
         const float* u_t = w.U + (size_t)(t - 1) * B * w.ldu;
