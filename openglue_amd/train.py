@@ -638,24 +638,18 @@ class ProjectedAttention(torch.autograd.Function):
     launch).  xq [Bz * nq, D], xkv [Bz * nk, D] token-major; returns [Bz * nq, D].
     Round 5: q, k and v are never copied out of the projection matrix -- the attention kernels read column ranges of it (row stride 3D, or
     2D for the k | v matrix of a cross layer) and the flash backward writes dk and dv into column ranges of the gradient matrix the conv
-    backward contracts; the stacked weights are built once in the forward and kept for the backward."""
+    backward contracts; the stacked weights are built once per layer and forward call and kept for the backward."""
 
     @staticmethod
     def stacked(mha, is_self: bool):
-        """The stacked projection weights of a layer -- self: (W [3D, D], b [3D]); cross: (Wq, bq, W [2D, D] of k | v, b [2D]) -- built once and kept
-        on the module until one of its six parameters changes (the optimizer's in-place update moves the parameter's version counter; a
-        parameter object that was replaced is not the one remembered): two concatenations per layer and step instead of two per call."""
+        """The stacked projection weights of a layer from its CURRENT parameters -- self: (W [3D, D], b [3D]); cross: (Wq, bq, W [2D, D] of k | v,
+        b [2D]).  superglue_forward_train builds them once per layer and forward call (the two propagations of a cross layer share them, the
+        backward reuses what the forward saved).  Deliberately not kept across calls: a parameter changed through `.data` does not move its
+        version counter, and a stale stack would be a silently wrong forward for the sake of 0.3 ms."""
         ps = (mha.in_proj_q.weight, mha.in_proj_q.bias, mha.in_proj_k.weight, mha.in_proj_k.bias, mha.in_proj_v.weight, mha.in_proj_v.bias)
-        key = "_og_train_stack_self" if is_self else "_og_train_stack_cross"
-        hit = getattr(mha, key, None)
-        if (hit is not None and all(a is b for a, b in zip(hit[0], ps)) and hit[1] == tuple(p._version for p in ps)
-                and hit[2][0].device == ps[0].device and hit[2][0].dtype == ps[0].dtype):
-            return hit[2]
         with torch.no_grad():
             Wq, bq, Wk, bk, Wv, bv = (p.detach().reshape(p.shape[0], -1) if p.dim() > 1 else p.detach() for p in ps)
-            val = (torch.cat([Wq, Wk, Wv]), torch.cat([bq, bk, bv])) if is_self else (Wq.contiguous(), bq, torch.cat([Wk, Wv]), torch.cat([bk, bv]))
-        object.__setattr__(mha, key, (ps, tuple(p._version for p in ps), val))     # not a buffer / submodule: plain attribute
-        return val
+            return (torch.cat([Wq, Wk, Wv]), torch.cat([bq, bk, bv])) if is_self else (Wq.contiguous(), bq, torch.cat([Wk, Wv]), torch.cat([bk, bv]))
 
     @staticmethod
     def forward(ctx, xq, xkv, Wq, bq, Wk, bk, Wv, bv, Bz, nq, nk, H, stack=None):
@@ -951,9 +945,14 @@ def superglue_forward_train(model, data, frozen_bn: bool = False):
     def w2(c):
         return c.weight.reshape(c.weight.shape[0], c.weight.shape[1])
 
+    stacks = {}                                                                    # per forward call: (layer, form) -> stacked projection weights
+
     def proj_attend(mha, xq, xkv, Bz, nq, nk):                                     # projections + attention, q / k / v not kept
+        key = (id(mha), xkv is None)
+        if key not in stacks:
+            stacks[key] = ProjectedAttention.stacked(mha, xkv is None)
         return ProjectedAttention.apply(xq, xkv, w2(mha.in_proj_q), mha.in_proj_q.bias, w2(mha.in_proj_k), mha.in_proj_k.bias,
-                                        w2(mha.in_proj_v), mha.in_proj_v.bias, Bz, nq, nk, H, ProjectedAttention.stacked(mha, xkv is None))
+                                        w2(mha.in_proj_v), mha.in_proj_v.bias, Bz, nq, nk, H, stacks[key])
 
     for li, layer in enumerate(model.attention_gnn.layers):
         mha = layer.module.mha
