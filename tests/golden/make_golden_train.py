@@ -5,6 +5,7 @@
     python tests/golden/make_golden_train.py eval_grad   # eval_grad.npz
     python tests/golden/make_golden_train.py variants    # train_variants.npz (linear / FAVOR attention, Siren encoder in train mode)
     python tests/golden/make_golden_train.py margin      # train_margin.npz (criterion with margin = 0.2: the metric loss on context_descriptors)
+    python tests/golden/make_golden_train.py c2          # train_c2.npz (the C2-sized training step: loss, gradient digests, running statistics)
 
 train_ot: the optimal-transport layer of the reference (SuperGlue.get_matching_probs, superglue.py:88-111, calling
 log_otp_solver, optimal_transport.py:20-28) on seeded score matrices, differentiated by autograd through two losses:
@@ -263,8 +264,39 @@ def main_variants():
     np.savez_compressed(os.path.join(HERE, "train_variants.npz"), **out)
 
 
+def main_c2():
+    """train_c2: the reference's training step AT THE SIZE THE STEP IS BENCHMARKED ON -- the BASELINE-config-2 model (256-d, 9 stages, 4 heads;
+    20 Sinkhorn iterations: the reference's training default, config/config.yaml:53), 4 pairs x 1024 x 1024 keypoints, train() mode, the
+    reference's own criterion (margin None).  Kept small: the loss, and per parameter the largest |gradient|, its L2 norm and its first 64
+    entries; the BatchNorm running statistics after the step; mean / std of the scores."""
+    B, N = 4, 1024
+    cfg = syn.make_config(descriptor_dim=256, num_stages=9, num_heads=4, num_iters=20)
+    ref = RefSuperGlue(cfg)
+    ref.load_state_dict(syn.make_state_dict(cfg, seed=0))
+    ref.train()
+    data = syn.make_batch(B, N, N, 256, 1, seed=1)
+    gt0, gt1 = gt_matches(B, N, N, torch.Generator().manual_seed(29))
+    res = ref(data)
+    loss = criterion({"gt_matches0": gt0, "gt_matches1": gt1}, res, margin=None)["loss"]          # utils/losses.py:7-53, unmodified
+    loss.backward()
+    out = {"meta": np.array([B, N, N]), "gt0": gt0.numpy(), "gt1": gt1.numpy(), "loss": np.float64(loss.item()),
+           "scores_mean_std": np.array([res["scores"].detach().double().mean().item(), res["scores"].detach().double().std().item()])}
+    for k, p in ref.named_parameters():
+        gflat = p.grad.detach().reshape(-1).double()
+        out[f"gmax_{k}"] = np.float64(gflat.abs().max().item())
+        out[f"gnorm_{k}"] = np.float64(gflat.norm().item())
+        out[f"ghead_{k}"] = gflat[:64].numpy().astype(np.float32)
+    for k, b in ref.named_buffers():
+        if "running" in k:
+            out[f"buf_{k}"] = b.detach().numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "train_c2.npz"), **out)
+    print("train_c2.npz: loss", loss.item(), "parameters", sum(1 for _ in ref.named_parameters()))
+
+
 if __name__ == "__main__":
-    if sys.argv[1:] == ["eval_grad"]:
+    if sys.argv[1:] == ["c2"]:
+        main_c2()
+    elif sys.argv[1:] == ["eval_grad"]:
         main_eval_grad()
     elif sys.argv[1:] == ["variants"]:
         main_variants()

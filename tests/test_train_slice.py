@@ -293,6 +293,82 @@ def test_training_step_against_reference_autograd(gpu_device, name):
             assert np.abs(b.cpu().numpy() - G[f"{name}_buf_{k}"]).max() < 1e-5, k
 
 
+# ----------------------------------------------------------------------------- the training step at the size it is benchmarked on
+GC2 = np.load(os.path.join(GOLDEN, "train_c2.npz"))
+
+
+def _c2_case():
+    from openglue_amd import synthetic as syn
+    cfg = syn.make_config(descriptor_dim=256, num_stages=9, num_heads=4, num_iters=20)
+    B, m, n = (int(v) for v in GC2["meta"])
+    return cfg, syn.make_state_dict(cfg, seed=0), syn.make_batch(B, m, n, 256, 1, seed=1), torch.from_numpy(GC2["gt0"]), torch.from_numpy(GC2["gt1"])
+
+
+C2_TOL = {"norm": 1e-3, "max": 5e-3, "head": 2e-2}
+
+
+def _check_c2_gradients(named_grads):
+    """per parameter: L2 norm, largest |gradient| and the first 64 entries (relative to the largest) against the digests the reference left in
+    train_c2.npz.  Tolerances C2_TOL: two fp32 CPU implementations of this step (the reference and the oracle) already differ by 1.9e-4 /
+    1.3e-3 / 6.5e-3 in these three measures -- bias gradients are sums over 8192 tokens that cancel to a thousandth of their terms.  Gradients
+    that are rounding noise in the reference too (|g| < 1e-7: the k biases -- softmax does not see a per-query constant) are skipped."""
+    worst = {"norm": (0.0, ""), "max": (0.0, ""), "head": (0.0, "")}
+    checked = 0
+    for k, g in named_grads:
+        gmax = float(GC2[f"gmax_{k}"])
+        if gmax < 1e-7:
+            continue
+        flat = g.reshape(-1).double()
+        errs = {"norm": abs(flat.norm().item() - float(GC2[f"gnorm_{k}"])) / float(GC2[f"gnorm_{k}"]),
+                "max": abs(flat.abs().max().item() - gmax) / gmax,
+                "head": float(np.abs(flat[:64].numpy() - GC2[f"ghead_{k}"].astype(np.float64)).max() / gmax)}
+        for name, e in errs.items():
+            if e > worst[name][0]:
+                worst[name] = (e, k)
+        checked += 1
+    assert checked >= 230, checked
+    for name, (e, k) in worst.items():
+        assert e < C2_TOL[name], (name, e, k)
+    return worst, checked
+
+
+def test_oracle_training_step_c2_sized_matches_the_reference():
+    """CPU: the oracle's training step at 4 pairs x 1024 x 1024 keypoints on the C2 model vs the digests of the reference's (train_c2.npz)."""
+    cfg, sd, data, gt0, gt1 = _c2_case()
+    params = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in sd.items()}
+    stats = {}
+    out = orc.superglue_forward(params, cfg, data, train_stats=stats)
+    loss = orc.nll_criterion(out["scores"], gt0, gt1)
+    assert abs(loss.item() - float(GC2["loss"])) < 1e-4 * float(GC2["loss"])
+    loss.backward()
+    _check_c2_gradients((k, p.grad.detach()) for k, p in params.items() if p.requires_grad and p.grad is not None and f"gmax_{k}" in GC2.files)
+    for k, v in stats.items():
+        assert np.abs(v.detach().numpy() - GC2[f"buf_{k}"]).max() < 1e-5, k
+
+
+@pytest.mark.gpu
+def test_training_step_c2_sized_against_reference(gpu_device):
+    """HIP: the training step bench.py and scripts/bench_train_step.py time (C2 model, 4 pairs x 1024 x 1024 keypoints, 20 Sinkhorn iterations)
+    against the reference's own step on the same inputs: loss, score statistics, every parameter gradient (digests), running statistics."""
+    from openglue_amd.superglue import SuperGlue
+    cfg, sd, data, gt0, gt1 = _c2_case()
+    model = SuperGlue(cfg)
+    model.load_state_dict(sd)
+    model = model.to(gpu_device).train()
+    out = model({k: (v.to(gpu_device) if torch.is_tensor(v) else v) for k, v in data.items()})
+    sc = out["scores"].detach().double()
+    assert abs(sc.mean().item() - GC2["scores_mean_std"][0]) < 1e-4 and abs(sc.std().item() - GC2["scores_mean_std"][1]) < 1e-4
+    loss = orc.nll_criterion(out["scores"], gt0.to(gpu_device), gt1.to(gpu_device))
+    assert abs(loss.item() - float(GC2["loss"])) < 1e-4 * float(GC2["loss"])
+    loss.backward()
+    worst, checked = _check_c2_gradients((k, p.grad.detach().cpu()) for k, p in model.named_parameters() if p.grad is not None)
+    print(f"[train_c2] loss {loss.item():.6f} vs {float(GC2['loss']):.6f}; {checked} parameter gradients, worst relative errors: "
+          + ", ".join(f"{n_} {e:.1e} ({k})" for n_, (e, k) in worst.items()))
+    for k, b in model.named_buffers():
+        if "running" in k:
+            assert np.abs(b.cpu().numpy() - GC2[f"buf_{k}"]).max() < 1e-5, k
+
+
 # ----------------------------------------------------------------------------- metric loss (criterion with margin): gradients through context_descriptors
 GM = np.load(os.path.join(GOLDEN, "train_margin.npz"))
 
