@@ -512,30 +512,22 @@ def _flash_backward_rows(q2, k2, v2, out, dout, lse, Bz, nq, nk, H, dq_out, dk_o
 
 def _flash_attention_backward(q32, k32, v32, out, dout, H, lse=None):
     """Flash backward (csrc/attention_train.hip): P is recomputed tile by tile in registers from q, k and the row log-sum-exp; nothing
-    of size Nq x Nk is ever written.  Token-major tensors in and out ([B, N, D]): no head-major copies either.  -> dq, dk, dv."""
+    of size Nq x Nk is ever written.  Token-major contiguous tensors in and out ([B, N, D]): no head-major copies either.  -> dq, dk, dv.
+    (The contiguous form of _flash_backward_rows; lse None = no forward kernel left one: an exact-fp32 pass computes it.)"""
     lib = _lib.load()
     B, Nq, D = q32.shape
     Nk = k32.shape[1]
     dh = D // H
     dev = q32.device
-    st = torch.cuda.current_stream(dev).cuda_stream
-    do = dout.detach().to(torch.float32).contiguous()
-    scale = dh ** -0.5
-    have_lse = lse is not None                              # from the forward kernel's online-softmax state (ops.attention(return_lse=True))
-    if not have_lse:
+    if lse is None:
         lse = torch.empty(B, H, Nq, device=dev, dtype=torch.float32)
-    delta = (do * out).reshape(B, Nq, H, dh).sum(-1)                                     # [B, Nq, H]
-    parts = lib.og_attention_backward_parts(Nk)
-    dq_part = torch.empty(parts, B, Nq, D, device=dev, dtype=torch.float32)
-    dk, dv = torch.empty_like(k32), torch.empty_like(v32)
-    with torch.cuda.device(dev):
-        if not have_lse:
-            _lib.check(lib.og_attention_train_lse(q32.data_ptr(), k32.data_ptr(), B, Nq, Nk, H, dh, scale, lse.data_ptr(), st),
+        with torch.cuda.device(dev):
+            _lib.check(lib.og_attention_train_lse(q32.data_ptr(), k32.data_ptr(), B, Nq, Nk, H, dh, dh ** -0.5, lse.data_ptr(), _stream(q32)),
                        "og_attention_train_lse")
-        _lib.check(lib.og_attention_backward(q32.data_ptr(), k32.data_ptr(), v32.data_ptr(), do.data_ptr(), lse.data_ptr(),
-                                             delta.data_ptr(), B, Nq, Nk, H, dh, scale, dq_part.data_ptr(), dk.data_ptr(),
-                                             dv.data_ptr(), st), "og_attention_backward")
-    return (dq_part.sum(0) if parts > 1 else dq_part[0]), dk, dv
+    dq, dk, dv = torch.empty_like(q32), torch.empty_like(k32), torch.empty_like(v32)
+    _flash_backward_rows(q32.reshape(B * Nq, D), k32.reshape(B * Nk, D), v32.reshape(B * Nk, D), out.reshape(B * Nq, D), dout.reshape(B * Nq, D), lse,
+                         B, Nq, Nk, H, dq.reshape(B * Nq, D), dk.reshape(B * Nk, D), dv.reshape(B * Nk, D))
+    return dq, dk, dv
 
 
 class SoftmaxAttention(torch.autograd.Function):
