@@ -369,6 +369,15 @@ def test_training_step_c2_sized_against_reference(gpu_device):
             assert np.abs(b.cpu().numpy() - GC2[f"buf_{k}"]).max() < 1e-5, k
 
 
+@pytest.mark.gpu
+def test_training_loop_with_adam_reduces_the_loss(gpu_device):
+    """examples/train_loop.py on a small model: the drop-in module under torch.optim.Adam (in-place parameter updates between steps, BatchNorm
+    running statistics moving) -- the NLL on pairs with known correspondences must fall, every step must stay finite."""
+    from examples.train_loop import run
+    losses = run(steps=12, pairs=2, kpts=128, dim=64, stages=2, lr=1e-3, log=lambda *_: None)
+    assert all(np.isfinite(losses)) and losses[-1] < 0.9 * losses[0], losses
+
+
 # ----------------------------------------------------------------------------- metric loss (criterion with margin): gradients through context_descriptors
 GM = np.load(os.path.join(GOLDEN, "train_margin.npz"))
 
