@@ -426,7 +426,7 @@ int og_attention_backward_parts(int32_t nk);
 int og_attention_backward(const float* q, const float* k, const float* v, const float* dout, const float* lse, const float* delta,
                           int32_t batch, int32_t nq, int32_t nk, int32_t num_heads, int32_t dh, float scale, float* dq_part, float* dk,
                           float* dv, void* stream);
-/* ABI v9 -- the same with ROW STRIDES (floats, multiples of 4, >= D) on q, k, v and on the dk, dv outputs, so that the training step hands over
+/* ABI v9 -- the same (the autograd of models/superglue/attention.py:8-19 inside attention_gnn.py:22-32) with ROW STRIDES (floats, multiples of 4, >= D) on q, k, v and on the dk, dv outputs, so that the training step hands over
  * column ranges of its [tokens][3D] projection matrix and receives dk, dv inside the [tokens][3D] gradient matrix (no slices copied out, no
  * concatenation); dout and dq_part rows stay D wide.  og_attention_delta: delta[row][h] = sum_c dout[row][h dh + c] out[row][h dh + c] for
  * contiguous [rows][num_heads * dh] tensors (what og_attention_backward wants as `delta`), one launch. */
@@ -434,7 +434,8 @@ int og_attention_backward_ld(const float* q, int64_t ldq, const float* k, int64_
                              const float* lse, const float* delta, int32_t batch, int32_t nq, int32_t nk, int32_t num_heads, int32_t dh,
                              float scale, float* dq_part, float* dk, int64_t lddk, float* dv, int64_t lddv, void* stream);
 int og_attention_delta(const float* dout, const float* out, int64_t rows, int32_t num_heads, int32_t dh, float* delta, void* stream);
-/* ABI v9 -- glue of the training step as single launches (openglue_amd/train.py):
+/* ABI v9 -- glue of the training step (MatchingTrainingModule.training_step, models/matching_module.py:93-105, through SuperGlue.forward) as single
+ * launches (openglue_amd/train.py):
  * og_split_f16_rows: x [rows][cols] fp32 (row stride ldx) -> (hi, lo) binary16 planes (row stride ldo), columns [0, scale_cols) multiplied by
  *   s1, then s2, first (the q columns of a q | k | v matrix: dh^-1/2, then the log2(e) of og_attention's base-2 softmax);
  * og_merge_f16: out[i] = float(hi[i]) + float(lo[i]) (og_attention's output planes back to fp32);
