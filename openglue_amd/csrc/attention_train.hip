@@ -66,13 +66,19 @@ __device__ __forceinline__ f32x16 rows_dot_rows(const float* X, int xrow0, const
     f32x16 acc = zero16();
     const float* xp = X + (xrow0 + (lane & 31)) * LD + (lane >> 5) * 4;
     const float* yp = Y + (yrow0 + (lane & 31)) * LD + (lane >> 5) * 4;
+    // every fragment requested before the first MFMA (the workgroup is one wave per SIMD: nothing else hides an LDS round trip in front of a chain
+    // of dependent MFMAs; read-then-use per k-step; the compiler still sinks part of them, forcing the order with sched_barrier was no faster: 182 vs 177 us per launch)
+    constexpr int KK = DHP / 8;
+    f32x4 a[KK], b[KK];
 #pragma unroll
-    for (int kk = 0; kk < DHP / 8; ++kk) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(xp + kk * 8);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(yp + kk * 8);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+    for (int kk = 0; kk < KK; ++kk) {
+        a[kk] = *reinterpret_cast<const f32x4*>(xp + kk * 8);
+        b[kk] = *reinterpret_cast<const f32x4*>(yp + kk * 8);
     }
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][e], b[kk][e], acc, 0, 0, 0);
     return acc;
 }
 
@@ -219,24 +225,40 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(AttnTrainArgs a) {
         // S and dP blocks: rows = queries 32 qi.., lane = key 32 kj + l31
         const f32x16 s = rows_dot_rows<DHP>(Qs, 32 * qi, Ks, 32 * kj, lane);
         const f32x16 dp = rows_dot_rows<DHP>(Os, 32 * qi, Vs, 32 * kj, lane);
-        float p[16], ds[16];
+        // (operands of the next MFMA block are requested from LDS before the arithmetic that precedes it: see rows_dot_rows)
+        float p[16], ds[16], lr[16], dr[16], bo[16][NB], bq[16][NB];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = 32 * qi + mfma32_row(r, lane);
-            const bool ok = key_ok && (i0 + row < a.nq);
-            const float pv = ok ? __expf(s[r] * a.scale - Ls[row]) : 0.f;
-            p[r] = pv;
-            ds[r] = pv * (dp[r] - Ds[row]) * a.scale;
+            lr[r] = Ls[row];
+            dr[r] = Ds[row];
         }
-        // dV += P^T dO, dK += dS^T Q: accumulator register r of lane half `hi` is query row rho = mfma32_row(r, lane); chain step r
-        // contracts the two rows rho(r, 0), rho(r, 1), the B operand reads the same rows of dO / Q
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = 32 * qi + mfma32_row(r, lane);
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                dv[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(p[r], Os[row * LD + nb * 32 + l31], dv[nb], 0, 0, 0);
-                dk[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[r], Qs[row * LD + nb * 32 + l31], dk[nb], 0, 0, 0);
+                bo[r][nb] = Os[row * LD + nb * 32 + l31];
+                bq[r][nb] = Qs[row * LD + nb * 32 + l31];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * qi + mfma32_row(r, lane);
+            const bool ok = key_ok && (i0 + row < a.nq);
+            const float e = __expf(s[r] * a.scale - lr[r]);       // computed for every lane, selected afterwards: no branch per register
+            const float pv = ok ? e : 0.f;
+            p[r] = pv;
+            ds[r] = pv * (dp[r] - dr[r]) * a.scale;
+        }
+        // dV += P^T dO, dK += dS^T Q: accumulator register r of lane half `hi` is query row rho = mfma32_row(r, lane); chain step r
+        // contracts the two rows rho(r, 0), rho(r, 1), the B operand reads the same rows of dO / Q
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                dv[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(p[r], bo[r][nb], dv[nb], 0, 0, 0);
+                dk[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[r], bq[r][nb], dk[nb], 0, 0, 0);
             }
         }
         // dQ block = dS K: dS with lane = query through this wave's LDS tile
@@ -247,17 +269,24 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(AttnTrainArgs a) {
         f32x16 dq[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) dq[nb] = zero16();
+        f32x4 av[4];
+        float kb[4][4][NB];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(&T[l31 * LDT + kk * 8 + hi * 4]);
+            av[kk] = *reinterpret_cast<const f32x4*>(&T[l31 * LDT + kk * 8 + hi * 4]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int key = 32 * kj + kk * 8 + hi * 4 + e;
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-                    dq[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], Ks[key * LD + nb * 32 + l31], dq[nb], 0, 0, 0);
+                for (int nb = 0; nb < NB; ++nb) kb[kk][e][nb] = Ks[key * LD + nb * 32 + l31];
             }
         }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) dq[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk][e], kb[kk][e][nb], dq[nb], 0, 0, 0);
         // the two key halves of a query half add up: wave kj = 1 hands its block over, wave kj = 0 writes the partial of this key block
         float* R = Rs + qi * 32 * DHP;
         if (kj == 1) {
