@@ -102,6 +102,13 @@ __device__ __forceinline__ void lds_read_tr16_b64(s16x4& d, unsigned addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
 }
 
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+template <int OFF>
+__device__ __forceinline__ void lds_read_tr8_b64(i32x2& d, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+
 template <int DH, class RD>
 __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a, RD rd) {
     constexpr int DHP = DH < 32 ? 32 : DH;        // Vᵀ rows padded to a full 32-row MFMA tile
@@ -485,7 +492,11 @@ __device__ __forceinline__ f32x16 og_attn_mfma(f16x8 a, f16x8 b, f32x16 c) {
 // GS = 2 / 4 (ONE or two pairs: fewer workgroups than a quarter / half of the CUs): the key tiles of a query tile are dealt to GS WORKGROUPS
 // (same XCD); each writes its unnormalised (O, m, l) to scratch, and the workgroup that arrives last (one counter per query tile) merges the
 // GS partial results in index order -- deterministic -- and runs the normal epilogue.
-template <int DH, class RD, int KS = 1, int GS = 1>
+// MX = 1 (round 6): the two P V CROSS products on the block-scaled 8-bit matrix instruction.  The plane `vl` then holds, per key and head, the row
+// [e4m3(V 2^-sv) x DH | e4m3((V - Vh) 2^(11 - sv)) x DH] (one byte per element: the same bytes as the f16 lo row) written by the projection epilogue;
+// P8h = e4m3(P), P8l = e4m3((P - Ph) 2^11) are made next to the f16 hi parts.  Per 64-key tile and dv block, Ph.Vl + Pl.Vh = 2^(sv - 11) (P8h.V8lo + P8l.V8hi):
+// two v_mfma_scale_f32_32x32x64_f8f6f4 (k = the lane's own 32 keys of the tile, constant E8M0 scales) instead of eight 32x32x16 f16 MFMAs.
+template <int DH, class RD, int KS = 1, int GS = 1, int MX = 0>
 #ifndef OG_ATTN_WG32
 #define OG_ATTN_WG32 2        // workgroups per CU the dh = 32 instantiation is compiled for (experiment: 3)
 #endif
@@ -503,10 +514,19 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
 
     static_assert(GS == 1 || KS == 1, "the workgroup-level key split is built for 4-wave workgroups (dh = 64 and, round 5, dh = 32: the 128-d family's single pairs)");
     const int id = blockIdx.x;
-    const int xcd = id & 7, local = id >> 3;
-    const int grp = (local / (a.qtiles * GS)) * 8 + xcd;   // (problem, head) group: all its query tiles (and key parts) on one XCD
+    int grp, qt, part;
+    if (GS > 1 && a.gs_scatter) {      // test knob (OG_ATTN_GS_SCATTER=1): the parts of a query tile are CONSECUTIVE workgroups, i.e. on different XCDs under the
+        part = id % GS;                // round-robin dispatch -- the hand-over below has to be right wherever the parts run
+        const int rest = id / GS;
+        grp = ((rest >> 3) / a.qtiles) * 8 + (rest & 7);
+        qt = (rest >> 3) % a.qtiles;
+    } else {
+        const int xcd = id & 7, local = id >> 3;
+        grp = (local / (a.qtiles * GS)) * 8 + xcd;         // (problem, head) group: all its query tiles (and key parts) on one XCD -- for SPEED only
+        const int qt_part = local % (a.qtiles * GS);
+        qt = qt_part / GS; part = qt_part % GS;
+    }
     if (grp >= a.nz * a.num_heads) return;
-    const int qt_part = local % (a.qtiles * GS), qt = qt_part / GS, part = qt_part % GS;
     const int z = grp / a.num_heads, h = grp - z * a.num_heads;
     const int gsel = z < a.split ? 0 : 1;
     const int zz = gsel ? z - a.split : z;
@@ -566,6 +586,16 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
         ksw[i] = (unsigned)(pc ^ (DH == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3))) * 16u;
     }
     vsw = (unsigned)(pc ^ (DH == 64 ? (((rl >> 1) & 1) << 2) : 0)) * 16u;
+    // MX: the 8-bit plane is read by ds_read_b64_tr_b8 -- 32 lanes = 8 key rows {0..3, 8..11} (+ 4 hi) x 32 bytes -- so its chunk swizzle is
+    // dh = 64: chunk ^ 2 (((r >> 1) & 1) | (((r >> 3) & 1) << 1)), dh = 32 (64-byte rows): chunk ^ (((r >> 3) & 1) << 1)
+    [[maybe_unused]] unsigned vsw8[2] = {0u, 0u};
+    if constexpr (MX) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = i * RPI + rl;
+            vsw8[i] = (unsigned)(pc ^ (DH == 64 ? ((((r >> 1) & 1) | (((r >> 3) & 1) << 1)) << 1) : (((r >> 3) & 1) << 1))) * 16u;
+        }
+    }
     const int64_t k_tile0 = (kv_row0 * a.ldk + h * DH) * 2, v_tile0 = (kv_row0 * a.ldv + h * DH) * 2;   // bytes, uniform
     // one tile = 8 DMA instructions per wave, issued in pairs (plane pair pp: 0 = K hi/lo, 1 = V hi/lo of piece i) so that
     // the main loop can spread them under its MFMA bursts: the vector-memory path takes 64 B/clk per CU, a burst of 8 per
@@ -584,6 +614,7 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
         voffs[i] = (unsigned)(r * ldvb) + vsw;
         asm volatile("" : "+v"(koffs[i]), "+v"(voffs[i]));
     }
+    static_assert(!MX || !OG_ATTN_ASMDMA, "the MX form uses the builtin DMA path");
     [[maybe_unused]] auto sptr = [](const char* p) {
         const uint64_t v = (uint64_t)(uintptr_t)p;
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi32 = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
@@ -622,6 +653,10 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
         } else {
             const int64_t o = v_tile0 + (int64_t)key0 * ldvb + (unsigned)(r * ldvb) + vsw;
             __builtin_amdgcn_global_load_lds((og_glb_void*)(reinterpret_cast<const char*>(a.vh) + o), (og_lds_void*)(dst), 16, 0, 0);
+            if constexpr (MX) {
+                const int64_t o8 = v_tile0 + (int64_t)key0 * ldvb + (unsigned)(r * ldvb) + vsw8[i & 1];
+                __builtin_amdgcn_global_load_lds((og_glb_void*)(reinterpret_cast<const char*>(a.vl) + o8), (og_lds_void*)(dst + PLANE), 16, 0, 0);
+            } else
             __builtin_amdgcn_global_load_lds((og_glb_void*)(reinterpret_cast<const char*>(a.vl) + o), (og_lds_void*)(dst + PLANE), 16, 0, 0);
         }
 #endif
@@ -667,9 +702,26 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
 #pragma unroll
         for (int d = 0; d < NDV; ++d) va[d] = lds0 + vrow + (DH == 64 ? 64 * (d ^ ((lane >> 3) & 1)) : 0);
     }
+    // MX: A operands of the 8-bit products.  One ds_read_b64_tr_b8 gives lane (dv, hi) the bytes of 8 keys {0..3, 8..11} + 4 hi + 16 n (+ 32 for n >= 2):
+    // lane i of a 16-lane group supplies the 8-byte chunk (key row i >> 1, dv 8 (i & 1) ..) and receives column i (scripts/probes/mx_pv.hip).
+    // va8[part][d]: part 0 = the hi bytes (chunks 0 ..), 1 = the lo bytes (chunks DH / 16 ..) of dv block d; the read index n is an immediate.
+    [[maybe_unused]] unsigned va8[2][NDV];
+    if constexpr (MX) {
+        const int i16 = lane & 15, ri = i16 >> 1, gi = (lane >> 4) & 1;
+        const int row = 4 * hi + (ri & 3) + 8 * (ri >> 2);
+        const int f = DH == 64 ? ((((ri >> 1) & 1) | ((ri >> 2) << 1)) << 1) : ((ri >> 2) << 1);
+#pragma unroll
+        for (int part = 0; part < 2; ++part)
+#pragma unroll
+            for (int d = 0; d < NDV; ++d) va8[part][d] = lds0 + row * ROWB + ((((part * DH + d * 32) / 16) ^ f) + gi) * 16 + 8 * (i16 & 1);
+    }
     // fragment registers, double-buffered by hand: K [buf][key block], V [buf][dv block] as two transposed halves
     f16x8 kh[2][2], kl[2][2];
-    s16x4 vh0[2][NDV], vh1[2][NDV], vl0[2][NDV], vl1[2][NDV];
+    s16x4 vh0[2][NDV], vh1[2][NDV], vl0[2][MX ? 1 : NDV], vl1[2][MX ? 1 : NDV];
+    [[maybe_unused]] i32x2 v8[2][4];                     // MX: [buffer][read n]: 8 key bytes each
+    [[maybe_unused]] const float mx_rscale = 0x1p-11f;
+    [[maybe_unused]] int mx_sa = a.mx_scale_a;            // E8M0 bytes of the A-side block scale: 127 + sv - 11 (byte 0)
+    asm volatile("" : "+v"(mx_sa));
 
 #if OG_ATTN_TRACE
     const int tsel = blockIdx.x == 8 * 40 ? 0 : blockIdx.x == 8 * 41 + 3 ? 1 : -1;     // two workgroups somewhere in the middle
@@ -704,6 +756,21 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
             else if constexpr ((j & 3) == 2) lds_read_tr16_b64<off + PLANE>(vl0[g & 1][d], va[d]);
             else lds_read_tr16_b64<off + PLANE + 8 * ROWB>(vl1[g & 1][d], va[d]);
         };
+        // MX: the 4 NDV reads a group g = (key block, half) needs: the f16 hi fragments (2 NDV) and its share of the 8-bit A operands -- NDV = 2: all four
+        // reads of product g; NDV = 1: reads 2 (g & 1), + 1 of product g >> 1 (its MFMA follows the odd group)
+        [[maybe_unused]] auto read_vm = [&](auto G, auto J) {
+            constexpr int g = decltype(G)::value, j = decltype(J)::value;
+            if constexpr (j < 2 * NDV) {
+                constexpr int d = j >> 1, off = b * BUFB + 2 * PLANE + g * 16 * ROWB;
+                if constexpr ((j & 1) == 0) lds_read_tr16_b64<off>(vh0[g & 1][d], va[d]);
+                else lds_read_tr16_b64<off + 8 * ROWB>(vh1[g & 1][d], va[d]);
+            } else {
+                constexpr int k = j - 2 * NDV, jp = NDV == 2 ? g : g >> 1, n = NDV == 2 ? k : 2 * (g & 1) + k;
+                constexpr int d = jp % NDV, part = 1 - jp / NDV;
+                constexpr int off = b * BUFB + 3 * PLANE + ((n >> 1) * 32 + 16 * (n & 1)) * ROWB;
+                lds_read_tr8_b64<off>(v8[jp & 1][n], va8[part][d]);
+            }
+        };
         auto fence = [] { __builtin_amdgcn_sched_barrier(0); };
 
         // ---- S' = K Q^T - m_run for the two 32-key blocks (independent accumulator chains, interleaved) ----
@@ -728,8 +795,13 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
                         if constexpr (c + 1 < NCH) {
                             read_k1(std::integral_constant<int, c + 1>{}, std::integral_constant<int, m>{});
                         } else if constexpr (2 * m < 4 * NDV) {          // last chunk: the first V fragments, they fly under the softmax
-                            read_v1(std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * m>{});
-                            read_v1(std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * m + 1>{});
+                            if constexpr (MX) {
+                                read_vm(std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * m>{});
+                                read_vm(std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * m + 1>{});
+                            } else {
+                                read_v1(std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * m>{});
+                                read_v1(std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * m + 1>{});
+                            }
                         }
                         fence();
                     }
@@ -767,6 +839,7 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
         // m_run -- the wave takes the slow path: tile maximum, new running max, rescale of l and O, and the exponentials again.
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         u32x4 pfw[2][2], plw[2][2];                       // packed (hi, hi) / (lo, lo) pairs: [key block][k-step of 16 keys]
+        [[maybe_unused]] i32x8 p8h, p8l;                  // MX: e4m3 bytes of P and of (P - Ph) 2^11: dword 4 kb + (r >> 2) = this lane's keys 8 (r >> 2) + 4 hi + 0..3 of block kb
         float tsum = 0.f;
         // Row sum: FOUR plain v_add_f32 chains.  NOT v_pk_add_f32: on gfx950 a packed-fp32 instruction does not issue while the matrix
         // pipe of its SIMD is busy -- beside a saturated MFMA stream of the other wave every other VALU class still gets a slot every
@@ -797,9 +870,14 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
                     add1(ps0, p0); add1(ps1, p1); add1(ps2, p2); add1(ps3, p3);
 #endif
                     unsigned ha, la, hb, lb;
-                    og_split4(p0, p1, p2, p3, ha, la, hb, lb);      // og_common.h: 3 instructions per pair, hazard-safe
+                    if constexpr (MX) {
+                        og_split4_mx(p0, p1, p2, p3, mx_rscale, ha, hb, la, lb);      // la / lb: the e4m3 quadruples of P and of its residual
+                        p8h[4 * kb + (r >> 2)] = (int)la; p8l[4 * kb + (r >> 2)] = (int)lb;
+                    } else {
+                        og_split4(p0, p1, p2, p3, ha, la, hb, lb);      // og_common.h: 3 instructions per pair, hazard-safe
+                        plw[kb][r >> 3][(r & 7) >> 1] = la; plw[kb][r >> 3][((r & 7) >> 1) + 1] = lb;
+                    }
                     pfw[kb][r >> 3][(r & 7) >> 1] = ha; pfw[kb][r >> 3][((r & 7) >> 1) + 1] = hb;
-                    plw[kb][r >> 3][(r & 7) >> 1] = la; plw[kb][r >> 3][((r & 7) >> 1) + 1] = lb;
                 }
 #if OG_ATTN_PKSUM
             tsum = psum2[0] + psum2[1];
@@ -811,7 +889,7 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
 #if !OG_ATTN_MAXFIRST
         if (!redo) {
             exp_split();
-            redo = __any(!(tsum <= SUM_LIMIT));           // wave-uniform; catches inf and NaN too
+            redo = __any(!(tsum <= (MX ? 256.f : SUM_LIMIT)));           // wave-uniform; catches inf and NaN too (MX: every p inside e4m3's 448)
         }
 #endif
         float mt = 0.f;
@@ -850,12 +928,49 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) { pf[kb][t] = __builtin_bit_cast(f16x8, pfw[kb][t]); pl[kb][t] = __builtin_bit_cast(f16x8, plw[kb][t]); }
+            for (int t = 0; t < 2; ++t) { pf[kb][t] = __builtin_bit_cast(f16x8, pfw[kb][t]); if constexpr (!MX) pl[kb][t] = __builtin_bit_cast(f16x8, plw[kb][t]); }
 
         OG_TP(3);
         // ---- O^T += V^T P^T of the same tile: group g = (key block kb, half t); A operand element e of lane (dv, hi) is
         //      key kb*32 + 16t + 8(e>>2) + 4hi + (e&3) -> two transposing reads per plane ----
         fence();
+        if constexpr (MX) {
+            static_for<4>([&](auto G) {
+                constexpr int g = decltype(G)::value;
+                constexpr int gb = g & 1, kb = g >> 1, t = g & 1;
+                constexpr bool has8 = NDV == 2 || (g & 1);                      // an 8-bit product closes this group
+                constexpr int jp = NDV == 2 ? g : g >> 1;
+                if constexpr (NDV == 2)
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vh0[gb][0]), "+v"(vh1[gb][0]), "+v"(vh0[gb][1]), "+v"(vh1[gb][1]),
+                                 "+v"(v8[jp & 1][0]), "+v"(v8[jp & 1][1]), "+v"(v8[jp & 1][2]), "+v"(v8[jp & 1][3]) :: "memory");
+                else
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vh0[gb][0]), "+v"(vh1[gb][0]),
+                                 "+v"(v8[jp & 1][0]), "+v"(v8[jp & 1][1]), "+v"(v8[jp & 1][2]), "+v"(v8[jp & 1][3]) :: "memory");
+                fence();
+                f16x8 vh[NDV];
+#pragma unroll
+                for (int d = 0; d < NDV; ++d) vh[d] = __builtin_bit_cast(f16x8, __builtin_shufflevector(vh0[gb][d], vh1[gb][d], 0, 1, 2, 3, 4, 5, 6, 7));
+                constexpr int SLOTS = NDV + (has8 ? 1 : 0), RPS = (4 * NDV + SLOTS - 1) / SLOTS;      // the next group's reads, spread behind this group's MFMAs
+                static_for<SLOTS>([&](auto M) {
+                    constexpr int m = decltype(M)::value;
+                    if constexpr (m < NDV) oacc[m] = og_attn_mfma(vh[m], pf[kb][t], oacc[m]);
+                    else {
+                        constexpr int d = jp % NDV, part = 1 - jp / NDV;            // part 1 = V8lo with P8h, part 0 = V8hi with P8l
+                        const i32x8 a8 = __builtin_shufflevector(__builtin_shufflevector(v8[jp & 1][0], v8[jp & 1][1], 0, 1, 2, 3),
+                                                                 __builtin_shufflevector(v8[jp & 1][2], v8[jp & 1][3], 0, 1, 2, 3), 0, 1, 2, 3, 4, 5, 6, 7);
+                        oacc[d] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, part ? p8h : p8l, oacc[d], 0, 0, 0, mx_sa, 0, 0x7F7F7F7F);
+                    }
+                    fence();
+                    if constexpr (g + 1 < 4) {
+                        static_for<RPS>([&](auto R) {
+                            constexpr int j = m * RPS + decltype(R)::value;
+                            if constexpr (j < 4 * NDV) read_vm(std::integral_constant<int, g + 1>{}, std::integral_constant<int, j>{});
+                        });
+                        fence();
+                    }
+                });
+            });
+        } else
         static_for<4>([&](auto G) {
             constexpr int g = decltype(G)::value;
             constexpr int gb = g & 1, kb = g >> 1, t = g & 1;
@@ -945,8 +1060,13 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
         constexpr int PSTRIDE = (16 * NDV + 2) * 64;      // floats per wave: [register][lane]
         float* const tile_base = a.partial + ((int64_t)(grp * a.qtiles + qt) * GS * 4) * PSTRIDE;
         float* const mine = tile_base + (part * 4 + wave) * PSTRIDE + lane;
-        // Agent-scope (sc1) accesses one by one, no fence: a device-scope release fence writes the WHOLE L2 back on this part (the first
-        // version, with __threadfence(): attention 0.72 -> 1.16 ms per single-pair step); the stores are complete when vmcnt reaches 0.
+        // Hand-over, independent of where the parts run (MI355X_MICROARCH.md: the block -> XCD map is undefined): every access to the scratch is an
+        // agent-scope relaxed atomic = `sc1` (write-through stores, L1-bypassing loads -- the form the guide lists as valid across XCDs: sc1 payload,
+        // vmcnt(0), sc1 flag, sc1 loads), the arrival counter is an agent-scope RMW, and the counter word also carries every part's XCC id: if the last
+        // arriver finds a part that ran on another XCD it takes a full agent-scope acquire (buffer_inv sc1) before it reads -- in the usual placement
+        // (all parts of a tile on one XCD, which the block index mapping arranges for speed) no fence is executed at all.  A device-scope RELEASE
+        // fence is deliberately not used: it writes the whole L2 back on this part (first version, with __threadfence(): attention 0.72 -> 1.16 ms
+        // per single-pair step); the write-through stores are complete when vmcnt reaches 0.
         auto st = [](float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
 #pragma unroll
         for (int d = 0; d < NDV; ++d)
@@ -959,12 +1079,25 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
         int* const s_last = reinterpret_cast<int*>(smem_all);
         if (tid == 0) {
             int* const cnt = a.counters + grp * a.qtiles + qt;
-            const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old == GS - 1) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // the last arriver re-arms the counter for the next launch
-            *s_last = old == GS - 1;
+            const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (31 << 11)) & 15u;                 // HW_REG_XCC_ID, XCC_ID [3:0]
+            const unsigned mine_word = 1u + (xcc << (8 + 4 * part));                              // arrivals in bits 0..7, part p's XCC id in bits 8 + 4p ..
+            const unsigned old = (unsigned)__hip_atomic_fetch_add(cnt, (int)mine_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool last = (old & 255u) == GS - 1;
+            int code = 0;
+            if (last) {
+                __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);           // the last arriver re-arms the counter for the next launch
+                const unsigned all = (old + mine_word) >> 8;
+                bool same = true;
+#pragma unroll
+                for (int p = 0; p < GS; ++p) same &= ((all >> (4 * p)) & 15u) == xcc;
+                code = same ? 1 : 2;
+            }
+            *s_last = code;
         }
         __syncthreads();
-        if (!*s_last) return;
+        const int arrival = *s_last;
+        if (!arrival) return;
+        if (arrival == 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                      // some part ran on another XCD
         // merge the GS partial results in index order (the same order whoever arrives last): m = max, O and l rescaled to it
         auto ld = [](const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
         const float* const src = tile_base + wave * PSTRIDE + lane;
@@ -1021,48 +1154,6 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
 
 }  // namespace
 
-namespace {
-__global__ void xcc_probe_kernel(unsigned* out) {
-    if (threadIdx.x == 0) out[blockIdx.x] = __builtin_amdgcn_s_getreg(20 | (31 << 11)) & 0x00F0000Fu;      // HW_REG_XCC_ID: XCC_ID [3:0], DIE_ID [23:20]
-}
-}  // namespace
-
-// The workgroup-level key split lets the parts of a query tile meet through one L2: plain agent-scope accesses, no device-wide fence.  That is only
-// right if workgroup i of a 1-D grid really runs on XCD i mod 8 (what the blockIdx -> (problem, head) mapping of every kernel here assumes for
-// SPEED).  Checked once per process AND DEVICE with a probe launch on a private stream; any failure or another dispatch order switches the split off.
-static bool og_xcd_round_robin_ok(hipStream_t caller) {
-    constexpr int MAXDEV = 64;
-    static std::atomic<int> states[MAXDEV];                // per DEVICE -- 0: not probed yet, 1: round robin verified, 2: anything else
-    int dev_id = 0;
-    if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= MAXDEV) { (void)hipGetLastError(); return false; }
-    std::atomic<int>& state = states[dev_id];
-    const int s0 = state.load(std::memory_order_acquire);
-    if (s0) return s0 == 1;
-    // the probe allocates and synchronises: never while the caller's stream is being captured into a graph (the launch then takes the unsplit
-    // kernel; an eager call probes later)
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(caller, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return false; }
-    constexpr int N = 1024;
-    unsigned* dev = nullptr;
-    hipStream_t st = nullptr;
-    bool good = false;
-    if (hipMalloc((void**)&dev, N * sizeof(unsigned)) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess) {
-        unsigned host[N];
-        hipLaunchKernelGGL(xcc_probe_kernel, dim3(N), dim3(64), 0, st, dev);
-        if (hipMemcpyAsync(host, dev, sizeof(host), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess) {
-            good = true;
-            for (int i = 8; i < N; ++i) good &= host[i] == host[i & 7];
-            for (int i = 1; i < 8; ++i)
-                for (int j = 0; j < i; ++j) good &= host[i] != host[j];          // eight distinct XCDs, each seeing every eighth workgroup
-        }
-    }
-    if (st) (void)hipStreamDestroy(st);
-    if (dev) (void)hipFree(dev);
-    (void)hipGetLastError();
-    state.store(good ? 1 : 2, std::memory_order_release);
-    return good;
-}
-
 int og_launch_attention(const AttnArgs& a, hipStream_t stream) {
     if (!a.qh || !a.ql || !a.kh || !a.kl || !a.vh || !a.vl || !a.oh || !a.ol || a.nz <= 0 || a.num_heads <= 0) return OG_E_INVALID;
     if ((a.ldq & 7) || (a.ldk & 7) || (a.ldv & 7) || (a.ldo & 3)) return OG_E_ALIGN;
@@ -1099,7 +1190,7 @@ int og_launch_attention(const AttnArgs& a, hipStream_t stream) {
     // (attention_dma_kernel<64, ., 1, GS>).  OG_ATTN_GSPLIT=0 / 2 / 4 forces.
     static const int gs_mode = [] { const char* e = getenv("OG_ATTN_GSPLIT"); return e ? atoi(e) : -1; }();
     int gs = 1;
-    if (dma && (a.dh == 64 || a.dh == 32) && a.partial && a.counters && (int)grid.x <= OG_ATTN_COUNTERS) {
+    if (!a.mx && dma && (a.dh == 64 || a.dh == 32) && a.partial && a.counters && (int)grid.x <= OG_ATTN_COUNTERS) {
         // The split launch may hold up to two workgroups per CU at dh = 32 (they do not wait for each other: the last arriver of a query tile merges),
         // one at dh = 64 -- measured in one call (profiles/r05_j_bench_attn_gsplit_maxwg_ab.jsonl): dh = 32, 512 against 256 workgroups: a single
         // 2048-keypoint pair 1.428 -> 1.394 ms per step, two pairs 1.703 -> 1.640, one 4096-keypoint pair 3.47 -> 3.24; dh = 64: one pair +-0, two pairs
@@ -1111,10 +1202,11 @@ int og_launch_attention(const AttnArgs& a, hipStream_t stream) {
         else if ((int)grid.x * 2 <= maxwg && (a.rag || nkmin >= 8 * KV_TILE)) gs = 2;
         if ((int)grid.x * gs > maxwg && gs_mode < 0) gs = 1;
         if ((int64_t)grid.x * gs * 4 * 34 * 64 > OG_ATTN_PARTIAL_FLOATS) gs = 1;
-        if (gs > 1 && !og_xcd_round_robin_ok(stream)) gs = 1;
     }
     if (gs > 1) {
         dim3 g2(grid.x * gs);
+        const char* const sc = getenv("OG_ATTN_GS_SCATTER");      // tests (read per launch, so that one process can compare both placements): deal the parts of a tile to different XCDs
+        a2.gs_scatter = sc && sc[0] == '1' ? 1 : 0;
         if (a.dh == 64) {
             if (a.rag) {
                 if (gs == 4) hipLaunchKernelGGL((attention_dma_kernel<64, RaggedDesc, 1, 4>), g2, block, 0, stream, a2, rd);
@@ -1134,10 +1226,23 @@ int og_launch_attention(const AttnArgs& a, hipStream_t stream) {
         }
         return og_launch_status();
     }
-    const bool ksplit = dma && a.dh == 64 && (ks_mode >= 0 ? ks_mode != 0 : ((int)grid.x <= 256 && (a.rag || nkmin >= 4 * KV_TILE)));
+    const bool ksplit = !a.mx && dma && a.dh == 64 && (ks_mode >= 0 ? ks_mode != 0 : ((int)grid.x <= 256 && (a.rag || nkmin >= 4 * KV_TILE)));
     if (ksplit) {
         if (a.rag) hipLaunchKernelGGL((attention_dma_kernel<64, RaggedDesc, 2>), grid, dim3(512), 0, stream, a2, rd);
         else hipLaunchKernelGGL((attention_dma_kernel<64, RaggedNone, 2>), grid, dim3(512), 0, stream, a2, RaggedNone{});
+        return og_launch_status();
+    }
+    if (a.mx) {          // 8-bit P V cross products: batch form of the LDS-DMA kernel only (the callers set mx only where the producers wrote the 8-bit rows)
+        if (!dma) return OG_E_SHAPE;
+        const int e = 127 + a.mx_sv - 11;
+        a2.mx_scale_a = e | (e << 8) | (e << 16) | (e << 24);
+        if (a.rag) {
+            if (a.dh == 64) hipLaunchKernelGGL((attention_dma_kernel<64, RaggedDesc, 1, 1, 1>), grid, block, 0, stream, a2, rd);
+            else hipLaunchKernelGGL((attention_dma_kernel<32, RaggedDesc, 1, 1, 1>), grid, block, 0, stream, a2, rd);
+        } else {
+            if (a.dh == 64) hipLaunchKernelGGL((attention_dma_kernel<64, RaggedNone, 1, 1, 1>), grid, block, 0, stream, a2, RaggedNone{});
+            else hipLaunchKernelGGL((attention_dma_kernel<32, RaggedNone, 1, 1, 1>), grid, block, 0, stream, a2, RaggedNone{});
+        }
         return og_launch_status();
     }
     if (a.rag) {
@@ -1191,5 +1296,7 @@ extern "C" int og_attention(const void* qh, const void* ql, int64_t ldq, const v
     a.q_base[0] = 0; a.q_step[0] = nq; a.kv_base[0] = 0; a.kv_step[0] = nk;
     a.nq[0] = nq; a.nk[0] = nk;
     a.q_base[1] = a.q_step[1] = a.kv_base[1] = a.kv_step[1] = 0; a.nq[1] = a.nk[1] = 0;
+    // experiments (scripts/bench_attention.py): OG_ATTN_MX_SV=<sv> declares that `vl` holds the 8-bit rows of the MX form (og_common.h: AttnArgs::mx)
+    if (const char* e = getenv("OG_ATTN_MX_SV")) { a.mx = 1; a.mx_sv = atoi(e); }
     return og_launch_attention(a, (hipStream_t)stream);
 }

@@ -85,6 +85,28 @@ __device__ __forceinline__ void og_split4(float x0, float x1, float x2, float x3
         : "v"(x0), "v"(x1), "v"(x2), "v"(x3));
 }
 
+// The same four values for the attention kernel's block-scaled P V cross products (attention.hip, MX form): the f16 hi pairs as above, plus
+// h8 = four e4m3 bytes of x0..x3 (the B operand of P8h . V8lo) and l8 = four e4m3 bytes of (x - hi) / rscale (B operand of P8l . V8hi; rscale = 2^-11:
+// the residual is brought to the scale of x, the MFMA's block scale takes the 2^-11 back).  x - hi is exact in fp32 (one v_fma_mix_f32 per value).
+// Byte e of h8 / l8 belongs to x_e: the k order of the 8-bit MFMA operand.  5 instructions per pair against og_split4's 3.
+__device__ __forceinline__ void og_split4_mx(float x0, float x1, float x2, float x3, float rscale, unsigned& ha, unsigned& hb, unsigned& h8, unsigned& l8) {
+    float t0, t1, t2, t3;
+    asm("s_nop 0\n\t"
+        "v_cvt_pk_f16_f32 %0, %8, %9\n\t"
+        "v_cvt_pk_f16_f32 %1, %10, %11\n\t"
+        "v_cvt_pk_fp8_f32 %2, %8, %9\n\t"
+        "v_fma_mix_f32 %4, %8, 1.0, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %5, %9, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %6, %10, 1.0, -%1 op_sel_hi:[0,0,1]\n\t"
+        "v_cvt_pk_fp8_f32 %2, %10, %11 op_sel:[0,0,1]\n\t"
+        "v_fma_mix_f32 %7, %11, 1.0, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_cvt_scalef32_pk_fp8_f32 %3, %4, %5, %12\n\t"
+        "s_nop 0\n\t"
+        "v_cvt_scalef32_pk_fp8_f32 %3, %6, %7, %12 op_sel:[0,0,0,1]"
+        : "=&v"(ha), "=&v"(hb), "=&v"(h8), "=&v"(l8), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(rscale));
+}
+
 // "hl32" operand format of the split-f16 GEMM (gemm_f16x3.hip): the hi and lo halves of a row live in ONE
 // row of 2K halves, interleaved in groups of 32 channels -- [hi 0..31 | lo 0..31 | hi 32..63 | lo 32..63 | ...]
 // -- so that the 32-channel k-slab a GEMM stage consumes is one full 128-byte cache line (64 B hi + 64 B lo).
@@ -215,6 +237,10 @@ struct AttnArgs {
     float* lse;               // optional (uniform single-geometry calls): [nz][num_heads][nq] row log-sum-exp of the scaled scores, natural units
     float* partial;           // optional scratch of OG_ATTN_PARTIAL_FLOATS floats + int* counters of OG_ATTN_COUNTERS zeroed ints: with both set, launches of
     int* counters;            // very few workgroups split the KEY range of a query tile over 2 or 4 workgroups (attention.hip: GS)
+    int gs_scatter;           // set by the launcher (test knob OG_ATTN_GS_SCATTER): key parts of a query tile on consecutive workgroups
+    int mx;                   // 1: `vl` holds the 8-bit rows [e4m3(V 2^-sv) | e4m3((V - Vh) 2^(11 - sv))] instead of the f16 lo parts: the P V cross products run on the
+    int mx_scale_a;           //    block-scaled 8-bit MFMA (attention.hip, MX); mx_scale_a = the E8M0 byte 127 + sv - 11 replicated (set by the launcher from mx_sv)
+    int mx_sv;                //    power-of-two exponent the producer divided V by before the e4m3 conversion
 };
 int og_launch_attention(const AttnArgs& a, hipStream_t stream);
 int og_launch_linear_attention(const AttnArgs& a, hipStream_t stream);   // attention = 'linear' (elu+1 feature map)

@@ -195,7 +195,7 @@ class SuperGlue(nn.Module):
         self._packed: Optional[torch.Tensor] = None
         self._packed_key = None
         self._tensor_cache = None
-        self._workspace: Dict[tuple, torch.Tensor] = {}
+        self._workspace: Dict[str, tuple] = {}
 
     # ------------------------------------------------------------------ shape / packing
     def _shape(self, B: int, m: int, n: int, match_threshold: float = 0.0) -> _lib.og_shape:
@@ -271,14 +271,20 @@ class SuperGlue(nn.Module):
         return rc
 
     def _get_workspace(self, dev, key, nbytes: int) -> torch.Tensor:
-        """One live workspace (shapes rarely change between calls); re-used while it is large enough."""
-        wkey = (str(dev),) + tuple(key)
-        ws = self._workspace.get(wkey)
-        if ws is None or ws.numel() < nbytes:
-            self._workspace.clear()
-            ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
-            self._workspace[wkey] = ws
-        return ws
+        """One live workspace per device, keyed by CAPACITY: any call whose og_workspace_bytes fits re-uses it, whatever its (B, m, n) -- real
+        pairs (inference.py) have a different keypoint count on every call.  It only grows (by at least a quarter, so a slowly rising count
+        does not re-allocate per call); og_forward re-arms everything it keeps in there (counters, status, exchange granules) on every call,
+        so no state of an earlier shape is ever read.  `key` is informational (kept for debugging: the shape that last sized it)."""
+        wkey = str(dev)
+        ent = self._workspace.get(wkey)
+        if ent is None or ent[0].numel() < nbytes:
+            grow = 0 if ent is None else ent[0].numel() + ent[0].numel() // 4
+            self._workspace.pop(wkey, None)      # drop the old buffer before the new one is requested
+            ent = None
+            ws = torch.empty(max(nbytes, grow), device=dev, dtype=torch.uint8)
+            ent = (ws, tuple(key))
+            self._workspace[wkey] = ent
+        return ent[0]
 
     def _pack(self, device: torch.device) -> torch.Tensor:
         """Packed weights on `device`, cached until a parameter changes."""

@@ -1,0 +1,260 @@
+// Probe (round 6): what a SOFTWARE-PIPELINED attention tile loop could reach on gfx950 against the phase structure the kernel has today.
+// Per 64-key tile and wave (32 queries, dh = 64, split-f16 x 3): 24 MFMAs of QK^T + 24 of PV (v_mfma_f32_32x32x16_f16), 16 ds_read_b128 (K fragments),
+// 32 ds_read_b64_tr_b16 (V fragments), and the softmax VALU stream: 32 v_exp_f32, the 3-instruction (hi, lo) split per pair, 32 row-sum adds.
+//   PHASES  : QK^T(t) | softmax(t) | PV(t)                      -- every wave alternates matrix and vector phases; the matrix pipe of a SIMD is fed by
+//                                                                  whichever OTHER wave happens to be in a matrix phase (attention_dma_kernel today)
+//   PIPE    : one stream of 48 MFMAs = PV(t-1) then QK^T(t+1), with softmax(t) cut into 8 blocks of 4 scores and dealt out behind the MFMAs
+//             (<= 4 vector instructions per gap), the LDS reads of the next group one MFMA ahead
+// Random N(0,1) operands (the clock under a matrix-heavy kernel depends on the data); compiled WITHOUT packed fp32 like attention.hip.
+//   hipcc --offload-arch=gfx950 -O3 -Xclang -target-feature -Xclang -packed-fp32-ops scripts/probes/attn_pipe.hip -o probe_attn_pipe
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <type_traits>
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split4(float x0, float x1, float x2, float x3, unsigned& ha, unsigned& la, unsigned& hb, unsigned& lb) {
+    asm("s_nop 0\n\t"
+        "v_cvt_pk_f16_f32 %0, %4, %5\n\t"
+        "v_cvt_pk_f16_f32 %2, %6, %7\n\t"
+        "v_fma_mixlo_f16 %1, %4, 1.0, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %3, %6, 1.0, -%2 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %5, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %3, %7, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(ha), "=&v"(la), "=&v"(hb), "=&v"(lb)
+        : "v"(x0), "v"(x1), "v"(x2), "v"(x3));
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) { static_for<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
+}
+template <int OFF> __device__ __forceinline__ void rd128(f16x8& d, unsigned addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF)); }
+template <int OFF> __device__ __forceinline__ void rdtr(s16x4& d, unsigned addr) { asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF)); }
+__device__ __forceinline__ void fence() { __builtin_amdgcn_sched_barrier(0); }
+
+constexpr int PLANE = 64 * 128;      // 64 keys x one 128-byte head row
+
+// MODE 0: phases, 1: pipelined.  WAVES = waves per workgroup (4: one per SIMD, 8: two per SIMD, one workgroup per CU either way)
+template <int MODE, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k(const f16x8* in, const char* kv, float* out, unsigned* cyc, int iters) {
+    __shared__ __attribute__((aligned(1024))) char smem[4 * PLANE];      // Kh | Kl | Vh | Vl of one tile (re-read every iteration: the DMA is not part of this probe)
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    for (int i = tid; i < 4 * PLANE / 16; i += 64 * WAVES) reinterpret_cast<uint4*>(smem)[i] = reinterpret_cast<const uint4*>(kv)[i];
+    __syncthreads();
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    unsigned kf[4], va[2];
+    for (int c = 0; c < 4; ++c) kf[c] = lds0 + l31 * 128 + (((2 * c + hi) ^ ((l31 >> 1) & 7)) * 16);
+    {
+        const int vrow = (4 * hi + ((lane & 15) >> 2)) * 128 + 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
+        for (int d = 0; d < 2; ++d) va[d] = lds0 + vrow + 64 * (d ^ ((lane >> 3) & 1));
+    }
+    f16x8 qh[4], ql[4];
+    for (int c = 0; c < 4; ++c) { qh[c] = in[lane + 64 * c]; ql[c] = in[lane + 64 * (4 + c)]; }
+    f32x16 oacc[2], sacc[2], negm;
+    for (int r = 0; r < 16; ++r) { oacc[0][r] = oacc[1][r] = 0.f; negm[r] = -40.f; sacc[0][r] = sacc[1][r] = -3.f - 0.1f * r; }
+    float l_run = 0.f;
+    u32x4 pfw[2][2], plw[2][2];          // P(t-1) as packed (hi, hi) / (lo, lo) pairs
+    for (int kb = 0; kb < 2; ++kb) for (int t = 0; t < 2; ++t) for (int e = 0; e < 4; ++e) { pfw[kb][t][e] = 0x2c002c00u; plw[kb][t][e] = 0x10001000u; }
+    f16x8 kh[2][2], kl[2][2];
+    s16x4 vh0[2][2], vh1[2][2], vl0[2][2], vl1[2][2];
+    auto read_k1 = [&](auto C, auto J) {
+        constexpr int c = decltype(C)::value, j = decltype(J)::value, kb = j >> 1;
+        if constexpr ((j & 1) == 0) rd128<kb * 32 * 128>(kh[c & 1][kb], kf[c]);
+        else rd128<PLANE + kb * 32 * 128>(kl[c & 1][kb], kf[c]);
+    };
+    auto read_v1 = [&](auto G, auto J) {
+        constexpr int g = decltype(G)::value, j = decltype(J)::value, d = j >> 2, off = 2 * PLANE + g * 16 * 128;
+        if constexpr ((j & 3) == 0) rdtr<off>(vh0[g & 1][d], va[d]);
+        else if constexpr ((j & 3) == 1) rdtr<off + 8 * 128>(vh1[g & 1][d], va[d]);
+        else if constexpr ((j & 3) == 2) rdtr<off + PLANE>(vl0[g & 1][d], va[d]);
+        else rdtr<off + PLANE + 8 * 128>(vl1[g & 1][d], va[d]);
+    };
+    auto mfma = [](f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); };
+#define WAIT_K(cb) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kh[cb][0]), "+v"(kh[cb][1]), "+v"(kl[cb][0]), "+v"(kl[cb][1]) :: "memory")
+#define WAIT_V(gb) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vh0[gb][0]), "+v"(vh1[gb][0]), "+v"(vl0[gb][0]), "+v"(vl1[gb][0]), "+v"(vh0[gb][1]), "+v"(vh1[gb][1]), "+v"(vl0[gb][1]), "+v"(vl1[gb][1]) :: "memory")
+    float ps0 = 0.f, ps1 = 0.f, ps2 = 0.f, ps3 = 0.f;
+    auto add1 = [](float& acc, float x) { acc += x; asm("" : "+v"(acc)); };
+
+    const unsigned t0 = (unsigned)__builtin_amdgcn_s_memtime();
+    if constexpr (MODE == 0) {
+        for (int it = 0; it < iters; ++it) {
+            // ---- QK^T ----
+            f32x16 s2[2];
+            fence();
+            static_for<4>([&](auto J) { read_k1(std::integral_constant<int, 0>{}, J); });
+            static_for<4>([&](auto C) {
+                constexpr int c = decltype(C)::value, cb = c & 1;
+                WAIT_K(cb); fence();
+                static_for<6>([&](auto M) {
+                    constexpr int m = decltype(M)::value, kb = m & 1, pass = m >> 1;
+                    if constexpr (pass == 0) s2[kb] = mfma(kl[cb][kb], qh[c], c == 0 ? negm : s2[kb]);
+                    else if constexpr (pass == 1) s2[kb] = mfma(kh[cb][kb], ql[c], s2[kb]);
+                    else s2[kb] = mfma(kh[cb][kb], qh[c], s2[kb]);
+                    fence();
+                    if constexpr (m < 4) {
+                        if constexpr (c + 1 < 4) read_k1(std::integral_constant<int, c + 1>{}, std::integral_constant<int, m>{});
+                        else { read_v1(std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * m>{}); read_v1(std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * m + 1>{}); }
+                        fence();
+                    }
+                });
+            });
+            // ---- softmax ----
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; r += 4) {
+                    const float p0 = __builtin_amdgcn_exp2f(s2[kb][r]), p1 = __builtin_amdgcn_exp2f(s2[kb][r + 1]), p2 = __builtin_amdgcn_exp2f(s2[kb][r + 2]), p3 = __builtin_amdgcn_exp2f(s2[kb][r + 3]);
+                    add1(ps0, p0); add1(ps1, p1); add1(ps2, p2); add1(ps3, p3);
+                    unsigned ha, la, hb, lb;
+                    split4(p0, p1, p2, p3, ha, la, hb, lb);
+                    pfw[kb][r >> 3][(r & 7) >> 1] = ha; pfw[kb][r >> 3][((r & 7) >> 1) + 1] = hb;
+                    plw[kb][r >> 3][(r & 7) >> 1] = la; plw[kb][r >> 3][((r & 7) >> 1) + 1] = lb;
+                }
+            // ---- PV ----
+            fence();
+            static_for<4>([&](auto G) {
+                constexpr int g = decltype(G)::value, gb = g & 1, kb = g >> 1, t = g & 1;
+                WAIT_V(gb); fence();
+                f16x8 vh[2], vl[2];
+                for (int d = 0; d < 2; ++d) {
+                    vh[d] = __builtin_bit_cast(f16x8, __builtin_shufflevector(vh0[gb][d], vh1[gb][d], 0, 1, 2, 3, 4, 5, 6, 7));
+                    vl[d] = __builtin_bit_cast(f16x8, __builtin_shufflevector(vl0[gb][d], vl1[gb][d], 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+                const f16x8 pf = __builtin_bit_cast(f16x8, pfw[kb][t]), pl = __builtin_bit_cast(f16x8, plw[kb][t]);
+                static_for<6>([&](auto M) {
+                    constexpr int m = decltype(M)::value, d = m % 2, pass = m / 2;
+                    if constexpr (pass == 0) oacc[d] = mfma(vl[d], pf, oacc[d]);
+                    else if constexpr (pass == 1) oacc[d] = mfma(vh[d], pl, oacc[d]);
+                    else oacc[d] = mfma(vh[d], pf, oacc[d]);
+                    fence();
+                    if constexpr (m < 4 && g + 1 < 4) { read_v1(std::integral_constant<int, g + 1>{}, std::integral_constant<int, 2 * m>{}); read_v1(std::integral_constant<int, g + 1>{}, std::integral_constant<int, 2 * m + 1>{}); fence(); }
+                });
+            });
+            if (WAVES > 4) __syncthreads();
+        }
+    } else {
+        // P(t-1) in pfw / plw, S(t) in sacc, the first V fragments of tile t-1 requested
+        static_for<8>([&](auto J) { read_v1(std::integral_constant<int, 0>{}, J); });
+        f32x16 sB[2];
+        u32x4 pfB[2][2], plB[2][2];
+        auto step = [&](f32x16 (&sacc)[2], f32x16 (&s2)[2], u32x4 (&pfw)[2][2], u32x4 (&plw)[2][2], u32x4 (&nfw)[2][2], u32x4 (&nlw)[2][2]) {
+            float p0, p1, p2, p3;
+            // softmax(t) block b (4 scores: register r = 4 (b & 3) of key block b >> 2), dealt out in five pieces behind MFMAs 6 b .. 6 b + 4
+            auto soft = [&](auto MM) {
+                constexpr int mm = decltype(MM)::value, b = mm / 6, ph = mm % 6, kb = b >> 2, r = 4 * (b & 3);
+                if constexpr (ph == 0) { p0 = __builtin_amdgcn_exp2f(sacc[kb][r]); p1 = __builtin_amdgcn_exp2f(sacc[kb][r + 1]); }
+                else if constexpr (ph == 1) { p2 = __builtin_amdgcn_exp2f(sacc[kb][r + 2]); p3 = __builtin_amdgcn_exp2f(sacc[kb][r + 3]); }
+                else if constexpr (ph == 2) {
+                    unsigned ha, la, hb, lb;
+                    split4(p0, p1, p2, p3, ha, la, hb, lb);
+                    nfw[kb][r >> 3][(r & 7) >> 1] = ha; nfw[kb][r >> 3][((r & 7) >> 1) + 1] = hb;
+                    nlw[kb][r >> 3][(r & 7) >> 1] = la; nlw[kb][r >> 3][((r & 7) >> 1) + 1] = lb;
+                } else if constexpr (ph == 3) { add1(ps0, p0); add1(ps1, p1); }
+                else if constexpr (ph == 4) { add1(ps2, p2); add1(ps3, p3); }
+                fence();
+            };
+            // ---- PV(t-1): MFMAs 0..23 ----
+            fence();
+            static_for<4>([&](auto G) {
+                constexpr int g = decltype(G)::value, gb = g & 1, kb = g >> 1, t = g & 1;
+                WAIT_V(gb); fence();
+                f16x8 vh[2], vl[2];
+                for (int d = 0; d < 2; ++d) {
+                    vh[d] = __builtin_bit_cast(f16x8, __builtin_shufflevector(vh0[gb][d], vh1[gb][d], 0, 1, 2, 3, 4, 5, 6, 7));
+                    vl[d] = __builtin_bit_cast(f16x8, __builtin_shufflevector(vl0[gb][d], vl1[gb][d], 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+                const f16x8 pf = __builtin_bit_cast(f16x8, pfw[kb][t]), pl = __builtin_bit_cast(f16x8, plw[kb][t]);
+                static_for<6>([&](auto M) {
+                    constexpr int m = decltype(M)::value, d = m % 2, pass = m / 2;
+                    if constexpr (pass == 0) oacc[d] = mfma(vl[d], pf, oacc[d]);
+                    else if constexpr (pass == 1) oacc[d] = mfma(vh[d], pl, oacc[d]);
+                    else oacc[d] = mfma(vh[d], pf, oacc[d]);
+                    fence();
+                    if constexpr (m < 4) {
+                        if constexpr (g + 1 < 4) { read_v1(std::integral_constant<int, g + 1>{}, std::integral_constant<int, 2 * m>{}); read_v1(std::integral_constant<int, g + 1>{}, std::integral_constant<int, 2 * m + 1>{}); }
+                        else read_k1(std::integral_constant<int, 0>{}, std::integral_constant<int, m>{});
+                        fence();
+                    }
+                    soft(std::integral_constant<int, 6 * g + m>{});
+                });
+            });
+            // ---- QK^T(t+1): MFMAs 24..47 ----
+            static_for<4>([&](auto C) {
+                constexpr int c = decltype(C)::value, cb = c & 1;
+                WAIT_K(cb); fence();
+                static_for<6>([&](auto M) {
+                    constexpr int m = decltype(M)::value, kb = m & 1, pass = m >> 1;
+                    if constexpr (pass == 0) s2[kb] = mfma(kl[cb][kb], qh[c], c == 0 ? negm : s2[kb]);
+                    else if constexpr (pass == 1) s2[kb] = mfma(kh[cb][kb], ql[c], s2[kb]);
+                    else s2[kb] = mfma(kh[cb][kb], qh[c], s2[kb]);
+                    fence();
+                    if constexpr (m < 4) {
+                        if constexpr (c + 1 < 4) read_k1(std::integral_constant<int, c + 1>{}, std::integral_constant<int, m>{});
+                        else { read_v1(std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * m>{}); read_v1(std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * m + 1>{}); }
+                        fence();
+                    }
+                    soft(std::integral_constant<int, 24 + 6 * c + m>{});
+                });
+            });
+            if (WAVES > 4) __syncthreads();
+        };
+        for (int it = 0; it < iters; it += 2) {
+            step(sacc, sB, pfw, plw, pfB, plB);
+            step(sB, sacc, pfB, plB, pfw, plw);
+        }
+    }
+    const unsigned t1 = (unsigned)__builtin_amdgcn_s_memtime();
+    l_run = (ps0 + ps1) + (ps2 + ps3);
+    float acc = l_run;
+    for (int d = 0; d < 2; ++d) for (int r = 0; r < 16; ++r) acc += oacc[d][r] + sacc[d][r];
+    for (int kb = 0; kb < 2; ++kb) for (int t = 0; t < 2; ++t) for (int e = 0; e < 4; ++e) acc += (float)(pfw[kb][t][e] ^ plw[kb][t][e]);
+    out[blockIdx.x * 64 * WAVES + tid] = acc;
+    if (lane == 0) cyc[blockIdx.x * WAVES + (tid >> 6)] = t1 - t0;
+}
+
+template <int MODE, int WAVES>
+void run(const char* name, const f16x8* in, const char* kv) {
+    float* out; unsigned* cyc;
+    const int blocks = 256 * 4, iters = 64;          // four rounds of one workgroup per CU
+    CHECK(hipMalloc(&out, (size_t)blocks * 64 * WAVES * 4)); CHECK(hipMalloc(&cyc, blocks * WAVES * 4));
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((k<MODE, WAVES>), dim3(blocks), dim3(64 * WAVES), 0, 0, in, kv, out, cyc, iters);
+    CHECK(hipDeviceSynchronize());
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, 0);
+    for (int rep = 0; rep < 5; ++rep) hipLaunchKernelGGL((k<MODE, WAVES>), dim3(blocks), dim3(64 * WAVES), 0, 0, in, kv, out, cyc, iters);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+    static unsigned h[256 * 4 * 8];
+    CHECK(hipMemcpy(h, cyc, blocks * WAVES * 4, hipMemcpyDeviceToHost));
+    double avg = 0; for (int i = 0; i < blocks * WAVES; ++i) avg += h[i]; avg /= (double)blocks * WAVES * iters;
+    int occ = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(&k<MODE, WAVES>), 64 * WAVES, 0);
+    const double flops = (double)blocks * WAVES * iters * 48 * 32768.0;
+    printf("%-60s [%d wg/CU] %6.0f cycles / tile / wave (MFMA issue alone 1536) -> %4.0f per SIMD and tile; kernel %7.1f us = %5.0f TFLOP/s executed\n", name, occ, avg, avg / (WAVES / 4), ms * 1e3,
+           flops / (ms * 1e-3) / 1e12);
+    hipFree(out); hipFree(cyc);
+}
+
+int main() {
+    // N(0,1) f16 operands
+    const int nin = 64 * 8, nkv = 4 * PLANE;
+    f16x8* in; char* kv;
+    CHECK(hipMalloc(&in, nin * sizeof(f16x8))); CHECK(hipMalloc(&kv, nkv));
+    {
+        _Float16* h = (_Float16*)malloc(nin * 16); _Float16* hk = (_Float16*)malloc(nkv);
+        srand(1);
+        auto nrm = [] { float s = 0; for (int i = 0; i < 12; ++i) s += rand() / (float)RAND_MAX; return s - 6.f; };
+        for (int i = 0; i < nin * 8; ++i) h[i] = (_Float16)(0.3f * nrm());
+        for (int i = 0; i < nkv / 2; ++i) hk[i] = (_Float16)(((i / (PLANE / 2)) & 1) ? 4.8828125e-4f * nrm() : nrm());
+        CHECK(hipMemcpy(in, h, nin * 16, hipMemcpyHostToDevice)); CHECK(hipMemcpy(kv, hk, nkv, hipMemcpyHostToDevice));
+    }
+    for (int rep = 0; rep < 2; ++rep) {
+        run<0, 4>("phases, one wave per SIMD", in, kv);
+        run<0, 8>("phases, two waves per SIMD (8-wave workgroup, barrier per tile)", in, kv);
+        run<1, 4>("pipelined, one wave per SIMD", in, kv);
+        run<1, 8>("pipelined, two waves per SIMD (8-wave workgroup)", in, kv);
+    }
+    return 0;
+}

@@ -178,6 +178,37 @@ def test_single_pair_regime_of_inference_py(gpu_device, D, n, B, iters):
     assert bad == 0 and int(diff.sum()) <= 2, (int(diff.sum()), bad)
 
 
+@pytest.mark.parametrize("D,n", [(256, 1024), (128, 2048)])
+def test_key_split_hand_over_is_placement_independent(gpu_device, monkeypatch, D, n):
+    """The key range of a query tile is split over 2 / 4 WORKGROUPS for one or two pairs (attention.hip, GS); their partial (O, m, l) meet in scratch.
+    The hardware guide calls the workgroup -> XCD map undefined, so the hand-over must not rest on it: OG_ATTN_GS_SCATTER=1 deals the parts of every
+    tile to CONSECUTIVE workgroups (= different XCDs under the round-robin dispatch), where the last arriver sees foreign XCC ids in the counter word
+    and takes the agent-scope acquire.  Same arithmetic in the same order either way, so the scores must be BIT-identical to the co-located run --
+    repeatedly, with a second stream keeping part of the chip busy (a stale line shows up under uneven load, not on an idle chip)."""
+    cfg = syn.make_config(descriptor_dim=D, num_stages=3, num_heads=4, num_iters=10, side_info_size=1)
+    sd = syn.make_state_dict(cfg, seed=0)
+    model = _build(cfg, sd, gpu_device)
+    data = to_device(syn.make_batch(1, n, n - 37, D, 1, seed=5), gpu_device)
+    monkeypatch.delenv("OG_ATTN_GS_SCATTER", raising=False)
+    base = model(data)["scores"].clone()
+    side = torch.cuda.Stream(device=gpu_device)
+    a = torch.randn(2048, 2048, device=gpu_device)
+    for rep in range(12):
+        monkeypatch.setenv("OG_ATTN_GS_SCATTER", "1" if rep % 2 == 0 else "0")
+        with torch.cuda.stream(side):
+            for _ in range(1 + rep % 3):
+                a = (a @ a) * 1e-3
+        got = model(data)["scores"]
+        assert model.check_status() == 0
+        assert torch.equal(got, base), (rep, (got - base).abs().max().item())
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref = orc.superglue_forward(sd, cfg, {k: v.cpu() for k, v in data.items()})["scores"]
+    err = (base.cpu() - ref).abs().max().item()
+    parity_note(f"[key split, scattered parts D={D} n={n}] bit-identical to the co-located run over 12 calls; scores err {err:.2e}")
+    assert err < TOL_SCORES
+
+
 def test_dustbin_dominated_regime_unit_norm_descriptors(gpu_device):
     """Unit-norm descriptors with random-init weights: every keypoint goes to the dustbin, 0 valid matches, top-1/top-2 gaps
     of a few 1e-6 -- the regime real SuperPoint/SIFT inputs are in before training.  Scores must
