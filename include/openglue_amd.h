@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define OG_ABI_VERSION 9
+#define OG_ABI_VERSION 10
 
 #define OG_E_INVALID   (-1)  /* NULL pointer / non-positive size                         */
 #define OG_E_SHAPE     (-2)  /* unsupported shape (see og_check_shape)                   */
@@ -294,10 +294,12 @@ int og_gemm_nt_f16x3_reshl(const void* A, int64_t lda, const void* B, int64_t ld
  * 1 / 256 for streams packed here.  Same arithmetic as og_gemm_nt_f16x3.  ABI v8: og_proj_block takes K; launches of more than 8192 rows whose column
  * ranges are whole groups of 128 channels (and split_row a multiple of 128, yh / yl 128-byte aligned) take the batch kernel (proj_stream_kernel:
  * 128-token workgroups, the x fragments in registers, weights through an LDS ring) -- og_proj_block_pack writes its stream behind the small-batch
- * one, ldy must then equal N.  OG_PROJ_STREAM=0 / 1 forces either kernel. */
+ * one.  OG_PROJ_STREAM=0 / 1 forces either kernel.  ABI v10: N (the row count of W the stream was packed for) is an argument -- it locates the batch
+ * stream behind the small-batch one; before, it was read off ldy, which silently mis-addressed the stream for an output plane padded beyond N.
+ * ldy >= N, a multiple of 64 halves for the batch kernel. */
 size_t og_proj_block_stream_bytes(int32_t N, int32_t K);
 int og_proj_block_pack(int32_t N, int32_t K, const float* W, void* stream_host);
-int og_proj_block(const void* x_rows, int64_t ld, int32_t M, int32_t K, const void* stream_dev, const float* bias, const float* inv_scale_dev,
+int og_proj_block(const void* x_rows, int64_t ld, int32_t M, int32_t K, int32_t N, const void* stream_dev, const float* bias, const float* inv_scale_dev,
                   void* yh, void* yl, int64_t ldy, int32_t split_row, int32_t a0, int32_t a1, int32_t b0, int32_t b1, void* stream);
 
 size_t og_mlp_block_stream_bytes(int32_t D);

@@ -11,7 +11,7 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OPENGLUE_AMD_LIB") or os.path.join(HERE, "lib", "libopenglue_amd.so")   # override: A/B builds
 
-OG_ABI_VERSION = 9
+OG_ABI_VERSION = 10
 OG_FLAG_RESIDUAL, OG_FLAG_USE_OFFSET, OG_FLAG_NO_DESCRIPTORS, OG_FLAG_SIREN_ENCODER, OG_FLAG_LINEAR_ATTENTION = 1, 2, 4, 8, 16
 OG_FLAG_FAVOR_RELU = 32
 OG_MAX_HIDDEN = 8
@@ -108,7 +108,7 @@ SYMBOLS = {
                                          _vp, _vp, _i64, _i32, _vp]),
     "og_proj_block_stream_bytes": (_sz, [_i32, _i32]),
     "og_proj_block_pack": (C.c_int, [_i32, _i32, _vp, _vp]),
-    "og_proj_block": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "og_proj_block": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
     "og_mlp_block_stream_bytes": (_sz, [_i32]),
     "og_mlp_block_pack": (C.c_int, [_i32, _vp, _vp, _vp]),
     "og_mlp_block": (C.c_int, [_i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),

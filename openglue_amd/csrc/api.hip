@@ -5,6 +5,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <dlfcn.h>
+#include <stdio.h>
 
 #include "og_common.h"
 
@@ -72,7 +74,9 @@ PackedLayout packed_layout(const og_shape& s) {
         L.o_wqkvs = lo; lo = al64(lo + (int64_t)(og_proj_stream_bytes(qkv_width(s), (int)D) / 4));
     }
     L.o_wqkvb = -1;
-    if (!(s.flags & OG_FLAG_FAVOR_RELU) && og_proj_stream_big_bytes(qkv_width(s), (int)D)) {
+    // only where og_forward can take the batch projection kernel: the 128-d family (at D = 256 the copy was 0.75 MB per layer of dead weight and
+    // packing time; the K = 256 form of the kernel stays reachable through the stage entry og_proj_block, which packs its own stream)
+    if (!(s.flags & OG_FLAG_FAVOR_RELU) && D == 128 && og_proj_stream_big_bytes(qkv_width(s), (int)D)) {
         L.o_wqkvb = lo; lo = al64(lo + (int64_t)(og_proj_stream_big_bytes(qkv_width(s), (int)D) / 4));
     }
     L.layer_stride = lo;
@@ -404,6 +408,35 @@ struct Profiler {
     }
     void end(int i) { if (i >= 0) (void)hipEventRecord(ev[2 * i + 1], st); }
 };
+// roctx ranges around the stages of a forward (tracing): OG_ROCTX=1 makes every og_forward* call push / pop named ranges --
+// "og_forward", "encoder", "gnn self l", "gnn cross l", "final_proj", "scores", "sinkhorn", "matches" -- which `rocprofv3 --marker-trace` records next to the
+// kernel trace.  The marker library is looked up at run time (no link dependency; absent library or unset variable: the calls are no-ops).
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        const char* e = getenv("OG_ROCTX");
+        if (!e || e[0] != '1') return;
+        for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) continue;
+            push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+            pop = (int (*)())dlsym(h, "roctxRangePop");
+            if (push && pop) return;
+            push = nullptr; pop = nullptr;
+        }
+    }
+};
+struct Range {
+    static const Roctx& rt() { static const Roctx r; return r; }
+    bool on;
+    explicit Range(const char* name) : on(rt().push != nullptr) { if (on) rt().push(name); }
+    Range(const char* name, int idx) : on(rt().push != nullptr) {
+        if (on) { char buf[48]; snprintf(buf, sizeof buf, "%s %d", name, idx); rt().push(buf); }
+    }
+    ~Range() { if (on) rt().pop(); }
+    Range(const Range&) = delete;
+};
 struct Scope {
     Profiler* p; int i;
     Scope(Profiler* pp, int c) : p(pp), i(pp ? pp->begin(c) : -1) {}
@@ -470,8 +503,10 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
         return og_launch_gemm_f16x3(g, st);
     };
 
+    Range r_forward("og_forward");
     // ---- 1. keypoint encoder (superglue.py:41-55): x = desc + MLP([k^, side]) -> X32 and the x half of XO ----
     {
+        Range r_stage("encoder");
         float* EI = ws + W.ei;         // [T][32]
         float* Ea = ws + W.ea;         // [T][enc_maxw]
         float* Eb = ws + W.eb;
@@ -608,12 +643,16 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
     for (int l = 0; l < s.num_stages; ++l) {
         // self layer 2l: both images through the same weights (attention_gnn.py:63-66)
         const float* lw = pk + L.layer0 + (int64_t)(2 * l) * L.layer_stride;
-        if ((rc = qkv_proj(lw, 0, T, 0, QW))) return rc;
-        if ((rc = attention(2 * B, B, 0, m, m, 0, m, m, T0, n, n, T0, n, n, 1))) return rc;
-        if ((rc = mlp(lw, 0, T))) return rc;
+        {
+            Range r_stage("gnn self", l);
+            if ((rc = qkv_proj(lw, 0, T, 0, QW))) return rc;
+            if ((rc = attention(2 * B, B, 0, m, m, 0, m, m, T0, n, n, T0, n, n, 1))) return rc;
+            if ((rc = mlp(lw, 0, T))) return rc;
+        }
         if ((rc = tap_here(2 * l + 1))) return rc;
         // cross layer 2l+1: image 0 first, then image 1 against the UPDATED image 0 (attention_gnn.py:74-77)
         lw = pk + L.layer0 + (int64_t)(2 * l + 1) * L.layer_stride;
+        Range r_stage("gnn cross", l);
         for (int side = 0; side < 2; ++side) {
             const int64_t qr0 = side ? T0 : 0, qR = side ? T1 : T0;       // query rows
             if (side == 0) {
@@ -652,6 +691,7 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
     //         channel-first context_descriptors.  Split-f16 kernel on the x rows of XO (fp32-class, 16/3 the fp32-MFMA rate).
     _Float16* Gh = (_Float16*)G;                       // [T] hl32 rows of 2D halves (the slot holds T*D floats)
     for (int side = 0; side < 2; ++side) {
+        Range r_stage("final_proj", side);
         const int64_t r0 = side ? T0 : 0, R = side ? T1 : T0;
         const bool resid = s.flags & OG_FLAG_RESIDUAL;
         GemmHArgs g{};
@@ -675,6 +715,7 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
         g.scale = (float)pow((double)D, -0.5);
         g.rag = rag;                       // ragged: pair z multiplies rows off0[z].. of G by rows T0 + off1[z].. of G
         if (rag) g.B = Gh;
+        Range r_stage("scores");
         Scope sc(prof, OG_STAGE_GEMM_F16X3);
         if (B > 1 || rag) rc = og_launch_gemm_f16x3(g, st);
         else { g.batch = 0; rc = og_launch_gemm_f16x3(g, st); }
@@ -683,6 +724,7 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
 
     // ---- 5. Sinkhorn with dustbins -> scores (superglue.py:88-111) ----
     {
+        Range r_stage("sinkhorn");
         Scope sc(prof, OG_STAGE_SINKHORN);
         // with matches requested, the scores kernel also leaves every row's max / argmax in the extraction's workspace
         RowBest rb{nullptr, nullptr, 0};
@@ -693,6 +735,7 @@ int forward_impl(const og_shape* shape, const og_inputs* in, const void* packed_
 
     // ---- 6. mutual-NN matches (matching_module.py:174-187) ----
     if (outp->matches0) {
+        Range r_stage("matches");
         Scope sc(prof, OG_STAGE_MATCHES);
         if ((rc = og_launch_matches(outp->scores, B, m, n, s.match_threshold, outp->matches0, outp->matching_scores0,
                                     outp->matches1, outp->matching_scores1, ws + W.match, st, rag, true))) return rc;

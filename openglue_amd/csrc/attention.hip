@@ -109,6 +109,10 @@ __device__ __forceinline__ void lds_read_tr8_b64(i32x2& d, unsigned addr) {
     asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
 }
 
+// pipelined loop: K fragment read order -- pieces 0, 1 = hi of key blocks 0, 1 (double-buffered by chunk), 2, 3 = lo (ONE buffer: the pass-0 MFMAs alone read it)
+// -> read_k1's piece index (key block j >> 1, plane j & 1)
+__device__ constexpr int og_korder(int q) { return q == 0 ? 0 : q == 1 ? 2 : q == 2 ? 1 : 3; }
+
 template <int DH, class RD>
 __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a, RD rd) {
     constexpr int DHP = DH < 32 ? 32 : DH;        // Vᵀ rows padded to a full 32-row MFMA tile
@@ -473,6 +477,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a, RD rd) {
 #ifndef OG_ATTN_ABL16
 #define OG_ATTN_ABL16 0
 #endif
+#ifndef OG_PIPE_ABL
+#define OG_PIPE_ABL 0          // timing experiments on the pipelined loop (results WRONG): 1 = no DMA inside the steps, 2 = no barrier between the steps
+#endif
 __device__ __forceinline__ f32x16 og_attn_mfma(f16x8 a, f16x8 b, f32x16 c) {
 #if OG_ATTN_ABL16
     typedef float f32x4_ __attribute__((ext_vector_type(4)));
@@ -496,7 +503,9 @@ __device__ __forceinline__ f32x16 og_attn_mfma(f16x8 a, f16x8 b, f32x16 c) {
 // [e4m3(V 2^-sv) x DH | e4m3((V - Vh) 2^(11 - sv)) x DH] (one byte per element: the same bytes as the f16 lo row) written by the projection epilogue;
 // P8h = e4m3(P), P8l = e4m3((P - Ph) 2^11) are made next to the f16 hi parts.  Per 64-key tile and dv block, Ph.Vl + Pl.Vh = 2^(sv - 11) (P8h.V8lo + P8l.V8hi):
 // two v_mfma_scale_f32_32x32x64_f8f6f4 (k = the lane's own 32 keys of the tile, constant E8M0 scales) instead of eight 32x32x16 f16 MFMAs.
-template <int DH, class RD, int KS = 1, int GS = 1, int MX = 0>
+// PIPE = 1 (round 6): the tile loop software-pipelined inside every wave -- one stream of 48 MFMAs per step, PV(t-1) then QK^T(t+1), with softmax(t)
+// dealt out behind them in pieces of <= 7 vector instructions (comment at the loop).
+template <int DH, class RD, int KS = 1, int GS = 1, int MX = 0, int PIPE = 0>
 #ifndef OG_ATTN_WG32
 #define OG_ATTN_WG32 2        // workgroups per CU the dh = 32 instantiation is compiled for (experiment: 3)
 #endif
@@ -579,6 +588,7 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
     const int rl = lane / LPR, pc = lane % LPR;
     const int ldkb = (int)a.ldk * 2, ldvb = (int)a.ldv * 2;          // row strides in bytes
     [[maybe_unused]] const unsigned lds0_dma = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    [[maybe_unused]] __attribute__((address_space(3))) char* const smem_lds = (__attribute__((address_space(3))) char*)smem;
     unsigned ksw[2], vsw;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -645,7 +655,9 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
 #else
         int r = wave * 16 + i * RPI + rl;
         r = r < last ? r : last;
-        char* dst = smem + b * BUFB + (wave * 16 + i * RPI) * ROWB + pp * 2 * PLANE;
+        // (an LDS-typed base cast once at kernel entry: a generic -> LDS cast at a call site the optimiser cannot see through emits an illegal
+        //  V_CMP against src_shared_base on this compiler)
+        __attribute__((address_space(3))) char* const dst = smem_lds + b * BUFB + (wave * 16 + i * RPI) * ROWB + pp * 2 * PLANE;
         if constexpr (pp == 0) {
             const int64_t o = k_tile0 + (int64_t)key0 * ldkb + (unsigned)(r * ldkb) + ksw[i];
             __builtin_amdgcn_global_load_lds((og_glb_void*)(reinterpret_cast<const char*>(a.kh) + o), (og_lds_void*)(dst), 16, 0, 0);
@@ -669,6 +681,10 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
     };
     const int ntiles = (nk + KV_TILE - 1) / KV_TILE;
     if (ntiles > 0) issue_tile(0, std::integral_constant<int, 0>{});
+    if constexpr (PIPE) {        // the pipelined loop computes QK^T one tile ahead: K(1) travels with tile 0
+        static_assert(KS == 1 && GS == 1 && MX == 0, "the pipelined loop is built for the batch form");
+        if (ntiles > 1) static_for<NPI>([&](auto I) { issue_pair(1, std::integral_constant<int, 1>{}, I, std::integral_constant<int, 0>{}); });
+    }
 
     // ---- Q fragments (B operand): lane (query l31, k-group hi) holds Q[q][16c + 8hi + e] ----
     f16x8 qh[NCH], ql[NCH];
@@ -1014,6 +1030,287 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
             for (int i = 0; i < 8; ++i) og_attn_trace_buf[tsel][wave][kt][i] = tp[i];
 #endif
     };
+
+    // ---------------------------------------------------------------------------------------------------------------------------------------------
+    // PIPE: the software-pipelined tile loop (round 6).  The phase structure above -- QK^T(t) | softmax(t) | PV(t) per wave -- leaves the matrix pipe of
+    // a SIMD to whichever OTHER wave happens to be in a matrix phase; measured (scripts/probes/attn_pipe.hip, profiles/r06_b_probe_attn_pipe.log) the same
+    // instruction mix costs 1932 cycles per SIMD and tile in phases and 1535 (= the 48 MFMAs' own issue time) when every wave runs ONE continuous MFMA
+    // stream with the vector work of another tile dealt out behind the MFMAs.  Step t of a wave:
+    //     MFMAs  0..23   O += V(t-1)^T P(t-1)^T      (4 groups of 16 keys; the V fragments of group g+1 are read behind the MFMAs of group g)
+    //     MFMAs 24..47   S(t+1) = K(t+1) Q^T - m_run   (4 chunks of 16 channels; K fragments one chunk ahead)
+    //     vector stream  softmax(t): 8 blocks of 4 scores = 4 v_exp, the (hi, lo) split, 4 row-sum adds; block 0 in front of the first MFMA (it covers
+    //                    the latency of the first V reads), block k behind MFMAs 6 (k - 1) .. 6 (k - 1) + 4 in five pieces
+    //     DMA            V(t) and K(t+2) into the OTHER buffer (its V was consumed by PV(t-2), its K by QK^T(t), both in step t-1), wave w's four
+    //                    instruction pairs behind MFMAs 2 + 12 j + 3 w
+    //     end of step    the running max (rare slow path: rescale O, l, S(t), S(t+1), redo P(t)), s_waitcnt vmcnt(0), ONE barrier
+    // State in registers between steps: S(t) and P(t-1) in, S(t+1) and P(t) out -- two sets used alternately (steps AB and BA), so nothing is copied.
+    // Buffer b = (t - 1) & 1 holds V(t-1) and K(t+1).  Prologue: QK^T(0), softmax(0) on the slow path (it sets m_run), QK^T(1).
+    if constexpr (PIPE) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        f32x16 sA[2], sB[2];
+        u32x4 pfA[2][2], plA[2][2], pfB[2][2], plB[2][2];
+        auto fence = [] { __builtin_amdgcn_sched_barrier(0); };
+        // LDS reads of buffer b (compile-time), one instruction per call
+        auto read_k1 = [&](auto BUF, auto C, auto J) {
+            constexpr int b = decltype(BUF)::value, c = decltype(C)::value, j = decltype(J)::value, kb = j >> 1;
+            if constexpr ((j & 1) == 0) lds_read_b128<b * BUFB + kb * 32 * ROWB>(kh[c & 1][kb], kf[c]);
+            else lds_read_b128<b * BUFB + PLANE + kb * 32 * ROWB>(kl[0][kb], kf[c]);
+        };
+        auto read_v1 = [&](auto BUF, auto G, auto J) {
+            constexpr int b = decltype(BUF)::value, g = decltype(G)::value, j = decltype(J)::value, d = j >> 2, off = b * BUFB + 2 * PLANE + g * 16 * ROWB;
+            if constexpr ((j & 3) == 0) lds_read_tr16_b64<off>(vh0[g & 1][d], va[d]);
+            else if constexpr ((j & 3) == 1) lds_read_tr16_b64<off + 8 * ROWB>(vh1[g & 1][d], va[d]);
+            else if constexpr ((j & 3) == 2) lds_read_tr16_b64<off + PLANE>(vl0[0][d], va[d]);
+            else lds_read_tr16_b64<off + PLANE + 8 * ROWB>(vl1[0][d], va[d]);
+        };
+        auto add1 = [](float& acc, float x) { acc += x; asm("" : "+v"(acc)); };
+        // the whole softmax of one tile in one go: prologue (tile 0) and the slow path
+        auto exp_split_all = [&](f32x16 (&sc)[2], u32x4 (&pf)[2][2], u32x4 (&pl)[2][2]) -> float {
+            float ps0 = 0.f, ps1 = 0.f, ps2 = 0.f, ps3 = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; r += 4) {
+                    const float p0 = __builtin_amdgcn_exp2f(sc[kb][r]), p1 = __builtin_amdgcn_exp2f(sc[kb][r + 1]);
+                    const float p2 = __builtin_amdgcn_exp2f(sc[kb][r + 2]), p3 = __builtin_amdgcn_exp2f(sc[kb][r + 3]);
+                    add1(ps0, p0); add1(ps1, p1); add1(ps2, p2); add1(ps3, p3);
+                    unsigned ha, la, hb, lb;
+                    og_split4(p0, p1, p2, p3, ha, la, hb, lb);
+                    pf[kb][r >> 3][(r & 7) >> 1] = ha; pf[kb][r >> 3][((r & 7) >> 1) + 1] = hb;
+                    pl[kb][r >> 3][(r & 7) >> 1] = la; pl[kb][r >> 3][((r & 7) >> 1) + 1] = lb;
+                }
+            return (ps0 + ps1) + (ps2 + ps3);
+        };
+        auto row_max = [&](const f32x16 (&sc)[2]) -> float {
+            float mt = sc[0][0];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sc[kb][r]);
+            // the other half of the keys sits 32 lanes away: v_permlane32_swap (no address register, no LDS round trip, unlike ds_bpermute)
+            // (inline asm on two distinct registers: given the same value twice, the builtin's result lost its second half -- the fmaxf below was folded away)
+            float a0 = mt, a1 = mt;
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a0), "+v"(a1));
+            return fmaxf(a0, a1);
+        };
+        auto mask_tile = [&](f32x16 (&sc)[2], int key0) {          // padded keys of the last tile -> -inf
+            int ln = lane;
+            asm volatile("" : "+v"(ln));          // opaque: the 32 key indices are made HERE, in the rare branch (hoisted out of the loop they were spilled)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key0 + kb * 32 + mfma32_row(r, ln);
+                    sc[kb][r] = key < nk ? sc[kb][r] : OG_NEG_INF;
+                }
+        };
+        // S(kt) = K(kt) Q^T - m_run from buffer b, on its own (prologue only)
+        auto qk_alone = [&](auto BUF, f32x16 (&sn)[2], int kt) {
+            fence();
+            static_for<4>([&](auto J) { read_k1(BUF, std::integral_constant<int, 0>{}, J); });
+            static_for<NCH>([&](auto C) {
+                constexpr int c = decltype(C)::value, cb = c & 1;
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kh[cb][0]), "+v"(kh[cb][1]), "+v"(kl[0][0]), "+v"(kl[0][1]) :: "memory");
+                fence();
+                static_for<6>([&](auto M) {
+                    constexpr int m = decltype(M)::value, kb = m & 1, pass = m >> 1;
+                    if constexpr (pass == 0) sn[kb] = og_attn_mfma(kl[0][kb], qh[c], c == 0 ? negm : sn[kb]);
+                    else if constexpr (pass == 1) sn[kb] = og_attn_mfma(kh[cb][kb], ql[c], sn[kb]);
+                    else sn[kb] = og_attn_mfma(kh[cb][kb], qh[c], sn[kb]);
+                    fence();
+                    if constexpr (m < 4 && c + 1 < NCH) { read_k1(BUF, std::integral_constant<int, c + 1>{}, std::integral_constant<int, og_korder(m)>{}); fence(); }
+                });
+            });
+            if (kt * KV_TILE + KV_TILE > nk) mask_tile(sn, kt * KV_TILE);
+        };
+        // One step.  BUF: the buffer of V(t-1) and K(t+1); (sc, pf, pl) = S(t), P(t-1) in; (sn, nf, nl) = S(t+1), P(t) out.  The last two steps have no
+        // QK^T (no tile t+1), the last one no softmax either: wave-uniform run-time branches inside ONE body per buffer parity -- eight compile-time variants
+        // of a 48-MFMA body cost ~70 KB of code and register-allocation trouble at their joins (spills; a spilled LDS-read destination is stored BEFORE its
+        // data arrive, so spills are not only slow here, they are wrong).  The last step's vector stream runs on dead score registers; its results are unused.
+        auto step = [&](int t, auto BUF, f32x16 (&sc)[2], u32x4 (&pfw)[2][2], u32x4 (&plw)[2][2], f32x16 (&sn)[2], u32x4 (&nfw)[2][2], u32x4 (&nlw)[2][2]) {
+            constexpr int b = decltype(BUF)::value;
+            using BB = std::integral_constant<int, b>; using BO = std::integral_constant<int, b ^ 1>;
+            const bool has_soft = t < ntiles, has_qk = t + 1 < ntiles;
+            const bool dma_v = t < ntiles, dma_k = t + 2 < ntiles;             // V(t), K(t+2) -> buffer b ^ 1
+            float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f, ps0 = 0.f, ps1 = 0.f, ps2 = 0.f, ps3 = 0.f;
+            // P(t) is written word by word: "define" the eight vectors first, or the words not written yet keep the previous contents alive (32 registers)
+            asm volatile("" : "=v"(nfw[0][0]), "=v"(nfw[0][1]), "=v"(nfw[1][0]), "=v"(nfw[1][1]), "=v"(nlw[0][0]), "=v"(nlw[0][1]), "=v"(nlw[1][0]), "=v"(nlw[1][1]));
+            // softmax(t), block blk = (key block blk >> 2, registers 4 (blk & 3) ..), piece ph
+            auto soft = [&](auto BLK, auto PH) {
+                constexpr int blk = decltype(BLK)::value, ph = decltype(PH)::value, kb = blk >> 2, r = 4 * (blk & 3);
+                if constexpr (ph == 0) { p0 = __builtin_amdgcn_exp2f(sc[kb][r]); p1 = __builtin_amdgcn_exp2f(sc[kb][r + 1]); }
+                else if constexpr (ph == 1) { p2 = __builtin_amdgcn_exp2f(sc[kb][r + 2]); p3 = __builtin_amdgcn_exp2f(sc[kb][r + 3]); }
+                else if constexpr (ph == 2) {
+                    unsigned ha, la, hb, lb;
+                    og_split4(p0, p1, p2, p3, ha, la, hb, lb);
+                    nfw[kb][r >> 3][(r & 7) >> 1] = ha; nfw[kb][r >> 3][((r & 7) >> 1) + 1] = hb;
+                    nlw[kb][r >> 3][(r & 7) >> 1] = la; nlw[kb][r >> 3][((r & 7) >> 1) + 1] = lb;
+                } else if constexpr (ph == 3) { add1(ps0, p0); add1(ps1, p1); }
+                else if constexpr (ph == 4) { add1(ps2, p2); add1(ps3, p3); }
+                fence();
+            };
+            // behind slot mm of the step: the softmax piece and, for the wave whose turn it is, one DMA pair
+            auto behind = [&](auto MM) {
+                constexpr int mm = decltype(MM)::value;
+                if constexpr (mm % 6 < 5 && mm / 6 + 1 < 8) soft(std::integral_constant<int, mm / 6 + 1>{}, std::integral_constant<int, mm % 6>{});
+                if constexpr (mm >= 2 && (mm - 2) % 3 == 0) {
+                    constexpr int j = (mm - 2) / 12, w = ((mm - 2) % 12) / 3;       // pair j: 0, 1 = K(t+2) pieces, 2, 3 = V(t) pieces
+                    constexpr int i = j & 1, pp = j >> 1;
+                    if constexpr (i < NPI) {
+#if !(OG_PIPE_ABL & 1)
+                        if (wave == w && (pp == 0 ? dma_k : dma_v)) issue_pair(pp == 0 ? t + 2 : t, BO{}, std::integral_constant<int, i>{}, std::integral_constant<int, pp>{});
+                        fence();
+#endif
+                    }
+                }
+            };
+            // a step has 24 NDV MFMAs and 48 slots for the vector / DMA pieces: 2 / NDV slots behind every MFMA
+            auto after_mfma = [&](auto K) {
+                constexpr int k = decltype(K)::value, SPM = 2 / NDV;
+                static_for<SPM>([&](auto I) { behind(std::integral_constant<int, k * SPM + decltype(I)::value>{}); });
+            };
+            fence();
+            // the first V fragments of tile t-1; the running-max decision and block 0 of the softmax cover their latency
+            static_for<4 * NDV>([&](auto J) { read_v1(BB{}, std::integral_constant<int, 0>{}, J); });
+            fence();
+            // ---- the running max moves BEFORE the exponentials (the phase form reads the need off the row sum afterwards and keeps S(t) alive for a second
+            //      pass; here the 32 score registers must die block by block -- the step holds S(t+1), P(t-1) and P(t) next to them -- and the max tree's
+            //      ~16 vector instructions ride in front of the first MFMA, where the wave waits for its V fragments anyway).  Slow path (rare): new
+            //      m_run, S(t) -= delta at once; O and l, which still gather P(t-1) V(t-1) at the OLD scale in this step, are rescaled at its end. ----
+            float alpha = 1.f;
+            bool moved = false;
+            if (has_soft) {
+                const float mt = row_max(sc);
+                moved = __any(mt > RESCALE_THR);
+                if (moved) {
+                    const float delta = fmaxf(mt, 0.f);
+                    m_run += delta;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) negm[r] = -m_run;
+                    alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sc[kb][r] -= delta;
+                }
+            }
+            fence();
+            static_for<5>([&](auto PH) { soft(std::integral_constant<int, 0>{}, PH); });
+            // ---- O^T += V(t-1)^T P(t-1)^T ----
+            static_for<4>([&](auto G) {
+                constexpr int g = decltype(G)::value, gb = g & 1, kb = g >> 1, tt = g & 1;
+                if constexpr (NDV == 2)
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vh0[gb][0]), "+v"(vh1[gb][0]), "+v"(vl0[0][0]), "+v"(vl1[0][0]),
+                                 "+v"(vh0[gb][NDV - 1]), "+v"(vh1[gb][NDV - 1]), "+v"(vl0[0][NDV - 1]), "+v"(vl1[0][NDV - 1]) :: "memory");
+                else
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vh0[gb][0]), "+v"(vh1[gb][0]), "+v"(vl0[0][0]), "+v"(vl1[0][0]) :: "memory");
+                fence();
+                f16x8 vh[NDV], vl[NDV];
+#pragma unroll
+                for (int d = 0; d < NDV; ++d) {
+                    vh[d] = __builtin_bit_cast(f16x8, __builtin_shufflevector(vh0[gb][d], vh1[gb][d], 0, 1, 2, 3, 4, 5, 6, 7));
+                    vl[d] = __builtin_bit_cast(f16x8, __builtin_shufflevector(vl0[0][d], vl1[0][d], 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+                const f16x8 pf = __builtin_bit_cast(f16x8, pfw[kb][tt]), pl = __builtin_bit_cast(f16x8, plw[kb][tt]);
+                static_for<3 * NDV>([&](auto M) {
+                    constexpr int m = decltype(M)::value, d = m % NDV, pass = m / NDV;
+                    if constexpr (pass == 0) oacc[d] = og_attn_mfma(vl[d], pf, oacc[d]);
+                    else if constexpr (pass == 1) oacc[d] = og_attn_mfma(vh[d], pl, oacc[d]);
+                    else oacc[d] = og_attn_mfma(vh[d], pf, oacc[d]);
+                    fence();
+                    // the next group's fragments.  The lo fragments are SINGLE-buffered (16 registers less): they feed the pass-0 MFMAs only (m < NDV), so
+                    // their next reads go out behind the later MFMAs of the group, the double-buffered hi fragments behind the first ones.
+                    if constexpr (g + 1 < 4) {
+                        if constexpr (m < NDV) {                       // hi of dv block m
+                            read_v1(BB{}, std::integral_constant<int, g + 1>{}, std::integral_constant<int, 4 * m>{});
+                            read_v1(BB{}, std::integral_constant<int, g + 1>{}, std::integral_constant<int, 4 * m + 1>{});
+                            fence();
+                        } else if constexpr (m < 2 * NDV) {            // lo of dv block m - NDV: every pass-0 MFMA has been issued
+                            read_v1(BB{}, std::integral_constant<int, g + 1>{}, std::integral_constant<int, 4 * (m - NDV) + 2>{});
+                            read_v1(BB{}, std::integral_constant<int, g + 1>{}, std::integral_constant<int, 4 * (m - NDV) + 3>{});
+                            fence();
+                        }
+                    } else if constexpr (m >= 3 * NDV - 4 || NDV == 1) {          // the first K fragments of tile t+1 (hi first, see the QK^T loop)
+                        constexpr int q = NDV == 2 ? m - 2 : m;                   // NDV = 2: behind MFMAs 2..5; NDV = 1: 0..2, the fourth with the third
+                        if constexpr (q >= 0) {
+                            if (has_qk) read_k1(BB{}, std::integral_constant<int, 0>{}, std::integral_constant<int, og_korder(q)>{});
+                            if constexpr (NDV == 1 && m == 2) { if (has_qk) read_k1(BB{}, std::integral_constant<int, 0>{}, std::integral_constant<int, og_korder(3)>{}); }
+                            fence();
+                        }
+                    }
+                    after_mfma(std::integral_constant<int, 3 * NDV * g + m>{});
+                });
+            });
+            // ---- S(t+1) = K(t+1) Q^T - m_run ----
+            if (has_qk) {
+                static_for<NCH>([&](auto C) {
+                    constexpr int c = decltype(C)::value, cb = c & 1;
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kh[cb][0]), "+v"(kh[cb][1]), "+v"(kl[0][0]), "+v"(kl[0][1]) :: "memory");
+                    fence();
+                    static_for<6>([&](auto M) {
+                        constexpr int m = decltype(M)::value, kb = m & 1, pass = m >> 1;
+                        if constexpr (pass == 0) sn[kb] = og_attn_mfma(kl[0][kb], qh[c], c == 0 ? negm : sn[kb]);
+                        else if constexpr (pass == 1) sn[kb] = og_attn_mfma(kh[cb][kb], ql[c], sn[kb]);
+                        else sn[kb] = og_attn_mfma(kh[cb][kb], qh[c], sn[kb]);
+                        fence();
+                        // the next chunk's fragments: hi (double-buffered) behind MFMAs 0, 1; lo (single-buffered, read by MFMAs 0, 1 only) behind 2, 3
+                        if constexpr (m < 4 && c + 1 < NCH) { read_k1(BB{}, std::integral_constant<int, c + 1>{}, std::integral_constant<int, og_korder(m)>{}); fence(); }
+                        after_mfma(std::integral_constant<int, 12 * NDV + 6 * c + m>{});
+                    });
+                });
+                if ((t + 1) * KV_TILE + KV_TILE > nk) mask_tile(sn, (t + 1) * KV_TILE);
+            } else {
+                // no QK^T in this step: the rest of the softmax and of the DMA slots on their own
+                static_for<24>([&](auto M) { behind(std::integral_constant<int, 24 + decltype(M)::value>{}); });
+                asm volatile("" : "=v"(sn[0]), "=v"(sn[1]));      // S(t+1) does not exist: "defined" here, so that the old contents are not kept alive through the step
+            }
+            // ---- l and, after a move of the running max, O: every P(t-1) V(t-1) product of this step is in ----
+            if (has_soft) {
+                if (moved) {
+#pragma unroll
+                    for (int d = 0; d < NDV; ++d)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+                }
+                l_run = l_run * alpha + ((ps0 + ps1) + (ps2 + ps3));
+            }
+            if (t < ntiles) {               // another step follows: its V(t) / K(t+2) pieces landed, everybody is done with this step's buffer
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if !(OG_PIPE_ABL & 2)
+                __syncthreads();
+#endif
+            }
+        };
+        using B0 = std::integral_constant<int, 0>; using B1 = std::integral_constant<int, 1>;
+        // ---- prologue: S(0) -> m_run, P(0); S(1) ----
+        qk_alone(B0{}, sB, 0);
+        {
+            const float mt = row_max(sB);
+            m_run = mt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) negm[r] = -m_run;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sB[kb][r] -= mt;
+            l_run = exp_split_all(sB, pfA, plA);
+        }
+        if (ntiles > 1) {
+            __syncthreads();                                     // everybody has read K(0): its planes take K(2)
+            if (ntiles > 2) static_for<NPI>([&](auto I) { issue_pair(2, B0{}, I, std::integral_constant<int, 0>{}); });
+            qk_alone(B1{}, sA, 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        // ---- steps t = 1 .. ntiles: AB (t odd, buffer 0) and BA (t even, buffer 1) ----
+        // (both steps of the loop body always run: a step skipped by a branch would keep the state it does not touch alive around it -- 64 registers)
+        int t = 1;
+        for (; t + 1 <= ntiles; t += 2) {
+            step(t, B0{}, sA, pfA, plA, sB, pfB, plB);
+            step(t + 1, B1{}, sB, pfB, plB, sA, pfA, plA);
+        }
+        if (t <= ntiles) step(t, B0{}, sA, pfA, plA, sB, pfB, plB);
+    } else
     if (ntiles > 0) {
         using B0 = std::integral_constant<int, 0>; using B1 = std::integral_constant<int, 1>;
         int kt = 0;
@@ -1242,6 +1539,19 @@ int og_launch_attention(const AttnArgs& a, hipStream_t stream) {
         } else {
             if (a.dh == 64) hipLaunchKernelGGL((attention_dma_kernel<64, RaggedNone, 1, 1, 1>), grid, block, 0, stream, a2, RaggedNone{});
             else hipLaunchKernelGGL((attention_dma_kernel<32, RaggedNone, 1, 1, 1>), grid, block, 0, stream, a2, RaggedNone{});
+        }
+        return og_launch_status();
+    }
+    // the software-pipelined tile loop (PIPE) for the batch form; OG_ATTN_PIPE=0 / 1 forces
+    static const int pipe_mode = [] { const char* e = getenv("OG_ATTN_PIPE"); return e ? atoi(e) : -1; }();
+    const bool pipe = dma && (pipe_mode >= 0 ? pipe_mode != 0 : false);
+    if (pipe) {
+        if (a.rag) {
+            if (a.dh == 64) hipLaunchKernelGGL((attention_dma_kernel<64, RaggedDesc, 1, 1, 0, 1>), grid, block, 0, stream, a2, rd);
+            else hipLaunchKernelGGL((attention_dma_kernel<32, RaggedDesc, 1, 1, 0, 1>), grid, block, 0, stream, a2, rd);
+        } else {
+            if (a.dh == 64) hipLaunchKernelGGL((attention_dma_kernel<64, RaggedNone, 1, 1, 0, 1>), grid, block, 0, stream, a2, RaggedNone{});
+            else hipLaunchKernelGGL((attention_dma_kernel<32, RaggedNone, 1, 1, 0, 1>), grid, block, 0, stream, a2, RaggedNone{});
         }
         return og_launch_status();
     }

@@ -1500,6 +1500,7 @@ bool og_pack_proj_stream_big(int N, int K, const double* W, void* out, double S)
 // GEMM, but kv 42.6 / 33.5 and the cross launch 87.6 / ~56: C2 8.92 -> 8.99 ms, so the tile GEMMs keep the 256-d batches.
 // `full`: the launch produces every column of the matrix for all its rows (a self layer's q | k | v).  OG_PROJ_STREAM=2 (experiment): at K = 256 the stream
 // kernel takes those launches only (95 against 104.5 us in the micro-benchmark), the tile GEMMs the cross / kv forms.
+// (og_forward packs the batch stream for K = 128 only -- api.hip: packed_layout -- so forcing the K = 256 form reaches the stage entry og_proj_block alone)
 bool og_proj_stream_wanted(int M, int K, bool full) {
     static const int mode = [] { const char* e = getenv("OG_PROJ_STREAM"); return e ? atoi(e) : -1; }();
     if (mode == 2) return M > 8192 && (K == 128 || full);
@@ -1539,16 +1540,17 @@ extern "C" int og_proj_block_pack(int32_t N, int32_t K, const float* W, void* st
     return ok ? 0 : OG_E_RANGE;
 }
 
-extern "C" int og_proj_block(const void* x_rows, int64_t ld, int32_t M, int32_t K, const void* stream_dev, const float* bias, const float* inv_scale_dev,
+extern "C" int og_proj_block(const void* x_rows, int64_t ld, int32_t M, int32_t K, int32_t N, const void* stream_dev, const float* bias, const float* inv_scale_dev,
                              void* yh, void* yl, int64_t ldy, int32_t split_row, int32_t a0, int32_t a1, int32_t b0, int32_t b1, void* stream) {
     og_clear_status();
-    if (a0 < 0 || b0 < 0 || a1 < a0 || b1 < b0 || ldy < 32 * (int64_t)(a1 > b1 ? a1 : b1)) return OG_E_SHAPE;
-    // batches: the 128-token kernel (its stream sits behind the small one) when the ranges are whole 128-channel groups; N = ldy here
+    if (N <= 0 || (N % 32) || a0 < 0 || b0 < 0 || a1 < a0 || b1 < b0 || 32 * (int64_t)(a1 > b1 ? a1 : b1) > N || ldy < N) return OG_E_SHAPE;
+    if (!og_proj_stream_bytes(N, K)) return OG_E_SHAPE;
+    // batches: the 128-token kernel (its stream sits behind the small one, located by N: ABI v10) when the ranges are whole 128-channel groups
     // (the stage entry of BOTH kernels: above 8192 rows it runs proj_stream_kernel at either width, whatever og_forward prefers)
     static const int ps_mode = [] { const char* e = getenv("OG_PROJ_STREAM"); return e ? atoi(e) : -1; }();
-    if ((ps_mode >= 0 ? ps_mode != 0 : M > 8192) && og_proj_stream_big_bytes((int)ldy, K) && !(a0 % 4) && !(a1 % 4) && !(b0 % 4) && !(b1 % 4) && a1 - a0 <= 32 && b1 - b0 <= 32 &&
-        !(split_row > 0 && split_row < M && (split_row % MT)) && !((uintptr_t)yh & 127) && !((uintptr_t)yl & 127))
-        return og_launch_proj_stream((const _Float16*)x_rows, ld, M, K, (const char*)stream_dev + og_proj_stream_bytes((int)ldy, K), bias, inv_scale_dev,
+    if ((ps_mode >= 0 ? ps_mode != 0 : M > 8192) && og_proj_stream_big_bytes(N, K) && !(a0 % 4) && !(a1 % 4) && !(b0 % 4) && !(b1 % 4) && a1 - a0 <= 32 && b1 - b0 <= 32 &&
+        !(ldy & 63) && !(split_row > 0 && split_row < M && (split_row % MT)) && !((uintptr_t)yh & 127) && !((uintptr_t)yl & 127))
+        return og_launch_proj_stream((const _Float16*)x_rows, ld, M, K, (const char*)stream_dev + og_proj_stream_bytes(N, K), bias, inv_scale_dev,
                                      (_Float16*)yh, (_Float16*)yl, ldy, split_row, a0 / 4, a1 / 4, b0 / 4, b1 / 4, (hipStream_t)stream);
     return og_launch_proj_small((const _Float16*)x_rows, ld, M, K, (const char*)stream_dev, bias, inv_scale_dev, (_Float16*)yh, (_Float16*)yl, ldy,
                                 split_row, a0, a1, b0, b1, (hipStream_t)stream);

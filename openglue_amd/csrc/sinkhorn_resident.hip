@@ -908,7 +908,7 @@ int rs_rows_per_wave(int B, int m, int n, int cus) {
     for (int rw = 4; rw <= 8; rw *= 2) {                             // the finest geometry that still fits ONE launch (and, by default, fills <= all CUs from <= half of them)
         if (want > 1 && want != rw) continue;
         const RsGeom q = rs_geom(m, n, rw);
-        if (q.W != 1 || q.X != 1 || (int64_t)B * q.G > 256) continue;
+        if (q.W != 1 || q.X != 1 || (int64_t)B * q.G > 256 || B > rs_pairs_per_round(q, cus)) continue;      // ONE launch: with the per-XCD map a round holds 8 (32 / Gx) pairs -- 8 once Gx > 16 (9-12 pairs of 513-900 rows took two launches of the 4-row geometry)
         if (want < 0 && (int64_t)B * rs_geom(m, n, 2 * rw).G > 128) continue;      // the next coarser geometry already uses more than half the chip: stay there
         return rw;
     }

@@ -182,7 +182,7 @@ def proj_block(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, split_row: 
     yh = torch.zeros(M, N, device=x.device, dtype=torch.float16)
     yl = torch.zeros_like(yh)
     a, b = cols_a or (0, N), cols_b or (0, N)
-    _lib.check(lib.og_proj_block(rows.data_ptr(), 2 * K, M, K, stream_dev.data_ptr(), bias.data_ptr(), inv.data_ptr(), yh.data_ptr(), yl.data_ptr(), N,
+    _lib.check(lib.og_proj_block(rows.data_ptr(), 2 * K, M, K, N, stream_dev.data_ptr(), bias.data_ptr(), inv.data_ptr(), yh.data_ptr(), yl.data_ptr(), N,
                                  split_row, a[0] // 32, a[1] // 32, b[0] // 32, b[1] // 32, _stream()), "og_proj_block")
     return merge_f16(yh, yl)
 

@@ -91,8 +91,22 @@ def register_favor_base(cls: Optional[type]) -> None:
     _FAVOR_BASE = cls
 
 
+_FAVOR_WARNED = False
+
+
 def _favor_container(embed_dim: int, base: Optional[type]) -> nn.Module:
     if base is None:
+        # a host that HAS the reference's FavorAttention loaded but did not register it gets no redraws from the reference's
+        # FavorAttentionProjectionRedrawCallback (its isinstance test matches nothing) -- say so once; nothing is imported from the host.
+        global _FAVOR_WARNED
+        import sys
+        if not _FAVOR_WARNED and "models.superglue.attention" in sys.modules:
+            _FAVOR_WARNED = True
+            import warnings
+            warnings.warn("openglue_amd: attention = 'favor_relu' without a registered FavorAttention base: the host's "
+                          "FavorAttentionProjectionRedrawCallback (isinstance(module, FavorAttention)) will not find these modules and the "
+                          "projection is never resampled.  Call openglue_amd.superglue.register_favor_base(models.superglue.attention."
+                          "FavorAttention) or pass SuperGlue(config, favor_base=...) -- INTEGRATION.md.", RuntimeWarning, stacklevel=3)
         return _FavorFeatures(embed_dim)
     cls = _HOSTED_FAVOR.get(base)
     if cls is None:

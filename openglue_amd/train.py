@@ -180,7 +180,23 @@ def _gemm_fast(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = 
     return out * (1.0 / s)
 
 
-_SPLITK_WGS = int(_os.environ.get("OG_TRAIN_SPLITK_WGS", "512"))           # experiments: the workgroup count a split-K weight gradient aims at
+def _env_int(name: str, default: int, lo: int = 1) -> int:
+    """An experiment knob from the environment: a malformed or out-of-range value falls back to the default with a warning (never an import error)."""
+    raw = _os.environ.get(name)
+    if raw is None:
+        return default
+    try:
+        v = int(raw)
+    except ValueError:
+        v = None
+    if v is None or v < lo:
+        import warnings
+        warnings.warn(f"{name}={raw!r} ignored (expected an integer >= {lo}); using {default}", RuntimeWarning)
+        return default
+    return v
+
+
+_SPLITK_WGS = _env_int("OG_TRAIN_SPLITK_WGS", 512)           # experiments: the workgroup count a split-K weight gradient aims at
 
 
 def _gemm_splitk(dz: torch.Tensor, x: torch.Tensor, with_colsum: bool = False):

@@ -216,6 +216,136 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k(const f16x8* in, cons
     if (lane == 0) cyc[blockIdx.x * WAVES + (tid >> 6)] = t1 - t0;
 }
 
+// QB = 2: ONE wave per SIMD (4-wave workgroup, one per CU: 100 KB of LDS declared), every wave owns TWO 32-query blocks: the K / V fragments, the LDS reads
+// and the tile's DMA serve 64 queries, the step is 96 MFMAs with the softmax of both blocks (16 pieces of 4 scores) dealt out behind them.
+__global__ __launch_bounds__(256, 1) void k2(const f16x8* in, const char* kv, float* out, unsigned* cyc, int iters) {
+    __shared__ __attribute__((aligned(1024))) char smem[100 * 1024];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    for (int i = tid; i < 4 * PLANE / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = reinterpret_cast<const uint4*>(kv)[i];
+    if (iters < 0) smem[90 * 1024 + tid] = 1;
+    __syncthreads();
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    unsigned kf[4], va[2];
+    for (int c = 0; c < 4; ++c) kf[c] = lds0 + l31 * 128 + (((2 * c + hi) ^ ((l31 >> 1) & 7)) * 16);
+    {
+        const int vrow = (4 * hi + ((lane & 15) >> 2)) * 128 + 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
+        for (int d = 0; d < 2; ++d) va[d] = lds0 + vrow + 64 * (d ^ ((lane >> 3) & 1));
+    }
+    f16x8 qh[2][4], ql[2][4];
+    for (int q = 0; q < 2; ++q) for (int c = 0; c < 4; ++c) { qh[q][c] = in[(lane + 64 * (c + 4 * q)) & 511]; ql[q][c] = in[(lane + 64 * (4 + c) + 17 * q) & 511]; }
+    f32x16 oacc[2][2], sA[2][2], sB[2][2], negm;
+    for (int r = 0; r < 16; ++r) { negm[r] = -40.f; for (int q = 0; q < 2; ++q) for (int j = 0; j < 2; ++j) { oacc[q][j][r] = 0.f; sA[q][j][r] = -3.f - 0.1f * r - q; } }
+    u32x4 pfA[2][2][2], plA[2][2][2], pfB[2][2][2], plB[2][2][2];
+    for (int q = 0; q < 2; ++q) for (int kb = 0; kb < 2; ++kb) for (int t = 0; t < 2; ++t) for (int e = 0; e < 4; ++e) { pfA[q][kb][t][e] = 0x2c002c00u; plA[q][kb][t][e] = 0x10001000u; }
+    f16x8 kh[2][2], kl[2][2];
+    s16x4 vh0[2][2], vh1[2][2], vl0[2][2], vl1[2][2];
+    auto read_k1 = [&](auto C, auto J) {
+        constexpr int c = decltype(C)::value, j = decltype(J)::value, kb = j >> 1;
+        if constexpr ((j & 1) == 0) rd128<kb * 32 * 128>(kh[c & 1][kb], kf[c]);
+        else rd128<PLANE + kb * 32 * 128>(kl[c & 1][kb], kf[c]);
+    };
+    auto read_v1 = [&](auto G, auto J) {
+        constexpr int g = decltype(G)::value, j = decltype(J)::value, d = j >> 2, off = 2 * PLANE + g * 16 * 128;
+        if constexpr ((j & 3) == 0) rdtr<off>(vh0[g & 1][d], va[d]);
+        else if constexpr ((j & 3) == 1) rdtr<off + 8 * 128>(vh1[g & 1][d], va[d]);
+        else if constexpr ((j & 3) == 2) rdtr<off + PLANE>(vl0[g & 1][d], va[d]);
+        else rdtr<off + PLANE + 8 * 128>(vl1[g & 1][d], va[d]);
+    };
+    auto mfma = [](f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); };
+    float ps0 = 0.f, ps1 = 0.f, ps2 = 0.f, ps3 = 0.f;
+    auto add1 = [](float& acc, float x) { acc += x; asm("" : "+v"(acc)); };
+    const unsigned t0 = (unsigned)__builtin_amdgcn_s_memtime();
+    static_for<8>([&](auto J) { read_v1(std::integral_constant<int, 0>{}, J); });
+    auto step = [&](f32x16 (&sc)[2][2], f32x16 (&sn)[2][2], u32x4 (&pfw)[2][2][2], u32x4 (&plw)[2][2][2], u32x4 (&nfw)[2][2][2], u32x4 (&nlw)[2][2][2]) {
+        float p0, p1, p2, p3;
+        // slot mm (0..95): block b = mm / 6 = (q = b >> 3, key block (b >> 2) & 1, registers 4 (b & 3) ..), piece mm % 6
+        auto soft = [&](auto MM) {
+            constexpr int mm = decltype(MM)::value, b = mm / 6, ph = mm % 6, q = b >> 3, kb = (b >> 2) & 1, r = 4 * (b & 3);
+            if constexpr (ph == 0) { p0 = __builtin_amdgcn_exp2f(sc[q][kb][r]); p1 = __builtin_amdgcn_exp2f(sc[q][kb][r + 1]); }
+            else if constexpr (ph == 1) { p2 = __builtin_amdgcn_exp2f(sc[q][kb][r + 2]); p3 = __builtin_amdgcn_exp2f(sc[q][kb][r + 3]); }
+            else if constexpr (ph == 2) {
+                unsigned ha, la, hb, lb;
+                split4(p0, p1, p2, p3, ha, la, hb, lb);
+                nfw[q][kb][r >> 3][(r & 7) >> 1] = ha; nfw[q][kb][r >> 3][((r & 7) >> 1) + 1] = hb;
+                nlw[q][kb][r >> 3][(r & 7) >> 1] = la; nlw[q][kb][r >> 3][((r & 7) >> 1) + 1] = lb;
+            } else if constexpr (ph == 3) { add1(ps0, p0); add1(ps1, p1); }
+            else if constexpr (ph == 4) { add1(ps2, p2); add1(ps3, p3); }
+            fence();
+        };
+        fence();
+        static_for<4>([&](auto G) {
+            constexpr int g = decltype(G)::value, gb = g & 1, kb = g >> 1, t = g & 1;
+            WAIT_V(gb); fence();
+            f16x8 vh[2], vl[2];
+            for (int d = 0; d < 2; ++d) {
+                vh[d] = __builtin_bit_cast(f16x8, __builtin_shufflevector(vh0[gb][d], vh1[gb][d], 0, 1, 2, 3, 4, 5, 6, 7));
+                vl[d] = __builtin_bit_cast(f16x8, __builtin_shufflevector(vl0[gb][d], vl1[gb][d], 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+            static_for<12>([&](auto M) {
+                constexpr int m = decltype(M)::value, d = m & 1, q = (m >> 1) & 1, pass = m >> 2;
+                const f16x8 pf = __builtin_bit_cast(f16x8, pfw[q][kb][t]), pl = __builtin_bit_cast(f16x8, plw[q][kb][t]);
+                if constexpr (pass == 0) oacc[q][d] = mfma(vl[d], pf, oacc[q][d]);
+                else if constexpr (pass == 1) oacc[q][d] = mfma(vh[d], pl, oacc[q][d]);
+                else oacc[q][d] = mfma(vh[d], pf, oacc[q][d]);
+                fence();
+                if constexpr (m >= 4 && m < 8) {
+                    if constexpr (g + 1 < 4) { read_v1(std::integral_constant<int, g + 1>{}, std::integral_constant<int, 2 * (m - 4)>{}); read_v1(std::integral_constant<int, g + 1>{}, std::integral_constant<int, 2 * (m - 4) + 1>{}); }
+                    else read_k1(std::integral_constant<int, 0>{}, std::integral_constant<int, m - 4>{});
+                    fence();
+                }
+                soft(std::integral_constant<int, 12 * g + m>{});
+            });
+        });
+        static_for<4>([&](auto C) {
+            constexpr int c = decltype(C)::value, cb = c & 1;
+            WAIT_K(cb); fence();
+            static_for<12>([&](auto M) {
+                constexpr int m = decltype(M)::value, kb = m & 1, q = (m >> 1) & 1, pass = m >> 2;
+                if constexpr (pass == 0) sn[q][kb] = mfma(kl[cb][kb], qh[q][c], c == 0 ? negm : sn[q][kb]);
+                else if constexpr (pass == 1) sn[q][kb] = mfma(kh[cb][kb], ql[q][c], sn[q][kb]);
+                else sn[q][kb] = mfma(kh[cb][kb], qh[q][c], sn[q][kb]);
+                fence();
+                if constexpr (m >= 4 && m < 8) {
+                    if constexpr (c + 1 < 4) read_k1(std::integral_constant<int, c + 1>{}, std::integral_constant<int, m - 4>{});
+                    else { read_v1(std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * (m - 4)>{}); read_v1(std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * (m - 4) + 1>{}); }
+                    fence();
+                }
+                soft(std::integral_constant<int, 48 + 12 * c + m>{});
+            });
+        });
+    };
+    for (int it = 0; it < iters; it += 2) {
+        step(sA, sB, pfA, plA, pfB, plB);
+        step(sB, sA, pfB, plB, pfA, plA);
+    }
+    const unsigned t1 = (unsigned)__builtin_amdgcn_s_memtime();
+    float acc = (ps0 + ps1) + (ps2 + ps3);
+    for (int q = 0; q < 2; ++q) for (int d = 0; d < 2; ++d) for (int r = 0; r < 16; ++r) acc += oacc[q][d][r] + sA[q][d][r];
+    for (int q = 0; q < 2; ++q) for (int kb = 0; kb < 2; ++kb) for (int t = 0; t < 2; ++t) for (int e = 0; e < 4; ++e) acc += (float)(pfA[q][kb][t][e] ^ plA[q][kb][t][e]);
+    out[blockIdx.x * 256 + tid] = acc;
+    if (lane == 0) cyc[blockIdx.x * 4 + (tid >> 6)] = t1 - t0;
+}
+
+void run2(const char* name, const f16x8* in, const char* kv) {
+    float* out; unsigned* cyc;
+    const int blocks = 256 * 2, iters = 64;
+    CHECK(hipMalloc(&out, (size_t)blocks * 256 * 4)); CHECK(hipMalloc(&cyc, blocks * 4 * 4));
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(k2, dim3(blocks), dim3(256), 0, 0, in, kv, out, cyc, iters);
+    CHECK(hipDeviceSynchronize());
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, 0);
+    for (int rep = 0; rep < 5; ++rep) hipLaunchKernelGGL(k2, dim3(blocks), dim3(256), 0, 0, in, kv, out, cyc, iters);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+    static unsigned h[256 * 2 * 4];
+    CHECK(hipMemcpy(h, cyc, blocks * 4 * 4, hipMemcpyDeviceToHost));
+    double avg = 0; for (int i = 0; i < blocks * 4; ++i) avg += h[i]; avg /= (double)blocks * 4 * iters;
+    int occ = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(&k2), 256, 0);
+    const double flops = (double)blocks * 4 * iters * 96 * 32768.0;
+    printf("%-60s [%d wg/CU] %6.0f cycles / 64-query tile / wave (MFMA issue alone 3072) -> %4.0f per SIMD and 32-query tile; kernel %7.1f us = %5.0f TFLOP/s executed\n", name, occ, avg, avg / 2,
+           ms * 1e3, flops / (ms * 1e-3) / 1e12);
+    hipFree(out); hipFree(cyc);
+}
+
 template <int MODE, int WAVES>
 void run(const char* name, const f16x8* in, const char* kv) {
     float* out; unsigned* cyc;
@@ -255,6 +385,7 @@ int main() {
         run<0, 8>("phases, two waves per SIMD (8-wave workgroup, barrier per tile)", in, kv);
         run<1, 4>("pipelined, one wave per SIMD", in, kv);
         run<1, 8>("pipelined, two waves per SIMD (8-wave workgroup)", in, kv);
+        run2("pipelined, ONE wave per SIMD, 64 queries per wave", in, kv);
     }
     return 0;
 }

@@ -386,6 +386,17 @@ def test_resident_sinkhorn_few_pairs_geometry_selection(monkeypatch):
             if r in (4, 8):
                 tiles = max(2, -(-m // (r * 8)))
                 assert tiles <= 32 and B * tiles <= 256, (B, m, r)
+    # a round of the per-XCD map holds 8 (32 / Gx) pairs -- 9 to 12 pairs of 513-900 rows are 20-29 row blocks each at 4 rows per wave (8 pairs per
+    # launch: two launches), 10-15 at 8 rows per wave (16-24 pairs: one launch).  The heuristic must pick a geometry whose ONE launch holds the batch.
+    for B in (9, 10, 12):
+        for m in (640, 800, 900):
+            assert rpw(B, m, 1000) == 8, (B, m, rpw(B, m, 1000))
+    for B in range(1, 33):
+        for m in (100, 513, 640, 800, 1024):
+            r = rpw(B, m, 1000)
+            if r in (4, 8):
+                gx = max(2, -(-m // (r * 8)))
+                assert B <= 8 * (32 // gx), (B, m, r, gx)
     monkeypatch.setenv("OG_SINKHORN_FEW", "0")
     assert rpw(1, 1024, 1024) == 16
     monkeypatch.setenv("OG_SINKHORN_FEW", "8")

@@ -188,7 +188,8 @@ def test_key_split_hand_over_is_placement_independent(gpu_device, monkeypatch, D
     cfg = syn.make_config(descriptor_dim=D, num_stages=3, num_heads=4, num_iters=10, side_info_size=1)
     sd = syn.make_state_dict(cfg, seed=0)
     model = _build(cfg, sd, gpu_device)
-    data = to_device(syn.make_batch(1, n, n - 37, D, 1, seed=5), gpu_device)
+    data_cpu = syn.make_batch(1, n, n - 37, D, 1, seed=5)
+    data = to_device(data_cpu, gpu_device)
     monkeypatch.delenv("OG_ATTN_GS_SCATTER", raising=False)
     base = model(data)["scores"].clone()
     side = torch.cuda.Stream(device=gpu_device)
@@ -203,7 +204,7 @@ def test_key_split_hand_over_is_placement_independent(gpu_device, monkeypatch, D
         assert torch.equal(got, base), (rep, (got - base).abs().max().item())
     torch.cuda.synchronize()
     with torch.no_grad():
-        ref = orc.superglue_forward(sd, cfg, {k: v.cpu() for k, v in data.items()})["scores"]
+        ref = orc.superglue_forward(sd, cfg, data_cpu)["scores"]
     err = (base.cpu() - ref).abs().max().item()
     parity_note(f"[key split, scattered parts D={D} n={n}] bit-identical to the co-located run over 12 calls; scores err {err:.2e}")
     assert err < TOL_SCORES
