@@ -519,7 +519,8 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
     constexpr int PLANE = KV_TILE * ROWB;           // bytes: 64 keys x one head row
     constexpr int BUFB = 4 * PLANE;                 // Kh | Kl | Vh | Vl
     static_assert(KS == 1 || KS == 2, "key split");
-    __shared__ __attribute__((aligned(1024))) char smem_all[KS * 2 * BUFB];
+    // phase form: two buffers of Kh | Kl | Vh | Vl; pipelined form: a K ring of two slots (Kh | Kl) and a V ring of THREE (Vh | Vl): 80 KB, two workgroups = the CU's 160 KB
+    __shared__ __attribute__((aligned(1024))) char smem_all[PIPE ? 10 * PLANE : KS * 2 * BUFB];
 
     static_assert(GS == 1 || KS == 1, "the workgroup-level key split is built for 4-wave workgroups (dh = 64 and, round 5, dh = 32: the 128-d family's single pairs)");
     const int id = blockIdx.x;
@@ -680,11 +681,43 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
         });
     };
     const int ntiles = (nk + KV_TILE - 1) / KV_TILE;
-    if (ntiles > 0) issue_tile(0, std::integral_constant<int, 0>{});
-    if constexpr (PIPE) {        // the pipelined loop computes QK^T one tile ahead: K(1) travels with tile 0
+    // pipelined form: one (hi, lo) pair of DMA instructions of tile kt, piece i, into the ring slot at byte offset slot_off (run-time: K slot (kt & 1) * 2 PLANE,
+    // V slot 4 PLANE + (kt % 3) * 2 PLANE)
+    [[maybe_unused]] auto pipe_dma = [&](int kt, auto I, auto PP, int slot_off) {
+        // scalar plane bases + ONE 32-bit lane offset (koffs / voffs, four registers in all), both instructions in one asm block: with per-lane 64-bit addresses
+        // the compiler kept ~10 lane constants for them, spilled some around the loop, and every reload's vmcnt(0) drained the DMA queue (the guide's pitfall)
+        constexpr int i = decltype(I)::value, pp = decltype(PP)::value;
+        const int key0 = kt * KV_TILE;
+        const int last = nk - 1 - key0;
+        unsigned off = pp == 0 ? koffs[i] : voffs[i];
+        if (last < KV_TILE - 1) {                        // wave-uniform: only the last tile of a problem clamps its rows
+            int r = wave * 16 + i * RPI + rl;
+            r = r < last ? r : last;
+            off = pp == 0 ? (unsigned)(r * ldkb) + ksw[i] : (unsigned)(r * ldvb) + vsw;
+        }
+        const int64_t o = pp == 0 ? k_tile0 + (int64_t)key0 * ldkb : v_tile0 + (int64_t)key0 * ldvb;       // uniform
+        const char* bh = sptr(reinterpret_cast<const char*>(pp == 0 ? a.kh : a.vh) + o);
+        const char* bl = sptr(reinterpret_cast<const char*>(pp == 0 ? a.kl : a.vl) + o);
+        const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0_dma + (unsigned)slot_off + (unsigned)((wave * 16 + i * RPI) * ROWB));
+        asm volatile("s_mov_b32 m0, %3\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dwordx4 %0, %1\n\t"
+                     "s_add_u32 m0, m0, %4\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dwordx4 %0, %2"
+                     :: "v"(off), "s"(bh), "s"(bl), "s"(m0v), "n"(PLANE) : "memory");
+    };
+    if constexpr (PIPE) {        // the pipelined loop computes QK^T one tile ahead and reads V one step after its barrier: K(0), V(0), K(1), V(1) up front
         static_assert(KS == 1 && GS == 1 && MX == 0, "the pipelined loop is built for the batch form");
-        if (ntiles > 1) static_for<NPI>([&](auto I) { issue_pair(1, std::integral_constant<int, 1>{}, I, std::integral_constant<int, 0>{}); });
-    }
+        static_for<NPI>([&](auto I) {
+            pipe_dma(0, I, std::integral_constant<int, 0>{}, 0);
+            pipe_dma(0, I, std::integral_constant<int, 1>{}, 4 * PLANE);
+            if (ntiles > 1) {
+                pipe_dma(1, I, std::integral_constant<int, 0>{}, 2 * PLANE);
+                pipe_dma(1, I, std::integral_constant<int, 1>{}, 6 * PLANE);
+            }
+        });
+    } else if (ntiles > 0) issue_tile(0, std::integral_constant<int, 0>{});
 
     // ---- Q fragments (B operand): lane (query l31, k-group hi) holds Q[q][16c + 8hi + e] ----
     f16x8 qh[NCH], ql[NCH];
@@ -1050,20 +1083,44 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
         f32x16 sA[2], sB[2];
         u32x4 pfA[2][2], plA[2][2], pfB[2][2], plB[2][2];
         auto fence = [] { __builtin_amdgcn_sched_barrier(0); };
-        // LDS reads of buffer b (compile-time), one instruction per call
-        auto read_k1 = [&](auto BUF, auto C, auto J) {
-            constexpr int b = decltype(BUF)::value, c = decltype(C)::value, j = decltype(J)::value, kb = j >> 1;
-            if constexpr ((j & 1) == 0) lds_read_b128<b * BUFB + kb * 32 * ROWB>(kh[c & 1][kb], kf[c]);
-            else lds_read_b128<b * BUFB + PLANE + kb * 32 * ROWB>(kl[0][kb], kf[c]);
+        // LDS reads from a ring slot: the slot's byte offset is folded into the address registers once per step (kfs, vas), everything else is an immediate
+        // (moved IN PLACE -- the fragment address registers are this loop's alone -- so the ring costs no registers)
+        int k_off_now = 0, v_off_now = 0;
+        auto set_k_slot = [&](int off) {
+            const unsigned d = (unsigned)(off - k_off_now);
+            k_off_now = off;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) kf[c] += d;
         };
-        auto read_v1 = [&](auto BUF, auto G, auto J) {
-            constexpr int b = decltype(BUF)::value, g = decltype(G)::value, j = decltype(J)::value, d = j >> 2, off = b * BUFB + 2 * PLANE + g * 16 * ROWB;
+        auto set_v_slot = [&](int off) {
+            const unsigned d = (unsigned)(off - v_off_now);
+            v_off_now = off;
+#pragma unroll
+            for (int d2 = 0; d2 < NDV; ++d2) va[d2] += d;
+        };
+        auto read_k1 = [&](auto C, auto J) {
+            constexpr int c = decltype(C)::value, j = decltype(J)::value, kb = j >> 1;
+            if constexpr ((j & 1) == 0) lds_read_b128<kb * 32 * ROWB>(kh[c & 1][kb], kf[c]);
+            else lds_read_b128<PLANE + kb * 32 * ROWB>(kl[0][kb], kf[c]);
+        };
+        auto read_v1 = [&](auto G, auto J) {
+            constexpr int g = decltype(G)::value, j = decltype(J)::value, d = j >> 2, off = g * 16 * ROWB;
             if constexpr ((j & 3) == 0) lds_read_tr16_b64<off>(vh0[g & 1][d], va[d]);
             else if constexpr ((j & 3) == 1) lds_read_tr16_b64<off + 8 * ROWB>(vh1[g & 1][d], va[d]);
             else if constexpr ((j & 3) == 2) lds_read_tr16_b64<off + PLANE>(vl0[0][d], va[d]);
             else lds_read_tr16_b64<off + PLANE + 8 * ROWB>(vl1[0][d], va[d]);
         };
         auto add1 = [](float& acc, float x) { acc += x; asm("" : "+v"(acc)); };
+        // -m_run in all sixteen registers of a C operand, made right in front of the two MFMAs that open the QK^T chains (held for the whole step it is 16
+        // registers the loop does not have; opaque, so that the compiler does not hoist the broadcast back out)
+        auto make_negm = [&]() {
+            float nm = -m_run;
+            asm volatile("" : "+v"(nm));
+            f32x16 v;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = nm;
+            return v;
+        };
         // the whole softmax of one tile in one go: prologue (tile 0) and the slow path
         auto exp_split_all = [&](f32x16 (&sc)[2], u32x4 (&pf)[2][2], u32x4 (&pl)[2][2]) -> float {
             float ps0 = 0.f, ps1 = 0.f, ps2 = 0.f, ps3 = 0.f;
@@ -1105,9 +1162,11 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
                 }
         };
         // S(kt) = K(kt) Q^T - m_run from buffer b, on its own (prologue only)
-        auto qk_alone = [&](auto BUF, f32x16 (&sn)[2], int kt) {
+        auto qk_alone = [&](int kslot_off, f32x16 (&sn)[2], int kt) {
+            set_k_slot(kslot_off);
             fence();
-            static_for<4>([&](auto J) { read_k1(BUF, std::integral_constant<int, 0>{}, J); });
+            static_for<4>([&](auto J) { read_k1(std::integral_constant<int, 0>{}, J); });
+            const f32x16 negm = make_negm();
             static_for<NCH>([&](auto C) {
                 constexpr int c = decltype(C)::value, cb = c & 1;
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kh[cb][0]), "+v"(kh[cb][1]), "+v"(kl[0][0]), "+v"(kl[0][1]) :: "memory");
@@ -1118,7 +1177,7 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
                     else if constexpr (pass == 1) sn[kb] = og_attn_mfma(kh[cb][kb], ql[c], sn[kb]);
                     else sn[kb] = og_attn_mfma(kh[cb][kb], qh[c], sn[kb]);
                     fence();
-                    if constexpr (m < 4 && c + 1 < NCH) { read_k1(BUF, std::integral_constant<int, c + 1>{}, std::integral_constant<int, og_korder(m)>{}); fence(); }
+                    if constexpr (m < 4 && c + 1 < NCH) { read_k1(std::integral_constant<int, c + 1>{}, std::integral_constant<int, og_korder(m)>{}); fence(); }
                 });
             });
             if (kt * KV_TILE + KV_TILE > nk) mask_tile(sn, kt * KV_TILE);
@@ -1127,11 +1186,16 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
         // QK^T (no tile t+1), the last one no softmax either: wave-uniform run-time branches inside ONE body per buffer parity -- eight compile-time variants
         // of a 48-MFMA body cost ~70 KB of code and register-allocation trouble at their joins (spills; a spilled LDS-read destination is stored BEFORE its
         // data arrive, so spills are not only slow here, they are wrong).  The last step's vector stream runs on dead score registers; its results are unused.
-        auto step = [&](int t, auto BUF, f32x16 (&sc)[2], u32x4 (&pfw)[2][2], u32x4 (&plw)[2][2], f32x16 (&sn)[2], u32x4 (&nfw)[2][2], u32x4 (&nlw)[2][2]) {
-            constexpr int b = decltype(BUF)::value;
-            using BB = std::integral_constant<int, b>; using BO = std::integral_constant<int, b ^ 1>;
+        // ring bookkeeping (wave-uniform): V(kt) lives in V slot kt % 3, K(kt) in K slot kt & 1
+        int vslot_cur = 0;                                                      // slot of V(t-1) in step t; t starts at 1
+        auto vslot_off = [](int sl) { return 4 * PLANE + sl * 2 * PLANE; };
+        auto step = [&](int t, f32x16 (&sc)[2], u32x4 (&pfw)[2][2], u32x4 (&plw)[2][2], f32x16 (&sn)[2], u32x4 (&nfw)[2][2], u32x4 (&nlw)[2][2]) {
             const bool has_soft = t < ntiles, has_qk = t + 1 < ntiles;
-            const bool dma_v = t < ntiles, dma_k = t + 2 < ntiles;             // V(t), K(t+2) -> buffer b ^ 1
+            const bool dma_v = t + 1 < ntiles, dma_k = t + 2 < ntiles;         // V(t+1) -> V slot (t+1) % 3 (held V(t-2)), K(t+2) -> K slot t & 1 (held K(t)): both consumed in step t-1
+            const int vslot_next = vslot_cur == 2 ? 0 : vslot_cur + 1;        // slot of V(t)
+            const int vslot_dma = vslot_next == 2 ? 0 : vslot_next + 1;       // slot of V(t+1)
+            const int kdma_off = (t & 1) * 2 * PLANE, vdma_off = vslot_off(vslot_dma);
+            set_k_slot(((t + 1) & 1) * 2 * PLANE);                            // K(t+1); the V addresses of V(t-1) were set when its first fragments were requested
             float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f, ps0 = 0.f, ps1 = 0.f, ps2 = 0.f, ps3 = 0.f;
             // P(t) is written word by word: "define" the eight vectors first, or the words not written yet keep the previous contents alive (32 registers)
             asm volatile("" : "=v"(nfw[0][0]), "=v"(nfw[0][1]), "=v"(nfw[1][0]), "=v"(nfw[1][1]), "=v"(nlw[0][0]), "=v"(nlw[0][1]), "=v"(nlw[1][0]), "=v"(nlw[1][1]));
@@ -1158,7 +1222,7 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
                     constexpr int i = j & 1, pp = j >> 1;
                     if constexpr (i < NPI) {
 #if !(OG_PIPE_ABL & 1)
-                        if (wave == w && (pp == 0 ? dma_k : dma_v)) issue_pair(pp == 0 ? t + 2 : t, BO{}, std::integral_constant<int, i>{}, std::integral_constant<int, pp>{});
+                        if (wave == w && (pp == 0 ? dma_k : dma_v)) pipe_dma(pp == 0 ? t + 2 : t + 1, std::integral_constant<int, i>{}, std::integral_constant<int, pp>{}, pp == 0 ? kdma_off : vdma_off);
                         fence();
 #endif
                     }
@@ -1170,9 +1234,8 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
                 static_for<SPM>([&](auto I) { behind(std::integral_constant<int, k * SPM + decltype(I)::value>{}); });
             };
             fence();
-            // the first V fragments of tile t-1; the running-max decision and block 0 of the softmax cover their latency
-            static_for<4 * NDV>([&](auto J) { read_v1(BB{}, std::integral_constant<int, 0>{}, J); });
-            fence();
+            // (the first V fragments of tile t-1 were requested before the barrier that ended the previous step: V travels TWO steps ahead of its use through
+            //  a ring of three slots, so it was visible to every wave a whole step ago -- nothing waits on a fresh LDS read behind the barrier)
             // ---- the running max moves BEFORE the exponentials (the phase form reads the need off the row sum afterwards and keeps S(t) alive for a second
             //      pass; here the 32 score registers must die block by block -- the step holds S(t+1), P(t-1) and P(t) next to them -- and the max tree's
             //      ~16 vector instructions ride in front of the first MFMA, where the wave waits for its V fragments anyway).  Slow path (rare): new
@@ -1185,8 +1248,6 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
                 if (moved) {
                     const float delta = fmaxf(mt, 0.f);
                     m_run += delta;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) negm[r] = -m_run;
                     alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb)
@@ -1222,19 +1283,19 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
                     // their next reads go out behind the later MFMAs of the group, the double-buffered hi fragments behind the first ones.
                     if constexpr (g + 1 < 4) {
                         if constexpr (m < NDV) {                       // hi of dv block m
-                            read_v1(BB{}, std::integral_constant<int, g + 1>{}, std::integral_constant<int, 4 * m>{});
-                            read_v1(BB{}, std::integral_constant<int, g + 1>{}, std::integral_constant<int, 4 * m + 1>{});
+                            read_v1(std::integral_constant<int, g + 1>{}, std::integral_constant<int, 4 * m>{});
+                            read_v1(std::integral_constant<int, g + 1>{}, std::integral_constant<int, 4 * m + 1>{});
                             fence();
                         } else if constexpr (m < 2 * NDV) {            // lo of dv block m - NDV: every pass-0 MFMA has been issued
-                            read_v1(BB{}, std::integral_constant<int, g + 1>{}, std::integral_constant<int, 4 * (m - NDV) + 2>{});
-                            read_v1(BB{}, std::integral_constant<int, g + 1>{}, std::integral_constant<int, 4 * (m - NDV) + 3>{});
+                            read_v1(std::integral_constant<int, g + 1>{}, std::integral_constant<int, 4 * (m - NDV) + 2>{});
+                            read_v1(std::integral_constant<int, g + 1>{}, std::integral_constant<int, 4 * (m - NDV) + 3>{});
                             fence();
                         }
                     } else if constexpr (m >= 3 * NDV - 4 || NDV == 1) {          // the first K fragments of tile t+1 (hi first, see the QK^T loop)
                         constexpr int q = NDV == 2 ? m - 2 : m;                   // NDV = 2: behind MFMAs 2..5; NDV = 1: 0..2, the fourth with the third
                         if constexpr (q >= 0) {
-                            if (has_qk) read_k1(BB{}, std::integral_constant<int, 0>{}, std::integral_constant<int, og_korder(q)>{});
-                            if constexpr (NDV == 1 && m == 2) { if (has_qk) read_k1(BB{}, std::integral_constant<int, 0>{}, std::integral_constant<int, og_korder(3)>{}); }
+                            if (has_qk) read_k1(std::integral_constant<int, 0>{}, std::integral_constant<int, og_korder(q)>{});
+                            if constexpr (NDV == 1 && m == 2) { if (has_qk) read_k1(std::integral_constant<int, 0>{}, std::integral_constant<int, og_korder(3)>{}); }
                             fence();
                         }
                     }
@@ -1243,6 +1304,7 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
             });
             // ---- S(t+1) = K(t+1) Q^T - m_run ----
             if (has_qk) {
+                const f32x16 negm = make_negm();
                 static_for<NCH>([&](auto C) {
                     constexpr int c = decltype(C)::value, cb = c & 1;
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kh[cb][0]), "+v"(kh[cb][1]), "+v"(kl[0][0]), "+v"(kl[0][1]) :: "memory");
@@ -1254,7 +1316,7 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
                         else sn[kb] = og_attn_mfma(kh[cb][kb], qh[c], sn[kb]);
                         fence();
                         // the next chunk's fragments: hi (double-buffered) behind MFMAs 0, 1; lo (single-buffered, read by MFMAs 0, 1 only) behind 2, 3
-                        if constexpr (m < 4 && c + 1 < NCH) { read_k1(BB{}, std::integral_constant<int, c + 1>{}, std::integral_constant<int, og_korder(m)>{}); fence(); }
+                        if constexpr (m < 4 && c + 1 < NCH) { read_k1(std::integral_constant<int, c + 1>{}, std::integral_constant<int, og_korder(m)>{}); fence(); }
                         after_mfma(std::integral_constant<int, 12 * NDV + 6 * c + m>{});
                     });
                 });
@@ -1274,21 +1336,22 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
                 }
                 l_run = l_run * alpha + ((ps0 + ps1) + (ps2 + ps3));
             }
-            if (t < ntiles) {               // another step follows: its V(t) / K(t+2) pieces landed, everybody is done with this step's buffer
+            if (t < ntiles) {               // another step follows: the first fragments of ITS V tile (V(t): landed a step ago), then: this step's DMA pieces landed,
+                set_v_slot(vslot_off(vslot_next));          // everybody is done with the slots the next step's DMA will overwrite
+                static_for<4 * NDV>([&](auto J) { read_v1(std::integral_constant<int, 0>{}, J); });
+                fence();
+                vslot_cur = vslot_next;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #if !(OG_PIPE_ABL & 2)
                 __syncthreads();
 #endif
             }
         };
-        using B0 = std::integral_constant<int, 0>; using B1 = std::integral_constant<int, 1>;
         // ---- prologue: S(0) -> m_run, P(0); S(1) ----
-        qk_alone(B0{}, sB, 0);
+        qk_alone(0, sB, 0);
         {
             const float mt = row_max(sB);
             m_run = mt;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) negm[r] = -m_run;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -1296,9 +1359,14 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
             l_run = exp_split_all(sB, pfA, plA);
         }
         if (ntiles > 1) {
-            __syncthreads();                                     // everybody has read K(0): its planes take K(2)
-            if (ntiles > 2) static_for<NPI>([&](auto I) { issue_pair(2, B0{}, I, std::integral_constant<int, 0>{}); });
-            qk_alone(B1{}, sA, 1);
+            __syncthreads();                                     // everybody has read K(0): its slot takes K(2)
+            if (ntiles > 2) static_for<NPI>([&](auto I) { pipe_dma(2, I, std::integral_constant<int, 0>{}, 0); });
+            qk_alone(2 * PLANE, sA, 1);
+        }
+        set_v_slot(vslot_off(0));                                // the first fragments of V(0) for step 1
+        static_for<4 * NDV>([&](auto J) { read_v1(std::integral_constant<int, 0>{}, J); });
+        fence();
+        if (ntiles > 1) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
@@ -1306,10 +1374,10 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
         // (both steps of the loop body always run: a step skipped by a branch would keep the state it does not touch alive around it -- 64 registers)
         int t = 1;
         for (; t + 1 <= ntiles; t += 2) {
-            step(t, B0{}, sA, pfA, plA, sB, pfB, plB);
-            step(t + 1, B1{}, sB, pfB, plB, sA, pfA, plA);
+            step(t, sA, pfA, plA, sB, pfB, plB);
+            step(t + 1, sB, pfB, plB, sA, pfA, plA);
         }
-        if (t <= ntiles) step(t, B0{}, sA, pfA, plA, sB, pfB, plB);
+        if (t <= ntiles) step(t, sA, pfA, plA, sB, pfB, plB);
     } else
     if (ntiles > 0) {
         using B0 = std::integral_constant<int, 0>; using B1 = std::integral_constant<int, 1>;
