@@ -49,10 +49,10 @@ def _newest(*names):
     return os.path.join(ROOT, "profiles", names[-1])
 
 
-PMC_SUMMARY = _newest("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json")
-TRAFFIC_SUMMARY = _newest("r05_traffic_c2.json", "r04_traffic_c2.json", "r03_traffic_c2.json")
-TRAFFIC_BY_CONFIG = {"C3": _newest("r05_traffic_c3.json", "r04_traffic_c3.json", "r03_traffic_c3.json"),
-                     "C4": _newest("r05_traffic_c4.json", "r04_traffic_c4.json", "r03_traffic_c4.json")}
+PMC_SUMMARY = _newest("r06_pmc_summary.json", "r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json")
+TRAFFIC_SUMMARY = _newest("r06_traffic_c2.json", "r05_traffic_c2.json", "r04_traffic_c2.json", "r03_traffic_c2.json")
+TRAFFIC_BY_CONFIG = {"C3": _newest("r06_traffic_c3.json", "r05_traffic_c3.json", "r04_traffic_c3.json", "r03_traffic_c3.json"),
+                     "C4": _newest("r06_traffic_c4.json", "r05_traffic_c4.json", "r04_traffic_c4.json", "r03_traffic_c4.json")}
 # oracle (the port bench.py times on the GPU box) vs the unmodified reference, timed side by side in the BUILD container where
 # /root/reference exists (scripts/port_vs_reference.py); pasted into cpu_baseline with its source
 PORT_VS_REFERENCE = _newest("r05_port_vs_reference.json", "r04_port_vs_reference.json")
@@ -679,8 +679,10 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "step_ms_spread": spread,
             "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("the reference's shipped 128-d operating point (config/features/sift_opencv.yaml:2-4, config/config.yaml:53), not a BASELINE config: "
-                                    if args.config == "S128" else f"BASELINE configs[{'1' if args.config == 'C2' else args.config}]: ") + f"{m}x{n} kpts, {kw['descriptor_dim']}-dim, "
+            "config": {"workload": ({"S128": "the reference's shipped 128-d operating point (config/features/sift_opencv.yaml:2-4, config/config.yaml:53), not a BASELINE config: ",
+                                     "S256": "the reference's shipped 256-d operating point (config/features/superpoint_magicleap.yaml:2-4, config/config.yaml:53), not a BASELINE config: ",
+                                     "C4i20": "BASELINE configs[3] at the reference's default 20 Sinkhorn iterations (config/config.yaml:53; C4 runs 100): "}.get(
+                                         args.config, f"BASELINE configs[{'1' if args.config == 'C2' else args.config}]: ")) + f"{m}x{n} kpts, {kw['descriptor_dim']}-dim, "
                                    f"{kw['num_stages']} self+cross stages, {kw['num_heads']} heads, {kw['num_iters']} Sinkhorn iters, "
                                    f"batch={B} pairs/GPU, random-init weights, seeded synthetic keypoints/descriptors",
                        "arithmetic": ARITHMETIC, "global_batch": world * B,
@@ -723,8 +725,10 @@ def main():
         torch.cuda.synchronize()
         line["value_incl_h2d"] = round(B * args.steps / (time.perf_counter() - t0), 2)
         # only in the driver's own invocation (C2 at its default batch, one GPU): sweeps over --batch / --config and profiler runs stay what they name
-        line["training_step"] = (_training_step(dev) if (world == 1 and args.config == "C2" and args.batch is None and args.global_batch is None
-                                                         and not args.no_training_step) else None)
+        want_train = world == 1 and args.config == "C2" and args.batch is None and args.global_batch is None and not args.no_training_step
+        line["training_step"] = _training_step(dev) if want_train else None
+        # ... and at the reference's OWN training shape: batch_size_per_gpu 2 (config/config.yaml:12) x up to 2048 keypoints, 20 iterations
+        line["training_step_reference_shape"] = _training_step(dev, B=2, N=2048, iters=20, steps=5) if want_train else None
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, sd, kw, m, n)
         else:

@@ -38,6 +38,12 @@ CONFIGS = {
     # (descriptor_dim 128, max_keypoints 2048), config/config.yaml:44,53 (laf_to_sideinfo_method 'none' = response only, num_iters 20)
     "S128": dict(descriptor_dim=128, num_stages=9, num_heads=4, num_iters=20, side_info_size=1,
                  kpts=(2048, 2048), batch=32),
+    # ... and for its 256-d family: config/features/superpoint_magicleap.yaml:2-4 (descriptor_dim 256, max_keypoints 2048), num_iters 20
+    "S256": dict(descriptor_dim=256, num_stages=9, num_heads=4, num_iters=20, side_info_size=1,
+                 kpts=(2048, 2048), batch=32),
+    # BASELINE configs[3] leaves the Sinkhorn iteration count open: C4 runs 100 like configs[1-2]; this is the sibling at the reference's default 20
+    "C4i20": dict(descriptor_dim=128, num_stages=9, num_heads=4, num_iters=20, side_info_size=6,
+                  kpts=(4096, 4096), batch=8),
 }
 
 

@@ -53,7 +53,10 @@ for nk in (1, 40, 64, 65, 128, 150, 192, 256, 300, 320, 333, 1000, 1024):
     worst = max(worst, run_case(2, 77, nk, 128, 4))
 worst = max(worst, run_case(4, 256, 640, 256, 4, spike=True))
 worst = max(worst, run_case(4, 256, 1000, 128, 4, spike=True))
+worst = max(worst, run_case(8, 1024, 1024, 256, 4))
 print(f"[pipe={mode}] worst error over the edge cases: {worst:.3e}")
+if os.environ.get("OG_CHECK_NO_TIMING"):
+    sys.exit(0)
 run_case(64, 1024, 1024, 256, 4, reps=20)
 run_case(32, 1024, 1024, 256, 4, reps=20)
 run_case(64, 2048, 2048, 256, 4, reps=10)

@@ -6,6 +6,7 @@ Bar (BASELINE.json north_star): log-assignment scores within 1e-3 of the fp32 or
 may only differ if it is a near-tie in the FLOAT64 oracle (top-1/top-2 gap < 1e-4, or its column is, or its matching score
 sits at the threshold): such rows are counted and printed, every other difference fails ("explained-mismatch = 0")."""
 import math
+import os
 
 import pytest
 import torch
@@ -208,6 +209,51 @@ def test_key_split_hand_over_is_placement_independent(gpu_device, monkeypatch, D
     err = (base.cpu() - ref).abs().max().item()
     parity_note(f"[key split, scattered parts D={D} n={n}] bit-identical to the co-located run over 12 calls; scores err {err:.2e}")
     assert err < TOL_SCORES
+
+
+def test_workspace_is_keyed_by_capacity_not_by_shape(gpu_device):
+    """Real pairs (inference.py) have a different keypoint count on every call: the module keeps ONE workspace per device and re-uses it for every call that
+    fits (superglue.py: _get_workspace) instead of re-allocating per (B, m, n).  A sequence of shrinking, growing and ragged shapes through one module must
+    give the results of a fresh module per call, and the buffer must stay put while the calls fit."""
+    cfg = syn.make_config(descriptor_dim=64, num_stages=2, num_heads=4, num_iters=10, side_info_size=1)
+    sd = syn.make_state_dict(cfg, seed=1)
+    model = _build(cfg, sd, gpu_device)
+    ptrs = []
+    for i, (B, m, n) in enumerate([(2, 700, 650), (1, 300, 333), (2, 512, 128), (1, 700, 650), (3, 200, 180), (1, 1100, 900), (2, 64, 64)]):
+        data = to_device(syn.make_batch(B, m, n, 64, 1, seed=20 + i), gpu_device)
+        got = model.match(data, MATCH_THRESHOLD)
+        assert model.check_status() == 0
+        fresh = _build(cfg, sd, gpu_device).match(data, MATCH_THRESHOLD)
+        assert torch.equal(got["scores"], fresh["scores"]) and torch.equal(got["matches0"], fresh["matches0"]), (B, m, n)
+        ptrs.append(next(iter(model._workspace.values()))[0].data_ptr())
+    assert len(model._workspace) == 1
+    assert ptrs[0] == ptrs[1] == ptrs[2] == ptrs[3] == ptrs[4]          # everything up to here fits the first call's buffer
+    assert ptrs[5] == ptrs[6]                                           # ... and after the one growth (1100 x 900) again
+
+
+def test_roctx_ranges_do_not_disturb_the_call(gpu_device):
+    """OG_ROCTX=1 (read once per process, so: a child process) makes og_forward push / pop named roctx ranges around its stages (csrc/api.hip: Range;
+    SURVEY section 5, tracing).  Without a profiler attached they are no-ops of the marker library; the scores must be bit-identical to the parent's."""
+    import subprocess, sys, tempfile
+    cfg = syn.make_config(descriptor_dim=64, num_stages=2, num_heads=4, num_iters=5, side_info_size=1)
+    sd = syn.make_state_dict(cfg, seed=0)
+    model = _build(cfg, sd, gpu_device)
+    data = to_device(syn.make_batch(2, 150, 130, 64, 1, seed=3), gpu_device)
+    base = model(data)["scores"].cpu()
+    code = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "from openglue_amd import synthetic as syn\nfrom openglue_amd.superglue import SuperGlue\n"
+        "cfg = syn.make_config(descriptor_dim=64, num_stages=2, num_heads=4, num_iters=5, side_info_size=1)\n"
+        "m = SuperGlue(cfg); m.load_state_dict(syn.make_state_dict(cfg, seed=0)); m = m.to('cuda:0').eval()\n"
+        "d = {k: (v.to('cuda:0') if torch.is_tensor(v) else v) for k, v in syn.make_batch(2, 150, 130, 64, 1, seed=3).items()}\n"
+        "torch.save(m(d)['scores'].cpu(), sys.argv[1])\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "s.pt")
+        env = dict(os.environ, OG_ROCTX="1")
+        r = subprocess.run([sys.executable, "-c", code, out], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got = torch.load(out)
+    assert torch.equal(got, base)
 
 
 def test_dustbin_dominated_regime_unit_norm_descriptors(gpu_device):
