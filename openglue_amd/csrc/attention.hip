@@ -509,13 +509,19 @@ template <int DH, class RD, int KS = 1, int GS = 1, int MX = 0, int PIPE = 0>
 #ifndef OG_ATTN_WG32
 #define OG_ATTN_WG32 2        // workgroups per CU the dh = 32 instantiation is compiled for (experiment: 3)
 #endif
-__global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2) void attention_dma_kernel(AttnArgs a, RD rd) {      // (dh = 32 would fit three workgroups per CU: measured 4 % slower)
+__global__ __launch_bounds__(PIPE == 2 ? 512 : 256 * KS, PIPE == 2 ? 2 : KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2) void attention_dma_kernel(AttnArgs a, RD rd) {      // (dh = 32 would fit three workgroups per CU: measured 4 % slower)
     static_assert(DH == 64 || DH == 32, "head rows of 128 or 64 bytes");
     constexpr int NDV = DH / 32, NCH = DH / 16;
     constexpr int ROWB = DH * 2;                    // bytes of a head row of one plane: a full 128-byte line (dh = 64) or half of one
     constexpr int RPI = 1024 / ROWB;                // rows per DMA instruction (8 or 16), LPR lanes per row
     constexpr int LPR = ROWB / 16;
-    constexpr int NPI = 16 / RPI;                   // DMA pieces per wave and plane: the wave fills rows [16w, 16w + 16)
+    // PIPE = 2: the pipelined loop in an EIGHT-wave workgroup of 256 queries (one per CU: the two waves of a SIMD share the K / V tiles, so a tile's DMA and
+    // its 32 instructions serve twice the queries); every wave fills RW = 8 rows of each plane instead of 16
+    constexpr int NWAVES = PIPE == 2 ? 8 : 4;
+    constexpr int QT = PIPE == 2 ? 2 * Q_TILE : Q_TILE;
+    constexpr int RW = KV_TILE / NWAVES;
+    static_assert(PIPE != 2 || DH == 64, "the eight-wave form needs RW >= the rows of one DMA instruction");
+    constexpr int NPI = RW / RPI;                   // DMA pieces per wave and plane: the wave fills rows [RW w, RW w + RW)
     constexpr int PLANE = KV_TILE * ROWB;           // bytes: 64 keys x one head row
     constexpr int BUFB = 4 * PLANE;                 // Kh | Kl | Vh | Vl
     static_assert(KS == 1 || KS == 2, "key split");
@@ -553,7 +559,7 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
         q_row0 = q_is0 ? r0 : r1; nq = q_is0 ? m_b : n_b;
         kv_row0 = kv_is0 ? r0 : r1; nk = kv_is0 ? m_b : n_b;
     }
-    const int q0 = qt * Q_TILE;
+    const int q0 = qt * QT;
     if (q0 >= nq) return;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -593,7 +599,7 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
     unsigned ksw[2], vsw;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int r = i * RPI + rl;                                   // + 16 w: a multiple of 16, invisible to either swizzle
+        const int r = i * RPI + rl + (PIPE == 2 ? RW * wave : 0);     // + 16 w: a multiple of 16, invisible to either swizzle (PIPE = 2: + 8 w, visible to K's)
         ksw[i] = (unsigned)(pc ^ (DH == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3))) * 16u;
     }
     vsw = (unsigned)(pc ^ (DH == 64 ? (((rl >> 1) & 1) << 2) : 0)) * 16u;
@@ -620,7 +626,7 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
     unsigned koffs[NPI], voffs[NPI];
 #pragma unroll
     for (int i = 0; i < NPI; ++i) {
-        const int r = wave * 16 + i * RPI + rl;
+        const int r = wave * RW + i * RPI + rl;
         koffs[i] = (unsigned)(r * ldkb) + ksw[i];
         voffs[i] = (unsigned)(r * ldvb) + vsw;
         asm volatile("" : "+v"(koffs[i]), "+v"(voffs[i]));
@@ -691,14 +697,14 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
         const int last = nk - 1 - key0;
         unsigned off = pp == 0 ? koffs[i] : voffs[i];
         if (last < KV_TILE - 1) {                        // wave-uniform: only the last tile of a problem clamps its rows
-            int r = wave * 16 + i * RPI + rl;
+            int r = wave * RW + i * RPI + rl;
             r = r < last ? r : last;
             off = pp == 0 ? (unsigned)(r * ldkb) + ksw[i] : (unsigned)(r * ldvb) + vsw;
         }
         const int64_t o = pp == 0 ? k_tile0 + (int64_t)key0 * ldkb : v_tile0 + (int64_t)key0 * ldvb;       // uniform
         const char* bh = sptr(reinterpret_cast<const char*>(pp == 0 ? a.kh : a.vh) + o);
         const char* bl = sptr(reinterpret_cast<const char*>(pp == 0 ? a.kl : a.vl) + o);
-        const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0_dma + (unsigned)slot_off + (unsigned)((wave * 16 + i * RPI) * ROWB));
+        const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0_dma + (unsigned)slot_off + (unsigned)((wave * RW + i * RPI) * ROWB));
         asm volatile("s_mov_b32 m0, %3\n\t"
                      "s_nop 0\n\t"
                      "global_load_lds_dwordx4 %0, %1\n\t"
@@ -709,6 +715,7 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
     };
     if constexpr (PIPE) {        // the pipelined loop computes QK^T one tile ahead and reads V one step after its barrier: K(0), V(0), K(1), V(1) up front
         static_assert(KS == 1 && GS == 1 && MX == 0, "the pipelined loop is built for the batch form");
+        static_assert(NPI >= 1, "rows per wave");
         static_for<NPI>([&](auto I) {
             pipe_dma(0, I, std::integral_constant<int, 0>{}, 0);
             pipe_dma(0, I, std::integral_constant<int, 1>{}, 4 * PLANE);
@@ -1218,7 +1225,9 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : DH == 32 ? OG_ATTN_WG32 : 2
                 constexpr int mm = decltype(MM)::value;
                 if constexpr (mm % 6 < 5 && mm / 6 + 1 < 8) soft(std::integral_constant<int, mm / 6 + 1>{}, std::integral_constant<int, mm % 6>{});
                 if constexpr (mm >= 2 && (mm - 2) % 3 == 0) {
-                    constexpr int j = (mm - 2) / 12, w = ((mm - 2) % 12) / 3;       // pair j: 0, 1 = K(t+2) pieces, 2, 3 = V(t) pieces
+                    // four waves: pair j = 0, 1 = K(t+2) pieces, 2, 3 = V(t+1) pieces of wave w; eight waves (one piece per plane pair): K of waves 0..7, then V
+                    constexpr int k16 = (mm - 2) / 3;
+                    constexpr int j = PIPE == 2 ? 2 * (k16 >> 3) : (mm - 2) / 12, w = PIPE == 2 ? (k16 & 7) : ((mm - 2) % 12) / 3;
                     constexpr int i = j & 1, pp = j >> 1;
                     if constexpr (i < NPI) {
 #if !(OG_PIPE_ABL & 1)
@@ -1613,6 +1622,18 @@ int og_launch_attention(const AttnArgs& a, hipStream_t stream) {
     // the software-pipelined tile loop (PIPE) for the batch form; OG_ATTN_PIPE=0 / 1 forces
     static const int pipe_mode = [] { const char* e = getenv("OG_ATTN_PIPE"); return e ? atoi(e) : -1; }();
     const bool pipe = dma && (pipe_mode >= 0 ? pipe_mode != 0 : false);
+#ifndef OG_ATTN_PIPE8
+#define OG_ATTN_PIPE8 0      // experiment build (scripts/build_attn_ablation.sh pipe8 -DOG_ATTN_PIPE8=1): instantiates the eight-wave form, OG_ATTN_PIPE=2 selects it.
+#endif                       // Measured (profiles/r06_j_attention_pipe8_ab.log): parity as the other forms, 230 vs 221 us at the C2 shape, 840 vs 773 us at 2048 keys.
+#if OG_ATTN_PIPE8
+    if (pipe && pipe_mode == 2 && a.dh == 64) {          // eight waves, 256 queries per workgroup
+        a2.qtiles = (nqmax + 2 * Q_TILE - 1) / (2 * Q_TILE);
+        dim3 grid8(groups8 * a2.qtiles);
+        if (a.rag) hipLaunchKernelGGL((attention_dma_kernel<64, RaggedDesc, 1, 1, 0, 2>), grid8, dim3(512), 0, stream, a2, rd);
+        else hipLaunchKernelGGL((attention_dma_kernel<64, RaggedNone, 1, 1, 0, 2>), grid8, dim3(512), 0, stream, a2, RaggedNone{});
+        return og_launch_status();
+    }
+#endif
     if (pipe) {
         if (a.rag) {
             if (a.dh == 64) hipLaunchKernelGGL((attention_dma_kernel<64, RaggedDesc, 1, 1, 0, 1>), grid, block, 0, stream, a2, rd);
