@@ -63,7 +63,7 @@ typedef struct og_shape {
     int32_t batch;                  /* B image pairs                                             */
     int32_t m, n;                   /* keypoints per image 0 / image 1                           */
     int32_t desc_dim;               /* D = descriptor_dim = attention_gnn.embed_dim (mult. of 64) */
-    int32_t num_heads;              /* H; head h owns channels h*D/H .. (h+1)*D/H-1 (attention_gnn.py:24-26); D/H in {16,32,64}
+    int32_t num_heads;              /* H; head h owns channels h*D/H .. (h+1)*D/H-1 (attention_gnn.py:24-26); D/H in {16,32,64,128} (128: inference only, round 6)
                                        (OG_FLAG_FAVOR_RELU: H == 1, any D <= 256) */
     int32_t num_stages;             /* L self+cross stages (attention_gnn.py:84-89)              */
     int32_t side_info;              /* s = positional_encoding.side_info_size (2+s <= 32)        */
@@ -310,7 +310,7 @@ int og_mlp_block(int32_t D, void* xo_rows, int64_t ld, int32_t M, const void* st
 /* softmax attention (attention.py:8-19) for `batch` independent problems and H heads, operands and
  * result as split-f16 planes: q [batch][nq][ldq] (columns h*dh.. of row i = head h, PRE-SCALED by
  * dh^-0.5 * log2(e): the kernel evaluates softmax as 2^(q.k - max)), k, v [batch][nk][ld*],
- * out [batch][nq][ldo]; leading dimensions in elements.  dh in {16,32,64}.
+ * out [batch][nq][ldo]; leading dimensions in elements.  dh in {16,32,64,128}.
  * ABI v6: lse (may be NULL) [batch][num_heads][nq] receives the row log-sum-exp of the scaled scores in natural units,
  * ln sum_j exp(dh^-0.5 q_i . k_j) -- what a backward pass that recomputes the attention matrix needs (og_attention_backward). */
 int og_attention(const void* qh, const void* ql, int64_t ldq, const void* kh, const void* kl, int64_t ldk,

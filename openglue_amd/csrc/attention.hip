@@ -114,7 +114,7 @@ __device__ __forceinline__ void lds_read_tr8_b64(i32x2& d, unsigned addr) {
 __device__ constexpr int og_korder(int q) { return q == 0 ? 0 : q == 1 ? 2 : q == 2 ? 1 : 3; }
 
 template <int DH, class RD>
-__global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a, RD rd) {
+__global__ __launch_bounds__(256, DH > 64 ? 1 : 2) void attention_kernel(AttnArgs a, RD rd) {      // dh = 128 (round 6: two heads at 256-d): 136 KB of LDS, one workgroup per CU
     constexpr int DHP = DH < 32 ? 32 : DH;        // Vᵀ rows padded to a full 32-row MFMA tile
     constexpr int NDV = DHP / 32;                 // output row blocks
     constexpr int NCH = DH / 16;                  // 16-wide k chunks of the QKᵀ contraction
@@ -1647,6 +1647,7 @@ int og_launch_attention(const AttnArgs& a, hipStream_t stream) {
     if (a.rag) {
         switch (a.dh) {
             case 16: hipLaunchKernelGGL((attention_kernel<16, RaggedDesc>), grid, block, 0, stream, a2, rd); break;
+            case 128: hipLaunchKernelGGL((attention_kernel<128, RaggedDesc>), grid, block, 0, stream, a2, rd); break;      // register-staged kernel, generic in the head size
             case 32:
                 if (dma) hipLaunchKernelGGL((attention_dma_kernel<32, RaggedDesc>), grid, block, 0, stream, a2, rd);
                 else hipLaunchKernelGGL((attention_kernel<32, RaggedDesc>), grid, block, 0, stream, a2, rd);
@@ -1660,6 +1661,7 @@ int og_launch_attention(const AttnArgs& a, hipStream_t stream) {
     } else {          // uniform batch: no descriptor in the kernarg segment (og_common.h: RaggedNone)
         switch (a.dh) {
             case 16: hipLaunchKernelGGL((attention_kernel<16, RaggedNone>), grid, block, 0, stream, a2, RaggedNone{}); break;
+            case 128: hipLaunchKernelGGL((attention_kernel<128, RaggedNone>), grid, block, 0, stream, a2, RaggedNone{}); break;      // register-staged kernel, generic in the head size
             case 32:
                 if (dma) hipLaunchKernelGGL((attention_dma_kernel<32, RaggedNone>), grid, block, 0, stream, a2, RaggedNone{});
                 else hipLaunchKernelGGL((attention_kernel<32, RaggedNone>), grid, block, 0, stream, a2, RaggedNone{});

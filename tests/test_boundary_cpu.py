@@ -368,6 +368,22 @@ def test_favor_base_is_an_explicit_switch():
         ogs.register_favor_base(None)
 
 
+def test_favor_without_registered_base_warns_once_when_the_host_class_is_loaded(monkeypatch):
+    """with the reference's FavorAttention importable in the process but NOT registered, its redraw callback (isinstance test) finds nothing and the
+    projection is silently never resampled -- the module says so once (nothing is imported from the host: only sys.modules is looked at)."""
+    import sys, types, warnings
+    import openglue_amd.superglue as ogs
+    cfg = syn.make_config(descriptor_dim=64, num_stages=1, num_heads=1, num_iters=2, attention="favor_relu")
+    monkeypatch.setattr(ogs, "_FAVOR_WARNED", False)
+    monkeypatch.setitem(sys.modules, "models.superglue.attention", types.ModuleType("models.superglue.attention"))
+    ogs.register_favor_base(None)
+    with pytest.warns(RuntimeWarning, match="register_favor_base"):
+        ogs.SuperGlue(cfg)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        ogs.SuperGlue(cfg)                      # once per process
+
+
 def test_resident_sinkhorn_few_pairs_geometry_selection(monkeypatch):
     """Host arithmetic of the few-pairs geometries (csrc/sinkhorn_resident.hip: rs_rows_per_wave, round 5): launches of one to eight pairs of
     <= 1024 x 1024 keypoints take 4 rows per wave (a pair = 32 tiles on one XCD), 9 to 16 pairs take 8, anything that fills the chip -- or is wider

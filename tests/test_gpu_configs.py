@@ -211,6 +211,25 @@ def test_key_split_hand_over_is_placement_independent(gpu_device, monkeypatch, D
     assert err < TOL_SCORES
 
 
+@pytest.mark.parametrize("D,H", [(256, 2), (128, 1)])
+def test_head_size_128(gpu_device, D, H):
+    """The reference is generic in the head size (attention_gnn.py:22-26); besides 16 / 32 / 64 this library runs 128 -- two heads at 256-d, one at 128-d --
+    on the register-staged attention kernel (csrc/attention.hip: attention_kernel<128>; round 6).  Whole path against the per-pair CPU oracle."""
+    cfg = syn.make_config(descriptor_dim=D, num_stages=3, num_heads=H, num_iters=20, side_info_size=1)
+    sd = syn.make_state_dict(cfg, seed=0)
+    model = _build(cfg, sd, gpu_device)
+    data = syn.make_batch(2, 300, 333, D, 1, seed=11)
+    out = model.match(to_device(data, gpu_device), MATCH_THRESHOLD)
+    assert model.check_status() == 0
+    with torch.no_grad():
+        ref = orc.match_pairs(sd, cfg, data, MATCH_THRESHOLD)
+    err = (out["scores"].cpu() - ref["scores"]).abs().max().item()
+    diff = int((out["matches0"].cpu() != ref["matches0"]).sum())
+    parity_note(f"[head size 128: D={D} H={H}] scores err {err:.2e} exempt={diff}")
+    assert err < TOL_SCORES, err
+    assert diff <= 1
+
+
 def test_workspace_is_keyed_by_capacity_not_by_shape(gpu_device):
     """Real pairs (inference.py) have a different keypoint count on every call: the module keeps ONE workspace per device and re-uses it for every call that
     fits (superglue.py: _get_workspace) instead of re-allocating per (B, m, n).  A sequence of shrinking, growing and ragged shapes through one module must
