@@ -157,7 +157,10 @@ __global__ __launch_bounds__(256) void attention_lse_kernel(AttnTrainArgs a) {
 
 // ------------------------------------------------------------------------------------------------------------------
 template <int DH>
-__global__ __launch_bounds__(256) void attention_bwd_kernel(AttnTrainArgs a) {
+#ifndef OG_ATTN_BWD_WGS
+#define OG_ATTN_BWD_WGS 2     // workgroups per CU the kernel is built for (1 = rounds 3-5: 105 KB of LDS, ~300 registers)
+#endif
+__global__ __launch_bounds__(256, OG_ATTN_BWD_WGS) void attention_bwd_kernel(AttnTrainArgs a) {
     constexpr int DHP = DH < 32 ? 32 : DH;
     constexpr int NB = DHP / 32;                  // 32-column blocks of a head
     using IO = TileIO<DH, DHP>;
@@ -165,12 +168,21 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(AttnTrainArgs a) {
     constexpr int LDT = 32 + 4;                   // per-wave 32 x 32 transpose tile
     __shared__ __attribute__((aligned(16))) float Ks[BC * LD];
     __shared__ __attribute__((aligned(16))) float Vs[BC * LD];
-    __shared__ __attribute__((aligned(16))) float Qs[BR * LD];
-    __shared__ __attribute__((aligned(16))) float Os[BR * LD];          // dO
-    __shared__ __attribute__((aligned(16))) float Ts[4 * 32 * LDT];     // dS, lane = query, one tile per wave
-    __shared__ __attribute__((aligned(16))) float Rs[2 * 32 * DHP];     // partial sums handed from one wave of a pair to the other
     __shared__ float Ls[BR], Ds[BR];
-
+    // Round 6: two workgroups per CU (the kernel is one wave per SIMD with three barriers per block: the second workgroup is what fills the
+    // matrix pipe under them -- the lesson of the fp32 GEMM's tile work).  By LDS that needs <= 80 KB; at dh = 64 the Q and dO tiles, the per-wave
+    // transpose tiles (dS with lane = query) and the hand-over area of the partial sums added up to 105 KB.  The last two now live INSIDE the Q | dO
+    // area, which is dead by then: every wave has its B operands of the step (bo, bq) in registers before the first tile write, and a barrier
+    // separates the last read of Q / dO by any wave from the first write over them.  Hand-over area = the first 4096 floats (inside Q), transpose
+    // tiles = the last 4608 (the end of Q and all of dO): disjoint, so a wave may hand its dQ block over while another still reads its tile.  70 KB.
+    constexpr bool ALIAS = DH == 64;
+    constexpr int TSZ = 4 * 32 * LDT, RSZ = 2 * 32 * DHP;
+    static_assert(!ALIAS || (RSZ + TSZ <= 2 * BR * LD), "hand-over area and transpose tiles side by side inside Q | dO");
+    __shared__ __attribute__((aligned(16))) float QO[2 * BR * LD + (ALIAS ? 0 : TSZ + RSZ)];
+    float* const Qs = QO;
+    float* const Os = QO + BR * LD;                                     // dO
+    float* const Ts = ALIAS ? QO + 2 * BR * LD - TSZ : QO + 2 * BR * LD;          // dS, lane = query, one tile per wave
+    float* const Rs = ALIAS ? QO : QO + 2 * BR * LD + TSZ;              // partial sums handed from one wave of a pair to the other
     const int nkb = (a.nk + BC - 1) / BC;
     const int z = blockIdx.x / nkb, jb = blockIdx.x - z * nkb;
     const int b = z / a.H, h = z - b * a.H;
@@ -261,7 +273,8 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(AttnTrainArgs a) {
                 dk[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[r], bq[r][nb], dk[nb], 0, 0, 0);
             }
         }
-        // dQ block = dS K: dS with lane = query through this wave's LDS tile
+        // dQ block = dS K: dS with lane = query through this wave's LDS tile (dh = 64: inside the Q | dO area: every wave is past its reads of both)
+        if constexpr (ALIAS) __syncthreads();
 #pragma unroll
         for (int r = 0; r < 16; ++r) T[mfma32_row(r, lane) * LDT + l31] = ds[r];
         __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): the tile is read back by the same wave
