@@ -561,6 +561,12 @@ __global__ __launch_bounds__(PIPE == 2 ? 512 : 256 * KS, PIPE == 2 ? 2 : KS == 2
     }
     const int q0 = qt * QT;
     if (q0 >= nq) return;
+#ifndef OG_ATTN_PRIO
+#define OG_ATTN_PRIO 0        // experiment (round 6): static wave priority 1 for every other workgroup -- bit (OG_ATTN_PRIO - 1) of its index inside the XCD --
+#endif                        // so that the two workgroups sharing a CU do not arbitrate as equals (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+#if OG_ATTN_PRIO
+    if (((id >> 3) >> (OG_ATTN_PRIO - 1)) & 1) __builtin_amdgcn_s_setprio(1);
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
