@@ -1532,6 +1532,446 @@ __global__ __launch_bounds__(PIPE == 2 ? 512 : 256 * KS, PIPE == 2 ? 2 : KS == 2
 }
 
 
+
+// -----------------------------------------------------------------------------------------------------------------------------------------------------
+// attention_p16_kernel (round 6): the software-pipelined loop of attention_dma_kernel<64, ., 1, 1, 0, 1> on v_mfma_f32_16x16x32_f16 -- the f16 MFMA form that
+// costs the least energy per flop on this part (scripts/probes/mfma_energy.hip: +19 % sustained under the power cap in isolation; the timing build of the
+// 32x32x16 kernels issued as pairs of 16x16x32, profiles/r06_n_attention_abl16.log: -7 % for the phase form, -13 % for the pipelined form).  dh = 64, batch form.
+//
+// Tiling of a wave's 64-key x 32-query tile in 16 x 16 blocks (lane l: column l & 15, k-group / row-group g = l >> 4):
+//   S^T block (i, j) = keys 16 i.. x queries 16 j..:  A = K rows (lane: key 16 i + (l & 15), channels 32 s + 8 g ..), B = Q^T (lane: query 16 j + (l & 15),
+//       the same channels), two k-steps s; accumulator register r = key 16 i + 4 g + r.  A lane owns TWO queries (j = 0, 1) and 16 keys of each per tile.
+//   O^T block (t, j) = channels 16 t.. x queries 16 j..:  B = P^T straight from the exponentiated accumulators -- for k-step s the lane's eight values are
+//       blocks i = 2 s, 2 s + 1 = keys 32 s + 16 (e >> 2) + 4 g + (e & 3) -- and A = V^T by two transposing reads per plane (rows = those keys).
+//   Row statistics of a query live in the four lanes {c, c + 16, c + 32, c + 48}: v_permlane16_swap + v_permlane32_swap.
+// LDS: K rows swizzled as everywhere (chunk ^ ((row >> 1) & 7): the 16-lane groups of a ds_read_b128 -- rows 0-3, 12-15 at chunk c and rows 4-11 at chunk c ^ 1 --
+// still cover sixteen distinct 16-byte slots); V rows chunk ^ (((row >> 1) & 3) << 1): a transposing read's 32 lanes fetch 8 key rows x 32 bytes.
+// Loop structure, ring slots, DMA and the running-max handling are the PIPE form's (see there).
+template <class RD>
+__global__ __launch_bounds__(256, 2) void attention_p16_kernel(AttnArgs a, RD rd) {
+    constexpr int DH = 64, ROWB = 128, RPI = 8, LPR = 8, NPI = 2, RW = 16;
+    constexpr int PLANE = KV_TILE * ROWB;
+    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(1024))) char smem_all[10 * PLANE];      // K ring of two slots (Kh | Kl), V ring of three (Vh | Vl)
+
+    const int id = blockIdx.x;
+    const int xcd = id & 7, local = id >> 3;
+    const int grp = (local / a.qtiles) * 8 + xcd;          // (problem, head) group: all its query tiles on one XCD (speed only)
+    if (grp >= a.nz * a.num_heads) return;
+    const int qt = local % a.qtiles;
+    const int z = grp / a.num_heads, h = grp - z * a.num_heads;
+    const int gsel = z < a.split ? 0 : 1;
+    const int zz = gsel ? z - a.split : z;
+    int nq = a.nq[gsel], nk = a.nk[gsel];
+    int64_t q_row0 = a.q_base[gsel] + (int64_t)zz * a.q_step[gsel];
+    int64_t kv_row0 = a.kv_base[gsel] + (int64_t)zz * a.kv_step[gsel];
+    if (rd.B > 0) {          // ragged batch: per-pair row ranges of the packed token matrix
+        const int T0 = rd.off0[rd.B];
+        const int b = z < rd.B ? z : z - rd.B;
+        const int r0 = rd.off0[b], m_b = rd.off0[b + 1] - r0;
+        const int r1 = T0 + rd.off1[b], n_b = rd.off1[b + 1] - rd.off1[b];
+        const bool q_is0 = a.rag_mode == 1 ? z < rd.B : a.rag_mode == 2;
+        const bool kv_is0 = a.rag_mode == 1 ? q_is0 : !q_is0;
+        q_row0 = q_is0 ? r0 : r1; nq = q_is0 ? m_b : n_b;
+        kv_row0 = kv_is0 ? r0 : r1; nk = kv_is0 ? m_b : n_b;
+    }
+    const int q0 = qt * Q_TILE;
+    if (q0 >= nq) return;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c16 = lane & 15, g = lane >> 4;
+    char* const smem = smem_all;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+    // ---- DMA: wave w fills rows [16 w, 16 w + 16) of each plane, two pieces of eight rows; K source chunk ^ ((r >> 1) & 7), V source chunk ^ (((r >> 1) & 3) << 1) ----
+    const int rl = lane / LPR, pc = lane % LPR;
+    const int ldkb = (int)a.ldk * 2, ldvb = (int)a.ldv * 2;
+    unsigned ksw[2], vsw[2], koffs[2], voffs[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = i * RPI + rl;                                   // + 16 w: invisible to either swizzle
+        ksw[i] = (unsigned)(pc ^ ((r >> 1) & 7)) * 16u;
+        vsw[i] = (unsigned)(pc ^ (((r >> 1) & 3) << 1)) * 16u;
+        const int rr = wave * RW + r;
+        koffs[i] = (unsigned)(rr * ldkb) + ksw[i];
+        voffs[i] = (unsigned)(rr * ldvb) + vsw[i];
+        asm volatile("" : "+v"(koffs[i]), "+v"(voffs[i]));
+    }
+    const int64_t k_tile0 = (kv_row0 * a.ldk + h * DH) * 2, v_tile0 = (kv_row0 * a.ldv + h * DH) * 2;   // bytes, uniform
+    auto sptr = [](const char* p) {
+        const uint64_t v = (uint64_t)(uintptr_t)p;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi32 = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        return reinterpret_cast<const char*>((uintptr_t)(((uint64_t)hi32 << 32) | lo));
+    };
+    auto dma = [&](int kt, auto I, auto PP, int slot_off) {          // one (hi, lo) instruction pair of tile kt, piece i, into the ring slot at slot_off
+        constexpr int i = decltype(I)::value, pp = decltype(PP)::value;
+        const int key0 = kt * KV_TILE;
+        const int last = nk - 1 - key0;
+        unsigned off = pp == 0 ? koffs[i] : voffs[i];
+        if (last < KV_TILE - 1) {                        // wave-uniform: only the last tile of a problem clamps its rows
+            int r = wave * RW + i * RPI + rl;
+            r = r < last ? r : last;
+            off = pp == 0 ? (unsigned)(r * ldkb) + ksw[i] : (unsigned)(r * ldvb) + vsw[i];
+        }
+        const int64_t o = pp == 0 ? k_tile0 + (int64_t)key0 * ldkb : v_tile0 + (int64_t)key0 * ldvb;       // uniform
+        const char* bh = sptr(reinterpret_cast<const char*>(pp == 0 ? a.kh : a.vh) + o);
+        const char* bl = sptr(reinterpret_cast<const char*>(pp == 0 ? a.kl : a.vl) + o);
+        const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)slot_off + (unsigned)((wave * RW + i * RPI) * ROWB));
+        asm volatile("s_mov_b32 m0, %3\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dwordx4 %0, %1\n\t"
+                     "s_add_u32 m0, m0, %4\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dwordx4 %0, %2"
+                     :: "v"(off), "s"(bh), "s"(bl), "s"(m0v), "n"(PLANE) : "memory");
+    };
+    const int ntiles = (nk + KV_TILE - 1) / KV_TILE;
+    static_for<NPI>([&](auto I) {
+        dma(0, I, std::integral_constant<int, 0>{}, 0);
+        dma(0, I, std::integral_constant<int, 1>{}, 4 * PLANE);
+        if (ntiles > 1) {
+            dma(1, I, std::integral_constant<int, 0>{}, 2 * PLANE);
+            dma(1, I, std::integral_constant<int, 1>{}, 6 * PLANE);
+        }
+    });
+
+    // ---- Q fragments (B operand of K Q^T): lane (query 16 j + c16, channels 32 s + 8 g ..) ----
+    f16x8 qh[2][2], ql[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int qi = q0 + wave * 32 + 16 * j + c16;
+        if (qi >= nq) qi = nq - 1;     // clamp: computed but never stored
+        const int64_t qo = (q_row0 + qi) * a.ldq + h * DH + 8 * g;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            qh[j][s] = *reinterpret_cast<const f16x8*>(a.qh + qo + 32 * s);
+            ql[j][s] = *reinterpret_cast<const f16x8*>(a.ql + qo + 32 * s);
+        }
+    }
+    f32x4_ oacc[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) oacc[t][j] = f32x4_{0.f, 0.f, 0.f, 0.f};
+    float m_run[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};
+
+    // fragment addresses (bytes), moved in place from ring slot to ring slot
+    unsigned kf[2], va[4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) kf[s] = lds0 + c16 * ROWB + (((4 * s + g) ^ ((c16 >> 1) & 7)) * 16);
+    {
+        const int fsw = ((2 * g + (c16 >> 3)) & 3) << 1;
+        const unsigned rowlane = (unsigned)((4 * g + (c16 >> 2)) * ROWB + 8 * (c16 & 1));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) va[t] = lds0 + rowlane + (unsigned)((((2 * t) ^ fsw) + ((c16 & 3) >> 1)) * 16);
+    }
+    int k_off_now = 0, v_off_now = 0;
+    auto set_k_slot = [&](int off) { const unsigned d = (unsigned)(off - k_off_now); k_off_now = off; kf[0] += d; kf[1] += d; };
+    auto set_v_slot = [&](int off) {
+        const unsigned d = (unsigned)(off - v_off_now);
+        v_off_now = off;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) va[t] += d;
+    };
+    // K chunk (key-tile pair ip, k-step s): hi fragments double-buffered by chunk parity, lo fragments in ONE buffer (only the pass-0 MFMAs read them)
+    f16x8 khf[2][2], klf[2];
+    auto read_k = [&](auto CC, auto Q) {                 // piece q of chunk cc: 0, 1 = hi of key tiles 2 ip, 2 ip + 1; 2, 3 = lo
+        constexpr int cc = decltype(CC)::value, q = decltype(Q)::value, ip = cc >> 1, s = cc & 1, aa = q & 1;
+        if constexpr (q < 2) lds_read_b128<(2 * ip + aa) * 16 * ROWB>(khf[cc & 1][aa], kf[s]);
+        else lds_read_b128<PLANE + (2 * ip + aa) * 16 * ROWB>(klf[aa], kf[s]);
+    };
+    // V chunk (k-step s, channel-tile pair tp): per channel tile two transposing reads per plane (keys 32 s + 4 g .., + 16); hi double-buffered, lo single
+    s16x4 vhf[2][2][2], vlf[2][2];                       // [buffer][tile b2][half], [tile b2][half]
+    auto read_v = [&](auto VC, auto Q) {                 // piece q of chunk vc: 0..3 = hi (tile q >> 1, half q & 1), 4..7 = lo
+        constexpr int vc = decltype(VC)::value, q = decltype(Q)::value, s = vc >> 1, tp = vc & 1, b2 = (q >> 1) & 1, hh = q & 1, t = 2 * tp + b2;
+        if constexpr (q < 4) lds_read_tr16_b64<(32 * s + 16 * hh) * ROWB>(vhf[vc & 1][b2][hh], va[t]);
+        else lds_read_tr16_b64<PLANE + (32 * s + 16 * hh) * ROWB>(vlf[b2][hh], va[t]);
+    };
+    auto fence = [] { __builtin_amdgcn_sched_barrier(0); };
+    auto mfma16 = [](f16x8 x, f16x8 y, f32x4_ c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(x, y, c, 0, 0, 0); };
+    auto add1 = [](float& acc, float x) { acc += x; asm("" : "+v"(acc)); };
+    // maximum of a per-lane value over the four lanes that share a query column
+    auto max_over_groups = [](float v) {
+        float a0 = v, a1 = v;
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a0), "+v"(a1));
+        float b0 = fmaxf(a0, a1), b1 = b0;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(b0), "+v"(b1));
+        return fmaxf(b0, b1);
+    };
+    auto sum_over_groups = [](float v) {
+        float a0 = v, a1 = v;
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a0), "+v"(a1));
+        float b0 = a0 + a1, b1 = b0;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(b0), "+v"(b1));
+        return b0 + b1;
+    };
+    auto row_max = [&](const f32x4_ (&sc)[4][2], int j) {
+        float mt = sc[0][j][0];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mt = fmaxf(mt, sc[i][j][r]);
+        return max_over_groups(mt);
+    };
+    auto make_negm = [&](int j) {
+        float nm = -m_run[j];
+        asm volatile("" : "+v"(nm));
+        return f32x4_{nm, nm, nm, nm};
+    };
+    auto mask_tile = [&](f32x4_ (&sc)[4][2], int key0) {          // padded keys of the last tile -> -inf
+        int gg = g;
+        asm volatile("" : "+v"(gg));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = key0 + 16 * i + 4 * gg + r < nk;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) sc[i][j][r] = ok ? sc[i][j][r] : OG_NEG_INF;
+            }
+    };
+    // softmax of a whole tile in one go (prologue): S -> P as packed (hi, hi) / (lo, lo) words; returns the row sums of the lane's two queries
+    auto exp_split_all = [&](f32x4_ (&sc)[4][2], u32x4 (&pf)[2][2], u32x4 (&pl)[2][2], float (&sum)[2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float p0 = __builtin_amdgcn_exp2f(sc[i][j][0]), p1 = __builtin_amdgcn_exp2f(sc[i][j][1]);
+                const float p2 = __builtin_amdgcn_exp2f(sc[i][j][2]), p3 = __builtin_amdgcn_exp2f(sc[i][j][3]);
+                add1(ps0, p0); add1(ps1, p1); add1(ps0, p2); add1(ps1, p3);
+                unsigned ha, la, hb, lb;
+                og_split4(p0, p1, p2, p3, ha, la, hb, lb);
+                pf[j][i >> 1][(i & 1) * 2] = ha; pf[j][i >> 1][(i & 1) * 2 + 1] = hb;
+                pl[j][i >> 1][(i & 1) * 2] = la; pl[j][i >> 1][(i & 1) * 2 + 1] = lb;
+            }
+            sum[j] = ps0 + ps1;
+        }
+    };
+    // the twelve MFMAs of K chunk cc into the S accumulators `sn`, with the next chunk's fragment reads and `after(k)` behind MFMA k
+    auto qk_chunk = [&](auto CC, f32x4_ (&sn)[4][2], const f32x4_ (&negm)[2], auto NEXT, auto&& after) {
+        constexpr int cc = decltype(CC)::value, ip = cc >> 1, s = cc & 1, cb = cc & 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(khf[cb][0]), "+v"(khf[cb][1]), "+v"(klf[0]), "+v"(klf[1]) :: "memory");
+        fence();
+        static_for<12>([&](auto M) {
+            constexpr int m = decltype(M)::value, j = m & 1, aa = (m >> 1) & 1, pass = m >> 2, i = 2 * ip + aa;
+            if constexpr (pass == 0) sn[i][j] = mfma16(klf[aa], qh[j][s], s == 0 ? negm[j] : sn[i][j]);
+            else if constexpr (pass == 1) sn[i][j] = mfma16(khf[cb][aa], ql[j][s], sn[i][j]);
+            else sn[i][j] = mfma16(khf[cb][aa], qh[j][s], sn[i][j]);
+            fence();
+            constexpr int nx = decltype(NEXT)::value;            // next K chunk to request (-1: none): hi behind MFMAs 0, 1; lo behind 4, 5 (every pass-0 MFMA is out)
+            if constexpr (nx >= 0) {
+                if constexpr (m < 2) { read_k(std::integral_constant<int, nx>{}, std::integral_constant<int, m>{}); fence(); }
+                else if constexpr (m == 4 || m == 5) { read_k(std::integral_constant<int, nx>{}, std::integral_constant<int, m - 2>{}); fence(); }
+            }
+            after(std::integral_constant<int, 12 * cc + m>{});
+        });
+    };
+
+    f32x4_ sA[4][2], sB[4][2];
+    u32x4 pfA[2][2], plA[2][2], pfB[2][2], plB[2][2];
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    auto qk_alone = [&](int kslot_off, f32x4_ (&sn)[4][2], int kt) {
+        set_k_slot(kslot_off);
+        fence();
+        static_for<4>([&](auto Q) { read_k(std::integral_constant<int, 0>{}, Q); });
+        f32x4_ negm[2] = {make_negm(0), make_negm(1)};
+        auto nothing = [](auto) {};
+        qk_chunk(std::integral_constant<int, 0>{}, sn, negm, std::integral_constant<int, 1>{}, nothing);
+        qk_chunk(std::integral_constant<int, 1>{}, sn, negm, std::integral_constant<int, 2>{}, nothing);
+        qk_chunk(std::integral_constant<int, 2>{}, sn, negm, std::integral_constant<int, 3>{}, nothing);
+        qk_chunk(std::integral_constant<int, 3>{}, sn, negm, std::integral_constant<int, -1>{}, nothing);
+        if (kt * KV_TILE + KV_TILE > nk) mask_tile(sn, kt * KV_TILE);
+    };
+
+    // ring bookkeeping (wave-uniform): V(kt) lives in V slot kt % 3, K(kt) in K slot kt & 1
+    int vslot_cur = 0;
+    auto vslot_off = [](int sl) { return 4 * PLANE + sl * 2 * PLANE; };
+    // One step t: O += V(t-1)^T P(t-1)^T (24 MFMAs... 48 of 16x16x32), S(t+1) = K(t+1) Q^T - m_run (48), softmax(t) dealt out behind them.
+    auto step = [&](int t, f32x4_ (&sc)[4][2], u32x4 (&pfw)[2][2], u32x4 (&plw)[2][2], f32x4_ (&sn)[4][2], u32x4 (&nfw)[2][2], u32x4 (&nlw)[2][2]) {
+        const bool has_soft = t < ntiles, has_qk = t + 1 < ntiles;
+        const bool dma_v = t + 1 < ntiles, dma_k = t + 2 < ntiles;
+        const int vslot_next = vslot_cur == 2 ? 0 : vslot_cur + 1;
+        const int vslot_dma = vslot_next == 2 ? 0 : vslot_next + 1;
+        const int kdma_off = (t & 1) * 2 * PLANE, vdma_off = vslot_off(vslot_dma);
+        set_k_slot(((t + 1) & 1) * 2 * PLANE);
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f, psum[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+        asm volatile("" : "=v"(nfw[0][0]), "=v"(nfw[0][1]), "=v"(nfw[1][0]), "=v"(nfw[1][1]), "=v"(nlw[0][0]), "=v"(nlw[0][1]), "=v"(nlw[1][0]), "=v"(nlw[1][1]));
+        // softmax(t), block blk = (key tile i = blk >> 1, query tile j = blk & 1), piece ph
+        auto soft = [&](auto BLK, auto PH) {
+            constexpr int blk = decltype(BLK)::value, ph = decltype(PH)::value, i = blk >> 1, j = blk & 1;
+            if constexpr (ph == 0) { p0 = __builtin_amdgcn_exp2f(sc[i][j][0]); p1 = __builtin_amdgcn_exp2f(sc[i][j][1]); }
+            else if constexpr (ph == 1) { p2 = __builtin_amdgcn_exp2f(sc[i][j][2]); p3 = __builtin_amdgcn_exp2f(sc[i][j][3]); }
+            else if constexpr (ph == 2) {
+                unsigned ha, la, hb, lb;
+                og_split4(p0, p1, p2, p3, ha, la, hb, lb);
+                nfw[j][i >> 1][(i & 1) * 2] = ha; nfw[j][i >> 1][(i & 1) * 2 + 1] = hb;
+                nlw[j][i >> 1][(i & 1) * 2] = la; nlw[j][i >> 1][(i & 1) * 2 + 1] = lb;
+            } else if constexpr (ph == 3) { add1(psum[j][0], p0); add1(psum[j][1], p1); }
+            else if constexpr (ph == 4) { add1(psum[j][0], p2); add1(psum[j][1], p3); }
+            fence();
+        };
+        // behind MFMA number k of the step (0..95): a step has 96 MFMAs and 48 slots for vector / DMA pieces: one slot behind every second MFMA
+        auto behind = [&](auto K) {
+            constexpr int k = decltype(K)::value;
+            if constexpr ((k & 1) == 1) {
+                constexpr int mm = k >> 1;
+                if constexpr (mm % 6 < 5 && mm / 6 + 1 < 8) soft(std::integral_constant<int, mm / 6 + 1>{}, std::integral_constant<int, mm % 6>{});
+                if constexpr (mm >= 2 && (mm - 2) % 3 == 0) {
+                    constexpr int jj = (mm - 2) / 12, w = ((mm - 2) % 12) / 3;       // pair jj: 0, 1 = K(t+2) pieces, 2, 3 = V(t+1) pieces of wave w
+                    constexpr int i = jj & 1, pp = jj >> 1;
+                    if (wave == w && (pp == 0 ? dma_k : dma_v)) dma(pp == 0 ? t + 2 : t + 1, std::integral_constant<int, i>{}, std::integral_constant<int, pp>{}, pp == 0 ? kdma_off : vdma_off);
+                    fence();
+                }
+            }
+        };
+        fence();
+        // ---- the running max moves before the exponentials (as in the PIPE form), per query tile ----
+        float alpha[2] = {1.f, 1.f};
+        bool moved = false;
+        if (has_soft) {
+            const float mt0 = row_max(sc, 0), mt1 = row_max(sc, 1);
+            moved = __any(fmaxf(mt0, mt1) > RESCALE_THR);
+            if (moved) {
+                const float d0 = fmaxf(mt0, 0.f), d1 = fmaxf(mt1, 0.f);
+                m_run[0] += d0; m_run[1] += d1;
+                alpha[0] = __builtin_amdgcn_exp2f(-d0); alpha[1] = __builtin_amdgcn_exp2f(-d1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { sc[i][0][r] -= d0; sc[i][1][r] -= d1; }
+            }
+        }
+        fence();
+        static_for<5>([&](auto PH) { soft(std::integral_constant<int, 0>{}, PH); });
+        // ---- O^T += V(t-1)^T P(t-1)^T: chunks vc = (k-step s, channel-tile pair tp) ----
+        static_for<4>([&](auto VC) {
+            constexpr int vc = decltype(VC)::value, s = vc >> 1, tp = vc & 1, vb = vc & 1;
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vhf[vb][0][0]), "+v"(vhf[vb][0][1]), "+v"(vhf[vb][1][0]), "+v"(vhf[vb][1][1]),
+                         "+v"(vlf[0][0]), "+v"(vlf[0][1]), "+v"(vlf[1][0]), "+v"(vlf[1][1]) :: "memory");
+            fence();
+            f16x8 vh[2], vl[2];
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2) {
+                vh[b2] = __builtin_bit_cast(f16x8, __builtin_shufflevector(vhf[vb][b2][0], vhf[vb][b2][1], 0, 1, 2, 3, 4, 5, 6, 7));
+                vl[b2] = __builtin_bit_cast(f16x8, __builtin_shufflevector(vlf[b2][0], vlf[b2][1], 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+            static_for<12>([&](auto M) {
+                constexpr int m = decltype(M)::value, j = m & 1, b2 = (m >> 1) & 1, pass = m >> 2, tt = 2 * tp + b2;
+                const f16x8 pf = __builtin_bit_cast(f16x8, pfw[j][s]), pl = __builtin_bit_cast(f16x8, plw[j][s]);
+                if constexpr (pass == 0) oacc[tt][j] = mfma16(vl[b2], pf, oacc[tt][j]);
+                else if constexpr (pass == 1) oacc[tt][j] = mfma16(vh[b2], pl, oacc[tt][j]);
+                else oacc[tt][j] = mfma16(vh[b2], pf, oacc[tt][j]);
+                fence();
+                // the next chunk's fragments: hi pieces behind MFMAs 0..3, lo pieces (single buffer: every pass-0 MFMA is out after MFMA 3) behind 4..7;
+                // after the last V chunk: the first K fragments of tile t+1
+                if constexpr (vc + 1 < 4) {
+                    if constexpr (m < 8) { read_v(std::integral_constant<int, vc + 1>{}, std::integral_constant<int, m>{}); fence(); }
+                } else {
+                    if constexpr (m == 4 || m == 5) { if (has_qk) read_k(std::integral_constant<int, 0>{}, std::integral_constant<int, m - 4>{}); fence(); }
+                    else if constexpr (m == 6 || m == 7) { if (has_qk) read_k(std::integral_constant<int, 0>{}, std::integral_constant<int, m - 4>{}); fence(); }
+                }
+                behind(std::integral_constant<int, 12 * vc + m>{});
+            });
+        });
+        // ---- S(t+1) = K(t+1) Q^T - m_run ----
+        if (has_qk) {
+            f32x4_ negm[2] = {make_negm(0), make_negm(1)};
+            auto aft = [&](auto K) { behind(std::integral_constant<int, 48 + decltype(K)::value>{}); };
+            qk_chunk(std::integral_constant<int, 0>{}, sn, negm, std::integral_constant<int, 1>{}, aft);
+            qk_chunk(std::integral_constant<int, 1>{}, sn, negm, std::integral_constant<int, 2>{}, aft);
+            qk_chunk(std::integral_constant<int, 2>{}, sn, negm, std::integral_constant<int, 3>{}, aft);
+            qk_chunk(std::integral_constant<int, 3>{}, sn, negm, std::integral_constant<int, -1>{}, aft);
+            if ((t + 1) * KV_TILE + KV_TILE > nk) mask_tile(sn, (t + 1) * KV_TILE);
+        } else {
+            static_for<48>([&](auto M) { behind(std::integral_constant<int, 48 + decltype(M)::value>{}); });
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" : "=v"(sn[i][0]), "=v"(sn[i][1]));
+        }
+        if (has_soft) {
+            if (moved) {
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { oacc[tt][0][r] *= alpha[0]; oacc[tt][1][r] *= alpha[1]; }
+            }
+            l_run[0] = l_run[0] * alpha[0] + (psum[0][0] + psum[0][1]);
+            l_run[1] = l_run[1] * alpha[1] + (psum[1][0] + psum[1][1]);
+        }
+        if (t < ntiles) {
+            set_v_slot(vslot_off(vslot_next));
+            static_for<8>([&](auto Q) { read_v(std::integral_constant<int, 0>{}, Q); });
+            fence();
+            vslot_cur = vslot_next;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    };
+
+    // ---- prologue: S(0) -> m_run, P(0); S(1) ----
+    qk_alone(0, sB, 0);
+    {
+        const float mt0 = row_max(sB, 0), mt1 = row_max(sB, 1);
+        m_run[0] = mt0; m_run[1] = mt1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { sB[i][0][r] -= mt0; sB[i][1][r] -= mt1; }
+        exp_split_all(sB, pfA, plA, l_run);
+    }
+    if (ntiles > 1) {
+        __syncthreads();                                     // everybody has read K(0): its slot takes K(2)
+        if (ntiles > 2) static_for<NPI>([&](auto I) { dma(2, I, std::integral_constant<int, 0>{}, 0); });
+        qk_alone(2 * PLANE, sA, 1);
+    }
+    set_v_slot(vslot_off(0));
+    static_for<8>([&](auto Q) { read_v(std::integral_constant<int, 0>{}, Q); });
+    fence();
+    if (ntiles > 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    int t = 1;
+    for (; t + 1 <= ntiles; t += 2) {
+        step(t, sA, pfA, plA, sB, pfB, plB);
+        step(t + 1, sB, pfB, plB, sA, pfA, plA);
+    }
+    if (t <= ntiles) step(t, sA, pfA, plA, sB, pfB, plB);
+
+    // ---- normalise and store O[q][h * 64 + channel]: lane (query tile j, column c16) holds channels 16 tt + 4 g .. + 3 of each channel tile ----
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float l_tot = sum_over_groups(l_run[j]);
+        const float inv = 1.f / l_tot;
+        const int qi = q0 + wave * 32 + 16 * j + c16;
+        if (a.lse && g == 0 && qi < nq) a.lse[((int64_t)z * a.num_heads + h) * nq + qi] = (m_run[j] + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
+        if (qi < nq) {
+            const int64_t orow = (q_row0 + qi) * a.ldo;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const int dv = 16 * tt + 4 * g;
+                f16x4 vh, vl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float o = oacc[tt][j][e] * inv;
+                    asm("" : "+v"(o));
+                    _Float16 th, tl;
+                    og_split(o, th, tl);
+                    vh[e] = th; vl[e] = tl;
+                }
+                const int64_t oo = orow + (a.o_hl ? og_hl_col(h * DH + dv) : (int64_t)(h * DH + dv));
+                *reinterpret_cast<f16x4*>(a.oh + oo) = vh;
+                *reinterpret_cast<f16x4*>(a.ol + oo) = vl;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 int og_launch_attention(const AttnArgs& a, hipStream_t stream) {
@@ -1623,6 +2063,13 @@ int og_launch_attention(const AttnArgs& a, hipStream_t stream) {
             if (a.dh == 64) hipLaunchKernelGGL((attention_dma_kernel<64, RaggedNone, 1, 1, 1>), grid, block, 0, stream, a2, RaggedNone{});
             else hipLaunchKernelGGL((attention_dma_kernel<32, RaggedNone, 1, 1, 1>), grid, block, 0, stream, a2, RaggedNone{});
         }
+        return og_launch_status();
+    }
+    // the 16x16x32 pipelined kernel (dh = 64, batch form): OG_ATTN_P16=0 / 1
+    static const int p16_mode = [] { const char* e = getenv("OG_ATTN_P16"); return e ? atoi(e) : -1; }();
+    if (dma && a.dh == 64 && (p16_mode >= 0 ? p16_mode != 0 : false)) {
+        if (a.rag) hipLaunchKernelGGL((attention_p16_kernel<RaggedDesc>), grid, block, 0, stream, a2, rd);
+        else hipLaunchKernelGGL((attention_p16_kernel<RaggedNone>), grid, block, 0, stream, a2, RaggedNone{});
         return og_launch_status();
     }
     // the software-pipelined tile loop (PIPE) for the batch form; OG_ATTN_PIPE=0 / 1 forces

@@ -5,7 +5,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from openglue_amd import _lib, ops
 lib = _lib.load(); dev = torch.device("cuda:0")
-mode = os.environ.get("OG_ATTN_PIPE", "default")
+mode = os.environ.get("OG_ATTN_PIPE", "default") + ("+p16" if os.environ.get("OG_ATTN_P16", "0") == "1" else "")
 
 
 def run_case(Z, nq, nk, D, H, spike=False, reps=0, scales=(0.5, 2.0, 2.0)):

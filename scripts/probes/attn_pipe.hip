@@ -38,6 +38,21 @@ __device__ __forceinline__ void fence() { __builtin_amdgcn_sched_barrier(0); }
 
 constexpr int PLANE = 64 * 128;      // 64 keys x one 128-byte head row
 
+// -DPROBE_ABL16: every v_mfma_f32_32x32x16_f16 issued as TWO v_mfma_f32_16x16x32_f16 on the first eight accumulator registers -- the same flops and matrix-pipe
+// cycles in the form that sustained +19 % under the power cap in isolation (scripts/probes/mfma_energy.hip); results meaningless, timing only.
+__device__ __forceinline__ f32x16 probe_mfma(f16x8 a, f16x8 b, f32x16 c) {
+#ifdef PROBE_ABL16
+    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+    f32x4_ c0 = __builtin_shufflevector(c, c, 0, 1, 2, 3), c1 = __builtin_shufflevector(c, c, 4, 5, 6, 7);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c1, 0, 0, 0);
+    c[0] = c0[0]; c[1] = c0[1]; c[2] = c0[2]; c[3] = c0[3]; c[4] = c1[0]; c[5] = c1[1]; c[6] = c1[2]; c[7] = c1[3];
+    return c;
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
+}
+
 // MODE 0: phases, 1: pipelined.  WAVES = waves per workgroup (4: one per SIMD, 8: two per SIMD, one workgroup per CU either way)
 template <int MODE, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k(const f16x8* in, const char* kv, float* out, unsigned* cyc, int iters) {
@@ -73,7 +88,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k(const f16x8* in, cons
         else if constexpr ((j & 3) == 2) rdtr<off + PLANE>(vl0[g & 1][d], va[d]);
         else rdtr<off + PLANE + 8 * 128>(vl1[g & 1][d], va[d]);
     };
-    auto mfma = [](f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); };
+    auto mfma = [](f16x8 a, f16x8 b, f32x16 c) { return probe_mfma(a, b, c); };
 #define WAIT_K(cb) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kh[cb][0]), "+v"(kh[cb][1]), "+v"(kl[cb][0]), "+v"(kl[cb][1]) :: "memory")
 #define WAIT_V(gb) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vh0[gb][0]), "+v"(vh1[gb][0]), "+v"(vl0[gb][0]), "+v"(vl1[gb][0]), "+v"(vh0[gb][1]), "+v"(vh1[gb][1]), "+v"(vl0[gb][1]), "+v"(vl1[gb][1]) :: "memory")
     float ps0 = 0.f, ps1 = 0.f, ps2 = 0.f, ps3 = 0.f;
@@ -251,7 +266,7 @@ __global__ __launch_bounds__(256, 1) void k2(const f16x8* in, const char* kv, fl
         else if constexpr ((j & 3) == 2) rdtr<off + PLANE>(vl0[g & 1][d], va[d]);
         else rdtr<off + PLANE + 8 * 128>(vl1[g & 1][d], va[d]);
     };
-    auto mfma = [](f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); };
+    auto mfma = [](f16x8 a, f16x8 b, f32x16 c) { return probe_mfma(a, b, c); };
     float ps0 = 0.f, ps1 = 0.f, ps2 = 0.f, ps3 = 0.f;
     auto add1 = [](float& acc, float x) { acc += x; asm("" : "+v"(acc)); };
     const unsigned t0 = (unsigned)__builtin_amdgcn_s_memtime();
