@@ -63,7 +63,7 @@ typedef struct og_shape {
     int32_t batch;                  /* B image pairs                                             */
     int32_t m, n;                   /* keypoints per image 0 / image 1                           */
     int32_t desc_dim;               /* D = descriptor_dim = attention_gnn.embed_dim (mult. of 64) */
-    int32_t num_heads;              /* H; head h owns channels h*D/H .. (h+1)*D/H-1 (attention_gnn.py:24-26); D/H in {16,32,64,128} (128: inference only, round 6)
+    int32_t num_heads;              /* H; head h owns channels h*D/H .. (h+1)*D/H-1 (attention_gnn.py:24-26); D/H in {16,32,64,128} (128, round 6: register-staged attention kernel; training backward GEMM by GEMM)
                                        (OG_FLAG_FAVOR_RELU: H == 1, any D <= 256) */
     int32_t num_stages;             /* L self+cross stages (attention_gnn.py:84-89)              */
     int32_t side_info;              /* s = positional_encoding.side_info_size (2+s <= 32)        */

@@ -129,7 +129,7 @@ int check_shape(const og_shape* s) {
     const int dh = s->desc_dim / s->num_heads;
     if (s->flags & OG_FLAG_FAVOR_RELU) {      // the reference's FAVOR attention only runs with one head (openglue_amd.h)
         if (s->num_heads != 1 || s->desc_dim > 256 || (s->flags & OG_FLAG_LINEAR_ATTENTION)) return OG_E_SHAPE;
-    } else if (dh != 16 && dh != 32 && dh != 64 && dh != 128) return OG_E_SHAPE;      // 128 (round 6): the register-staged attention kernel; inference only
+    } else if (dh != 16 && dh != 32 && dh != 64 && dh != 128) return OG_E_SHAPE;      // 128 (round 6): the register-staged attention kernel
     if (s->num_stages < 0) return OG_E_SHAPE;
     if (s->side_info < 0 || 2 + s->side_info > 32) return OG_E_SHAPE;
     if (s->num_hidden < 0 || s->num_hidden > OG_MAX_HIDDEN) return OG_E_SHAPE;

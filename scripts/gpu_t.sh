@@ -1,3 +1,3 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-timeout 900 python -m pytest tests/test_gpu_configs.py -x -q -m gpu -k "head_size_128" 2>&1 | tail -8
+timeout 900 python -m pytest tests/test_train_slice.py -x -q -m gpu -k "softmax_attention_backward" 2>&1 | tail -8

@@ -491,12 +491,13 @@ def test_split_k_weight_gradient(gpu_device, T, Cout, Cin):
 
 # ----------------------------------------------------------------------------- flash attention backward (no Nq x Nk tensor)
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(2, 37, 53, 4, 16), (1, 64, 64, 2, 32), (2, 130, 97, 2, 64), (1, 200, 333, 4, 64), (3, 5, 3, 1, 16)])
+@pytest.mark.parametrize("shape", [(2, 37, 53, 4, 16), (1, 64, 64, 2, 32), (2, 130, 97, 2, 64), (1, 200, 333, 4, 64), (3, 5, 3, 1, 16), (2, 70, 90, 2, 128)])
 @pytest.mark.parametrize("flash_bwd", ["1", "0"])
 def test_softmax_attention_backward_against_float64(gpu_device, shape, flash_bwd, monkeypatch):
     """train.SoftmaxAttention (forward: the split-f16 flash kernel; backward: og_attention_train_lse + og_attention_backward, P
     recomputed in registers -- or with OG_TRAIN_FLASH_BWD=0 the GEMM-by-GEMM path) vs torch autograd in float64 of
-    softmax(q k^T / sqrt(d)) v per head (attention.py:8-19): ragged tile edges in queries and keys, all head sizes."""
+    softmax(q k^T / sqrt(d)) v per head (attention.py:8-19): ragged tile edges in queries and keys, all head sizes (128, round 6: forward on the
+    register-staged kernel, backward GEMM by GEMM -- the flash backward covers 16 / 32 / 64)."""
     from openglue_amd import train
     monkeypatch.setenv("OG_TRAIN_FLASH_BWD", flash_bwd)
     B, Nq, Nk, H, d = shape
