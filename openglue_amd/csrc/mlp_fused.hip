@@ -196,6 +196,29 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpFusedArgs g) {
                      "global_load_lds_dwordx4 %1, %2"
                      :: "v"(xoff[0]), "v"(xoff[1]), "s"(src), "s"(m0v) : "memory");
     };
+#ifndef OG_MLP_DMA_SPREAD
+#define OG_MLP_DMA_SPREAD 0      // experiment (round 6): the six LDS-DMA pieces of a stage one per free slot instead of 4 + 2 back to back
+#endif
+    [[maybe_unused]] auto issue_w1 = [&](int s, int slot, auto P) {      // piece p of this wave of weight stage s
+        constexpr int pce = decltype(P)::value;
+        const unsigned l16 = lane16;                           // (a plain use: asm operands alone do not capture inside a generic lambda)
+        const char* src = scalar_ptr(baseW + (int64_t)s * WSTAGE);
+        const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + slot * WSTAGE + wave * 4096);
+        asm volatile("s_mov_b32 m0, %2\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dwordx4 %0, %1 offset:%3"
+                     :: "v"(l16), "s"(src), "s"(m0v), "n"(1024 * pce) : "memory");
+    };
+    [[maybe_unused]] auto issue_x1 = [&](int xs, int slot, auto H) {     // piece h of this wave of token stage xs
+        constexpr int hh_ = decltype(H)::value;
+        const unsigned xo = xoff[hh_];
+        const char* src = scalar_ptr(baseX + (int64_t)(xs % G0) * 128);
+        const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + XOFF + slot * XSTAGE + wave * 2048 + hh_ * 1024);
+        asm volatile("s_mov_b32 m0, %2\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dwordx4 %0, %1"
+                     :: "v"(xo), "s"(src), "s"(m0v) : "memory");
+    };
 
 #endif
 
@@ -390,9 +413,15 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpFusedArgs g) {
             const bool ix = xs + 2 < XSTAGES;                           // X(xs+2) exists (W(s+2) always does during fc.0)
             const int wslot2 = prev3(wslot), xslot2 = prev3(xslot);     // slots of W(s+2), X(xs+2): (s + 2) % 3 = (s - 1) % 3
             const bool next_x = kg + 1 < G0;                            // the next stage is an fc.0 stage (reads token fragments)
+#if OG_MLP_DMA_SPREAD
+#define OG_SLOT_G0(k) { if ((k) == 2) issue_w1(s + 2, wslot2, std::integral_constant<int, 0>{}); if ((k) == 3) { read_x(1); issue_w1(s + 2, wslot2, std::integral_constant<int, 1>{}); } }
+#define OG_SLOT_G1(k) { if ((k) == 2) issue_w1(s + 2, wslot2, std::integral_constant<int, 2>{}); if ((k) == 3) issue_w1(s + 2, wslot2, std::integral_constant<int, 3>{}); }
+#define OG_SLOT_G2(k) { if (ix) { if ((k) == 2) issue_x1(xs + 2, xslot2, std::integral_constant<int, 0>{}); if ((k) == 3) issue_x1(xs + 2, xslot2, std::integral_constant<int, 1>{}); } }
+#else
 #define OG_SLOT_G0(k) { if ((k) == 2 && !(OG_MLP_ABL & 8)) issue_w4(s + 2, wslot2); if ((k) == 3) read_x(1); }   /* the weight pieces; the second k-step's token fragments */
 #define OG_SLOT_G1(k) { if ((k) == 2 && ix && !(OG_MLP_ABL & (8 | 32))) issue_x2(xs + 2, xslot2); }                  /* the token pieces */
 #define OG_SLOT_G2(k) {}
+#endif
 #define OG_SLOT_NONE(k) {}
             tie2(xh[0], xl[0]);
             OG_GROUP(acc0[0], acc0[1], xh[0], xl[0], 0, 3, 3, 3, 2, OG_SLOT_G0)
@@ -451,8 +480,13 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpFusedArgs g) {
                 (void)NXT;
                 // the next stage's B fragments: hidden block (jt + 1) / 2, k-step (jt + 1) & 1
                 auto conv = [&](int step) { if (jt + 1 < NJT) convert_step(acc0[(jt + 1 < NJT ? jt + 1 : jt) >> 1], (jt + 1) & 1, step, hb ^ 1); };
+#if OG_MLP_DMA_SPREAD
+#define OG_SLOT_P0(k) { if (iw) { if ((k) == 2) issue_w1(s + 2, wslot2, std::integral_constant<int, 0>{}); else issue_w1(s + 2, wslot2, std::integral_constant<int, 1>{}); } }
+#define OG_SLOT_P1(k) { if (iw) { if ((k) == 2) issue_w1(s + 2, wslot2, std::integral_constant<int, 2>{}); else issue_w1(s + 2, wslot2, std::integral_constant<int, 3>{}); } }
+#else
 #define OG_SLOT_P0(k) { if ((k) == 2 && iw && !(OG_MLP_ABL & 8)) issue_w4(s + 2, wslot2); }
 #define OG_SLOT_P1(k) {}
+#endif
 #define OG_SLOT_C2(k) conv((k) - 2)
 #define OG_SLOT_C3(k) conv((k))
                 OG_GROUP(acc3[0], acc3[1], bh, bl, 0, 3, 3, 3, 2, OG_SLOT_P0)
